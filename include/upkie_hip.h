@@ -1,0 +1,275 @@
+/*
+ * upkie_hip.h -- C-ABI of the MI355X-native batched Upkie simulation step.
+ *
+ * This is the drop-in boundary for the reference's backend plugin interface
+ * (upkie/envs/backends/backend.py:11-50: reset / step / get_spine_observation
+ * / close) batched over B independent environments. Every entry point takes
+ * plain pointers and sizes; device pointers are owned by the caller (PyTorch
+ * tensors on the Python side), launches go on the caller's hipStream_t and
+ * nothing here synchronises the device. No exception crosses this boundary:
+ * functions return 0 on success and a negative UpkieStatus on error, with a
+ * message available from upkie_sim_last_error().
+ *
+ * Data layout (all device buffers, fp32):
+ *   state    [UPKIE_STATE_WORDS][B]   struct-of-arrays, word index below
+ *   act/obs  row-major [B][d] as gymnasium.vector would hand them over
+ */
+#ifndef UPKIE_HIP_H_
+#define UPKIE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPKIE_NB 7 /* merged rigid bodies: trunk, L{thigh,calf,wheel}, R{..} */
+#define UPKIE_NJ 6 /* actuated joints, reference order (static_config.h:64-69,
+                      kinematic_tree.py:105-127): left_hip, left_knee,
+                      left_wheel, right_hip, right_knee, right_wheel */
+
+/* ---- per-env state words (SoA rows of the state buffer) ---------------- */
+enum UpkieStateWord {
+  UPKIE_S_POS = 0,      /* 3: base position in world                        */
+  UPKIE_S_QUAT = 3,     /* 4: base->world quaternion (w, x, y, z)           */
+  UPKIE_S_LINVEL = 7,   /* 3: base linear velocity, world frame             */
+  UPKIE_S_ANGVEL = 10,  /* 3: base angular velocity, world frame            */
+  UPKIE_S_Q = 13,       /* 6: joint angles                                  */
+  UPKIE_S_QD = 19,      /* 6: joint velocities                              */
+  UPKIE_S_LEGREF = 25,  /* 4: hip/knee low-pass targets (lh, lk, rh, rk),
+                              upkie_gyropod.py:246-267                      */
+  UPKIE_S_YAW = 29,     /* 1: integrated commanded yaw, upkie_gyropod.py:383 */
+  UPKIE_S_YAWVEL = 30,  /* 1: last commanded yaw velocity                   */
+  UPKIE_S_TORQUE = 31,  /* 6: last commanded joint torques (servo "torque"
+                              observation, pybullet_backend.py:456-458)     */
+  UPKIE_S_IMUVEL = 37,  /* 3: previous IMU linear velocity (world), for the
+                              finite-difference accelerometer :405-408      */
+  UPKIE_S_EPISODE = 40, /* 1: number of resets done so far (RNG stream id)  */
+  UPKIE_S_DONE = 41,    /* 1: 1.0 when the env terminated and awaits reset  */
+  UPKIE_S_MPC_V = 42,   /* 1: MPCBalancer.commanded_velocity                */
+  UPKIE_S_SE2_X = 43,   /* 1: dead-reckoned x, upkie_base_velocity.py:197   */
+  UPKIE_S_SE2_Y = 44,   /* 1: dead-reckoned y                               */
+  UPKIE_S_CONTACT = 45, /* 1: floor contact flag after the last substep     */
+  UPKIE_STATE_WORDS = 48
+};
+
+/* Words the fused Pendulum step reads and writes (29 physics/filter words +
+ * the done flag); everything else is untouched by that kernel. */
+#define UPKIE_PENDULUM_STATE_WORDS 29
+
+enum UpkieStatus {
+  UPKIE_OK = 0,
+  UPKIE_ERR_INVALID_ARGUMENT = -1,
+  UPKIE_ERR_UNSUPPORTED_MODEL = -2,
+  UPKIE_ERR_HIP = -3,
+  UPKIE_ERR_NO_DEVICE = -4
+};
+
+enum UpkieAutoreset {
+  UPKIE_AUTORESET_DISABLED = 0, /* caller resets through a mask             */
+  UPKIE_AUTORESET_NEXT_STEP = 1 /* gymnasium.vector default: an env that
+                                   terminated at step t is reset by step t+1,
+                                   which ignores its action                 */
+};
+
+/* Merged-fixed-link rigid-body model. Body frames are located at their joint
+ * origin and aligned with the base frame at the zero configuration, so the
+ * tree transforms are pure translations (the host-side URDF loader does this
+ * canonicalisation). Replaces what the reference gets from upkie_description's
+ * URDF through pybullet.loadURDF (pybullet_backend.py:121-125) and
+ * upkie/model/model.py:63-110. */
+typedef struct UpkieModel {
+  double mass[UPKIE_NB];
+  double com[UPKIE_NB][3];        /* centre of mass in body frame           */
+  double inertia[UPKIE_NB][6];    /* about the com: xx yy zz xy xz yz       */
+  double joint_pos[UPKIE_NJ][3];  /* joint origin in the parent body frame  */
+  double joint_axis[UPKIE_NJ][3]; /* unit rotation axis in body frame       */
+  double joint_lower[UPKIE_NJ];
+  double joint_upper[UPKIE_NJ];
+  double joint_effort[UPKIE_NJ];   /* N.m   */
+  double joint_velocity[UPKIE_NJ]; /* rad/s */
+  double joint_damping[UPKIE_NJ];  /* URDF <dynamics damping>, N.m.s/rad    */
+  double wheel_radius;             /* tire collision cylinder radius        */
+  double wheel_center[2][3];       /* tire centre in the wheel body frame   */
+  double wheel_base;               /* model.py:88 */
+  double left_sign;                /* +1 if left-wheeled, model.py:104      */
+  double imu_pos[3];               /* IMU origin in base frame              */
+  double rot_base_to_imu[9];       /* row-major, model.py:106               */
+  double gravity;                  /* 9.81, pybullet_backend.py:110         */
+  double contact_stiffness;        /* tire <contact> stiffness              */
+  double contact_damping;          /* tire <contact> damping                */
+  double friction_mu;              /* tire x plane lateral friction         */
+  double contact_breaking_threshold; /* floor_contact flag distance         */
+  double base_linear_damping;      /* Bullet default 0.04                   */
+  double base_angular_damping;     /* Bullet default 0.04                   */
+  double max_joint_velocity;       /* Bullet maxCoordinateVelocity, 100     */
+  int32_t pgs_iterations;          /* Bullet numSolverIterations, 50        */
+  int32_t enforce_joint_limits;    /* hip/knee limit rows in the solver     */
+} UpkieModel;
+
+/* Everything gym.make(...) kwargs decide for one batch of environments
+ * (entry_points.py:41-54,99-105; upkie_servos.py:115-124;
+ * upkie_gyropod.py:104-111; joint_properties.py:4-40;
+ * robot_state.py:52-120; robot_state_randomization.py:53-90). */
+typedef struct UpkieSimConfig {
+  int32_t num_envs;     /* B, envs hosted by this handle                    */
+  int32_t nb_substeps;  /* int(1000 * dt) unless given, backend :85-87      */
+  double dt;            /* 1 / frequency                                    */
+  double torque_control_kp; /* 20.0 */
+  double torque_control_kd; /* 1.0  */
+  double joint_friction[UPKIE_NJ];           /* JointProperties.friction   */
+  double torque_control_noise[UPKIE_NJ];     /* std dev, N.m               */
+  double torque_measurement_noise[UPKIE_NJ]; /* std dev, N.m               */
+  double fall_pitch;          /* 1.0 */
+  double max_ground_velocity; /* 3.0 */
+  double max_yaw_velocity;    /* 1.0 */
+  double leg_gain_scale;      /* 1.0 */
+  double max_gain_scale;      /* 5.0 */
+  /* nominal initial state (RobotState) */
+  double init_pos[3];
+  double init_quat[4]; /* w x y z */
+  double init_linvel[3];
+  double init_angvel[3];
+  double init_joint[UPKIE_NJ];
+  /* RobotStateRandomization magnitudes */
+  double rand_roll, rand_pitch, rand_x, rand_z, rand_omega_x, rand_omega_y;
+  double rand_linvel[3];
+  uint64_t seed;          /* Philox key                                     */
+  int64_t env_id_offset;  /* global index of local env 0 (multi-GPU shards) */
+  int32_t autoreset_mode; /* UpkieAutoreset                                 */
+  int32_t reserved0;
+  /* Fused linear-feedback agent (README.md:62-64): a = clip(g . obs, +-c)  */
+  double agent_gains[4];
+  double agent_clip;
+} UpkieSimConfig;
+
+typedef struct UpkieSim UpkieSim;
+
+/* Library / device probe. Returns the number of visible HIP devices (>= 0)
+ * or a negative status. */
+int upkie_hip_device_count(void);
+
+/* Create a simulation handle on the current HIP device: validates the model
+ * (all joint axes must be lateral, i.e. +-y of the base frame, as on every
+ * Upkie; UPKIE_ERR_UNSUPPORTED_MODEL otherwise) and uploads constants.
+ * Replaces PyBulletBackend.__init__ (pybullet_backend.py:55-197). */
+int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* model,
+                     UpkieSim** out);
+int upkie_sim_destroy(UpkieSim* sim);
+const char* upkie_sim_last_error(const UpkieSim* sim);
+
+/* Size in bytes the caller must allocate for the state buffer. */
+int64_t upkie_sim_state_bytes(const UpkieSim* sim);
+
+/* Optional per-env domain randomisation buffers (device pointers, may be
+ * NULL): inertia_scale[UPKIE_NB][B] multiplies mass and inertia of each body
+ * (pybullet_backend.py:571-601); ext_force[3][B] is a world-frame force
+ * applied at point `ext_point` of the trunk, re-applied every substep until
+ * overwritten (pybullet_backend.py:603-658). */
+int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_scale,
+                                const float* ext_force,
+                                const double ext_point[3]);
+
+/* Fill inertia_scale[UPKIE_NB][B] with 1 + U(-v, v), one draw per body and
+ * env (pybullet_backend.py:571-601). */
+int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale,
+                                    double inertia_variation, void* stream);
+
+/* Reset the envs whose mask byte is non-zero (all when mask is NULL):
+ * sample the initial state in the reference's draw order (robot_state.py:
+ * 182-187), zero joint velocities, run the one extra torque-free physics
+ * substep (pybullet_backend.py:220-232) and seed the Gyropod filter state
+ * (upkie_gyropod.py:236-240). obs6 (may be NULL) receives the Gyropod
+ * observation [B][6]. */
+int upkie_sim_reset(UpkieSim* sim, float* state, const uint8_t* mask,
+                    float* obs6, void* stream);
+
+/* One env.step() of UpkiePendulum (upkie_pendulum.py:124-142) for every env:
+ * act[B] ground velocity -> obs[B][4] = [pitch, position, pitch rate, velocity],
+ * reward[B] = 0, terminated[B], truncated[B] = 0. */
+int upkie_sim_step_pendulum(UpkieSim* sim, float* state, const float* act,
+                            float* obs, float* reward, uint8_t* terminated,
+                            uint8_t* truncated, void* stream);
+
+/* Same step with the README's linear-feedback agent evaluated on-device from
+ * the previous observation held in `obs` (in/out). */
+int upkie_sim_step_pendulum_agent(UpkieSim* sim, float* state, float* obs,
+                                  float* reward, uint8_t* terminated,
+                                  uint8_t* truncated, void* stream);
+
+/* One env.step() of UpkieGyropod (upkie_gyropod.py:354-392):
+ * act[B][2] -> obs[B][6]. */
+int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act,
+                           float* obs, float* reward, uint8_t* terminated,
+                           uint8_t* truncated, void* stream);
+
+/* One env.step() of UpkieServos (upkie_servos.py:316-344 + upkie_env.py:
+ * 196-242): act[B][6][6] in ACTION_KEYS order (position, velocity,
+ * feedforward_torque, kp_scale, kd_scale, maximum_torque) -> obs[B][6][5]
+ * (position, velocity, torque, temperature, voltage). */
+int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* act,
+                          float* obs, float* reward, uint8_t* terminated,
+                          uint8_t* truncated, void* stream);
+
+/* Full spine observation (pybullet_backend.py:313-490), materialised lazily.
+ * Any pointer may be NULL. */
+typedef struct UpkieSpineObservation {
+  float* pitch;                  /* [B]                                     */
+  float* angular_velocity;       /* [B][3] base in base                     */
+  float* linear_velocity;        /* [B][3] base in world                    */
+  float* rotation_base_to_world; /* [B][9] row-major                        */
+  uint8_t* floor_contact;        /* [B]                                     */
+  float* imu_orientation;        /* [B][4] w x y z, IMU in ARS              */
+  float* imu_angular_velocity;   /* [B][3]                                  */
+  float* imu_linear_acceleration;     /* [B][3]                             */
+  float* imu_raw_linear_acceleration; /* [B][3]                             */
+  float* servo;                  /* [B][6][5]                               */
+  float* wheel_odometry;         /* [B][2] position, velocity               */
+} UpkieSpineObservation;
+
+/* update_imu != 0 advances the finite-difference accelerometer memory the
+ * way one get_spine_observation() call does (pybullet_backend.py:405-408). */
+int upkie_sim_observe(UpkieSim* sim, float* state,
+                      const UpkieSpineObservation* out, int update_imu,
+                      void* stream);
+
+/* ---- MPC balancer (upkie/controllers/mpc_balancer.py:168-312) ---------- */
+typedef struct UpkieMpcConfig {
+  int32_t num_envs;
+  int32_t nb_timesteps;  /* N, 50 by default in the reference               */
+  int32_t admm_iterations;
+  int32_t reserved0;
+  double sampling_period;         /* 0.02 */
+  double leg_length;              /* 0.58 */
+  double max_ground_accel;        /* 10.0 */
+  double max_ground_velocity;     /* 3.0  */
+  double fall_pitch;              /* 1.0  */
+  double stage_input_cost_weight; /* 1e-3 */
+  double stage_state_cost_weight; /* 1e-3 */
+  double terminal_cost_weight;    /* 1.0  */
+  double admm_rho;
+} UpkieMpcConfig;
+
+typedef struct UpkieMpc UpkieMpc;
+
+int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out);
+int upkie_mpc_destroy(UpkieMpc* mpc);
+const char* upkie_mpc_last_error(const UpkieMpc* mpc);
+/* Bytes of the warm-start workspace [2 N][B] the caller allocates. */
+int64_t upkie_mpc_workspace_bytes(const UpkieMpc* mpc);
+/* MPCBalancer.reset (mpc_balancer.py:228-235) for masked envs. */
+int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded_velocity,
+                    const uint8_t* mask, void* stream);
+/* MPCBalancer.step (mpc_balancer.py:237-312) for every env. x0[B][4] =
+ * [ground position, pitch, ground velocity, pitch rate]; contact[B] floor
+ * contact flags; commanded_velocity[B] in/out; first_input[B] (may be NULL)
+ * receives plan.first_input. */
+int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0,
+                   const float* target_velocity, const uint8_t* contact,
+                   double dt, float* commanded_velocity, float* first_input,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPKIE_HIP_H_ */

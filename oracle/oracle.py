@@ -1,0 +1,278 @@
+"""ctypes front-end of the CPU fp64 oracle (TEST INFRASTRUCTURE ONLY).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline
+leg may import this module. The product package ``upkie_amd`` never does.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from upkie_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libupkie_oracle.so")
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class ServoCommand(C.Structure):
+    _fields_ = [
+        ("position", C.c_double),
+        ("velocity", C.c_double),
+        ("feedforward_torque", C.c_double),
+        ("kp_scale", C.c_double),
+        ("kd_scale", C.c_double),
+        ("maximum_torque", C.c_double),
+    ]
+
+
+class Randomization(C.Structure):
+    _fields_ = [
+        ("inertia_scale", C.c_void_p),
+        ("ext_force", C.c_void_p),
+        ("ext_point", C.c_double * 3),
+    ]
+
+
+class SpineObservation(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in abi.UpkieSpineObservation._fields_]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (no-op when the .so is up to date)."""
+    sources = [
+        os.path.join(_HERE, name)
+        for name in ("upkie_oracle.c", "upkie_oracle_mpc.c", "upkie_oracle.h")
+    ] + [os.path.join(_HERE, "..", "include", "upkie_hip.h")]
+    stale = force or not os.path.exists(_LIB_PATH)
+    if not stale:
+        mtime = os.path.getmtime(_LIB_PATH)
+        stale = any(
+            os.path.exists(s) and os.path.getmtime(s) > mtime for s in sources
+        )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_joint_torque.restype = C.c_double
+        _lib.oracle_joint_torque.argtypes = [
+            C.c_double,
+            C.c_double,
+            C.POINTER(ServoCommand),
+            C.c_double,
+            C.c_double,
+            C.c_double,
+        ]
+        _lib.oracle_total_mass.restype = C.c_double
+        _lib.oracle_energy.restype = C.c_double
+        _lib.oracle_substep.restype = C.c_int
+        _lib.oracle_mpc_solve_exact.restype = C.c_int
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def philox(counter, key):
+    ctr = (C.c_uint32 * 4)(*counter)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox4x32_10(ctr, k, out)
+    return list(out)
+
+
+def joint_torque(q, qd, cmd: dict, kp=20.0, kd=1.0, friction=0.0) -> float:
+    c = ServoCommand(
+        cmd["position"],
+        cmd["velocity"],
+        cmd.get("feedforward_torque", 0.0),
+        cmd.get("kp_scale", 1.0),
+        cmd.get("kd_scale", 1.0),
+        cmd["maximum_torque"],
+    )
+    return lib().oracle_joint_torque(q, qd, C.byref(c), kp, kd, friction)
+
+
+class Oracle:
+    """Batched fp64 restatement, SoA state ``[STATE_WORDS, B]`` float64."""
+
+    def __init__(self, model: abi.UpkieModel, config: abi.UpkieSimConfig):
+        self.model = model
+        self.config = config
+        self.B = config.num_envs
+        self.state = np.zeros((abi.STATE_WORDS, self.B), dtype=np.float64)
+        self.inertia_scale = None
+        self.ext_force = None
+        self.ext_point = np.zeros(3)
+        self._lib = lib()
+
+    # -- randomisation -----------------------------------------------------
+    def _rnd(self):
+        if self.inertia_scale is None and self.ext_force is None:
+            return None
+        r = Randomization()
+        r.inertia_scale = _ptr(self.inertia_scale)
+        r.ext_force = _ptr(self.ext_force)
+        r.ext_point[:] = list(self.ext_point)
+        self._rnd_keepalive = r
+        return C.byref(r)
+
+    def sample_inertia_scales(self, variation: float):
+        scale = np.zeros((abi.NB, self.B))
+        self._lib.oracle_sample_inertia_scales(
+            C.byref(self.config), C.c_double(variation), _ptr(scale)
+        )
+        return scale
+
+    # -- env API -----------------------------------------------------------
+    def reset(self, mask=None):
+        obs6 = np.zeros((self.B, 6))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._lib.oracle_reset(
+            C.byref(self.model),
+            C.byref(self.config),
+            _ptr(self.state),
+            _ptr(m),
+            self._rnd(),
+            _ptr(obs6),
+        )
+        return obs6
+
+    def _step(self, fn, act, obs_dim):
+        obs = np.zeros((self.B, obs_dim))
+        rew = np.zeros(self.B)
+        term = np.zeros(self.B, dtype=np.uint8)
+        trunc = np.zeros(self.B, dtype=np.uint8)
+        act = np.ascontiguousarray(act, dtype=np.float64)
+        fn(
+            C.byref(self.model),
+            C.byref(self.config),
+            _ptr(self.state),
+            _ptr(act),
+            _ptr(obs),
+            _ptr(rew),
+            _ptr(term),
+            _ptr(trunc),
+            self._rnd(),
+        )
+        return obs, rew, term, trunc
+
+    def step_pendulum(self, act):
+        return self._step(self._lib.oracle_step_pendulum, act, 4)
+
+    def step_gyropod(self, act):
+        return self._step(self._lib.oracle_step_gyropod, act, 6)
+
+    def step_servos(self, act):
+        obs, rew, term, trunc = self._step(self._lib.oracle_step_servos, act, 30)
+        return obs.reshape(self.B, 6, 5), rew, term, trunc
+
+    def step_pendulum_agent(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.float64).copy()
+        rew = np.zeros(self.B)
+        term = np.zeros(self.B, dtype=np.uint8)
+        trunc = np.zeros(self.B, dtype=np.uint8)
+        self._lib.oracle_step_pendulum_agent(
+            C.byref(self.model),
+            C.byref(self.config),
+            _ptr(self.state),
+            _ptr(obs),
+            _ptr(rew),
+            _ptr(term),
+            _ptr(trunc),
+            self._rnd(),
+        )
+        return obs, rew, term, trunc
+
+    def observe(self, update_imu: bool = True) -> dict:
+        B = self.B
+        out = {
+            "pitch": np.zeros(B),
+            "angular_velocity": np.zeros((B, 3)),
+            "linear_velocity": np.zeros((B, 3)),
+            "rotation_base_to_world": np.zeros((B, 9)),
+            "floor_contact": np.zeros(B, dtype=np.uint8),
+            "imu_orientation": np.zeros((B, 4)),
+            "imu_angular_velocity": np.zeros((B, 3)),
+            "imu_linear_acceleration": np.zeros((B, 3)),
+            "imu_raw_linear_acceleration": np.zeros((B, 3)),
+            "servo": np.zeros((B, 6, 5)),
+            "wheel_odometry": np.zeros((B, 2)),
+        }
+        so = SpineObservation()
+        for name in out:
+            setattr(so, name, _ptr(out[name]))
+        self._lib.oracle_observe(
+            C.byref(self.model),
+            C.byref(self.config),
+            _ptr(self.state),
+            C.byref(so),
+            C.c_int(1 if update_imu else 0),
+        )
+        return out
+
+    # -- low level ---------------------------------------------------------
+    def substep(self, env: int, tau, h: float) -> int:
+        s = np.ascontiguousarray(self.state[:, env])
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        scale = (
+            np.ascontiguousarray(self.inertia_scale[:, env])
+            if self.inertia_scale is not None
+            else None
+        )
+        force = (
+            np.ascontiguousarray(self.ext_force[:, env])
+            if self.ext_force is not None
+            else None
+        )
+        point = np.ascontiguousarray(self.ext_point, dtype=np.float64)
+        contact = self._lib.oracle_substep(
+            C.byref(self.model),
+            _ptr(s),
+            _ptr(tau),
+            C.c_double(h),
+            _ptr(scale),
+            _ptr(force),
+            _ptr(point),
+        )
+        self.state[:, env] = s
+        return contact
+
+
+def mass_matrix_and_bias(model, pos, quat, linvel, angvel, q, qd):
+    M = np.zeros((12, 12))
+    h = np.zeros(12)
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (pos, quat, linvel, angvel, q, qd)]
+    lib().oracle_mass_matrix_and_bias(C.byref(model), *[_ptr(a) for a in args], _ptr(M), _ptr(h))
+    return M, h
+
+
+def total_mass(model) -> float:
+    return lib().oracle_total_mass(C.byref(model))
+
+
+def center_of_mass(model, q=None):
+    q = np.zeros(6) if q is None else np.ascontiguousarray(q, dtype=np.float64)
+    out = np.zeros(3)
+    lib().oracle_center_of_mass(C.byref(model), _ptr(q), _ptr(out))
+    return out
+
+
+def energy(model, pos, quat, linvel, angvel, q, qd) -> float:
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (pos, quat, linvel, angvel, q, qd)]
+    return lib().oracle_energy(C.byref(model), *[_ptr(a) for a in args])

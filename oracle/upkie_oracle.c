@@ -1,0 +1,1044 @@
+/*
+ * upkie_oracle.c -- CPU fp64 restatement of the reference's env.step() path.
+ * TEST INFRASTRUCTURE ONLY (see upkie_oracle.h for the parity status).
+ *
+ * Formulation (deliberately NOT the one the HIP kernels use): every body's
+ * pose, velocity and Jacobians are written in the WORLD frame, the joint-space
+ * mass matrix is assembled as sum_i m_i Jv_i^T Jv_i + Jw_i^T I_i Jw_i, the bias
+ * vector by projecting Newton-Euler velocity-product forces, and the 12x12
+ * system is solved by dense Cholesky. Reference citations are file:line under
+ * /root/reference.
+ */
+#include "upkie_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#define NB UPKIE_NB
+#define NJ UPKIE_NJ
+#define NV 12
+#define NW UPKIE_STATE_WORDS
+#define MAXROWS 10
+
+/* ------------------------------------------------------------------ vec3 */
+static void v3_cross(const double a[3], const double b[3], double c[3]) {
+  double x = a[1] * b[2] - a[2] * b[1];
+  double y = a[2] * b[0] - a[0] * b[2];
+  double z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+static double v3_dot(const double a[3], const double b[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static void m3_mulv(const double R[9], const double v[3], double out[3]) {
+  double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  double y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  double z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  out[0] = x; out[1] = y; out[2] = z;
+}
+static void m3_tmulv(const double R[9], const double v[3], double out[3]) {
+  double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+  double y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+  double z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  out[0] = x; out[1] = y; out[2] = z;
+}
+static void m3_mul(const double A[9], const double B[9], double C[9]) {
+  double T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] +
+                     A[3 * i + 2] * B[6 + j];
+  memcpy(C, T, sizeof(T));
+}
+static void m3_transpose(const double A[9], double T[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * j + i];
+}
+
+/* upkie/utils/rotations.py:52-71, quat = [w, x, y, z] */
+static void quat_to_matrix(const double q[4], double R[9]) {
+  double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  R[0] = 1 - 2 * (qy * qy + qz * qz);
+  R[1] = 2 * (qx * qy - qz * qw);
+  R[2] = 2 * (qw * qy + qx * qz);
+  R[3] = 2 * (qx * qy + qz * qw);
+  R[4] = 1 - 2 * (qx * qx + qz * qz);
+  R[5] = 2 * (qy * qz - qx * qw);
+  R[6] = 2 * (qx * qz - qy * qw);
+  R[7] = 2 * (qy * qz + qx * qw);
+  R[8] = 1 - 2 * (qx * qx + qy * qy);
+}
+static void quat_mul(const double a[4], const double b[4], double c[4]) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  c[0] = w; c[1] = x; c[2] = y; c[3] = z;
+}
+/* Rodrigues rotation about a unit axis. */
+static void axis_angle_matrix(const double a[3], double angle, double R[9]) {
+  double c = cos(angle), s = sin(angle), t = 1.0 - c;
+  R[0] = c + t * a[0] * a[0];
+  R[1] = t * a[0] * a[1] - s * a[2];
+  R[2] = t * a[0] * a[2] + s * a[1];
+  R[3] = t * a[0] * a[1] + s * a[2];
+  R[4] = c + t * a[1] * a[1];
+  R[5] = t * a[1] * a[2] - s * a[0];
+  R[6] = t * a[0] * a[2] - s * a[1];
+  R[7] = t * a[1] * a[2] + s * a[0];
+  R[8] = c + t * a[2] * a[2];
+}
+
+/* scipy.spatial.transform.Rotation.from_matrix -> as_quat, as called by
+ * upkie/utils/rotations.py:16-33 (output reordered to w, x, y, z). */
+static void matrix_to_quat_scipy(const double m[9], double q_wxyz[4]) {
+  double decision[4] = {m[0], m[4], m[8], m[0] + m[4] + m[8]};
+  int choice = 0;
+  for (int i = 1; i < 4; ++i)
+    if (decision[i] > decision[choice]) choice = i;
+  double q[4]; /* x y z w */
+  if (choice != 3) {
+    int i = choice, j = (i + 1) % 3, k = (j + 1) % 3;
+    q[i] = 1 - decision[3] + 2 * m[3 * i + i];
+    q[j] = m[3 * j + i] + m[3 * i + j];
+    q[k] = m[3 * k + i] + m[3 * i + k];
+    q[3] = m[3 * k + j] - m[3 * j + k];
+  } else {
+    q[0] = m[7] - m[5];
+    q[1] = m[2] - m[6];
+    q[2] = m[3] - m[1];
+    q[3] = 1 + decision[3];
+  }
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q_wxyz[0] = q[3] / n;
+  q_wxyz[1] = q[0] / n;
+  q_wxyz[2] = q[1] / n;
+  q_wxyz[3] = q[2] / n;
+}
+
+/* --------------------------------------------------------------- Philox */
+void oracle_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
+                          uint32_t out[4]) {
+  uint32_t c0 = counter[0], c1 = counter[1], c2 = counter[2], c3 = counter[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2 };
+
+/* 24-bit uniforms in [0, 1): identical values in fp32 and fp64. */
+static void philox_uniform4(uint64_t seed, int64_t env, uint32_t episode,
+                            uint32_t stream, uint32_t block, double u[4]) {
+  uint32_t ctr[4] = {(uint32_t)((uint64_t)env & 0xffffffffu),
+                     (uint32_t)((uint64_t)env >> 32), episode,
+                     (stream << 24) | block};
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  uint32_t r[4];
+  oracle_philox4x32_10(ctr, key, r);
+  for (int i = 0; i < 4; ++i) u[i] = (double)(r[i] >> 8) * (1.0 / 16777216.0);
+}
+
+/* ------------------------------------------------------------ servo law */
+/* pybullet_backend.py:492-553 (noise handled by the caller). */
+double oracle_joint_torque(double q, double qd, const OracleServoCommand* cmd,
+                           double kp_gain, double kd_gain, double friction) {
+  double kp = cmd->kp_scale * kp_gain;                 /* :526 */
+  double kd = cmd->kd_scale * kd_gain;                 /* :527 */
+  double torque = cmd->feedforward_torque;             /* :530 */
+  torque += kd * (cmd->velocity - qd);                 /* :531 */
+  if (!isnan(cmd->position)) torque += kp * (cmd->position - q); /* :532 */
+  if (fabs(qd) > 1e-3) {                               /* :536-541 */
+    double sign = qd > 0.0 ? 1.0 : -1.0;
+    torque += -friction * sign;
+  }
+  /* np.clip, :552 */
+  if (torque < -cmd->maximum_torque) torque = -cmd->maximum_torque;
+  if (torque > cmd->maximum_torque) torque = cmd->maximum_torque;
+  return torque;
+}
+
+/* ------------------------------------------------------------ kinematics */
+typedef struct Kin {
+  double R[NB][9];  /* body -> world */
+  double o[NB][3];  /* body frame origin (joint origin) in world */
+  double c[NB][3];  /* centre of mass in world */
+  double a[NJ][3];  /* joint axes in world */
+  double Iw[NB][9]; /* inertia about com, world axes */
+  double m[NB];
+} Kin;
+
+static int parent_of(int body) { return (body == 1 || body == 4) ? 0 : body - 1; }
+/* is joint j (moving body j+1) on the path from the base to body i? */
+static int on_path(int j, int i) {
+  if (i == 0) return 0;
+  int leg_i = (i - 1) / 3, leg_j = j / 3;
+  return leg_i == leg_j && (j % 3) <= ((i - 1) % 3);
+}
+
+static void kinematics(const UpkieModel* model, const double* scale,
+                       const double pos[3], const double quat[4],
+                       const double q[NJ], Kin* k) {
+  quat_to_matrix(quat, k->R[0]);
+  memcpy(k->o[0], pos, 3 * sizeof(double));
+  for (int i = 1; i < NB; ++i) {
+    int p = parent_of(i), j = i - 1;
+    double Rj[9], r[3];
+    axis_angle_matrix(model->joint_axis[j], q[j], Rj);
+    m3_mul(k->R[p], Rj, k->R[i]);
+    m3_mulv(k->R[p], model->joint_pos[j], r);
+    for (int d = 0; d < 3; ++d) k->o[i][d] = k->o[p][d] + r[d];
+    m3_mulv(k->R[i], model->joint_axis[j], k->a[j]);
+  }
+  for (int i = 0; i < NB; ++i) {
+    double s = scale ? scale[i] : 1.0;
+    double r[3];
+    m3_mulv(k->R[i], model->com[i], r);
+    for (int d = 0; d < 3; ++d) k->c[i][d] = k->o[i][d] + r[d];
+    const double* I6 = model->inertia[i];
+    double Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5],
+                    I6[4], I6[5], I6[2]};
+    double Rt[9], T[9];
+    m3_transpose(k->R[i], Rt);
+    m3_mul(k->R[i], Ib, T);
+    m3_mul(T, Rt, k->Iw[i]);
+    for (int e = 0; e < 9; ++e) k->Iw[i][e] *= s;
+    k->m[i] = model->mass[i] * s;
+  }
+}
+
+/* Jacobian columns of a point P rigidly attached to body i:
+ * Jv[:,k] linear, Jw[:,k] angular, for generalised velocity
+ * [v_base(3), omega_base(3), qd(6)]. */
+static void point_jacobian(const Kin* k, int i, const double P[3],
+                           double Jv[3][NV], double Jw[3][NV]) {
+  memset(Jv, 0, sizeof(double) * 3 * NV);
+  memset(Jw, 0, sizeof(double) * 3 * NV);
+  double r[3] = {P[0] - k->o[0][0], P[1] - k->o[0][1], P[2] - k->o[0][2]};
+  for (int d = 0; d < 3; ++d) {
+    Jv[d][d] = 1.0;
+    Jw[d][3 + d] = 1.0;
+    double e[3] = {0, 0, 0}, x[3];
+    e[d] = 1.0;
+    v3_cross(e, r, x);
+    for (int r_ = 0; r_ < 3; ++r_) Jv[r_][3 + d] = x[r_];
+  }
+  for (int j = 0; j < NJ; ++j) {
+    if (!on_path(j, i)) continue;
+    double rj[3] = {P[0] - k->o[j + 1][0], P[1] - k->o[j + 1][1],
+                    P[2] - k->o[j + 1][2]};
+    double x[3];
+    v3_cross(k->a[j], rj, x);
+    for (int d = 0; d < 3; ++d) {
+      Jv[d][6 + j] = x[d];
+      Jw[d][6 + j] = k->a[j][d];
+    }
+  }
+}
+
+static void mass_matrix_and_bias(const Kin* k, double gravity,
+                                 const double linvel[3],
+                                 const double angvel[3], const double qd[NJ],
+                                 double M[NV * NV], double h[NV]) {
+  (void)linvel;
+  memset(M, 0, sizeof(double) * NV * NV);
+  memset(h, 0, sizeof(double) * NV);
+  /* velocity-product accelerations, Newton-Euler outward pass */
+  double w[NB][3], al[NB][3], ao[NB][3];
+  for (int d = 0; d < 3; ++d) {
+    w[0][d] = angvel[d];
+    al[0][d] = 0.0;
+    ao[0][d] = 0.0;
+  }
+  for (int i = 1; i < NB; ++i) {
+    int p = parent_of(i), j = i - 1;
+    double t[3], r[3], t2[3];
+    for (int d = 0; d < 3; ++d) w[i][d] = w[p][d] + k->a[j][d] * qd[j];
+    v3_cross(w[p], k->a[j], t);
+    for (int d = 0; d < 3; ++d) al[i][d] = al[p][d] + t[d] * qd[j];
+    for (int d = 0; d < 3; ++d) r[d] = k->o[i][d] - k->o[p][d];
+    v3_cross(al[p], r, t);
+    v3_cross(w[p], r, t2);
+    v3_cross(w[p], t2, t2);
+    for (int d = 0; d < 3; ++d) ao[i][d] = ao[p][d] + t[d] + t2[d];
+  }
+  for (int i = 0; i < NB; ++i) {
+    double Jv[3][NV], Jw[3][NV];
+    point_jacobian(k, i, k->c[i], Jv, Jw);
+    /* M += m Jv^T Jv + Jw^T Iw Jw */
+    for (int a = 0; a < NV; ++a) {
+      double IJw[3];
+      double col[3] = {Jw[0][a], Jw[1][a], Jw[2][a]};
+      m3_mulv(k->Iw[i], col, IJw);
+      for (int b = 0; b < NV; ++b) {
+        double s = 0.0;
+        for (int d = 0; d < 3; ++d)
+          s += k->m[i] * Jv[d][a] * Jv[d][b] + IJw[d] * Jw[d][b];
+        M[a * NV + b] += s;
+      }
+    }
+    /* bias force of body i */
+    double r[3], t[3], t2[3], ac[3], f[3], n[3], Iw_w[3], Iw_al[3];
+    for (int d = 0; d < 3; ++d) r[d] = k->c[i][d] - k->o[i][d];
+    v3_cross(al[i], r, t);
+    v3_cross(w[i], r, t2);
+    v3_cross(w[i], t2, t2);
+    for (int d = 0; d < 3; ++d) ac[d] = ao[i][d] + t[d] + t2[d];
+    ac[2] += gravity; /* a_c - g with g = (0, 0, -gravity) */
+    for (int d = 0; d < 3; ++d) f[d] = k->m[i] * ac[d];
+    m3_mulv(k->Iw[i], w[i], Iw_w);
+    m3_mulv(k->Iw[i], al[i], Iw_al);
+    v3_cross(w[i], Iw_w, t);
+    for (int d = 0; d < 3; ++d) n[d] = Iw_al[d] + t[d];
+    for (int a = 0; a < NV; ++a)
+      for (int d = 0; d < 3; ++d) h[a] += Jv[d][a] * f[d] + Jw[d][a] * n[d];
+  }
+}
+
+/* dense Cholesky M = L L^T (lower, in place in L), returns 0 on success */
+static int cholesky(int n, const double* A, double* L) {
+  memset(L, 0, sizeof(double) * n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) {
+        if (s <= 0.0) return -1;
+        L[i * n + i] = sqrt(s);
+      } else {
+        L[i * n + j] = s / L[j * n + j];
+      }
+    }
+  return 0;
+}
+static void cholesky_solve(int n, const double* L, const double* b, double* x) {
+  double y[64];
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k];
+    y[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+}
+
+void oracle_mass_matrix_and_bias(const UpkieModel* model, const double pos[3],
+                                 const double quat[4], const double linvel[3],
+                                 const double angvel[3], const double q[6],
+                                 const double qd[6], double M[144],
+                                 double h[12]) {
+  Kin k;
+  kinematics(model, NULL, pos, quat, q, &k);
+  mass_matrix_and_bias(&k, model->gravity, linvel, angvel, qd, M, h);
+}
+
+double oracle_total_mass(const UpkieModel* model) {
+  double m = 0.0;
+  for (int i = 0; i < NB; ++i) m += model->mass[i];
+  return m;
+}
+
+void oracle_center_of_mass(const UpkieModel* model, const double q[6],
+                           double com_in_base[3]) {
+  const double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+  Kin k;
+  kinematics(model, NULL, pos, quat, q, &k);
+  double m = 0.0, s[3] = {0, 0, 0};
+  for (int i = 0; i < NB; ++i) {
+    m += k.m[i];
+    for (int d = 0; d < 3; ++d) s[d] += k.m[i] * k.c[i][d];
+  }
+  for (int d = 0; d < 3; ++d) com_in_base[d] = s[d] / m;
+}
+
+double oracle_energy(const UpkieModel* model, const double pos[3],
+                     const double quat[4], const double linvel[3],
+                     const double angvel[3], const double q[6],
+                     const double qd[6]) {
+  Kin k;
+  kinematics(model, NULL, pos, quat, q, &k);
+  double M[NV * NV], h[NV], nu[NV];
+  mass_matrix_and_bias(&k, model->gravity, linvel, angvel, qd, M, h);
+  for (int d = 0; d < 3; ++d) {
+    nu[d] = linvel[d];
+    nu[3 + d] = angvel[d];
+  }
+  for (int j = 0; j < NJ; ++j) nu[6 + j] = qd[j];
+  double T = 0.0, V = 0.0;
+  for (int a = 0; a < NV; ++a)
+    for (int b = 0; b < NV; ++b) T += 0.5 * nu[a] * M[a * NV + b] * nu[b];
+  for (int i = 0; i < NB; ++i) V += k.m[i] * model->gravity * k.c[i][2];
+  return T + V;
+}
+
+/* --------------------------------------------------------------- substep */
+/* One Bullet-like stepSimulation() (call site pybullet_backend.py:306):
+ * free acceleration -> contact/limit rows -> PGS -> velocity update ->
+ * position integration (semi-implicit Euler, pinned by
+ * upkie/cpp/interfaces/tests/BulletInterfaceTest.cpp:263-285). */
+int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
+                   double h, const double* inertia_scale,
+                   const double* ext_force, const double* ext_point) {
+  double* pos = s + UPKIE_S_POS;
+  double* quat = s + UPKIE_S_QUAT;
+  double* linvel = s + UPKIE_S_LINVEL;
+  double* angvel = s + UPKIE_S_ANGVEL;
+  double* q = s + UPKIE_S_Q;
+  double* qd = s + UPKIE_S_QD;
+
+  Kin k;
+  kinematics(model, inertia_scale, pos, quat, q, &k);
+  double M[NV * NV], bias[NV], L[NV * NV];
+  mass_matrix_and_bias(&k, model->gravity, linvel, angvel, qd, M, bias);
+
+  /* generalised applied forces */
+  double Q[NV];
+  memset(Q, 0, sizeof(Q));
+  for (int j = 0; j < NJ; ++j) Q[6 + j] = tau[j] - model->joint_damping[j] * qd[j];
+  {
+    /* Bullet-style base damping, force ~ m v (k + k |v|) on the trunk */
+    double Jv[3][NV], Jw[3][NV], r[3], vc[3], t[3], F[3], T[3], Iw_w[3];
+    point_jacobian(&k, 0, k.c[0], Jv, Jw);
+    for (int d = 0; d < 3; ++d) r[d] = k.c[0][d] - k.o[0][d];
+    v3_cross(angvel, r, t);
+    for (int d = 0; d < 3; ++d) vc[d] = linvel[d] + t[d];
+    double vn = sqrt(v3_dot(vc, vc)), wn = sqrt(v3_dot(angvel, angvel));
+    double kl = model->base_linear_damping, ka = model->base_angular_damping;
+    m3_mulv(k.Iw[0], angvel, Iw_w);
+    for (int d = 0; d < 3; ++d) {
+      F[d] = -k.m[0] * vc[d] * (kl + kl * vn);
+      T[d] = -Iw_w[d] * (ka + ka * wn);
+    }
+    for (int a = 0; a < NV; ++a)
+      for (int d = 0; d < 3; ++d) Q[a] += Jv[d][a] * F[d] + Jw[d][a] * T[d];
+  }
+  if (ext_force) {
+    /* world-frame force at a trunk point, pybullet_backend.py:625-658 */
+    double Jv[3][NV], Jw[3][NV], r[3], P[3];
+    m3_mulv(k.R[0], ext_point, r);
+    for (int d = 0; d < 3; ++d) P[d] = k.o[0][d] + r[d];
+    point_jacobian(&k, 0, P, Jv, Jw);
+    for (int a = 0; a < NV; ++a)
+      for (int d = 0; d < 3; ++d) Q[a] += Jv[d][a] * ext_force[d];
+  }
+
+  cholesky(NV, M, L);
+  double rhs[NV], acc[NV], nu[NV];
+  for (int a = 0; a < NV; ++a) rhs[a] = Q[a] - bias[a];
+  cholesky_solve(NV, L, rhs, acc);
+  for (int d = 0; d < 3; ++d) {
+    nu[d] = linvel[d] + h * acc[d];
+    nu[3 + d] = angvel[d] + h * acc[3 + d];
+  }
+  for (int j = 0; j < NJ; ++j) nu[6 + j] = qd[j] + h * acc[6 + j];
+
+  /* constraint rows: per wheel (normal, t1, t2), then joint limits */
+  double J[MAXROWS][NV], MinvJt[MAXROWS][NV];
+  double rhs_c[MAXROWS], cfm[MAXROWS];
+  int kind[MAXROWS], normal_row[MAXROWS];
+  int nrows = 0, any_contact = 0;
+  double kpc = model->contact_stiffness, kdc = model->contact_damping;
+  double denom = h * kpc + kdc;
+  double erp = denom > 0 ? h * kpc / denom : 0.2;
+  double cfm_n = denom > 0 ? 1.0 / (denom * h) : 0.0;
+  for (int wheel = 0; wheel < 2; ++wheel) {
+    int body = 3 * wheel + 3, joint = 3 * wheel + 2;
+    double center[3], r[3];
+    m3_mulv(k.R[body], model->wheel_center[wheel], r);
+    for (int d = 0; d < 3; ++d) center[d] = k.o[body][d] + r[d];
+    const double* a = k.a[joint];
+    double n[3] = {0, 0, 1};
+    double u[3] = {-a[2] * a[0], -a[2] * a[1], 1.0 - a[2] * a[2]};
+    double un = sqrt(v3_dot(u, u));
+    if (un < 1e-6) continue; /* wheel lying flat on its side */
+    double P[3];
+    for (int d = 0; d < 3; ++d) P[d] = center[d] - model->wheel_radius * u[d] / un;
+    double dist = P[2];
+    /* A contact point exists below Bullet's manifold breaking threshold;
+     * that is also what getContactPoints reports (pybullet_backend.py:432). */
+    if (dist > model->contact_breaking_threshold) continue;
+    any_contact = 1;
+    double t1[3], t2[3];
+    v3_cross(a, n, t1);
+    double t1n = sqrt(v3_dot(t1, t1));
+    for (int d = 0; d < 3; ++d) t1[d] /= t1n;
+    v3_cross(n, t1, t2);
+    double Jv[3][NV], Jw[3][NV];
+    point_jacobian(&k, body, P, Jv, Jw);
+    const double* dirs[3] = {n, t1, t2};
+    for (int r_ = 0; r_ < 3; ++r_) {
+      for (int c = 0; c < NV; ++c)
+        J[nrows][c] = dirs[r_][0] * Jv[0][c] + dirs[r_][1] * Jv[1][c] +
+                      dirs[r_][2] * Jv[2][c];
+      double v = 0.0;
+      for (int c = 0; c < NV; ++c) v += J[nrows][c] * nu[c];
+      if (r_ == 0) {
+        kind[nrows] = 0;
+        normal_row[nrows] = nrows;
+        cfm[nrows] = cfm_n;
+        /* Bullet setupContactConstraint: penetration is pushed out with
+         * ERP, a separated point may only close its gap within the step */
+        rhs_c[nrows] = dist <= 0.0 ? -v + erp * (-dist) / h : -v - dist / h;
+      } else {
+        kind[nrows] = 1;
+        normal_row[nrows] = nrows - r_;
+        cfm[nrows] = 0.0;
+        rhs_c[nrows] = -v;
+      }
+      ++nrows;
+    }
+  }
+  if (model->enforce_joint_limits) {
+    for (int j = 0; j < NJ; ++j) {
+      if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30))
+        continue;
+      double sign = 0.0, err = 0.0;
+      if (q[j] <= model->joint_lower[j]) {
+        sign = 1.0;
+        err = model->joint_lower[j] - q[j];
+      } else if (q[j] >= model->joint_upper[j]) {
+        sign = -1.0;
+        err = q[j] - model->joint_upper[j];
+      } else {
+        continue;
+      }
+      memset(J[nrows], 0, sizeof(double) * NV);
+      J[nrows][6 + j] = sign;
+      kind[nrows] = 2;
+      normal_row[nrows] = nrows;
+      cfm[nrows] = 0.0;
+      rhs_c[nrows] = -sign * nu[6 + j] + 0.2 * err / h;
+      ++nrows;
+    }
+  }
+
+  double lam[MAXROWS];
+  memset(lam, 0, sizeof(lam));
+  if (nrows > 0) {
+    double W[MAXROWS][MAXROWS];
+    for (int r_ = 0; r_ < nrows; ++r_) cholesky_solve(NV, L, J[r_], MinvJt[r_]);
+    for (int a = 0; a < nrows; ++a)
+      for (int b = 0; b < nrows; ++b) {
+        double s_ = 0.0;
+        for (int c = 0; c < NV; ++c) s_ += J[a][c] * MinvJt[b][c];
+        W[a][b] = s_;
+      }
+    double mu = model->friction_mu;
+    for (int it = 0; it < model->pgs_iterations; ++it) {
+      for (int pass = 0; pass < 3; ++pass) { /* normals, friction, limits */
+        for (int r_ = 0; r_ < nrows; ++r_) {
+          if (kind[r_] != pass) continue;
+          double wl = 0.0;
+          for (int b = 0; b < nrows; ++b) wl += W[r_][b] * lam[b];
+          double delta = (rhs_c[r_] - wl - cfm[r_] * lam[r_]) / (W[r_][r_] + cfm[r_]);
+          double x = lam[r_] + delta;
+          if (kind[r_] == 1) {
+            double lim = mu * lam[normal_row[r_]];
+            if (x < -lim) x = -lim;
+            if (x > lim) x = lim;
+          } else if (x < 0.0) {
+            x = 0.0;
+          }
+          lam[r_] = x;
+        }
+      }
+    }
+    for (int r_ = 0; r_ < nrows; ++r_)
+      for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
+  }
+
+  /* Bullet clamps generalised joint speeds to maxCoordinateVelocity */
+  for (int j = 0; j < NJ; ++j) {
+    if (nu[6 + j] > model->max_joint_velocity) nu[6 + j] = model->max_joint_velocity;
+    if (nu[6 + j] < -model->max_joint_velocity) nu[6 + j] = -model->max_joint_velocity;
+  }
+
+  /* position integration with the NEW velocities */
+  for (int d = 0; d < 3; ++d) {
+    linvel[d] = nu[d];
+    angvel[d] = nu[3 + d];
+    pos[d] += h * nu[d];
+  }
+  for (int j = 0; j < NJ; ++j) {
+    qd[j] = nu[6 + j];
+    q[j] += h * nu[6 + j];
+  }
+  {
+    double wn = sqrt(v3_dot(angvel, angvel));
+    double half = 0.5 * h * wn;
+    double kfac = wn > 1e-9 ? sin(half) / wn : 0.5 * h;
+    double dq[4] = {cos(half), kfac * angvel[0], kfac * angvel[1], kfac * angvel[2]};
+    double qn[4];
+    quat_mul(dq, quat, qn);
+    double n = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int d = 0; d < 4; ++d) quat[d] = qn[d] / n;
+  }
+  s[UPKIE_S_CONTACT] = any_contact ? 1.0 : 0.0;
+  return any_contact;
+}
+
+/* ------------------------------------------------------- SoA <-> env state */
+static void load_env(const double* state, int B, int e, double s[NW]) {
+  for (int w = 0; w < NW; ++w) s[w] = state[(int64_t)w * B + e];
+}
+static void store_env(double* state, int B, int e, const double s[NW]) {
+  for (int w = 0; w < NW; ++w) state[(int64_t)w * B + e] = s[w];
+}
+static void env_randomization(const OracleRandomization* rnd, int B, int e,
+                              double scale[NB], double force[3],
+                              const double** scale_p, const double** force_p,
+                              const double** point_p) {
+  *scale_p = NULL;
+  *force_p = NULL;
+  *point_p = NULL;
+  if (!rnd) return;
+  if (rnd->inertia_scale) {
+    for (int i = 0; i < NB; ++i) scale[i] = rnd->inertia_scale[(int64_t)i * B + e];
+    *scale_p = scale;
+  }
+  if (rnd->ext_force) {
+    for (int d = 0; d < 3; ++d) force[d] = rnd->ext_force[(int64_t)d * B + e];
+    *force_p = force;
+    *point_p = rnd->ext_point;
+  }
+}
+
+/* ---------------------------------------------------------- observations */
+/* pybullet_backend.py:352 */
+static double pitch_from_quat(const double q[4]) {
+  double x = 2.0 * (q[0] * q[2] - q[3] * q[1]);
+  if (x > 1.0) x = 1.0;
+  if (x < -1.0) x = -1.0;
+  return asin(x);
+}
+/* pybullet_backend.py:476-490 */
+static void wheel_odometry(const UpkieModel* model, const double s[NW],
+                           double* position, double* velocity) {
+  double signed_radius = model->left_sign * model->wheel_radius;
+  *position = 0.5 * (s[UPKIE_S_Q + 2] - s[UPKIE_S_Q + 5]) * signed_radius;
+  *velocity = 0.5 * (s[UPKIE_S_QD + 2] - s[UPKIE_S_QD + 5]) * signed_radius;
+}
+/* upkie_gyropod.py:186-214 */
+static void gyropod_observation(const UpkieModel* model, const double s[NW],
+                                double obs[6]) {
+  double R[9], wb[3];
+  quat_to_matrix(s + UPKIE_S_QUAT, R);
+  m3_tmulv(R, s + UPKIE_S_ANGVEL, wb); /* pybullet_backend.py:355-361 */
+  wheel_odometry(model, s, &obs[0], &obs[3]);
+  obs[1] = pitch_from_quat(s + UPKIE_S_QUAT);
+  obs[2] = s[UPKIE_S_YAW];
+  obs[4] = wb[1];
+  obs[5] = s[UPKIE_S_YAWVEL];
+}
+
+/* ------------------------------------------------------------------ reset */
+static void euler_zyx_to_quat(double yaw, double pitch, double roll, double q[4]) {
+  double qz[4] = {cos(0.5 * yaw), 0, 0, sin(0.5 * yaw)};
+  double qy[4] = {cos(0.5 * pitch), 0, sin(0.5 * pitch), 0};
+  double qx[4] = {cos(0.5 * roll), sin(0.5 * roll), 0, 0};
+  double t[4];
+  quat_mul(qz, qy, t);
+  quat_mul(t, qx, q);
+}
+static double uniform(double low, double high, double u) { return low + (high - low) * u; }
+
+static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
+                      double s[NW], int64_t env_global, const double* scale,
+                      const double* force, const double* point) {
+  uint32_t episode = (uint32_t)s[UPKIE_S_EPISODE];
+  double u0[4], u1[4], u2[4];
+  philox_uniform4(cfg->seed, env_global, episode, STREAM_RESET, 0, u0);
+  philox_uniform4(cfg->seed, env_global, episode, STREAM_RESET, 1, u1);
+  philox_uniform4(cfg->seed, env_global, episode, STREAM_RESET, 2, u2);
+  /* draw order of RobotState.sample_state, robot_state.py:182-187:
+   * angular velocity, linear velocity, orientation, position */
+  double w[3], v[3], ypr[3], p[3];
+  w[0] = uniform(-cfg->rand_omega_x, cfg->rand_omega_x, u0[0]);
+  w[1] = uniform(-cfg->rand_omega_y, cfg->rand_omega_y, u0[1]);
+  w[2] = uniform(0.0, 0.0, u0[2]);
+  v[0] = uniform(-cfg->rand_linvel[0], cfg->rand_linvel[0], u0[3]);
+  v[1] = uniform(-cfg->rand_linvel[1], cfg->rand_linvel[1], u1[0]);
+  v[2] = uniform(-cfg->rand_linvel[2], cfg->rand_linvel[2], u1[1]);
+  ypr[0] = uniform(0.0, 0.0, u1[2]);
+  ypr[1] = uniform(-cfg->rand_pitch, cfg->rand_pitch, u1[3]);
+  ypr[2] = uniform(-cfg->rand_roll, cfg->rand_roll, u2[0]);
+  p[0] = uniform(-cfg->rand_x, cfg->rand_x, u2[1]);
+  p[1] = uniform(0.0, 0.0, u2[2]);
+  p[2] = uniform(0.0, cfg->rand_z, u2[3]);
+  double qr[4];
+  euler_zyx_to_quat(ypr[0], ypr[1], ypr[2], qr);
+  /* robot_state.py:158-160: base orientation * random orientation */
+  quat_mul(cfg->init_quat, qr, s + UPKIE_S_QUAT);
+  for (int d = 0; d < 3; ++d) {
+    s[UPKIE_S_POS + d] = cfg->init_pos[d] + p[d];
+    s[UPKIE_S_LINVEL + d] = cfg->init_linvel[d] + v[d];
+    /* pybullet_backend.py:253-258: body-frame omega handed to Bullet as a
+     * world-frame vector, reproduced as is */
+    s[UPKIE_S_ANGVEL + d] = cfg->init_angvel[d] + w[d];
+  }
+  for (int j = 0; j < NJ; ++j) {
+    s[UPKIE_S_Q + j] = cfg->init_joint[j];
+    s[UPKIE_S_QD + j] = 0.0; /* resetJointState zeroes velocities, :261-267 */
+  }
+  /* pybullet_backend.py:228: one stepSimulation() with no motor torque */
+  const double zero_tau[6] = {0, 0, 0, 0, 0, 0};
+  oracle_substep(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, force, point);
+  /* upkie_gyropod.py:236-240 */
+  s[UPKIE_S_LEGREF + 0] = s[UPKIE_S_Q + 0];
+  s[UPKIE_S_LEGREF + 1] = s[UPKIE_S_Q + 1];
+  s[UPKIE_S_LEGREF + 2] = s[UPKIE_S_Q + 3];
+  s[UPKIE_S_LEGREF + 3] = s[UPKIE_S_Q + 4];
+  s[UPKIE_S_YAW] = 0.0;
+  s[UPKIE_S_YAWVEL] = 0.0;
+  s[UPKIE_S_MPC_V] = 0.0;
+  s[UPKIE_S_SE2_X] = 0.0;
+  s[UPKIE_S_SE2_Y] = 0.0;
+  s[UPKIE_S_EPISODE] = (double)(episode + 1);
+  s[UPKIE_S_DONE] = 0.0;
+}
+
+void oracle_sample_inertia_scales(const UpkieSimConfig* cfg,
+                                  double inertia_variation, double* scale) {
+  int B = cfg->num_envs;
+  for (int e = 0; e < B; ++e) {
+    double u0[4], u1[4];
+    philox_uniform4(cfg->seed, cfg->env_id_offset + e, 0, STREAM_INERTIA, 0, u0);
+    philox_uniform4(cfg->seed, cfg->env_id_offset + e, 0, STREAM_INERTIA, 1, u1);
+    for (int i = 0; i < NB; ++i) {
+      double u = i < 4 ? u0[i] : u1[i - 4];
+      /* pybullet_backend.py:588-594 */
+      scale[(int64_t)i * B + e] = 1.0 + uniform(-inertia_variation, inertia_variation, u);
+    }
+  }
+}
+
+void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
+                  double* state, const uint8_t* mask,
+                  const OracleRandomization* rnd, double* obs6) {
+  int B = cfg->num_envs;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3];
+    const double *sp, *fp, *pp;
+    load_env(state, B, e, s);
+    if (!mask || mask[e]) {
+      env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+      reset_env(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp);
+      store_env(state, B, e, s);
+    }
+    if (obs6) gyropod_observation(model, s, obs6 + 6 * (int64_t)e);
+  }
+}
+
+/* ------------------------------------------------------------------ steps */
+/* clamp_and_warn, upkie/utils/clamp.py:42-58 (NaN passes through) */
+static double clamp_like_reference(double value, double lower, double upper) {
+  if (value < lower) return lower;
+  if (value > upper) return upper;
+  return value;
+}
+
+/* UpkieServos.get_spine_action, upkie_servos.py:316-344 */
+static void clamp_servo_commands(const UpkieModel* model,
+                                 const UpkieSimConfig* cfg,
+                                 OracleServoCommand cmd[NJ]) {
+  for (int j = 0; j < NJ; ++j) {
+    double eff = model->joint_effort[j], vel = model->joint_velocity[j];
+    cmd[j].position = clamp_like_reference(cmd[j].position, model->joint_lower[j], model->joint_upper[j]);
+    cmd[j].velocity = clamp_like_reference(cmd[j].velocity, -vel, vel);
+    cmd[j].feedforward_torque = clamp_like_reference(cmd[j].feedforward_torque, -eff, eff);
+    cmd[j].kp_scale = clamp_like_reference(cmd[j].kp_scale, 0.0, cfg->max_gain_scale);
+    cmd[j].kd_scale = clamp_like_reference(cmd[j].kd_scale, 0.0, cfg->max_gain_scale);
+    cmd[j].maximum_torque = clamp_like_reference(cmd[j].maximum_torque, 0.0, eff);
+  }
+}
+
+/* PyBulletBackend.step, pybullet_backend.py:269-311 */
+static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
+                         double s[NW], const OracleServoCommand cmd[NJ],
+                         const double* scale, const double* force,
+                         const double* point) {
+  double h = cfg->dt / cfg->nb_substeps;
+  for (int sub = 0; sub < cfg->nb_substeps; ++sub) {
+    double tau[NJ];
+    for (int j = 0; j < NJ; ++j) {
+      tau[j] = oracle_joint_torque(s[UPKIE_S_Q + j], s[UPKIE_S_QD + j], &cmd[j],
+                                   cfg->torque_control_kp, cfg->torque_control_kd,
+                                   cfg->joint_friction[j]);
+      s[UPKIE_S_TORQUE + j] = tau[j]; /* :293 */
+    }
+    oracle_substep(model, s, tau, h, scale, force, point);
+  }
+}
+
+/* UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331 */
+static void gyropod_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
+                             double s[NW], double ground_velocity_action,
+                             double yaw_velocity_action,
+                             OracleServoCommand cmd[NJ]) {
+  double v = clamp_like_reference(ground_velocity_action, -cfg->max_ground_velocity, cfg->max_ground_velocity);
+  double yawd = clamp_like_reference(yaw_velocity_action, -cfg->max_yaw_velocity, cfg->max_yaw_velocity);
+  double wheel_velocity = v / model->wheel_radius;             /* :316 */
+  double left_sign = model->left_sign;                         /* :317 */
+  double left = left_sign * wheel_velocity;                    /* :318 */
+  double right = -left_sign * wheel_velocity;                  /* :319 */
+  double contact_radius = 0.5 * model->wheel_base;             /* :322 */
+  double yaw_to_wheel = left_sign * contact_radius / model->wheel_radius;
+  left += yaw_to_wheel * yawd;                                 /* :324 */
+  right += yaw_to_wheel * yawd;                                /* :325 */
+  const int leg_joint[4] = {0, 1, 3, 4};
+  double alpha = cfg->dt / 1.0; /* filters.py:77, cutoff_period = 1.0 */
+  for (int l = 0; l < 4; ++l) {
+    double prev = s[UPKIE_S_LEGREF + l];
+    double target = prev + alpha * (0.0 - prev); /* filters.py:80 */
+    s[UPKIE_S_LEGREF + l] = target;
+    OracleServoCommand* c = &cmd[leg_joint[l]];
+    c->position = target;
+    c->velocity = 0.0; /* neutral action, upkie_servos.py:255-262 */
+    c->feedforward_torque = 0.0;
+    c->kp_scale = cfg->leg_gain_scale; /* upkie_gyropod.py:261-266 */
+    c->kd_scale = cfg->leg_gain_scale;
+    c->maximum_torque = model->joint_effort[leg_joint[l]];
+  }
+  const int wheel_joint[2] = {2, 5};
+  double wheel_cmd[2] = {left, right};
+  for (int wi = 0; wi < 2; ++wi) {
+    OracleServoCommand* c = &cmd[wheel_joint[wi]];
+    c->position = NAN; /* upkie_gyropod.py:280-287 */
+    c->velocity = wheel_cmd[wi];
+    c->feedforward_torque = 0.0;
+    c->kp_scale = 1.0;
+    c->kd_scale = 1.0;
+    c->maximum_torque = model->joint_effort[wheel_joint[wi]]; /* :289-290 */
+  }
+}
+
+static void autoreset_or_null(const UpkieModel* model, const UpkieSimConfig* cfg,
+                              double s[NW], int64_t env_global, const double* sp,
+                              const double* fp, const double* pp, int* did_reset) {
+  *did_reset = 0;
+  if (cfg->autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && s[UPKIE_S_DONE] != 0.0) {
+    reset_env(model, cfg, s, env_global, sp, fp, pp);
+    *did_reset = 1;
+  }
+}
+
+static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
+                             double s[NW], int64_t env_global, double a0,
+                             double a1, double obs6[6], uint8_t* terminated,
+                             const double* sp, const double* fp, const double* pp) {
+  int did_reset;
+  autoreset_or_null(model, cfg, s, env_global, sp, fp, pp, &did_reset);
+  if (did_reset) {
+    gyropod_observation(model, s, obs6);
+    *terminated = 0;
+    return;
+  }
+  OracleServoCommand cmd[NJ];
+  gyropod_commands(model, cfg, s, a0, a1, cmd);
+  clamp_servo_commands(model, cfg, cmd);
+  backend_step(model, cfg, s, cmd, sp, fp, pp);
+  s[UPKIE_S_YAW] += a1 * cfg->dt; /* upkie_gyropod.py:383-385, unclamped */
+  s[UPKIE_S_YAWVEL] = a1;
+  gyropod_observation(model, s, obs6);
+  /* __detect_fall, upkie_gyropod.py:344-345 */
+  *terminated = fabs(obs6[1]) > cfg->fall_pitch ? 1 : 0;
+  if (*terminated) s[UPKIE_S_DONE] = 1.0;
+}
+
+void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
+                         double* state, const double* act, double* obs,
+                         double* reward, uint8_t* terminated,
+                         uint8_t* truncated, const OracleRandomization* rnd) {
+  int B = cfg->num_envs;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3];
+    const double *sp, *fp, *pp;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[2 * e], act[2 * e + 1],
+                     obs + 6 * (int64_t)e, &terminated[e], sp, fp, pp);
+    reward[e] = 0.0; /* upkie_env.py:230 */
+    truncated[e] = 0;
+    store_env(state, B, e, s);
+  }
+}
+
+/* upkie_pendulum.py:17 */
+static const int kPendulumObsIndices[4] = {1, 0, 4, 3};
+
+void oracle_step_pendulum(const UpkieModel* model, const UpkieSimConfig* cfg,
+                          double* state, const double* act, double* obs,
+                          double* reward, uint8_t* terminated,
+                          uint8_t* truncated, const OracleRandomization* rnd) {
+  int B = cfg->num_envs;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3], obs6[6];
+    const double *sp, *fp, *pp;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    /* upkie_pendulum.py:139: action_2d = [action[0], 0.0] */
+    step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[e], 0.0, obs6,
+                     &terminated[e], sp, fp, pp);
+    for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
+    reward[e] = 0.0;
+    truncated[e] = 0;
+    store_env(state, B, e, s);
+  }
+}
+
+void oracle_step_pendulum_agent(const UpkieModel* model,
+                                const UpkieSimConfig* cfg, double* state,
+                                double* obs, double* reward,
+                                uint8_t* terminated, uint8_t* truncated,
+                                const OracleRandomization* rnd) {
+  int B = cfg->num_envs;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3], obs6[6];
+    const double *sp, *fp, *pp;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    /* README.md:62-64 / examples/pybullet/pd_balancing.py:23-31 */
+    double a = 0.0;
+    for (int i = 0; i < 4; ++i) a += cfg->agent_gains[i] * obs[4 * (int64_t)e + i];
+    a = clamp_like_reference(a, -cfg->agent_clip, cfg->agent_clip);
+    step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, a, 0.0, obs6,
+                     &terminated[e], sp, fp, pp);
+    for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
+    reward[e] = 0.0;
+    truncated[e] = 0;
+    store_env(state, B, e, s);
+  }
+}
+
+/* upkie_servos.py:288-306 with pybullet_backend.py:448-474 */
+static void servo_observation(const double s[NW], double obs[30]) {
+  for (int j = 0; j < NJ; ++j) {
+    obs[5 * j + 0] = s[UPKIE_S_Q + j];
+    obs[5 * j + 1] = s[UPKIE_S_QD + j];
+    obs[5 * j + 2] = s[UPKIE_S_TORQUE + j];
+    obs[5 * j + 3] = 42.0;
+    obs[5 * j + 4] = 18.0;
+  }
+}
+
+void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
+                        double* state, const double* act, double* obs,
+                        double* reward, uint8_t* terminated,
+                        uint8_t* truncated, const OracleRandomization* rnd) {
+  int B = cfg->num_envs;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3];
+    const double *sp, *fp, *pp;
+    int did_reset;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    autoreset_or_null(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp, &did_reset);
+    if (!did_reset) {
+      OracleServoCommand cmd[NJ];
+      const double* a = act + 36 * (int64_t)e;
+      for (int j = 0; j < NJ; ++j) {
+        cmd[j].position = a[6 * j + 0];
+        cmd[j].velocity = a[6 * j + 1];
+        cmd[j].feedforward_torque = a[6 * j + 2];
+        cmd[j].kp_scale = a[6 * j + 3];
+        cmd[j].kd_scale = a[6 * j + 4];
+        cmd[j].maximum_torque = a[6 * j + 5];
+      }
+      clamp_servo_commands(model, cfg, cmd);
+      backend_step(model, cfg, s, cmd, sp, fp, pp);
+    }
+    servo_observation(s, obs + 30 * (int64_t)e);
+    reward[e] = 0.0;
+    terminated[e] = 0; /* upkie_env.py:231-238: only the joystick ends it */
+    truncated[e] = 0;
+    store_env(state, B, e, s);
+  }
+}
+
+/* get_spine_observation, pybullet_backend.py:313-490 */
+void oracle_observe(const UpkieModel* model, const UpkieSimConfig* cfg,
+                    double* state, const OracleSpineObservation* out,
+                    int update_imu) {
+  int B = cfg->num_envs;
+  for (int e = 0; e < B; ++e) {
+    double s[NW], R[9], wb[3];
+    load_env(state, B, e, s);
+    quat_to_matrix(s + UPKIE_S_QUAT, R);
+    m3_tmulv(R, s + UPKIE_S_ANGVEL, wb);
+    if (out->pitch) out->pitch[e] = pitch_from_quat(s + UPKIE_S_QUAT);
+    for (int d = 0; d < 3; ++d) {
+      if (out->angular_velocity) out->angular_velocity[3 * e + d] = wb[d];
+      if (out->linear_velocity) out->linear_velocity[3 * e + d] = s[UPKIE_S_LINVEL + d];
+    }
+    if (out->rotation_base_to_world)
+      for (int i = 0; i < 9; ++i) out->rotation_base_to_world[9 * e + i] = R[i];
+    if (out->floor_contact) out->floor_contact[e] = s[UPKIE_S_CONTACT] != 0.0;
+    /* IMU, pybullet_backend.py:370-430 */
+    {
+      double Rbi_t[9], Riw[9], r[3], t[3], v_imu[3];
+      m3_transpose(model->rot_base_to_imu, Rbi_t); /* imu -> base */
+      m3_mul(R, Rbi_t, Riw);                       /* imu -> world */
+      m3_mulv(R, model->imu_pos, r);
+      v3_cross(s + UPKIE_S_ANGVEL, r, t);
+      for (int d = 0; d < 3; ++d) v_imu[d] = s[UPKIE_S_LINVEL + d] + t[d];
+      double Rars[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1}, Ria[9], quat[4];
+      m3_mul(Rars, Riw, Ria);
+      matrix_to_quat_scipy(Ria, quat);
+      double a_w[3], a_i[3], proper_w[3], proper_i[3], w_i[3];
+      for (int d = 0; d < 3; ++d) a_w[d] = (v_imu[d] - s[UPKIE_S_IMUVEL + d]) / cfg->dt;
+      if (update_imu)
+        for (int d = 0; d < 3; ++d) s[UPKIE_S_IMUVEL + d] = v_imu[d];
+      m3_tmulv(Riw, s + UPKIE_S_ANGVEL, w_i);
+      m3_tmulv(Riw, a_w, a_i);
+      proper_w[0] = a_w[0];
+      proper_w[1] = a_w[1];
+      proper_w[2] = a_w[2] + 9.81; /* :418: gravity literal, not model */
+      m3_tmulv(Riw, proper_w, proper_i);
+      for (int d = 0; d < 4; ++d)
+        if (out->imu_orientation) out->imu_orientation[4 * e + d] = quat[d];
+      for (int d = 0; d < 3; ++d) {
+        if (out->imu_angular_velocity) out->imu_angular_velocity[3 * e + d] = w_i[d];
+        if (out->imu_linear_acceleration) out->imu_linear_acceleration[3 * e + d] = a_i[d];
+        if (out->imu_raw_linear_acceleration) out->imu_raw_linear_acceleration[3 * e + d] = proper_i[d];
+      }
+    }
+    if (out->servo) servo_observation(s, out->servo + 30 * (int64_t)e);
+    if (out->wheel_odometry)
+      wheel_odometry(model, s, &out->wheel_odometry[2 * e], &out->wheel_odometry[2 * e + 1]);
+    if (update_imu) store_env(state, B, e, s);
+  }
+}
+
+/* ------------------------------------------------ helpers exposed to tests */
+void oracle_quat_to_matrix(const double quat_wxyz[4], double R[9]) { quat_to_matrix(quat_wxyz, R); }
+void oracle_matrix_to_quat(const double R[9], double quat_wxyz[4]) { matrix_to_quat_scipy(R, quat_wxyz); }
+void oracle_euler_zyx_compose(const double base_wxyz[4], const double ypr[3], double out_wxyz[4]) {
+  double qr[4];
+  euler_zyx_to_quat(ypr[0], ypr[1], ypr[2], qr);
+  quat_mul(base_wxyz, qr, out_wxyz);
+}
+double oracle_clamp(double value, double lower, double upper) { return clamp_like_reference(value, lower, upper); }
+/* upkie/utils/filters.py:63-80 */
+double oracle_low_pass_filter(double prev_output, double cutoff_period, double new_input, double dt) {
+  double alpha = dt / cutoff_period;
+  return prev_output + alpha * (new_input - prev_output);
+}
+double oracle_pitch_from_quat(const double quat_wxyz[4]) { return pitch_from_quat(quat_wxyz); }

@@ -1,0 +1,27 @@
+// Test-only: runs the product's device functions on the HOST so that a single
+// physics substep can be compared with the oracle without a GPU.
+#include "../upkie_amd/csrc/upkie_hip.hip"
+
+extern "C" int harness_substep(const UpkieModel* model, float* st, const float* tau, float h, const float* scale,
+                               const float* ext_force, const float* ext_point) {
+  DevModel M;
+  std::string why;
+  if (!convert_model(model, &M, &why)) return -1;
+  Phys s;
+  s.pos = v3(st[UPKIE_S_POS], st[UPKIE_S_POS + 1], st[UPKIE_S_POS + 2]);
+  s.qw = st[UPKIE_S_QUAT]; s.qx = st[UPKIE_S_QUAT + 1]; s.qy = st[UPKIE_S_QUAT + 2]; s.qz = st[UPKIE_S_QUAT + 3];
+  s.linvel = v3(st[UPKIE_S_LINVEL], st[UPKIE_S_LINVEL + 1], st[UPKIE_S_LINVEL + 2]);
+  s.angvel = v3(st[UPKIE_S_ANGVEL], st[UPKIE_S_ANGVEL + 1], st[UPKIE_S_ANGVEL + 2]);
+  for (int j = 0; j < 6; ++j) { s.q[j] = st[UPKIE_S_Q + j]; s.qd[j] = st[UPKIE_S_QD + j]; }
+  float t[6];
+  for (int j = 0; j < 6; ++j) t[j] = tau[j];
+  V3 f = ext_force ? v3(ext_force[0], ext_force[1], ext_force[2]) : v3(0, 0, 0);
+  V3 p = ext_point ? v3(ext_point[0], ext_point[1], ext_point[2]) : v3(0, 0, 0);
+  bool c = physics_substep(M, s, t, h, scale, ext_force != nullptr, f, p);
+  st[UPKIE_S_POS] = s.pos.x; st[UPKIE_S_POS + 1] = s.pos.y; st[UPKIE_S_POS + 2] = s.pos.z;
+  st[UPKIE_S_QUAT] = s.qw; st[UPKIE_S_QUAT + 1] = s.qx; st[UPKIE_S_QUAT + 2] = s.qy; st[UPKIE_S_QUAT + 3] = s.qz;
+  st[UPKIE_S_LINVEL] = s.linvel.x; st[UPKIE_S_LINVEL + 1] = s.linvel.y; st[UPKIE_S_LINVEL + 2] = s.linvel.z;
+  st[UPKIE_S_ANGVEL] = s.angvel.x; st[UPKIE_S_ANGVEL + 1] = s.angvel.y; st[UPKIE_S_ANGVEL + 2] = s.angvel.z;
+  for (int j = 0; j < 6; ++j) { st[UPKIE_S_Q + j] = s.q[j]; st[UPKIE_S_QD + j] = s.qd[j]; }
+  return c ? 1 : 0;
+}

@@ -1,0 +1,94 @@
+"""The C-ABI library loads, exports every symbol include/upkie_hip.h declares
+and the ctypes mirrors agree with the header. No compute calls (no GPU)."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from upkie_amd import abi, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "upkie_hip.h")
+
+
+@pytest.fixture(scope="module")
+def library():
+    lib.build()
+    return lib.load()
+
+
+def test_exports_every_declared_symbol(library):
+    with open(HEADER) as f:
+        text = f.read()
+    declared = set(re.findall(r"\b(upkie_[a-z_]+)\s*\(", text))
+    assert declared == set(lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(library, name) is not None
+
+
+def test_struct_layouts_match_header():
+    probe = r"""
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "upkie_hip.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu\n", sizeof(UpkieModel), sizeof(UpkieSimConfig), sizeof(UpkieMpcConfig), sizeof(UpkieSpineObservation));
+      printf("%zu %zu %zu %zu %zu\n", offsetof(UpkieModel, joint_pos), offsetof(UpkieModel, wheel_radius), offsetof(UpkieModel, gravity), offsetof(UpkieModel, pgs_iterations), offsetof(UpkieModel, enforce_joint_limits));
+      printf("%zu %zu %zu %zu %zu\n", offsetof(UpkieSimConfig, dt), offsetof(UpkieSimConfig, fall_pitch), offsetof(UpkieSimConfig, init_pos), offsetof(UpkieSimConfig, seed), offsetof(UpkieSimConfig, agent_clip));
+      printf("%zu %zu\n", offsetof(UpkieMpcConfig, sampling_period), offsetof(UpkieMpcConfig, admm_rho));
+      printf("%d %d %d %d\n", UPKIE_STATE_WORDS, UPKIE_S_TORQUE, UPKIE_S_DONE, UPKIE_S_CONTACT);
+      return 0;
+    }
+    """
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "probe.c")
+        exe = os.path.join(tmp, "probe")
+        with open(src, "w") as f:
+            f.write(probe)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    sizes = [int(x) for x in out[0].split()]
+    assert sizes == [C.sizeof(abi.UpkieModel), C.sizeof(abi.UpkieSimConfig), C.sizeof(abi.UpkieMpcConfig), C.sizeof(abi.UpkieSpineObservation)]
+    m = abi.UpkieModel
+    assert [int(x) for x in out[1].split()] == [m.joint_pos.offset, m.wheel_radius.offset, m.gravity.offset, m.pgs_iterations.offset, m.enforce_joint_limits.offset]
+    c = abi.UpkieSimConfig
+    assert [int(x) for x in out[2].split()] == [c.dt.offset, c.fall_pitch.offset, c.init_pos.offset, c.seed.offset, c.agent_clip.offset]
+    p = abi.UpkieMpcConfig
+    assert [int(x) for x in out[3].split()] == [p.sampling_period.offset, p.admm_rho.offset]
+    assert [int(x) for x in out[4].split()] == [abi.STATE_WORDS, abi.S_TORQUE, abi.S_DONE, abi.S_CONTACT]
+
+
+def test_no_silent_cpu_fallback(library):
+    """Without a GPU the product path must fail loudly, not compute elsewhere."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the failure path cannot be exercised")
+    assert library.upkie_hip_device_count() == 0
+    from upkie_amd.model.default_model import default_model
+
+    handle = C.c_void_p()
+    cfg, model = abi.default_sim_config(4), default_model()
+    status = library.upkie_sim_create(C.byref(cfg), C.byref(model), C.byref(handle))
+    assert status == abi.ERR_NO_DEVICE and not handle
+    assert b"no HIP device" in library.upkie_sim_last_error(None)
+    from upkie_amd.exceptions import UpkieRuntimeError
+    from upkie_amd.sim import BatchedSim
+
+    with pytest.raises(UpkieRuntimeError):
+        BatchedSim(cfg, model)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "upkie_amd")):
+        for name in files:
+            if name.endswith((".py", ".hip", ".hpp", ".h")):
+                with open(os.path.join(dirpath, name)) as f:
+                    text = f.read()
+                assert "import oracle" not in text and "from oracle" not in text, name
+                assert "upkie_oracle" not in text, name

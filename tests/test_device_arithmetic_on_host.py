@@ -1,0 +1,112 @@
+"""The product's device functions (upkie_amd/csrc/dynamics.hpp) are
+__host__ __device__: compile them for the host and compare single physics
+substeps with the oracle on random states. This checks the kernel arithmetic
+on CPU-only machines; the GPU tests then check the launches themselves."""
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from upkie_amd import abi
+from upkie_amd.model.default_model import default_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_harness.hip")
+LIB = os.path.join(ROOT, "tests", "_host_harness.so")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    deps = [SRC] + [os.path.join(ROOT, "upkie_amd", "csrc", n) for n in ("upkie_hip.hip", "dynamics.hpp", "mpc.hpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.run(
+            ["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB],
+            check=True, capture_output=True,
+        )
+    return C.CDLL(LIB)
+
+
+def random_state(rng, on_floor: bool):
+    s = np.zeros(abi.STATE_WORDS)
+    pitch = rng.uniform(-0.3, 0.3)
+    roll = rng.uniform(-0.05, 0.05)
+    yaw = rng.uniform(-3, 3)
+    cy, sy, cp, sp, cr, sr = np.cos(yaw / 2), np.sin(yaw / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(roll / 2), np.sin(roll / 2)
+    s[abi.S_QUAT : abi.S_QUAT + 4] = [
+        cy * cp * cr + sy * sp * sr, cy * cp * sr - sy * sp * cr, cy * sp * cr + sy * cp * sr, sy * cp * cr - cy * sp * sr]
+    s[abi.S_Q : abi.S_Q + 6] = rng.uniform(-0.4, 0.4, 6)
+    s[abi.S_QD : abi.S_QD + 6] = rng.uniform(-2, 2, 6)
+    s[abi.S_LINVEL : abi.S_LINVEL + 3] = rng.uniform(-0.5, 0.5, 3)
+    s[abi.S_ANGVEL : abi.S_ANGVEL + 3] = rng.uniform(-1, 1, 3)
+    s[abi.S_POS : abi.S_POS + 3] = [rng.uniform(-1, 1), rng.uniform(-1, 1), 0.6 if on_floor else 2.0]
+    return s
+
+
+def run_both(harness, model, s64, tau, h=1e-3, scale=None, force=None, point=None):
+    so = s64.copy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    O.lib().oracle_substep(C.byref(model), p(so), p(tau), C.c_double(h), p(scale), p(force), p(point))
+    s32 = s64.astype(np.float32)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32) if a is not None else None
+    t32, sc32, fo32, po32 = f32(tau), f32(scale), f32(force), f32(point)
+    harness.harness_substep.restype = C.c_int
+    rc = harness.harness_substep(C.byref(model), p(s32), p(t32), C.c_float(h), p(sc32), p(fo32), p(po32))
+    assert rc >= 0
+    return so, s32.astype(np.float64)
+
+
+@pytest.mark.parametrize("on_floor", [False, True])
+def test_substep_matches_oracle(harness, on_floor):
+    rng = np.random.default_rng(5)
+    model = default_model()
+    worst = np.zeros(25)
+    for _ in range(200):
+        s = random_state(rng, on_floor)
+        if on_floor:  # put the lower tire within the contact range of the floor
+            probe = s.copy()
+            O.lib().oracle_substep(C.byref(model), probe.ctypes.data_as(C.c_void_p), np.zeros(6).ctypes.data_as(C.c_void_p), C.c_double(0.0), None, None, None)
+        tau = rng.uniform(-1.5, 1.5, 6)
+        so, sh = run_both(harness, model, s, tau)
+        worst = np.maximum(worst, np.abs(so[:25] - sh[:25]))
+    assert worst[0:3].max() < 5e-7  # position
+    assert worst[3:7].max() < 5e-7  # quaternion
+    assert worst[7:10].max() < 2e-4  # linear velocity (gap / h amplifies fp32 z)
+    assert worst[10:13].max() < 1e-3  # angular velocity
+    assert worst[13:19].max() < 1e-6  # joint angles
+    assert worst[19:25].max() < 2e-2  # joint velocities (wheel inertia 2.8e-4)
+
+
+def test_substep_with_inertia_scales_and_external_force(harness):
+    rng = np.random.default_rng(6)
+    model = default_model()
+    for _ in range(50):
+        s = random_state(rng, True)
+        scale = rng.uniform(0.8, 1.2, 7)
+        force = rng.uniform(-20, 20, 3)
+        point = np.array([0.0, 0.0, -0.1])
+        so, sh = run_both(harness, model, s, rng.uniform(-1, 1, 6), scale=scale, force=force, point=point)
+        assert np.abs(so[7:10] - sh[7:10]).max() < 2e-4
+        assert np.abs(so[10:13] - sh[10:13]).max() < 1e-3
+        assert np.abs(so[0:7] - sh[0:7]).max() < 5e-7
+
+
+def test_free_fall_semi_implicit_euler_in_fp32(harness):
+    """BulletInterfaceTest.cpp:263-285 on the device arithmetic."""
+    model = default_model()
+    model.base_linear_damping = 0.0
+    model.base_angular_damping = 0.0
+    s = np.zeros(abi.STATE_WORDS, dtype=np.float32)
+    s[abi.S_QUAT] = 1.0
+    s[abi.S_POS + 2] = 1.0
+    tau = np.zeros(6, dtype=np.float32)
+    for _ in range(2):
+        harness.harness_substep(C.byref(model), s.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p), C.c_float(1e-3), None, None, None)
+    assert float(s[abi.S_POS + 2]) - 1.0 == pytest.approx(-3 * 9.81e-6, abs=2e-7)
+    assert float(s[abi.S_LINVEL + 2]) == pytest.approx(-2 * 9.81e-3, abs=1e-7)

@@ -1,0 +1,257 @@
+"""HIP path (through the C-ABI) vs the fp64 oracle on the same seeded inputs.
+
+Tolerances follow SURVEY.md Appendix A.9: fp32 kernel vs fp64 oracle, single
+step state relative 1e-5, 200-step closed loop |dtheta| <= 1e-3 rad,
+|dp| <= 1e-3 m; torques 1e-5 * max(1, |tau|) per substep (looser after
+accumulation over a step).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from upkie_amd import abi
+
+from .helpers import make_pair, randomized_config, state_errors
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_mostly_close(actual, desired, atol, fraction=0.99, hard_atol=None):
+    """Per-env comparison for regimes where a few envs sit on a physical
+    discontinuity (tire slip onset, torque saturation): `fraction` of the envs
+    must agree within `atol`, all of them within `hard_atol` if given."""
+    actual = np.asarray(actual, dtype=np.float64).reshape(len(actual), -1)
+    desired = np.asarray(desired, dtype=np.float64).reshape(len(desired), -1)
+    err = np.max(np.abs(actual - desired), axis=1)
+    ok = float(np.mean(err <= atol))
+    assert ok >= fraction, f"only {ok:.4f} of envs within {atol} (worst {err.max():.3e})"
+    if hard_atol is not None:
+        assert err.max() <= hard_atol, f"worst env error {err.max():.3e} > {hard_atol}"
+
+
+def test_library_sees_gpu():
+    from upkie_amd import lib
+
+    assert lib.load().upkie_hip_device_count() >= 1
+
+
+def test_reset_matches_oracle():
+    oracle, sim = make_pair(256, seed=3)
+    obs_o = oracle.reset()
+    obs_h = sim.reset().cpu().numpy()
+    err = state_errors(oracle.state, sim.state_numpy())
+    # fp32 floor: the state's z is quantised at 6e-8 m and the contact row
+    # divides the gap by h = 1 ms, so velocities can differ by ~6e-5 m/s
+    assert err["pos"] < 2e-6 and err["quat"] < 2e-6, err
+    assert err["linvel"] < 2e-4 and err["angvel"] < 1e-3, err
+    assert err["q"] < 2e-5 and err["qd"] < 5e-3, err
+    assert err["episode"] == 0 and err["done"] == 0 and err["contact"] == 0, err
+    np.testing.assert_allclose(obs_h, obs_o, atol=2e-5)
+    # randomisation bounds of the config hold on device too
+    pitch = obs_h[:, 1]
+    assert np.all(np.abs(pitch) <= 0.1 + 1e-3) and np.std(pitch) > 0.03
+
+
+def test_single_pendulum_step_matches_oracle():
+    """Tight single-step parity in the traction regime: commanded ground
+    velocity within 0.02 m/s of the current one, so the wheel torque
+    kd * (omega* - omega) stays below its 1.7 N.m cap."""
+    oracle, sim = make_pair(512, seed=1)
+    obs6 = oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(0)
+    act = (obs6[:, 3] + rng.uniform(-0.02, 0.02, 512)).astype(np.float32)
+    obs_o, rew_o, term_o, trunc_o = oracle.step_pendulum(act.astype(np.float64))
+    obs_h, rew_h, term_h, trunc_h = sim.step_pendulum(torch.from_numpy(act))
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 5e-6 and err["quat"] < 5e-6, err
+    assert err["linvel"] < 5e-4 and err["angvel"] < 2e-3, err
+    assert err["q"] < 5e-5 and err["qd"] < 1e-2, err
+    assert err["torque"] < 1e-2 and err["legref"] < 1e-6, err
+    np.testing.assert_allclose(obs_h.cpu().numpy()[:, :2], obs_o[:, :2], atol=2e-5)
+    np.testing.assert_allclose(obs_h.cpu().numpy()[:, 2:], obs_o[:, 2:], atol=2e-3)
+    assert np.array_equal(term_h.cpu().numpy(), term_o)
+    assert float(rew_h.abs().max()) == 0.0 and int(trunc_h.max()) == 0
+
+
+def test_single_pendulum_step_saturated_actions():
+    """Actions far from the current velocity saturate the wheel torque and
+    break traction; the 1 kHz explicit velocity loop on the bare wheel
+    inertia (kd dt / I_wheel = 3.6 > 2) then amplifies rounding differences
+    by ~2.6x per substep, so fp32 and fp64 can only agree loosely there."""
+    oracle, sim = make_pair(512, seed=1)
+    oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-1.0, 1.0, 512).astype(np.float32)
+    obs_o, _, term_o, _ = oracle.step_pendulum(act.astype(np.float64))
+    obs_h, _, term_h, _ = sim.step_pendulum(torch.from_numpy(act))
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 1e-4 and err["quat"] < 1e-4, err
+    assert err["linvel"] < 2e-2 and err["angvel"] < 5e-2, err
+    obs_h = obs_h.cpu().numpy()
+    assert np.max(np.abs(obs_h[:, :2] - obs_o[:, :2])) < 1e-3
+    assert np.array_equal(term_h.cpu().numpy(), term_o)
+
+
+def test_closed_loop_200_steps_matches_oracle():
+    oracle, sim = make_pair(128, seed=7)
+    obs_o = oracle.reset()[:, [1, 0, 4, 3]]
+    sim.reset()
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    for _ in range(200):
+        obs_o, _, term_o, _ = oracle.step_pendulum_agent(obs_o)
+        obs_h, _, term_h, _ = sim.step_pendulum_agent()
+    obs_h = obs_h.cpu().numpy()
+    assert np.max(np.abs(obs_h[:, 0] - obs_o[:, 0])) <= 1e-3  # pitch, rad
+    assert np.max(np.abs(obs_h[:, 1] - obs_o[:, 1])) <= 1e-3  # position, m
+    assert np.max(np.abs(obs_h[:, 2] - obs_o[:, 2])) <= 2e-2  # pitch rate
+    assert np.max(np.abs(obs_h[:, 3] - obs_o[:, 3])) <= 1e-2  # velocity
+    assert np.array_equal(term_h.cpu().numpy(), term_o)
+
+
+def test_gyropod_step_matches_oracle():
+    oracle, sim = make_pair(256, seed=5)
+    oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        act = rng.uniform(-1.5, 1.5, (256, 2)).astype(np.float32)
+        obs_o, _, term_o, _ = oracle.step_gyropod(act.astype(np.float64))
+        obs_h, _, term_h, _ = sim.step_gyropod(torch.from_numpy(act))
+    # random +-1.5 m/s commands saturate the wheel torque: see the saturated
+    # actions test for why a few envs can only agree loosely
+    assert_mostly_close(obs_h.cpu().numpy(), obs_o, atol=2e-3, fraction=0.97, hard_atol=0.1)
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["yaw"] < 1e-6 and err["pos"] < 1e-3, err
+
+
+def test_servos_step_matches_oracle():
+    """Torque-balancing style Servos actions (examples/pybullet/
+    torque_balancing.py:15-37): hips/knees hold position, wheels get a
+    feedforward torque and a small velocity target."""
+    oracle, sim = make_pair(256, seed=9)
+    oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(2)
+    act = np.zeros((256, 6, 6), dtype=np.float32)
+    act[:, :, 0] = rng.uniform(-0.05, 0.05, (256, 6))  # position
+    act[:, [2, 5], 0] = np.nan  # wheels: no position feedback
+    act[:, [2, 5], 1] = rng.uniform(-0.5, 0.5, (256, 2))  # wheel velocity
+    act[:, [2, 5], 2] = rng.uniform(-0.2, 0.2, (256, 2))  # feedforward torque
+    act[:, :, 3] = rng.uniform(0.5, 1.5, (256, 6))  # kp_scale
+    act[:, :, 4] = rng.uniform(0.5, 1.5, (256, 6))  # kd_scale
+    act[:, :, 5] = 16.0  # clamped to the wheel effort 1.7 on wheels
+    for _ in range(3):
+        obs_o, _, _, _ = oracle.step_servos(act.astype(np.float64))
+        obs_h, _, term_h, _ = sim.step_servos(torch.from_numpy(act))
+    obs_h = obs_h.cpu().numpy()
+    np.testing.assert_allclose(obs_h[:, :, 0], obs_o[:, :, 0], atol=2e-5)  # position
+    assert_mostly_close(obs_h[:, :, 1], obs_o[:, :, 1], atol=1e-2, fraction=0.99, hard_atol=0.1)  # velocity
+    assert_mostly_close(obs_h[:, :, 2], obs_o[:, :, 2], atol=1e-2, fraction=0.99, hard_atol=0.1)  # torque
+    assert np.all(obs_h[:, :, 3] == 42.0) and np.all(obs_h[:, :, 4] == 18.0)
+    assert int(term_h.max()) == 0
+
+
+def test_servos_clamping_matches_oracle():
+    """Every one of the 36 action scalars is clamped to the servo limits
+    (upkie_servos.py:316-344) before the torque law. With one 1 ms substep
+    per step the reported torque only depends on the pre-step state, so wild
+    out-of-range actions can be compared tightly."""
+    cfg = randomized_config(256, seed=6)
+    cfg.dt = 1e-3
+    cfg.nb_substeps = 1
+    oracle, sim = make_pair(256, cfg=cfg)
+    oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(3)
+    act = np.zeros((256, 6, 6), dtype=np.float32)
+    act[:, :, 0] = rng.uniform(-4.0, 4.0, (256, 6))  # beyond +-1.26 / +-2.51
+    act[:, [2, 5], 0] = np.nan
+    act[:, :, 1] = rng.uniform(-200.0, 200.0, (256, 6))  # beyond 28.8 / 111
+    act[:, :, 2] = rng.uniform(-30.0, 30.0, (256, 6))  # beyond 16 / 1.7
+    act[:, :, 3] = rng.uniform(-1.0, 8.0, (256, 6))  # beyond [0, 5]
+    act[:, :, 4] = rng.uniform(-1.0, 8.0, (256, 6))
+    act[:, :, 5] = rng.uniform(-2.0, 30.0, (256, 6))  # beyond [0, effort]
+    obs_o, _, _, _ = oracle.step_servos(act.astype(np.float64))
+    obs_h, _, _, _ = sim.step_servos(torch.from_numpy(act))
+    np.testing.assert_allclose(obs_h.cpu().numpy()[:, :, 2], obs_o[:, :, 2], atol=2e-3)
+    assert np.abs(obs_h.cpu().numpy()[:, [2, 5], 2]).max() <= 1.7 + 1e-6
+    assert np.abs(obs_h.cpu().numpy()[:, :, 2]).max() <= 16.0 + 1e-6
+
+
+def test_spine_observation_matches_oracle():
+    oracle, sim = make_pair(128, seed=11)
+    oracle.reset()
+    sim.reset()
+    act = np.full(128, 0.3, dtype=np.float32)
+    for _ in range(3):
+        oracle.step_pendulum(act.astype(np.float64))
+        sim.step_pendulum(torch.from_numpy(act))
+        obs_o = oracle.observe(update_imu=True)
+        obs_h = sim.observe(update_imu=True)
+    tol = {
+        "pitch": 1e-4,
+        "angular_velocity": 2e-3,
+        "linear_velocity": 1e-3,
+        "rotation_base_to_world": 1e-4,
+        "imu_orientation": 1e-4,
+        "imu_angular_velocity": 2e-3,
+        "imu_linear_acceleration": 0.25,  # finite difference over dt: 1e-3 / 5e-3
+        "imu_raw_linear_acceleration": 0.25,
+        "wheel_odometry": 5e-3,
+    }
+    for key, atol in tol.items():
+        a = obs_o[key].reshape(128, -1)
+        b = obs_h[key].cpu().numpy().reshape(128, -1)
+        assert np.max(np.abs(a - b)) <= atol, key
+    assert np.array_equal(obs_h["floor_contact"].cpu().numpy(), obs_o["floor_contact"])
+
+
+def test_autoreset_next_step():
+    cfg = randomized_config(64, seed=2, autoreset=True)
+    cfg.fall_pitch = 0.12  # just above the +-0.1 rad reset range: frequent falls
+    oracle, sim = make_pair(64, cfg=cfg)
+    oracle.reset()
+    sim.reset()
+    act = np.zeros(64, dtype=np.float32)  # wheels hold still: everyone tips over
+    resets = 0
+    in_sync = np.ones(64, dtype=bool)  # envs whose episodes ended on the same steps so far
+    for _ in range(300):
+        obs_o, _, term_o, _ = oracle.step_pendulum(act.astype(np.float64))
+        obs_h, rew_h, term_h, trunc_h = sim.step_pendulum(torch.from_numpy(act))
+        in_sync &= term_h.cpu().numpy() == term_o
+        resets += int(term_o.sum())
+    assert resets > 64  # every env fell and was reset at least once
+    # a fall threshold crossed within rounding can shift one env by a step
+    assert in_sync.mean() >= 0.9
+    episodes_o = oracle.state[abi.S_EPISODE]
+    episodes_h = sim.state_numpy()[abi.S_EPISODE]
+    assert np.array_equal(episodes_o[in_sync], episodes_h[in_sync])
+    assert episodes_h.min() >= 2
+    assert_mostly_close(obs_h.cpu().numpy()[in_sync], obs_o[in_sync], atol=5e-3, fraction=0.9)
+
+
+def test_randomization_buffers():
+    oracle, sim = make_pair(128, seed=4)
+    scale_h = sim.randomize_inertias(0.2).cpu().numpy()
+    scale_o = oracle.sample_inertia_scales(0.2)
+    np.testing.assert_allclose(scale_h, scale_o, atol=1e-6)
+    assert scale_h.min() >= 0.8 - 1e-6 and scale_h.max() <= 1.2 + 1e-6
+    oracle.inertia_scale = scale_o
+    force = np.zeros((3, 128))
+    force[0] = np.linspace(-10, 10, 128)
+    force[1] = 3.0
+    oracle.ext_force = force
+    oracle.ext_point = np.array([0.0, 0.0, -0.1])  # "torso" frame
+    sim.set_external_force(torch.from_numpy(force).float(), point=(0.0, 0.0, -0.1))
+    oracle.reset()
+    sim.reset()
+    act = np.zeros(128, dtype=np.float32)
+    for _ in range(10):
+        obs_o, _, _, _ = oracle.step_pendulum(act.astype(np.float64))
+        obs_h, _, _, _ = sim.step_pendulum(torch.from_numpy(act))
+    np.testing.assert_allclose(obs_h.cpu().numpy(), obs_o, atol=3e-3)
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 2e-4, err

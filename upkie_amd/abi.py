@@ -1,0 +1,222 @@
+"""ctypes mirror of ``include/upkie_hip.h`` (structs, enums, state words).
+
+Keep this file in lock-step with the header: ``tests/test_abi.py`` compiles a
+small C probe against the header and compares ``sizeof``/``offsetof`` of every
+struct with the classes below.
+"""
+
+import ctypes as C
+
+NB = 7  # merged bodies
+NJ = 6  # actuated joints
+
+## Joint order of the reference (static_config.h:64-69).
+JOINT_NAMES = (
+    "left_hip",
+    "left_knee",
+    "left_wheel",
+    "right_hip",
+    "right_knee",
+    "right_wheel",
+)
+
+## ACTION_KEYS of UpkieServos (upkie_servos.py:98-105).
+ACTION_KEYS = (
+    "position",
+    "velocity",
+    "feedforward_torque",
+    "kp_scale",
+    "kd_scale",
+    "maximum_torque",
+)
+
+## Observation keys per servo (upkie_servos.py:218-254).
+SERVO_OBS_KEYS = ("position", "velocity", "torque", "temperature", "voltage")
+
+# State word indices (enum UpkieStateWord)
+S_POS = 0
+S_QUAT = 3
+S_LINVEL = 7
+S_ANGVEL = 10
+S_Q = 13
+S_QD = 19
+S_LEGREF = 25
+S_YAW = 29
+S_YAWVEL = 30
+S_TORQUE = 31
+S_IMUVEL = 37
+S_EPISODE = 40
+S_DONE = 41
+S_MPC_V = 42
+S_SE2_X = 43
+S_SE2_Y = 44
+S_CONTACT = 45
+STATE_WORDS = 48
+PENDULUM_STATE_WORDS = 29
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_UNSUPPORTED_MODEL = -2
+ERR_HIP = -3
+ERR_NO_DEVICE = -4
+
+AUTORESET_DISABLED = 0
+AUTORESET_NEXT_STEP = 1
+
+
+class UpkieModel(C.Structure):
+    _fields_ = [
+        ("mass", C.c_double * NB),
+        ("com", (C.c_double * 3) * NB),
+        ("inertia", (C.c_double * 6) * NB),
+        ("joint_pos", (C.c_double * 3) * NJ),
+        ("joint_axis", (C.c_double * 3) * NJ),
+        ("joint_lower", C.c_double * NJ),
+        ("joint_upper", C.c_double * NJ),
+        ("joint_effort", C.c_double * NJ),
+        ("joint_velocity", C.c_double * NJ),
+        ("joint_damping", C.c_double * NJ),
+        ("wheel_radius", C.c_double),
+        ("wheel_center", (C.c_double * 3) * 2),
+        ("wheel_base", C.c_double),
+        ("left_sign", C.c_double),
+        ("imu_pos", C.c_double * 3),
+        ("rot_base_to_imu", C.c_double * 9),
+        ("gravity", C.c_double),
+        ("contact_stiffness", C.c_double),
+        ("contact_damping", C.c_double),
+        ("friction_mu", C.c_double),
+        ("contact_breaking_threshold", C.c_double),
+        ("base_linear_damping", C.c_double),
+        ("base_angular_damping", C.c_double),
+        ("max_joint_velocity", C.c_double),
+        ("pgs_iterations", C.c_int32),
+        ("enforce_joint_limits", C.c_int32),
+    ]
+
+
+class UpkieSimConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32),
+        ("nb_substeps", C.c_int32),
+        ("dt", C.c_double),
+        ("torque_control_kp", C.c_double),
+        ("torque_control_kd", C.c_double),
+        ("joint_friction", C.c_double * NJ),
+        ("torque_control_noise", C.c_double * NJ),
+        ("torque_measurement_noise", C.c_double * NJ),
+        ("fall_pitch", C.c_double),
+        ("max_ground_velocity", C.c_double),
+        ("max_yaw_velocity", C.c_double),
+        ("leg_gain_scale", C.c_double),
+        ("max_gain_scale", C.c_double),
+        ("init_pos", C.c_double * 3),
+        ("init_quat", C.c_double * 4),
+        ("init_linvel", C.c_double * 3),
+        ("init_angvel", C.c_double * 3),
+        ("init_joint", C.c_double * NJ),
+        ("rand_roll", C.c_double),
+        ("rand_pitch", C.c_double),
+        ("rand_x", C.c_double),
+        ("rand_z", C.c_double),
+        ("rand_omega_x", C.c_double),
+        ("rand_omega_y", C.c_double),
+        ("rand_linvel", C.c_double * 3),
+        ("seed", C.c_uint64),
+        ("env_id_offset", C.c_int64),
+        ("autoreset_mode", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("agent_gains", C.c_double * 4),
+        ("agent_clip", C.c_double),
+    ]
+
+
+class UpkieSpineObservation(C.Structure):
+    _fields_ = [
+        ("pitch", C.c_void_p),
+        ("angular_velocity", C.c_void_p),
+        ("linear_velocity", C.c_void_p),
+        ("rotation_base_to_world", C.c_void_p),
+        ("floor_contact", C.c_void_p),
+        ("imu_orientation", C.c_void_p),
+        ("imu_angular_velocity", C.c_void_p),
+        ("imu_linear_acceleration", C.c_void_p),
+        ("imu_raw_linear_acceleration", C.c_void_p),
+        ("servo", C.c_void_p),
+        ("wheel_odometry", C.c_void_p),
+    ]
+
+
+class UpkieMpcConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32),
+        ("nb_timesteps", C.c_int32),
+        ("admm_iterations", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("sampling_period", C.c_double),
+        ("leg_length", C.c_double),
+        ("max_ground_accel", C.c_double),
+        ("max_ground_velocity", C.c_double),
+        ("fall_pitch", C.c_double),
+        ("stage_input_cost_weight", C.c_double),
+        ("stage_state_cost_weight", C.c_double),
+        ("terminal_cost_weight", C.c_double),
+        ("admm_rho", C.c_double),
+    ]
+
+
+def default_sim_config(
+    num_envs: int = 1,
+    frequency: float = 200.0,
+    nb_substeps=None,
+    seed: int = 0,
+) -> UpkieSimConfig:
+    """Config with the reference's defaults.
+
+    ``dt = 1 / frequency`` (entry_points.py:57-58), ``nb_substeps =
+    int(1000 * dt)`` (pybullet_backend.py:85-87), kp = 20, kd = 1
+    (pybullet_backend.py:64-65), fall_pitch = 1, max_ground_velocity = 3
+    (upkie_pendulum.py:70-71), max_yaw_velocity = 1, leg_gain_scale = 1
+    (upkie_gyropod.py:107-110), max_gain_scale = 5 (upkie_servos.py:122),
+    initial base position (0, 0, 0.6) (upkie_env.py:87-90).
+    """
+    cfg = UpkieSimConfig()
+    dt = 1.0 / frequency
+    cfg.num_envs = num_envs
+    cfg.dt = dt
+    cfg.nb_substeps = (
+        int(nb_substeps) if nb_substeps is not None else int(1000.0 * dt)
+    )
+    cfg.torque_control_kp = 20.0
+    cfg.torque_control_kd = 1.0
+    cfg.fall_pitch = 1.0
+    cfg.max_ground_velocity = 3.0
+    cfg.max_yaw_velocity = 1.0
+    cfg.leg_gain_scale = 1.0
+    cfg.max_gain_scale = 5.0
+    cfg.init_pos[:] = [0.0, 0.0, 0.6]
+    cfg.init_quat[:] = [1.0, 0.0, 0.0, 0.0]
+    cfg.seed = seed
+    cfg.env_id_offset = 0
+    cfg.autoreset_mode = AUTORESET_DISABLED
+    cfg.agent_gains[:] = [10.0, 1.0, 0.0, 0.1]  # README.md:62
+    cfg.agent_clip = 0.99  # examples/pybullet/pd_balancing.py:29
+    return cfg
+
+
+def default_mpc_config(num_envs: int = 1, nb_timesteps: int = 50):
+    """MPCBalancer defaults (mpc_balancer.py:168-180)."""
+    cfg = UpkieMpcConfig()
+    cfg.num_envs = num_envs
+    cfg.nb_timesteps = nb_timesteps
+    cfg.admm_iterations = 60
+    cfg.sampling_period = 0.02
+    cfg.leg_length = 0.58
+    cfg.max_ground_accel = 10.0
+    cfg.max_ground_velocity = 3.0
+    cfg.fall_pitch = 1.0
+    cfg.stage_input_cost_weight = 1e-3
+    cfg.stage_state_cost_weight = 1e-3
+    cfg.terminal_cost_weight = 1.0
+    cfg.admm_rho = 0.05
+    return cfg

@@ -1,0 +1,617 @@
+// dynamics.hpp -- device-side rigid-body step of one Upkie, one env per lane.
+//
+// Formulation (fp32, everything expressed in the BASE frame about the base
+// origin; the legs are planar chains about the lateral axis so each link's
+// orientation relative to the base is one rotation about y):
+//   1. single-frame Newton-Euler pass for the bias forces,
+//   2. composite-rigid-body pass for the joint-space inertia matrix
+//        M = [ Mbb  F_L  F_R ]   Mbb 6x6 (base), F 6x3 per leg,
+//            [ F_L' H_L   0  ]   H 3x3 per leg (legs decouple given the base),
+//            [ F_R'  0   H_R ]
+//   3. leg elimination: A = Mbb - sum_leg F H^-1 F' (6x6), LDL' factorisation,
+//      reused for the free acceleration and the 6 contact-row solves,
+//   4. two tire/floor contacts x (normal, 2 friction) rows, Delassus matrix,
+//      fixed-iteration projected Gauss-Seidel with ERP/CFM from the tire's
+//      contact stiffness/damping,
+//   5. semi-implicit Euler (velocities first, then positions).
+// This replaces what the reference delegates to pybullet.stepSimulation()
+// (upkie/envs/backends/pybullet_backend.py:306).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/upkie_hip.h"
+
+// Host+device so that tests can single-step the very same arithmetic on the CPU
+// (tests/host_harness.hip); the product only ever calls these from kernels.
+#define UPKIE_HD __host__ __device__ __forceinline__
+
+namespace upkie {
+
+struct V3 {
+  float x, y, z;
+};
+UPKIE_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+UPKIE_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+UPKIE_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+UPKIE_HD V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+UPKIE_HD float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+UPKIE_HD V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Symmetric 3x3: xx yy zz xy xz yz
+struct S3 {
+  float xx, yy, zz, xy, xz, yz;
+};
+UPKIE_HD V3 mul(const S3& I, V3 v) {
+  return V3{I.xx * v.x + I.xy * v.y + I.xz * v.z, I.xy * v.x + I.yy * v.y + I.yz * v.z,
+            I.xz * v.x + I.yz * v.y + I.zz * v.z};
+}
+UPKIE_HD S3 operator+(const S3& a, const S3& b) {
+  return S3{a.xx + b.xx, a.yy + b.yy, a.zz + b.zz, a.xy + b.xy, a.xz + b.xz, a.yz + b.yz};
+}
+// Inertia about the frame origin of a body of mass m whose com sits at c,
+// given its inertia about the com (parallel axis theorem).
+UPKIE_HD S3 shift_to_origin(const S3& Ic, float m, V3 c) {
+  return S3{Ic.xx + m * (c.y * c.y + c.z * c.z), Ic.yy + m * (c.x * c.x + c.z * c.z),
+            Ic.zz + m * (c.x * c.x + c.y * c.y), Ic.xy - m * c.x * c.y, Ic.xz - m * c.x * c.z,
+            Ic.yz - m * c.y * c.z};
+}
+// Rotate a vector / a symmetric tensor by Ry(angle) given (c, s).
+UPKIE_HD V3 rot_y(float c, float s, V3 v) { return V3{c * v.x + s * v.z, v.y, c * v.z - s * v.x}; }
+UPKIE_HD S3 rot_y(float c, float s, const S3& I) {
+  float cc = c * c, ss = s * s, cs = c * s;
+  return S3{cc * I.xx + 2.f * cs * I.xz + ss * I.zz,
+            I.yy,
+            ss * I.xx - 2.f * cs * I.xz + cc * I.zz,
+            c * I.xy + s * I.yz,
+            (cc - ss) * I.xz + cs * (I.zz - I.xx),
+            c * I.yz - s * I.xy};
+}
+
+// Model constants, uniform across lanes (kernel argument => scalar loads).
+struct DevModel {
+  float mass[UPKIE_NB];
+  float com[UPKIE_NB][3];
+  float inertia[UPKIE_NB][6];
+  float joint_pos[UPKIE_NJ][3];
+  float joint_sign[UPKIE_NJ];  // axis = sign * y
+  float joint_lower[UPKIE_NJ];
+  float joint_upper[UPKIE_NJ];
+  float joint_effort[UPKIE_NJ];
+  float joint_velocity[UPKIE_NJ];
+  float joint_damping[UPKIE_NJ];
+  float wheel_radius;
+  float wheel_center[2][3];
+  float wheel_base;
+  float left_sign;
+  float imu_pos[3];
+  float rot_base_to_imu[9];
+  float gravity;
+  float contact_stiffness;
+  float contact_damping;
+  float friction_mu;
+  float contact_breaking_threshold;
+  float base_linear_damping;
+  float base_angular_damping;
+  float max_joint_velocity;
+  int pgs_iterations;
+  int wheel_axisymmetric;  // wheel inertia invariant under its own rotation
+};
+
+// Physics state of one env held in registers.
+struct Phys {
+  V3 pos;
+  float qw, qx, qy, qz;
+  V3 linvel;  // world
+  V3 angvel;  // world
+  float q[UPKIE_NJ];
+  float qd[UPKIE_NJ];
+};
+
+// 6x6 symmetric LDL' factorisation, unit lower L (15) + inverse pivots (6).
+struct Ldl6 {
+  float l10, l20, l21, l30, l31, l32, l40, l41, l42, l43, l50, l51, l52, l53, l54;
+  float i0, i1, i2, i3, i4, i5;
+};
+
+UPKIE_HD void ldl6_factor(const float (&A)[21], Ldl6& f) {
+  // A packed lower by rows: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) ...
+  float d0 = A[0];
+  f.i0 = 1.f / d0;
+  float a10 = A[1], a20 = A[3], a30 = A[6], a40 = A[10], a50 = A[15];
+  f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0; f.l40 = a40 * f.i0; f.l50 = a50 * f.i0;
+  float d1 = A[2] - f.l10 * a10;
+  f.i1 = 1.f / d1;
+  float a21 = A[4] - f.l20 * a10, a31 = A[7] - f.l30 * a10, a41 = A[11] - f.l40 * a10, a51 = A[16] - f.l50 * a10;
+  f.l21 = a21 * f.i1; f.l31 = a31 * f.i1; f.l41 = a41 * f.i1; f.l51 = a51 * f.i1;
+  float d2 = A[5] - f.l20 * a20 - f.l21 * a21;
+  f.i2 = 1.f / d2;
+  float a32 = A[8] - f.l30 * a20 - f.l31 * a21, a42 = A[12] - f.l40 * a20 - f.l41 * a21,
+        a52 = A[17] - f.l50 * a20 - f.l51 * a21;
+  f.l32 = a32 * f.i2; f.l42 = a42 * f.i2; f.l52 = a52 * f.i2;
+  float d3 = A[9] - f.l30 * a30 - f.l31 * a31 - f.l32 * a32;
+  f.i3 = 1.f / d3;
+  float a43 = A[13] - f.l40 * a30 - f.l41 * a31 - f.l42 * a32,
+        a53 = A[18] - f.l50 * a30 - f.l51 * a31 - f.l52 * a32;
+  f.l43 = a43 * f.i3; f.l53 = a53 * f.i3;
+  float d4 = A[14] - f.l40 * a40 - f.l41 * a41 - f.l42 * a42 - f.l43 * a43;
+  f.i4 = 1.f / d4;
+  float a54 = A[19] - f.l50 * a40 - f.l51 * a41 - f.l52 * a42 - f.l53 * a43;
+  f.l54 = a54 * f.i4;
+  float d5 = A[20] - f.l50 * a50 - f.l51 * a51 - f.l52 * a52 - f.l53 * a53 - f.l54 * a54;
+  f.i5 = 1.f / d5;
+}
+
+UPKIE_HD void ldl6_solve(const Ldl6& f, float (&x)[6]) {
+  // forward: L y = b
+  x[1] -= f.l10 * x[0];
+  x[2] -= f.l20 * x[0] + f.l21 * x[1];
+  x[3] -= f.l30 * x[0] + f.l31 * x[1] + f.l32 * x[2];
+  x[4] -= f.l40 * x[0] + f.l41 * x[1] + f.l42 * x[2] + f.l43 * x[3];
+  x[5] -= f.l50 * x[0] + f.l51 * x[1] + f.l52 * x[2] + f.l53 * x[3] + f.l54 * x[4];
+  x[0] *= f.i0; x[1] *= f.i1; x[2] *= f.i2; x[3] *= f.i3; x[4] *= f.i4; x[5] *= f.i5;
+  // backward: L' x = y
+  x[4] -= f.l54 * x[5];
+  x[3] -= f.l43 * x[4] + f.l53 * x[5];
+  x[2] -= f.l32 * x[3] + f.l42 * x[4] + f.l52 * x[5];
+  x[1] -= f.l21 * x[2] + f.l31 * x[3] + f.l41 * x[4] + f.l51 * x[5];
+  x[0] -= f.l10 * x[1] + f.l20 * x[2] + f.l30 * x[3] + f.l40 * x[4] + f.l50 * x[5];
+}
+
+// Everything one leg contributes to the base-level system.
+struct Leg {
+  // kinematics (base frame)
+  V3 o[3];  // joint origins: hip, knee, wheel
+  // columns F_k = I^c_k S_k, k = hip, knee, wheel: linear (f) and angular (n)
+  float F[3][6];
+  float Hinv[6];  // symmetric inverse of the 3x3 leg block: 00 11 22 01 02 12
+  // D = F Hinv (6x3): rows 0-2 linear, 3-5 angular
+  float D[6][3];
+  float bias[3];  // joint-space bias of the leg
+  float sgn[3];   // axis signs
+};
+
+// Composite inertia about the base origin: mass, first moment, second moment.
+struct Composite {
+  float m;
+  V3 h;
+  S3 I;
+};
+
+// One leg: kinematics, single-frame Newton-Euler (bias) and composite pass.
+// `body0` is the index of the thigh body, `joint0` of the hip joint.
+// Adds the leg's composite inertia to `total` and its bias wrench about the
+// base origin to (bias_f, bias_n).
+UPKIE_HD void leg_pass(const DevModel& M, const float* scale, int body0, int joint0,
+                                         const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ], V3 w0, V3 gn,
+                                         Leg& L, Composite& total, V3& bias_f, V3& bias_n) {
+  float cs[3], sn[3];
+  float psi = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    L.sgn[k] = M.joint_sign[joint0 + k];
+    psi = fmaf(L.sgn[k], q[joint0 + k], psi);
+    if (k == 2 && M.wheel_axisymmetric) {
+      cs[k] = 1.f;
+      sn[k] = 0.f;
+    } else {
+      sincosf(psi, &sn[k], &cs[k]);
+    }
+  }
+  // joint origins
+  L.o[0] = v3(M.joint_pos[joint0][0], M.joint_pos[joint0][1], M.joint_pos[joint0][2]);
+  L.o[1] = L.o[0] + rot_y(cs[0], sn[0], v3(M.joint_pos[joint0 + 1][0], M.joint_pos[joint0 + 1][1], M.joint_pos[joint0 + 1][2]));
+  L.o[2] = L.o[1] + rot_y(cs[1], sn[1], v3(M.joint_pos[joint0 + 2][0], M.joint_pos[joint0 + 2][1], M.joint_pos[joint0 + 2][2]));
+
+  // outward pass: velocities and velocity-product accelerations
+  V3 w = w0, al = v3(0.f, 0.f, 0.f), ao = v3(0.f, 0.f, 0.f), oprev = v3(0.f, 0.f, 0.f);
+  V3 Nb[3], fb[3];  // per-body wrench about the base origin
+  float mb[3];
+  V3 cb[3];
+  S3 Ib[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int b = body0 + k, j = joint0 + k;
+    float sc = scale ? scale[b] : 1.f;
+    float m = M.mass[b] * sc;
+    V3 r = L.o[k] - oprev;
+    // origin acceleration uses the PARENT's omega/alpha
+    ao = ao + cross(al, r) + cross(w, cross(w, r));
+    float sq = L.sgn[k] * qd[j];
+    // omega_p x a = sign * (omega_p x y) = sign * (-wz, 0, wx)
+    al = al + sq * v3(-w.z, 0.f, w.x);
+    w.y += sq;
+    V3 rc = rot_y(cs[k], sn[k], v3(M.com[b][0], M.com[b][1], M.com[b][2]));
+    V3 c = L.o[k] + rc;
+    S3 Ic = rot_y(cs[k], sn[k], S3{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]});
+    Ic = S3{sc * Ic.xx, sc * Ic.yy, sc * Ic.zz, sc * Ic.xy, sc * Ic.xz, sc * Ic.yz};
+    V3 ac = ao + cross(al, rc) + cross(w, cross(w, rc));
+    V3 f = m * (ac + gn);
+    V3 n = mul(Ic, al) + cross(w, mul(Ic, w));
+    fb[k] = f;
+    Nb[k] = n + cross(c, f);
+    mb[k] = m;
+    cb[k] = c;
+    Ib[k] = shift_to_origin(Ic, m, c);
+    oprev = L.o[k];
+  }
+  // inward pass: composite wrench / inertia, joint-space projections
+  Composite C{0.f, v3(0.f, 0.f, 0.f), S3{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+  V3 fc = v3(0.f, 0.f, 0.f), Nc = v3(0.f, 0.f, 0.f);
+  float H[3][3];
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    fc = fc + fb[k];
+    Nc = Nc + Nb[k];
+    C.m += mb[k];
+    C.h = C.h + mb[k] * cb[k];
+    C.I = C.I + Ib[k];
+    float s = L.sgn[k];
+    V3 o = L.o[k];
+    // S = [a; o x a], a = s*y: o x y = (-o.z, 0, o.x)
+    V3 oxa = s * v3(-o.z, 0.f, o.x);
+    // bias_j = a.N + (o x a).f
+    L.bias[k] = s * Nc.y + dot(oxa, fc);
+    // F = I^c S: f = m (o x a) + a x h ; n = I a + h x (o x a)
+    V3 axh = s * v3(C.h.z, 0.f, -C.h.x);
+    V3 Ff = C.m * oxa + axh;
+    V3 Fn = s * v3(C.I.xy, C.I.yy, C.I.yz) + cross(C.h, oxa);
+    L.F[k][0] = Ff.x; L.F[k][1] = Ff.y; L.F[k][2] = Ff.z;
+    L.F[k][3] = Fn.x; L.F[k][4] = Fn.y; L.F[k][5] = Fn.z;
+  }
+  // H_jk = S_j . F_k for j <= k (ancestor), symmetric
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float s = L.sgn[j];
+    V3 o = L.o[j];
+    V3 oxa = s * v3(-o.z, 0.f, o.x);
+#pragma unroll
+    for (int k = j; k < 3; ++k) {
+      float hjk = s * L.F[k][4] + oxa.x * L.F[k][0] + oxa.z * L.F[k][2];
+      H[j][k] = hjk;
+      H[k][j] = hjk;
+    }
+  }
+  // inverse of the SPD 3x3 block through its Cholesky factor
+  {
+    float l00 = sqrtf(H[0][0]);
+    float i00 = 1.f / l00;
+    float l10 = H[1][0] * i00, l20 = H[2][0] * i00;
+    float l11 = sqrtf(H[1][1] - l10 * l10);
+    float i11 = 1.f / l11;
+    float l21 = (H[2][1] - l20 * l10) * i11;
+    float l22 = sqrtf(H[2][2] - l20 * l20 - l21 * l21);
+    float i22 = 1.f / l22;
+    // Linv (lower): m00 m10 m11 m20 m21 m22
+    float m00 = i00, m11 = i11, m22 = i22;
+    float m10 = -l10 * m00 * i11;
+    float m21 = -l21 * m11 * i22;
+    float m20 = -(l20 * m00 + l21 * m10) * i22;
+    // Hinv = Linv' Linv
+    L.Hinv[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    L.Hinv[1] = m11 * m11 + m21 * m21;
+    L.Hinv[2] = m22 * m22;
+    L.Hinv[3] = m10 * m11 + m20 * m21;
+    L.Hinv[4] = m20 * m22;
+    L.Hinv[5] = m21 * m22;
+  }
+  // D = F Hinv
+  {
+    const float* h = L.Hinv;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float f0 = L.F[0][r], f1 = L.F[1][r], f2 = L.F[2][r];
+      L.D[r][0] = f0 * h[0] + f1 * h[3] + f2 * h[4];
+      L.D[r][1] = f0 * h[3] + f1 * h[1] + f2 * h[5];
+      L.D[r][2] = f0 * h[4] + f1 * h[5] + f2 * h[2];
+    }
+  }
+  total.m += C.m;
+  total.h = total.h + C.h;
+  total.I = total.I + C.I;
+  bias_f = bias_f + fc;
+  bias_n = bias_n + Nc;
+}
+
+// Factored system: solve M x = b for b = (base 6, left 3, right 3).
+struct System {
+  Ldl6 A;
+  Leg leg[2];
+};
+
+// x overwrites b. `has_leg[l]` false means the leg part of b is zero.
+template <bool LEFT, bool RIGHT>
+UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], float (&br)[3]) {
+  // y = b_base - D_L b_L - D_R b_R
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float y = bb[r];
+    if (LEFT) y -= S.leg[0].D[r][0] * bl[0] + S.leg[0].D[r][1] * bl[1] + S.leg[0].D[r][2] * bl[2];
+    if (RIGHT) y -= S.leg[1].D[r][0] * br[0] + S.leg[1].D[r][1] * br[1] + S.leg[1].D[r][2] * br[2];
+    bb[r] = y;
+  }
+  ldl6_solve(S.A, bb);
+  // x_leg = Hinv b_leg - D' x_base
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    float(&b)[3] = l == 0 ? bl : br;
+    const Leg& G = S.leg[l];
+    const float* h = G.Hinv;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if ((l == 0 && LEFT) || (l == 1 && RIGHT)) {
+      x0 = h[0] * b[0] + h[3] * b[1] + h[4] * b[2];
+      x1 = h[3] * b[0] + h[1] * b[1] + h[5] * b[2];
+      x2 = h[4] * b[0] + h[5] * b[1] + h[2] * b[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      x0 -= G.D[r][0] * bb[r];
+      x1 -= G.D[r][1] * bb[r];
+      x2 -= G.D[r][2] * bb[r];
+    }
+    b[0] = x0; b[1] = x1; b[2] = x2;
+  }
+}
+
+// One physics substep of duration h. tau: commanded joint torques.
+// scale: per-body inertia scales of this env or nullptr. ext_force (world
+// frame) acts on the trunk at base-frame point ext_point when has_ext.
+// Returns the floor-contact flag.
+UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPKIE_NJ], float h,
+                                                const float* scale, bool has_ext, V3 ext_force, V3 ext_point) {
+  // rotation base -> world (upkie/utils/rotations.py:52-71)
+  float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+  float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
+  float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+  float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+  // base-frame velocities
+  V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
+             r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
+  V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
+             r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
+  V3 nB = v3(r20, r21, r22);  // world z in base coordinates
+  V3 gn = M.gravity * nB;
+
+  // trunk
+  float sc0 = scale ? scale[0] : 1.f;
+  float m0 = M.mass[0] * sc0;
+  V3 c0 = v3(M.com[0][0], M.com[0][1], M.com[0][2]);
+  S3 I0 = S3{sc0 * M.inertia[0][0], sc0 * M.inertia[0][1], sc0 * M.inertia[0][2], sc0 * M.inertia[0][3], sc0 * M.inertia[0][4], sc0 * M.inertia[0][5]};
+  V3 I0w = mul(I0, wB);
+  V3 bias_f, bias_n;
+  {
+    V3 ac = cross(wB, cross(wB, c0));
+    V3 f = m0 * (ac + gn);
+    V3 n = cross(wB, I0w);
+    bias_f = f;
+    bias_n = n + cross(c0, f);
+  }
+  Composite total{m0, m0 * c0, shift_to_origin(I0, m0, c0)};
+
+  System S;
+  leg_pass(M, scale, 1, 0, s.q, s.qd, wB, gn, S.leg[0], total, bias_f, bias_n);
+  leg_pass(M, scale, 4, 3, s.q, s.qd, wB, gn, S.leg[1], total, bias_f, bias_n);
+
+  // base block (generalised velocity [v, omega]) minus the legs' Schur terms
+  {
+    float A[21];
+    V3 hh = total.h;
+    // rows 0-2: m I ; rows 3-5 x cols 0-2: [h]x ; rows 3-5 x cols 3-5: I
+    A[0] = total.m;
+    A[1] = 0.f; A[2] = total.m;
+    A[3] = 0.f; A[4] = 0.f; A[5] = total.m;
+    A[6] = 0.f;   A[7] = -hh.z; A[8] = hh.y;  A[9] = total.I.xx;
+    A[10] = hh.z; A[11] = 0.f;  A[12] = -hh.x; A[13] = total.I.xy; A[14] = total.I.yy;
+    A[15] = -hh.y; A[16] = hh.x; A[17] = 0.f;  A[18] = total.I.xz; A[19] = total.I.yz; A[20] = total.I.zz;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const Leg& G = S.leg[l];
+      int idx = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          A[idx] -= G.D[r][0] * G.F[0][c] + G.D[r][1] * G.F[1][c] + G.D[r][2] * G.F[2][c];
+          ++idx;
+        }
+      }
+    }
+    ldl6_factor(A, S.A);
+  }
+
+  // applied generalised forces minus bias
+  float bb[6], bl[3], br[3];
+  {
+    // Bullet-style base damping on the trunk: F = -m v (k + k|v|) at its com
+    V3 vc = vB + cross(wB, c0);
+    float vn = sqrtf(dot(vc, vc)), wn = sqrtf(dot(wB, wB));
+    float kl = M.base_linear_damping, ka = M.base_angular_damping;
+    V3 F = (-m0 * (kl + kl * vn)) * vc;
+    V3 T = (-(ka + ka * wn)) * I0w;
+    V3 Ntot = T + cross(c0, F);
+    if (has_ext) {
+      V3 Fe = v3(r00 * ext_force.x + r10 * ext_force.y + r20 * ext_force.z, r01 * ext_force.x + r11 * ext_force.y + r21 * ext_force.z,
+                 r02 * ext_force.x + r12 * ext_force.y + r22 * ext_force.z);
+      F = F + Fe;
+      Ntot = Ntot + cross(ext_point, Fe);
+    }
+    bb[0] = F.x - bias_f.x; bb[1] = F.y - bias_f.y; bb[2] = F.z - bias_f.z;
+    bb[3] = Ntot.x - bias_n.x; bb[4] = Ntot.y - bias_n.y; bb[5] = Ntot.z - bias_n.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bl[k] = tau[k] - M.joint_damping[k] * s.qd[k] - S.leg[0].bias[k];
+      br[k] = tau[3 + k] - M.joint_damping[3 + k] * s.qd[3 + k] - S.leg[1].bias[k];
+    }
+  }
+  system_solve<true, true>(S, bb, bl, br);
+  // free velocity nu = [vB, wB, qd] + h * acc
+  float nu[12];
+  nu[0] = fmaf(h, bb[0], vB.x); nu[1] = fmaf(h, bb[1], vB.y); nu[2] = fmaf(h, bb[2], vB.z);
+  nu[3] = fmaf(h, bb[3], wB.x); nu[4] = fmaf(h, bb[4], wB.y); nu[5] = fmaf(h, bb[5], wB.z);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    nu[6 + k] = fmaf(h, bl[k], s.qd[k]);
+    nu[9 + k] = fmaf(h, br[k], s.qd[3 + k]);
+  }
+
+  // ---- tire / floor contacts -------------------------------------------
+  // Rows 3w+0..2 = (normal, t1, t2) of wheel w. Row r of wheel w only touches
+  // the base and leg w: J = [d ; P x d ; leg part (3)].
+  float Jb[6][6], Jl[6][3];     // Jacobian rows
+  float Xb[6][6], Xl[6][3], Xo[6][3];  // M^-1 J' : base, own leg, other leg
+  float rhs[6];
+  bool active[2];
+  bool any_contact = false;
+  float un = sqrtf(nB.x * nB.x + nB.z * nB.z);
+  float iun = 1.f / fmaxf(un, 1e-12f);
+  float denom = h * M.contact_stiffness + M.contact_damping;
+  float erp = denom > 0.f ? h * M.contact_stiffness / denom : 0.2f;
+  float cfm = denom > 0.f ? 1.f / (denom * h) : 0.f;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const Leg& G = S.leg[w];
+    float sa = G.sgn[2];  // wheel axis = sa * y
+    V3 wc = v3(M.wheel_center[w][0], M.wheel_center[w][1], M.wheel_center[w][2]);
+    V3 center = G.o[2] + wc;  // wheel_center must lie on the axis unless the wheel angle is tracked
+    // lowest point of the tire circle: P = center - r * u / |u|, u = n - (n.a) a
+    V3 dlow = v3(-nB.x * iun, 0.f, -nB.z * iun);
+    V3 P = center + M.wheel_radius * dlow;
+    float dist = s.pos.z + dot(nB, P);
+    // a contact point exists below the manifold breaking threshold
+    active[w] = un >= 1e-6f && dist <= M.contact_breaking_threshold;
+    any_contact = any_contact || active[w];
+    V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);  // a x n / |a x n|
+    V3 t2 = cross(nB, t1);
+    V3 dirs[3] = {nB, t1, t2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int r = 3 * w + k;
+      V3 d = dirs[k];
+      V3 Pxd = cross(P, d);
+      Jb[r][0] = d.x; Jb[r][1] = d.y; Jb[r][2] = d.z;
+      Jb[r][3] = Pxd.x; Jb[r][4] = Pxd.y; Jb[r][5] = Pxd.z;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        V3 rr = P - G.o[j];
+        // (a x rr) . d, a = s*y : y x rr = (rr.z, 0, -rr.x)
+        Jl[r][j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
+      }
+      float v = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v = fmaf(Jb[r][c], nu[c], v);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v = fmaf(Jl[r][j], nu[6 + 3 * w + j], v);
+      // penetration is pushed out with ERP; a separated point may only close
+      // its gap within the step (continuous at dist = 0)
+      rhs[r] = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) / h : -v - dist / h) : -v;
+      // X = M^-1 J'
+      float xb[6], xl[3], xr[3];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) xb[c] = Jb[r][c];
+      if (w == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xl[j] = Jl[r][j]; xr[j] = 0.f; }
+        system_solve<true, false>(S, xb, xl, xr);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Xl[r][j] = xl[j]; Xo[r][j] = xr[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xl[j] = 0.f; xr[j] = Jl[r][j]; }
+        system_solve<false, true>(S, xb, xl, xr);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Xl[r][j] = xr[j]; Xo[r][j] = xl[j]; }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Xb[r][c] = xb[c];
+    }
+  }
+  if (active[0] || active[1]) {
+    // Delassus matrix W = J M^-1 J' (symmetric)
+    float W[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = a; b < 6; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc = fmaf(Jb[a][c], Xb[b][c], acc);
+        bool same = (a / 3) == (b / 3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = fmaf(Jl[a][j], same ? Xl[b][j] : Xo[b][j], acc);
+        W[a][b] = acc;
+        W[b][a] = acc;
+      }
+    }
+    float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float idiag[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) idiag[r] = 1.f / (W[r][r] + ((r % 3) == 0 ? cfm : 0.f));
+    float mu = M.friction_mu;
+    for (int it = 0; it < M.pgs_iterations; ++it) {
+      // normals of both wheels first, then friction rows
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          bool is_normal = (r % 3) == 0;
+          if (is_normal != (pass == 0)) continue;
+          float wl = 0.f;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
+          float x;
+          if (is_normal) {
+            x = lam[r] + (rhs[r] - wl - cfm * lam[r]) * idiag[r];
+            x = fmaxf(x, 0.f);
+          } else {
+            x = lam[r] + (rhs[r] - wl) * idiag[r];
+            float lim = mu * lam[3 * (r / 3)];
+            x = fminf(fmaxf(x, -lim), lim);
+          }
+          lam[r] = active[r / 3] ? x : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      int w = r / 3;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) nu[c] = fmaf(Xb[r][c], lam[r], nu[c]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        nu[6 + 3 * w + j] = fmaf(Xl[r][j], lam[r], nu[6 + 3 * w + j]);
+        nu[6 + 3 * (1 - w) + j] = fmaf(Xo[r][j], lam[r], nu[6 + 3 * (1 - w) + j]);
+      }
+    }
+  }
+
+  // ---- integrate (semi-implicit Euler: new velocities move positions) ----
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    float v = fminf(fmaxf(nu[6 + j], -M.max_joint_velocity), M.max_joint_velocity);
+    s.qd[j] = v;
+    s.q[j] = fmaf(h, v, s.q[j]);
+  }
+  s.linvel = v3(r00 * nu[0] + r01 * nu[1] + r02 * nu[2], r10 * nu[0] + r11 * nu[1] + r12 * nu[2], r20 * nu[0] + r21 * nu[1] + r22 * nu[2]);
+  s.angvel = v3(r00 * nu[3] + r01 * nu[4] + r02 * nu[5], r10 * nu[3] + r11 * nu[4] + r12 * nu[5], r20 * nu[3] + r21 * nu[4] + r22 * nu[5]);
+  s.pos = s.pos + h * s.linvel;
+  {
+    float wn = sqrtf(dot(s.angvel, s.angvel));
+    float half = 0.5f * h * wn;
+    float sh, ch;
+    sincosf(half, &sh, &ch);
+    float k = wn > 1e-9f ? sh / wn : 0.5f * h;
+    float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
+    // q <- dq * q (world-frame angular velocity)
+    float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+    float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+    float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+    float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+    float inv = 1.f / sqrtf(nw * nw + nx * nx + ny * ny + nz * nz);
+    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
+  }
+  return any_contact;
+}
+
+}  // namespace upkie

@@ -1,0 +1,242 @@
+// mpc.hpp -- batched MPC balancer (upkie/controllers/mpc_balancer.py:168-312).
+//
+// The reference builds a condensed box-constrained QP once (qpmpc's
+// WheeledInvertedPendulum + MPCQP) and re-solves it every step with ProxQP,
+// changing only the cost vector. Here:
+//   host (fp64, once): Phi/Psi condensing, P, the affine cost map
+//     q = Kx x0 + kv v*, and Minv = (P + rho I)^-1;
+//   device (fp32, every step): fixed-iteration ADMM
+//     U <- Minv (rho (z - y) - q);  z <- clip(U + y, +-a_max);  y <- y + U - z
+//   with the dense product done on the matrix cores: one wave owns 16 envs and
+//   computes U[Np x 16] = Minv[Np x Np] . R[Np x 16] with
+//   v_mfma_f32_16x16x4_f32 (exact fp32). The rows of Minv are permuted per
+//   16-row tile (i -> 4 (i % 4) + i / 4) so that the accumulator a lane ends up
+//   holding is exactly the B-operand element it must feed to the next
+//   iteration: no cross-lane movement at all in the loop.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/upkie_hip.h"
+
+namespace upkie {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct MpcDev {
+  const float* minv;  // [Np][Np] row-permuted
+  const float* kx;    // [Np][4]
+  const float* kv;    // [Np]
+  int num_envs;
+  int n;       // horizon length N
+  int iterations;
+  float rho;
+  float bound;  // max_ground_accel
+  float max_ground_velocity;
+  float fall_pitch;
+};
+
+// logical horizon index held by (tile t, lane group g, register r)
+__device__ __forceinline__ int mpc_index(int t, int g, int r) { return 16 * t + 4 * r + g; }
+
+template <int T>
+__global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
+                                                       const float* __restrict__ v_target,
+                                                       const uint8_t* __restrict__ contact, float dt,
+                                                       float* __restrict__ commanded, float* __restrict__ first_input) {
+  constexpr int NP = 16 * T;
+  const int lane = threadIdx.x;
+  const int col = lane & 15, g = lane >> 4;
+  const int B = P.num_envs;
+  const int env = blockIdx.x * 16 + col;
+  const bool live = env < B;
+  const int N = P.n;
+
+  // A operands: a[t][s] = Minv_perm[16 t + col][4 s + g]
+  float a[T][4 * T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int s = 0; s < 4 * T; ++s) a[t][s] = P.minv[(size_t)(16 * t + col) * NP + 4 * s + g];
+
+  float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float vt = live ? v_target[env] : 0.f;
+  float q[T][4], z[T][4], y[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      const float4 k = reinterpret_cast<const float4*>(P.kx)[n];
+      q[t][r] = k.x * x.x + k.y * x.y + k.z * x.z + k.w * x.w + P.kv[n] * vt;
+      const bool in = live && n < N;
+      z[t][r] = in ? ws[(size_t)n * B + env] : 0.f;
+      y[t][r] = in ? ws[(size_t)(N + n) * B + env] : 0.f;
+    }
+
+  for (int it = 0; it < P.iterations; ++it) {
+    float rb[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rb[t][r] = P.rho * (z[t][r] - y[t][r]) - q[t][r];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      // two independent accumulators per tile hide the MFMA latency
+      floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4 * T; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], rb[s / 4][s % 4], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s + 1], rb[(s + 1) / 4][(s + 1) % 4], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float u = acc0[r] + acc1[r];
+        const float w = u + y[t][r];
+        const float zi = fminf(fmaxf(w, -P.bound), P.bound);
+        y[t][r] = y[t][r] + u - zi;
+        z[t][r] = zi;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      if (live && n < N) {
+        ws[(size_t)n * B + env] = z[t][r];
+        ws[(size_t)(N + n) * B + env] = y[t][r];
+      }
+    }
+  if (live && g == 0) {
+    const float u0 = z[0][0];  // plan.first_input, mpc_balancer.py:307
+    if (first_input) first_input[env] = u0;
+    const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
+    float v = commanded[env];
+    if (fallen || !contact[env]) {
+      v = v + (dt / 0.1f) * (0.f - v);  // :295-301
+    } else {
+      v = v + u0 * dt / 2.0f;  // :305-311
+      v = fminf(fmaxf(v, -P.max_ground_velocity), P.max_ground_velocity);
+    }
+    commanded[env] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __restrict__ ws, float* __restrict__ commanded,
+                                                        const uint8_t* __restrict__ mask) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  if (mask && !mask[e]) return;
+  for (int n = 0; n < 2 * N; ++n) ws[(size_t)n * B + e] = 0.f;
+  commanded[e] = 0.f;  // mpc_balancer.py:232
+}
+
+// ------------------------------------------------------------ host setup
+// Exact zero-order-hold discretisation of the wheeled inverted pendulum and
+// condensing, as qpmpc's WheeledInvertedPendulum.build_mpc_problem + MPCQP do
+// (third-party, restated from the published algorithm).
+inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* minv_perm, std::vector<float>* kx,
+                           std::vector<float>* kv, std::string* why) {
+  const int N = c.nb_timesteps;
+  const double T = c.sampling_period, g = 9.81;
+  const double omega = std::sqrt(g / c.leg_length);
+  const double ch = std::cosh(T * omega), sh = std::sinh(T * omega);
+  const double A[4][4] = {{1, 0, T, 0}, {0, ch, 0, sh / omega}, {0, 0, 1, 0}, {0, omega * sh, 0, ch}};
+  const double Bv[4] = {T * T / 2.0, (1.0 - ch) / g, T, -omega * sh / g};
+  std::vector<double> P((size_t)N * N, 0.0), Kx((size_t)N * 4, 0.0), Kv(N, 0.0);
+  std::vector<double> phi(16, 0.0), psi((size_t)4 * N, 0.0);
+  for (int i = 0; i < 4; ++i) phi[5 * i] = 1.0;
+  for (int i = 0; i < N; ++i) P[(size_t)i * N + i] = c.stage_input_cost_weight;
+  for (int k = 0; k <= N; ++k) {
+    const double w = k == N ? c.terminal_cost_weight : c.stage_state_cost_weight;
+    for (int i = 0; i < N; ++i) {
+      for (int j = 0; j < N; ++j) {
+        double s = 0;
+        for (int l = 0; l < 4; ++l) s += psi[(size_t)N * l + i] * psi[(size_t)N * l + j];
+        P[(size_t)i * N + j] += w * s;
+      }
+      for (int col = 0; col < 4; ++col) {
+        double s = 0;
+        for (int l = 0; l < 4; ++l) s += psi[(size_t)N * l + i] * (phi[4 * l + col] - ((l == 0 && col == 0) ? 1.0 : 0.0));
+        Kx[(size_t)i * 4 + col] += w * s;
+      }
+      Kv[i] -= w * (psi[i] * (k * T) + psi[(size_t)2 * N + i]);
+    }
+    if (k == N) break;
+    std::vector<double> nphi(16), npsi((size_t)4 * N);
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 4; ++j) {
+        double s = 0;
+        for (int l = 0; l < 4; ++l) s += A[i][l] * phi[4 * l + j];
+        nphi[4 * i + j] = s;
+      }
+      for (int j = 0; j < N; ++j) {
+        double s = 0;
+        for (int l = 0; l < 4; ++l) s += A[i][l] * psi[(size_t)N * l + j];
+        npsi[(size_t)N * i + j] = s;
+      }
+      npsi[(size_t)N * i + k] = Bv[i];
+    }
+    phi.swap(nphi);
+    psi.swap(npsi);
+  }
+  // Minv = (P + rho I)^-1 through Cholesky, padded with identity / (1 + rho)
+  std::vector<double> L((size_t)N * N, 0.0), Minv((size_t)N * N, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = P[(size_t)i * N + j] + (i == j ? c.admm_rho : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[(size_t)i * N + k] * L[(size_t)j * N + k];
+      if (i == j) {
+        if (s <= 0) {
+          *why = "P + rho I is not positive definite";
+          return false;
+        }
+        L[(size_t)i * N + i] = std::sqrt(s);
+      } else {
+        L[(size_t)i * N + j] = s / L[(size_t)j * N + j];
+      }
+    }
+  std::vector<double> yv(N), xv(N);
+  for (int col = 0; col < N; ++col) {
+    for (int i = 0; i < N; ++i) {
+      double s = i == col ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= L[(size_t)i * N + k] * yv[k];
+      yv[i] = s / L[(size_t)i * N + i];
+    }
+    for (int i = N - 1; i >= 0; --i) {
+      double s = yv[i];
+      for (int k = i + 1; k < N; ++k) s -= L[(size_t)k * N + i] * xv[k];
+      xv[i] = s / L[(size_t)i * N + i];
+    }
+    for (int r = 0; r < N; ++r) Minv[(size_t)r * N + col] = xv[r];
+  }
+  minv_perm->assign((size_t)np * np, 0.f);
+  kx->assign((size_t)np * 4, 0.f);
+  kv->assign(np, 0.f);
+  for (int p = 0; p < np; ++p) {
+    const int t = p / 16, i = p % 16;
+    const int row = 16 * t + 4 * (i % 4) + i / 4;  // logical row behind permuted row p
+    for (int col = 0; col < np; ++col) {
+      double v;
+      if (row < N && col < N)
+        v = Minv[(size_t)row * N + col];
+      else
+        v = row == col ? 1.0 / (1.0 + c.admm_rho) : 0.0;
+      (*minv_perm)[(size_t)p * np + col] = (float)v;
+    }
+  }
+  for (int n = 0; n < N; ++n) {
+    for (int col = 0; col < 4; ++col) (*kx)[(size_t)n * 4 + col] = (float)Kx[(size_t)n * 4 + col];
+    (*kv)[n] = (float)Kv[n];
+  }
+  return true;
+}
+
+}  // namespace upkie

@@ -1,0 +1,895 @@
+// upkie_hip.hip -- fused env.step() kernels for gfx950 and the C-ABI of
+// include/upkie_hip.h.
+//
+// One launch = one env.step() of B environments: each lane loads its env's
+// state words (struct-of-arrays, coalesced), runs the action map, the
+// nb_substeps x {6 servo torques -> physics substep} loop entirely in
+// registers, and writes state + observation + flags back. Model and config
+// constants are kernel arguments (scalar loads, SGPR-resident).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "dynamics.hpp"
+#include "mpc.hpp"
+
+namespace upkie {
+
+struct DevConfig {
+  int num_envs;
+  int nb_substeps;
+  float dt;
+  float h;  // dt / nb_substeps
+  float kp, kd;
+  float joint_friction[UPKIE_NJ];
+  float fall_pitch, max_ground_velocity, max_yaw_velocity, leg_gain_scale, max_gain_scale;
+  float init_pos[3], init_quat[4], init_linvel[3], init_angvel[3], init_joint[UPKIE_NJ];
+  float rand_roll, rand_pitch, rand_x, rand_z, rand_omega_x, rand_omega_y, rand_linvel[3];
+  unsigned seed_lo, seed_hi;
+  unsigned env_lo, env_hi;  // env_id_offset
+  int autoreset_mode;
+  float agent_gains[4];
+  float agent_clip;
+  float ext_point[3];
+};
+
+enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4 };
+
+// ------------------------------------------------------------------ Philox
+// Philox4x32-10 (Salmon et al., SC'11): counter = (env id lo/hi, episode,
+// stream<<24 | block), key = seed: results do not depend on how envs are sharded.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2 };
+
+__device__ __forceinline__ void philox_uniform4(const DevConfig& C, unsigned env_local, unsigned episode, unsigned stream,
+                                                unsigned block, float (&u)[4]) {
+  unsigned lo = C.env_lo + env_local;
+  unsigned hi = C.env_hi + (lo < C.env_lo ? 1u : 0u);
+  unsigned r[4];
+  philox4x32_10(lo, hi, episode, (stream << 24) | block, C.seed_lo, C.seed_hi, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (float)(r[i] >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float uniform(float low, float high, float u) { return fmaf(high - low, u, low); }
+
+// clamp_and_warn (upkie/utils/clamp.py:42-58): NaN passes through.
+__device__ __forceinline__ float clamp_ref(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Servo {
+  float position, velocity, feedforward_torque, kp_scale, kd_scale, maximum_torque;
+};
+
+// moteus-like torque law, pybullet_backend.py:492-553.
+__device__ __forceinline__ float joint_torque(float q, float qd, const Servo& c, float kp_gain, float kd_gain, float friction) {
+  float kp = c.kp_scale * kp_gain;
+  float kd = c.kd_scale * kd_gain;
+  float torque = c.feedforward_torque;
+  torque += kd * (c.velocity - qd);
+  if (!isnan(c.position)) torque += kp * (c.position - q);
+  if (fabsf(qd) > 1e-3f) torque += qd > 0.f ? -friction : friction;
+  torque = torque < -c.maximum_torque ? -c.maximum_torque : torque;
+  torque = torque > c.maximum_torque ? c.maximum_torque : torque;
+  return torque;
+}
+
+__device__ __forceinline__ void quat_mul(const float (&a)[4], const float (&b)[4], float (&c)[4]) {
+  c[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  c[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  c[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  c[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+// Initial-state sampling: RobotState.sample_state draw order
+// (robot_state.py:182-187) and _reset_robot_state (pybullet_backend.py:234-267).
+__device__ __forceinline__ void sample_init_state(const DevConfig& C, unsigned env_local, unsigned episode, Phys& s) {
+  float u0[4], u1[4], u2[4];
+  philox_uniform4(C, env_local, episode, STREAM_RESET, 0, u0);
+  philox_uniform4(C, env_local, episode, STREAM_RESET, 1, u1);
+  philox_uniform4(C, env_local, episode, STREAM_RESET, 2, u2);
+  float wx = uniform(-C.rand_omega_x, C.rand_omega_x, u0[0]);
+  float wy = uniform(-C.rand_omega_y, C.rand_omega_y, u0[1]);
+  float wz = uniform(0.f, 0.f, u0[2]);
+  float vx = uniform(-C.rand_linvel[0], C.rand_linvel[0], u0[3]);
+  float vy = uniform(-C.rand_linvel[1], C.rand_linvel[1], u1[0]);
+  float vz = uniform(-C.rand_linvel[2], C.rand_linvel[2], u1[1]);
+  float yaw = uniform(0.f, 0.f, u1[2]);
+  float pitch = uniform(-C.rand_pitch, C.rand_pitch, u1[3]);
+  float roll = uniform(-C.rand_roll, C.rand_roll, u2[0]);
+  float px = uniform(-C.rand_x, C.rand_x, u2[1]);
+  float py = uniform(0.f, 0.f, u2[2]);
+  float pz = uniform(0.f, C.rand_z, u2[3]);
+  // ScipyRotation.from_euler("ZYX", [yaw, pitch, roll]) = Rz Ry Rx
+  float sy, cy, sp, cp, sr, cr;
+  sincosf(0.5f * yaw, &sy, &cy);
+  sincosf(0.5f * pitch, &sp, &cp);
+  sincosf(0.5f * roll, &sr, &cr);
+  float qz[4] = {cy, 0.f, 0.f, sy}, qy[4] = {cp, 0.f, sp, 0.f}, qx[4] = {cr, sr, 0.f, 0.f};
+  float t[4], qr[4], q0[4] = {C.init_quat[0], C.init_quat[1], C.init_quat[2], C.init_quat[3]}, q[4];
+  quat_mul(qz, qy, t);
+  quat_mul(t, qx, qr);
+  quat_mul(q0, qr, q);  // robot_state.py:158-160
+  s.qw = q[0]; s.qx = q[1]; s.qy = q[2]; s.qz = q[3];
+  s.pos = v3(C.init_pos[0] + px, C.init_pos[1] + py, C.init_pos[2] + pz);
+  s.linvel = v3(C.init_linvel[0] + vx, C.init_linvel[1] + vy, C.init_linvel[2] + vz);
+  // body-frame omega handed over as a world-frame vector, pybullet_backend.py:253-258
+  s.angvel = v3(C.init_angvel[0] + wx, C.init_angvel[1] + wy, C.init_angvel[2] + wz);
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    s.q[j] = C.init_joint[j];
+    s.qd[j] = 0.f;  // resetJointState zeroes velocities, :261-267
+  }
+}
+
+// Gyropod observation, upkie_gyropod.py:186-214 on top of
+// pybullet_backend.py:333-368,476-490.
+__device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phys& s, float yaw, float yawvel, float (&obs)[6]) {
+  float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+  float r01 = 2.f * (qx * qy - qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r21 = 2.f * (qy * qz + qx * qw);
+  float x = 2.f * (qw * qy - qz * qx);
+  x = fminf(fmaxf(x, -1.f), 1.f);
+  float signed_radius = M.left_sign * M.wheel_radius;
+  obs[0] = 0.5f * (s.q[2] - s.q[5]) * signed_radius;
+  obs[1] = asinf(x);
+  obs[2] = yaw;
+  obs[3] = 0.5f * (s.qd[2] - s.qd[5]) * signed_radius;
+  obs[4] = r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z;
+  obs[5] = yawvel;
+}
+
+template <int MODE, bool RAND>
+__global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float* __restrict__ state,
+                                                   const float* __restrict__ act, float* __restrict__ obs,
+                                                   float* __restrict__ reward, uint8_t* __restrict__ terminated,
+                                                   uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
+                                                   const float* __restrict__ inertia_scale,
+                                                   const float* __restrict__ ext_force) {
+  const int B = C.num_envs;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  float* st = state + e;
+#define SW(w) st[(size_t)(w) * B]
+
+  // ---- load ----------------------------------------------------------
+  Phys s;
+  s.pos = v3(SW(UPKIE_S_POS), SW(UPKIE_S_POS + 1), SW(UPKIE_S_POS + 2));
+  s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
+  s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
+  s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    s.q[j] = SW(UPKIE_S_Q + j);
+    s.qd[j] = SW(UPKIE_S_QD + j);
+  }
+  float legref[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) legref[l] = SW(UPKIE_S_LEGREF + l);
+  float yaw = 0.f, yawvel = 0.f;
+  if (MODE == MODE_GYROPOD) {
+    yaw = SW(UPKIE_S_YAW);
+    yawvel = SW(UPKIE_S_YAWVEL);
+  }
+  float scale[UPKIE_NB];
+  V3 fext = v3(0.f, 0.f, 0.f);
+  bool has_ext = false;
+  if (RAND) {
+    if (inertia_scale) {
+#pragma unroll
+      for (int i = 0; i < UPKIE_NB; ++i) scale[i] = inertia_scale[(size_t)i * B + e];
+    } else {
+#pragma unroll
+      for (int i = 0; i < UPKIE_NB; ++i) scale[i] = 1.f;
+    }
+    if (ext_force) {
+      has_ext = true;
+      fext = v3(ext_force[e], ext_force[(size_t)B + e], ext_force[(size_t)2 * B + e]);
+    }
+  }
+  const V3 ext_point = v3(C.ext_point[0], C.ext_point[1], C.ext_point[2]);
+
+  bool do_reset;
+  if (MODE == MODE_RESET) {
+    do_reset = mask ? mask[e] != 0 : true;
+  } else {
+    do_reset = C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && SW(UPKIE_S_DONE) != 0.f;
+  }
+
+  if (MODE == MODE_RESET && !do_reset) {
+    // untouched env: only report its current observation
+    if (obs) {
+      float o6[6];
+      gyropod_observation(M, s, SW(UPKIE_S_YAW), SW(UPKIE_S_YAWVEL), o6);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = o6[i];
+    }
+    return;
+  }
+
+  // ---- action map ------------------------------------------------------
+  Servo cmd[UPKIE_NJ];
+  float a0 = 0.f, a1 = 0.f;
+  unsigned episode = 0;
+  if (do_reset) {
+    episode = (unsigned)SW(UPKIE_S_EPISODE);
+    sample_init_state(C, (unsigned)e, episode, s);
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) cmd[j] = Servo{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // no motor torque, :228
+  } else if (MODE == MODE_SERVOS) {
+    // UpkieServos.get_spine_action, upkie_servos.py:316-344
+    const float* a = act + (size_t)36 * e;
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      float eff = M.joint_effort[j], vel = M.joint_velocity[j];
+      cmd[j].position = clamp_ref(a[6 * j + 0], M.joint_lower[j], M.joint_upper[j]);
+      cmd[j].velocity = clamp_ref(a[6 * j + 1], -vel, vel);
+      cmd[j].feedforward_torque = clamp_ref(a[6 * j + 2], -eff, eff);
+      cmd[j].kp_scale = clamp_ref(a[6 * j + 3], 0.f, C.max_gain_scale);
+      cmd[j].kd_scale = clamp_ref(a[6 * j + 4], 0.f, C.max_gain_scale);
+      cmd[j].maximum_torque = clamp_ref(a[6 * j + 5], 0.f, eff);
+    }
+  } else if (MODE != MODE_RESET) {
+    if (MODE == MODE_PENDULUM) {
+      a0 = act[e];  // upkie_pendulum.py:139: [action[0], 0.0]
+    } else if (MODE == MODE_PENDULUM_AGENT) {
+      // README.md:62-64: action = gains . observation, clipped
+      const float4 o = reinterpret_cast<const float4*>(obs)[e];
+      a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
+      a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
+    } else {
+      a0 = act[2 * (size_t)e];
+      a1 = act[2 * (size_t)e + 1];
+    }
+    // UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331
+    float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
+    float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
+    float wheel_velocity = v / M.wheel_radius;
+    float left = M.left_sign * wheel_velocity, right = -M.left_sign * wheel_velocity;
+    float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) / M.wheel_radius;
+    left = fmaf(yaw_to_wheel, yawd, left);
+    right = fmaf(yaw_to_wheel, yawd, right);
+    const float alpha = C.dt / 1.0f;  // filters.py:77, cutoff_period = 1 s
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int j = (l < 2) ? l : l + 1;  // lh, lk, rh, rk
+      legref[l] = legref[l] + alpha * (0.f - legref[l]);
+      // then UpkieServos clamps every field, upkie_servos.py:331-342
+      cmd[j].position = clamp_ref(legref[l], M.joint_lower[j], M.joint_upper[j]);
+      cmd[j].velocity = 0.f;
+      cmd[j].feedforward_torque = 0.f;
+      cmd[j].kp_scale = clamp_ref(C.leg_gain_scale, 0.f, C.max_gain_scale);
+      cmd[j].kd_scale = cmd[j].kp_scale;
+      cmd[j].maximum_torque = M.joint_effort[j];
+    }
+#pragma unroll
+    for (int wi = 0; wi < 2; ++wi) {
+      const int j = 3 * wi + 2;
+      cmd[j].position = NAN;
+      cmd[j].velocity = clamp_ref(wi == 0 ? left : right, -M.joint_velocity[j], M.joint_velocity[j]);
+      cmd[j].feedforward_torque = 0.f;
+      cmd[j].kp_scale = 1.f;
+      cmd[j].kd_scale = 1.f;
+      cmd[j].maximum_torque = M.joint_effort[j];
+    }
+  }
+
+  // ---- PyBulletBackend.step: substeps of {torques; stepSimulation} -------
+  float tau[UPKIE_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool contact = false;
+  const int nsub = do_reset ? 1 : C.nb_substeps;
+  for (int sub = 0; sub < C.nb_substeps; ++sub) {
+    if (sub >= nsub) break;
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) tau[j] = joint_torque(s.q[j], s.qd[j], cmd[j], C.kp, C.kd, C.joint_friction[j]);
+    contact = physics_substep(M, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
+  }
+
+  // ---- wrapper post-processing -----------------------------------------
+  bool fallen = false;
+  float obs6[6];
+  if (do_reset) {
+    // upkie_gyropod.py:236-240
+    legref[0] = s.q[0]; legref[1] = s.q[1]; legref[2] = s.q[3]; legref[3] = s.q[4];
+    yaw = 0.f;
+    yawvel = 0.f;
+    SW(UPKIE_S_YAW) = 0.f;
+    SW(UPKIE_S_YAWVEL) = 0.f;
+    SW(UPKIE_S_MPC_V) = 0.f;
+    SW(UPKIE_S_SE2_X) = 0.f;
+    SW(UPKIE_S_SE2_Y) = 0.f;
+    SW(UPKIE_S_EPISODE) = (float)(episode + 1);
+    SW(UPKIE_S_DONE) = 0.f;
+    gyropod_observation(M, s, yaw, yawvel, obs6);
+  } else {
+    if (MODE == MODE_GYROPOD) {
+      yaw = fmaf(a1, C.dt, yaw);  // upkie_gyropod.py:383-385 (unclamped action)
+      yawvel = a1;
+      SW(UPKIE_S_YAW) = yaw;
+      SW(UPKIE_S_YAWVEL) = yawvel;
+    }
+    gyropod_observation(M, s, yaw, yawvel, obs6);
+    if (MODE != MODE_SERVOS) {
+      fallen = fabsf(obs6[1]) > C.fall_pitch;  // upkie_gyropod.py:344-345
+      if (fallen) SW(UPKIE_S_DONE) = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) SW(UPKIE_S_TORQUE + j) = tau[j];  // pybullet_backend.py:293
+  }
+
+  // ---- store -------------------------------------------------------------
+  SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
+  SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
+  SW(UPKIE_S_LINVEL) = s.linvel.x; SW(UPKIE_S_LINVEL + 1) = s.linvel.y; SW(UPKIE_S_LINVEL + 2) = s.linvel.z;
+  SW(UPKIE_S_ANGVEL) = s.angvel.x; SW(UPKIE_S_ANGVEL + 1) = s.angvel.y; SW(UPKIE_S_ANGVEL + 2) = s.angvel.z;
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    SW(UPKIE_S_Q + j) = s.q[j];
+    SW(UPKIE_S_QD + j) = s.qd[j];
+  }
+  if (MODE != MODE_SERVOS) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) SW(UPKIE_S_LEGREF + l) = legref[l];
+  }
+  SW(UPKIE_S_CONTACT) = contact ? 1.f : 0.f;
+
+  if (MODE == MODE_RESET) {
+    if (obs) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = obs6[i];
+    }
+    return;
+  }
+  if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
+    // _PENDULUM_OBS_INDICES = [1, 0, 4, 3], upkie_pendulum.py:17
+    reinterpret_cast<float4*>(obs)[e] = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+  } else if (MODE == MODE_GYROPOD) {
+    float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
+    o2[0] = make_float2(obs6[0], obs6[1]);
+    o2[1] = make_float2(obs6[2], obs6[3]);
+    o2[2] = make_float2(obs6[4], obs6[5]);
+  } else {
+    // upkie_servos.py:288-306 / pybullet_backend.py:448-474
+    float* o = obs + (size_t)30 * e;
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      o[5 * j + 0] = s.q[j];
+      o[5 * j + 1] = s.qd[j];
+      o[5 * j + 2] = do_reset ? SW(UPKIE_S_TORQUE + j) : tau[j];
+      o[5 * j + 3] = 42.0f;
+      o[5 * j + 4] = 18.0f;
+    }
+  }
+  reward[e] = 0.f;  // upkie_env.py:230
+  terminated[e] = fallen ? 1 : 0;
+  truncated[e] = 0;
+#undef SW
+}
+
+// Full spine observation, pybullet_backend.py:313-490.
+struct ObsPtrs {
+  float* pitch;
+  float* angular_velocity;
+  float* linear_velocity;
+  float* rotation_base_to_world;
+  uint8_t* floor_contact;
+  float* imu_orientation;
+  float* imu_angular_velocity;
+  float* imu_linear_acceleration;
+  float* imu_raw_linear_acceleration;
+  float* servo;
+  float* wheel_odometry;
+};
+
+__device__ __forceinline__ void mat3_mul(const float (&A)[9], const float (&Bm)[9], float (&Cm)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Cm[3 * i + j] = A[3 * i] * Bm[j] + A[3 * i + 1] * Bm[3 + j] + A[3 * i + 2] * Bm[6 + j];
+}
+
+__global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, float* __restrict__ state, ObsPtrs out,
+                                                      int update_imu) {
+  const int B = C.num_envs;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  float* st = state + e;
+#define SW(w) st[(size_t)(w) * B]
+  float qw = SW(UPKIE_S_QUAT), qx = SW(UPKIE_S_QUAT + 1), qy = SW(UPKIE_S_QUAT + 2), qz = SW(UPKIE_S_QUAT + 3);
+  float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qz * qw), 2.f * (qw * qy + qx * qz),
+                2.f * (qx * qy + qz * qw), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qx * qw),
+                2.f * (qx * qz - qy * qw), 2.f * (qy * qz + qx * qw), 1.f - 2.f * (qx * qx + qy * qy)};
+  float v[3] = {SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2)};
+  float w[3] = {SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2)};
+  float wb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wb[i] = R[i] * w[0] + R[3 + i] * w[1] + R[6 + i] * w[2];
+  if (out.pitch) {
+    float x = fminf(fmaxf(2.f * (qw * qy - qz * qx), -1.f), 1.f);
+    out.pitch[e] = asinf(x);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (out.angular_velocity) out.angular_velocity[3 * (size_t)e + d] = wb[d];
+    if (out.linear_velocity) out.linear_velocity[3 * (size_t)e + d] = v[d];
+  }
+  if (out.rotation_base_to_world) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.rotation_base_to_world[9 * (size_t)e + i] = R[i];
+  }
+  if (out.floor_contact) out.floor_contact[e] = SW(UPKIE_S_CONTACT) != 0.f ? 1 : 0;
+  {
+    // IMU block, pybullet_backend.py:370-430
+    float Rbi_t[9], Riw[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rbi_t[3 * i + j] = M.rot_base_to_imu[3 * j + i];
+    mat3_mul(R, Rbi_t, Riw);
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = R[3 * i] * M.imu_pos[0] + R[3 * i + 1] * M.imu_pos[1] + R[3 * i + 2] * M.imu_pos[2];
+    float v_imu[3] = {v[0] + w[1] * r[2] - w[2] * r[1], v[1] + w[2] * r[0] - w[0] * r[2], v[2] + w[0] * r[1] - w[1] * r[0]};
+    // rotation_world_to_ars = diag(1, -1, -1), :385
+    float m[9] = {Riw[0], Riw[1], Riw[2], -Riw[3], -Riw[4], -Riw[5], -Riw[6], -Riw[7], -Riw[8]};
+    // scipy Rotation.from_matrix -> quaternion (rotations.py:16-33)
+    float dec[4] = {m[0], m[4], m[8], m[0] + m[4] + m[8]};
+    int choice = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (dec[i] > dec[choice]) choice = i;
+    float q[4];  // x y z w
+    if (choice == 3) {
+      q[0] = m[7] - m[5]; q[1] = m[2] - m[6]; q[2] = m[3] - m[1]; q[3] = 1.f + dec[3];
+    } else if (choice == 0) {
+      q[0] = 1.f - dec[3] + 2.f * m[0]; q[1] = m[3] + m[1]; q[2] = m[6] + m[2]; q[3] = m[7] - m[5];
+    } else if (choice == 1) {
+      q[1] = 1.f - dec[3] + 2.f * m[4]; q[2] = m[7] + m[5]; q[0] = m[1] + m[3]; q[3] = m[2] - m[6];
+    } else {
+      q[2] = 1.f - dec[3] + 2.f * m[8]; q[0] = m[2] + m[6]; q[1] = m[5] + m[7]; q[3] = m[3] - m[1];
+    }
+    float qn = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float a_w[3], a_i[3], p_i[3], w_i[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a_w[d] = (v_imu[d] - SW(UPKIE_S_IMUVEL + d)) / C.dt;
+    if (update_imu) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) SW(UPKIE_S_IMUVEL + d) = v_imu[d];
+    }
+    float pw[3] = {a_w[0], a_w[1], a_w[2] + 9.81f};  // :418
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      w_i[i] = Riw[i] * w[0] + Riw[3 + i] * w[1] + Riw[6 + i] * w[2];
+      a_i[i] = Riw[i] * a_w[0] + Riw[3 + i] * a_w[1] + Riw[6 + i] * a_w[2];
+      p_i[i] = Riw[i] * pw[0] + Riw[3 + i] * pw[1] + Riw[6 + i] * pw[2];
+    }
+    if (out.imu_orientation) {
+      out.imu_orientation[4 * (size_t)e + 0] = q[3] * qn;
+      out.imu_orientation[4 * (size_t)e + 1] = q[0] * qn;
+      out.imu_orientation[4 * (size_t)e + 2] = q[1] * qn;
+      out.imu_orientation[4 * (size_t)e + 3] = q[2] * qn;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (out.imu_angular_velocity) out.imu_angular_velocity[3 * (size_t)e + d] = w_i[d];
+      if (out.imu_linear_acceleration) out.imu_linear_acceleration[3 * (size_t)e + d] = a_i[d];
+      if (out.imu_raw_linear_acceleration) out.imu_raw_linear_acceleration[3 * (size_t)e + d] = p_i[d];
+    }
+  }
+  float ql = SW(UPKIE_S_Q + 2), qr = SW(UPKIE_S_Q + 5), qdl = SW(UPKIE_S_QD + 2), qdr = SW(UPKIE_S_QD + 5);
+  if (out.servo) {
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      float* o = out.servo + 30 * (size_t)e + 5 * j;
+      o[0] = SW(UPKIE_S_Q + j);
+      o[1] = SW(UPKIE_S_QD + j);
+      o[2] = SW(UPKIE_S_TORQUE + j);
+      o[3] = 42.0f;
+      o[4] = 18.0f;
+    }
+  }
+  if (out.wheel_odometry) {
+    float sr = M.left_sign * M.wheel_radius;
+    out.wheel_odometry[2 * (size_t)e] = 0.5f * (ql - qr) * sr;
+    out.wheel_odometry[2 * (size_t)e + 1] = 0.5f * (qdl - qdr) * sr;
+  }
+#undef SW
+}
+
+// inertia_scale[body][env] = 1 + U(-v, v), pybullet_backend.py:588-594.
+__global__ __launch_bounds__(64) void inertia_scale_kernel(DevConfig C, float* __restrict__ scale, float variation) {
+  const int B = C.num_envs;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  float u0[4], u1[4];
+  philox_uniform4(C, (unsigned)e, 0u, STREAM_INERTIA, 0, u0);
+  philox_uniform4(C, (unsigned)e, 0u, STREAM_INERTIA, 1, u1);
+#pragma unroll
+  for (int i = 0; i < UPKIE_NB; ++i) {
+    float u = i < 4 ? u0[i] : u1[i - 4];
+    scale[(size_t)i * B + e] = 1.f + uniform(-variation, variation, u);
+  }
+}
+
+}  // namespace upkie
+
+// =========================================================== C-ABI (host)
+using namespace upkie;
+
+struct UpkieSim {
+  DevModel model;
+  DevConfig config;
+  const float* inertia_scale = nullptr;
+  const float* ext_force = nullptr;
+  std::string error;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(UpkieSim* sim, int status, const std::string& msg) {
+  if (sim) sim->error = msg;
+  g_create_error = msg;
+  return status;
+}
+
+static int check_hip(UpkieSim* sim, hipError_t err, const char* what) {
+  if (err == hipSuccess) return UPKIE_OK;
+  return fail(sim, UPKIE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+extern "C" int upkie_hip_device_count(void) {
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
+  std::memset(d, 0, sizeof(*d));
+  for (int i = 0; i < UPKIE_NB; ++i) {
+    d->mass[i] = (float)m->mass[i];
+    if (!(m->mass[i] > 0.0)) {
+      *why = "body masses must be positive";
+      return false;
+    }
+    for (int k = 0; k < 3; ++k) d->com[i][k] = (float)m->com[i][k];
+    for (int k = 0; k < 6; ++k) d->inertia[i][k] = (float)m->inertia[i][k];
+  }
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    const double* a = m->joint_axis[j];
+    if (std::fabs(a[0]) > 1e-6 || std::fabs(a[2]) > 1e-6 || std::fabs(std::fabs(a[1]) - 1.0) > 1e-6) {
+      *why = "joint axes must be lateral (+-y of the base frame at zero configuration)";
+      return false;
+    }
+    d->joint_sign[j] = a[1] > 0 ? 1.f : -1.f;
+    for (int k = 0; k < 3; ++k) d->joint_pos[j][k] = (float)m->joint_pos[j][k];
+    d->joint_lower[j] = (float)m->joint_lower[j];
+    d->joint_upper[j] = (float)m->joint_upper[j];
+    d->joint_effort[j] = (float)m->joint_effort[j];
+    d->joint_velocity[j] = (float)m->joint_velocity[j];
+    d->joint_damping[j] = (float)m->joint_damping[j];
+  }
+  d->wheel_radius = (float)m->wheel_radius;
+  bool axisym = true;
+  for (int w = 0; w < 2; ++w) {
+    if (std::fabs(m->wheel_center[w][0]) > 1e-9 || std::fabs(m->wheel_center[w][2]) > 1e-9) {
+      *why = "tire centres must lie on the wheel axis";
+      return false;
+    }
+    for (int k = 0; k < 3; ++k) d->wheel_center[w][k] = (float)m->wheel_center[w][k];
+    int b = 3 * w + 3;
+    const double* I = m->inertia[b];
+    const double* c = m->com[b];
+    if (std::fabs(c[0]) > 1e-9 || std::fabs(c[2]) > 1e-9 || std::fabs(I[0] - I[2]) > 1e-12 || std::fabs(I[3]) > 1e-12 ||
+        std::fabs(I[4]) > 1e-12 || std::fabs(I[5]) > 1e-12)
+      axisym = false;
+  }
+  d->wheel_axisymmetric = axisym ? 1 : 0;
+  d->wheel_base = (float)m->wheel_base;
+  d->left_sign = (float)m->left_sign;
+  for (int k = 0; k < 3; ++k) d->imu_pos[k] = (float)m->imu_pos[k];
+  for (int k = 0; k < 9; ++k) d->rot_base_to_imu[k] = (float)m->rot_base_to_imu[k];
+  d->gravity = (float)m->gravity;
+  d->contact_stiffness = (float)m->contact_stiffness;
+  d->contact_damping = (float)m->contact_damping;
+  d->friction_mu = (float)m->friction_mu;
+  d->contact_breaking_threshold = (float)m->contact_breaking_threshold;
+  d->base_linear_damping = (float)m->base_linear_damping;
+  d->base_angular_damping = (float)m->base_angular_damping;
+  d->max_joint_velocity = (float)m->max_joint_velocity;
+  d->pgs_iterations = m->pgs_iterations;
+  if (m->enforce_joint_limits) {
+    *why = "enforce_joint_limits is not supported by the HIP path yet";
+    return false;
+  }
+  return true;
+}
+
+static bool convert_config(const UpkieSimConfig* c, DevConfig* d, std::string* why) {
+  std::memset(d, 0, sizeof(*d));
+  if (c->num_envs <= 0 || c->nb_substeps <= 0 || !(c->dt > 0.0)) {
+    *why = "num_envs, nb_substeps and dt must be positive";
+    return false;
+  }
+  // low_pass_filter asserts alpha < 0.5 (filters.py:78-79)
+  if (c->dt / 1.0 >= 0.5) {
+    *why = "dt too large for the leg low-pass filter (alpha >= 0.5)";
+    return false;
+  }
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    if (c->torque_control_noise[j] > 1e-10 || c->torque_measurement_noise[j] > 1e-10) {
+      *why = "torque noise is not supported by the HIP path yet";
+      return false;
+    }
+    d->joint_friction[j] = (float)c->joint_friction[j];
+    d->init_joint[j] = (float)c->init_joint[j];
+  }
+  d->num_envs = c->num_envs;
+  d->nb_substeps = c->nb_substeps;
+  d->dt = (float)c->dt;
+  d->h = (float)(c->dt / c->nb_substeps);
+  d->kp = (float)c->torque_control_kp;
+  d->kd = (float)c->torque_control_kd;
+  d->fall_pitch = (float)c->fall_pitch;
+  d->max_ground_velocity = (float)c->max_ground_velocity;
+  d->max_yaw_velocity = (float)c->max_yaw_velocity;
+  d->leg_gain_scale = (float)c->leg_gain_scale;
+  d->max_gain_scale = (float)c->max_gain_scale;
+  for (int k = 0; k < 3; ++k) {
+    d->init_pos[k] = (float)c->init_pos[k];
+    d->init_linvel[k] = (float)c->init_linvel[k];
+    d->init_angvel[k] = (float)c->init_angvel[k];
+    d->rand_linvel[k] = (float)c->rand_linvel[k];
+  }
+  double qn = 0;
+  for (int k = 0; k < 4; ++k) qn += c->init_quat[k] * c->init_quat[k];
+  if (std::fabs(qn - 1.0) > 1e-5) {  // rotations.py:50-51
+    *why = "init_quat is not normalized";
+    return false;
+  }
+  for (int k = 0; k < 4; ++k) d->init_quat[k] = (float)c->init_quat[k];
+  d->rand_roll = (float)c->rand_roll;
+  d->rand_pitch = (float)c->rand_pitch;
+  d->rand_x = (float)c->rand_x;
+  d->rand_z = (float)c->rand_z;
+  d->rand_omega_x = (float)c->rand_omega_x;
+  d->rand_omega_y = (float)c->rand_omega_y;
+  d->seed_lo = (unsigned)(c->seed & 0xffffffffu);
+  d->seed_hi = (unsigned)(c->seed >> 32);
+  d->env_lo = (unsigned)((uint64_t)c->env_id_offset & 0xffffffffu);
+  d->env_hi = (unsigned)((uint64_t)c->env_id_offset >> 32);
+  d->autoreset_mode = c->autoreset_mode;
+  for (int k = 0; k < 4; ++k) d->agent_gains[k] = (float)c->agent_gains[k];
+  d->agent_clip = (float)c->agent_clip;
+  return true;
+}
+
+extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* model, UpkieSim** out) {
+  if (!config || !model || !out) return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (upkie_hip_device_count() <= 0) return fail(nullptr, UPKIE_ERR_NO_DEVICE, "no HIP device visible");
+  UpkieSim* sim = new (std::nothrow) UpkieSim();
+  if (!sim) return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "out of host memory");
+  std::string why;
+  if (!convert_model(model, &sim->model, &why)) {
+    delete sim;
+    return fail(nullptr, UPKIE_ERR_UNSUPPORTED_MODEL, why);
+  }
+  if (!convert_config(config, &sim->config, &why)) {
+    delete sim;
+    return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
+  }
+  *out = sim;
+  return UPKIE_OK;
+}
+
+extern "C" int upkie_sim_destroy(UpkieSim* sim) {
+  delete sim;
+  return UPKIE_OK;
+}
+
+extern "C" const char* upkie_sim_last_error(const UpkieSim* sim) {
+  return sim ? sim->error.c_str() : g_create_error.c_str();
+}
+
+extern "C" int64_t upkie_sim_state_bytes(const UpkieSim* sim) {
+  return sim ? (int64_t)UPKIE_STATE_WORDS * sim->config.num_envs * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_scale, const float* ext_force,
+                                           const double ext_point[3]) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  sim->inertia_scale = inertia_scale;
+  sim->ext_force = ext_force;
+  for (int k = 0; k < 3; ++k) sim->config.ext_point[k] = ext_point ? (float)ext_point[k] : 0.f;
+  return UPKIE_OK;
+}
+
+static dim3 grid_for(int B) { return dim3((unsigned)((B + 63) / 64)); }
+
+extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale, double inertia_variation, void* stream) {
+  if (!sim || !inertia_scale) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(inertia_scale_kernel, grid_for(sim->config.num_envs), dim3(64), 0, (hipStream_t)stream, sim->config,
+                     inertia_scale, (float)inertia_variation);
+  return check_hip(sim, hipGetLastError(), "inertia_scale_kernel");
+}
+
+template <int MODE>
+static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
+                       uint8_t* truncated, const uint8_t* mask, void* stream) {
+  if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (MODE != MODE_RESET && (!obs || !reward || !terminated || !truncated))
+    return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
+  if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS) && !act)
+    return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
+  const bool rnd = sim->inertia_scale || sim->ext_force;
+  dim3 grid = grid_for(sim->config.num_envs), block(64);
+  if (rnd) {
+    hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
+                       reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force);
+  } else {
+    hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
+                       reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr);
+  }
+  return check_hip(sim, hipGetLastError(), "step_kernel");
+}
+
+extern "C" int upkie_sim_reset(UpkieSim* sim, float* state, const uint8_t* mask, float* obs6, void* stream) {
+  return launch_step<MODE_RESET>(sim, state, nullptr, obs6, nullptr, nullptr, nullptr, mask, stream);
+}
+
+extern "C" int upkie_sim_step_pendulum(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
+                                       uint8_t* terminated, uint8_t* truncated, void* stream) {
+  return launch_step<MODE_PENDULUM>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_step_pendulum_agent(UpkieSim* sim, float* state, float* obs, float* reward, uint8_t* terminated,
+                                             uint8_t* truncated, void* stream) {
+  return launch_step<MODE_PENDULUM_AGENT>(sim, state, nullptr, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
+                                      uint8_t* terminated, uint8_t* truncated, void* stream) {
+  return launch_step<MODE_GYROPOD>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
+                                     uint8_t* terminated, uint8_t* truncated, void* stream) {
+  return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineObservation* out, int update_imu, void* stream) {
+  if (!sim || !state || !out) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  ObsPtrs p;
+  p.pitch = out->pitch;
+  p.angular_velocity = out->angular_velocity;
+  p.linear_velocity = out->linear_velocity;
+  p.rotation_base_to_world = out->rotation_base_to_world;
+  p.floor_contact = out->floor_contact;
+  p.imu_orientation = out->imu_orientation;
+  p.imu_angular_velocity = out->imu_angular_velocity;
+  p.imu_linear_acceleration = out->imu_linear_acceleration;
+  p.imu_raw_linear_acceleration = out->imu_raw_linear_acceleration;
+  p.servo = out->servo;
+  p.wheel_odometry = out->wheel_odometry;
+  hipLaunchKernelGGL(observe_kernel, grid_for(sim->config.num_envs), dim3(64), 0, (hipStream_t)stream, sim->model, sim->config,
+                     state, p, update_imu);
+  return check_hip(sim, hipGetLastError(), "observe_kernel");
+}
+
+// ------------------------------------------------------------------- MPC
+struct UpkieMpc {
+  MpcDev dev;
+  int tiles = 0;
+  float* d_minv = nullptr;
+  float* d_kx = nullptr;
+  float* d_kv = nullptr;
+  std::string error;
+};
+
+static int mpc_fail(UpkieMpc* mpc, int status, const std::string& msg) {
+  if (mpc) mpc->error = msg;
+  g_create_error = msg;
+  return status;
+}
+
+extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
+  if (!config || !out) return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (config->num_envs <= 0 || config->nb_timesteps <= 0 || config->admm_iterations <= 0 || !(config->admm_rho > 0.0))
+    return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "num_envs, nb_timesteps, admm_iterations, admm_rho must be positive");
+  if (config->nb_timesteps > 64)
+    return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "nb_timesteps > 64 is not supported by the HIP path");
+  if (upkie_hip_device_count() <= 0) return mpc_fail(nullptr, UPKIE_ERR_NO_DEVICE, "no HIP device visible");
+  UpkieMpc* mpc = new (std::nothrow) UpkieMpc();
+  if (!mpc) return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "out of host memory");
+  mpc->tiles = (config->nb_timesteps + 15) / 16;
+  const int np = 16 * mpc->tiles;
+  std::vector<float> minv, kx, kv;
+  std::string why;
+  if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why)) {
+    delete mpc;
+    return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
+  }
+  hipError_t err = hipMalloc(&mpc->d_minv, minv.size() * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&mpc->d_kx, kx.size() * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&mpc->d_kv, kv.size() * sizeof(float));
+  if (err == hipSuccess) err = hipMemcpy(mpc->d_minv, minv.data(), minv.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(mpc->d_kx, kx.data(), kx.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(mpc->d_kv, kv.data(), kv.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    std::string msg = std::string("hipMalloc/hipMemcpy: ") + hipGetErrorString(err);
+    upkie_mpc_destroy(mpc);
+    return mpc_fail(nullptr, UPKIE_ERR_HIP, msg);
+  }
+  mpc->dev.minv = mpc->d_minv;
+  mpc->dev.kx = mpc->d_kx;
+  mpc->dev.kv = mpc->d_kv;
+  mpc->dev.num_envs = config->num_envs;
+  mpc->dev.n = config->nb_timesteps;
+  mpc->dev.iterations = config->admm_iterations;
+  mpc->dev.rho = (float)config->admm_rho;
+  mpc->dev.bound = (float)config->max_ground_accel;
+  mpc->dev.max_ground_velocity = (float)config->max_ground_velocity;
+  mpc->dev.fall_pitch = (float)config->fall_pitch;
+  *out = mpc;
+  return UPKIE_OK;
+}
+
+extern "C" int upkie_mpc_destroy(UpkieMpc* mpc) {
+  if (!mpc) return UPKIE_OK;
+  if (mpc->d_minv) (void)hipFree(mpc->d_minv);
+  if (mpc->d_kx) (void)hipFree(mpc->d_kx);
+  if (mpc->d_kv) (void)hipFree(mpc->d_kv);
+  delete mpc;
+  return UPKIE_OK;
+}
+
+extern "C" const char* upkie_mpc_last_error(const UpkieMpc* mpc) { return mpc ? mpc->error.c_str() : g_create_error.c_str(); }
+
+extern "C" int64_t upkie_mpc_workspace_bytes(const UpkieMpc* mpc) {
+  return mpc ? (int64_t)2 * mpc->dev.n * mpc->dev.num_envs * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded_velocity, const uint8_t* mask, void* stream) {
+  if (!mpc || !workspace || !commanded_velocity) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(mpc_reset_kernel, grid_for(mpc->dev.num_envs), dim3(64), 0, (hipStream_t)stream, mpc->dev.num_envs,
+                     mpc->dev.n, workspace, commanded_velocity, mask);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));
+}
+
+extern "C" int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0, const float* target_velocity,
+                              const uint8_t* contact, double dt, float* commanded_velocity, float* first_input, void* stream) {
+  if (!mpc || !workspace || !x0 || !target_velocity || !contact || !commanded_velocity)
+    return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (!(dt / 0.1 < 0.5)) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
+  dim3 grid((unsigned)((mpc->dev.num_envs + 15) / 16)), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  switch (mpc->tiles) {
+    case 1: hipLaunchKernelGGL(mpc_step_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
+    case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
+    case 3: hipLaunchKernelGGL(mpc_step_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
+    default: hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
+  }
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));
+}

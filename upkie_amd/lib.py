@@ -1,0 +1,164 @@
+"""Loader of the HIP shared library behind ``include/upkie_hip.h``.
+
+The product path has NO CPU fallback: if the library is missing or no HIP
+device is visible, calls fail loudly with `UpkieHipError` /
+`MissingOptionalDependency`-style messages rather than computing elsewhere.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+from .exceptions import UpkieRuntimeError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libupkie_hip.so")
+SOURCES = [
+    os.path.join(_HERE, "csrc", "upkie_hip.hip"),
+    os.path.join(_HERE, "csrc", "dynamics.hpp"),
+    os.path.join(_HERE, "csrc", "mpc.hpp"),
+    os.path.join(_HERE, "..", "include", "upkie_hip.h"),
+]
+
+## Every symbol `include/upkie_hip.h` declares.
+EXPORTED_SYMBOLS = (
+    "upkie_hip_device_count",
+    "upkie_sim_create",
+    "upkie_sim_destroy",
+    "upkie_sim_last_error",
+    "upkie_sim_state_bytes",
+    "upkie_sim_set_randomization",
+    "upkie_sim_sample_inertia_scales",
+    "upkie_sim_reset",
+    "upkie_sim_step_pendulum",
+    "upkie_sim_step_pendulum_agent",
+    "upkie_sim_step_gyropod",
+    "upkie_sim_step_servos",
+    "upkie_sim_observe",
+    "upkie_mpc_create",
+    "upkie_mpc_destroy",
+    "upkie_mpc_last_error",
+    "upkie_mpc_workspace_bytes",
+    "upkie_mpc_reset",
+    "upkie_mpc_step",
+)
+
+
+class UpkieHipError(UpkieRuntimeError):
+    """Error reported by the HIP library (status code + message)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"upkie_hip status {status}: {message}")
+        self.status = status
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (in-tree)."""
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        mtime = os.path.getmtime(LIB_PATH)
+        stale = any(
+            os.path.exists(s) and os.path.getmtime(s) > mtime for s in SOURCES
+        )
+    if stale:
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        cmd = [
+            "hipcc",
+            "--offload-arch=gfx950",
+            "-O3",
+            "-std=c++17",
+            "-shared",
+            "-fPIC",
+            SOURCES[0],
+            "-o",
+            LIB_PATH,
+        ]
+        result = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or result.returncode != 0:
+            print(result.stdout)
+            print(result.stderr)
+        if result.returncode != 0:
+            raise UpkieRuntimeError("hipcc failed to build libupkie_hip.so")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UpkieRuntimeError(
+            f"{LIB_PATH} not found: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.upkie_hip_device_count.restype = C.c_int
+    lib.upkie_sim_create.restype = C.c_int
+    lib.upkie_sim_create.argtypes = [
+        C.POINTER(abi.UpkieSimConfig),
+        C.POINTER(abi.UpkieModel),
+        C.POINTER(vp),
+    ]
+    lib.upkie_sim_destroy.restype = C.c_int
+    lib.upkie_sim_destroy.argtypes = [vp]
+    lib.upkie_sim_last_error.restype = C.c_char_p
+    lib.upkie_sim_last_error.argtypes = [vp]
+    lib.upkie_sim_state_bytes.restype = C.c_int64
+    lib.upkie_sim_state_bytes.argtypes = [vp]
+    lib.upkie_sim_set_randomization.restype = C.c_int
+    lib.upkie_sim_set_randomization.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
+    lib.upkie_sim_sample_inertia_scales.restype = C.c_int
+    lib.upkie_sim_sample_inertia_scales.argtypes = [vp, vp, C.c_double, vp]
+    lib.upkie_sim_reset.restype = C.c_int
+    lib.upkie_sim_reset.argtypes = [vp, vp, vp, vp, vp]
+    for name in (
+        "upkie_sim_step_pendulum",
+        "upkie_sim_step_gyropod",
+        "upkie_sim_step_servos",
+    ):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.upkie_sim_step_pendulum_agent.restype = C.c_int
+    lib.upkie_sim_step_pendulum_agent.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.upkie_sim_observe.restype = C.c_int
+    lib.upkie_sim_observe.argtypes = [
+        vp,
+        vp,
+        C.POINTER(abi.UpkieSpineObservation),
+        C.c_int,
+        vp,
+    ]
+    lib.upkie_mpc_create.restype = C.c_int
+    lib.upkie_mpc_create.argtypes = [C.POINTER(abi.UpkieMpcConfig), C.POINTER(vp)]
+    lib.upkie_mpc_destroy.restype = C.c_int
+    lib.upkie_mpc_destroy.argtypes = [vp]
+    lib.upkie_mpc_last_error.restype = C.c_char_p
+    lib.upkie_mpc_last_error.argtypes = [vp]
+    lib.upkie_mpc_workspace_bytes.restype = C.c_int64
+    lib.upkie_mpc_workspace_bytes.argtypes = [vp]
+    lib.upkie_mpc_reset.restype = C.c_int
+    lib.upkie_mpc_reset.argtypes = [vp, vp, vp, vp, vp]
+    lib.upkie_mpc_step.restype = C.c_int
+    lib.upkie_mpc_step.argtypes = [vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(status: int, handle=None, what: str = "sim") -> None:
+    """Raise `UpkieHipError` on a negative status."""
+    if status >= 0:
+        return
+    lib = load()
+    if what == "mpc":
+        msg = lib.upkie_mpc_last_error(handle)
+    else:
+        msg = lib.upkie_sim_last_error(handle)
+    raise UpkieHipError(status, msg.decode() if msg else "")

@@ -1,0 +1,233 @@
+"""Batched simulation handle: PyTorch tensors for device memory and streams,
+the HIP library for every bit of arithmetic.
+
+This is the batched counterpart of the reference's ``PyBulletBackend``
+(upkie/envs/backends/pybullet_backend.py:31): one instance owns B
+independent robots living in one ``[STATE_WORDS, B]`` fp32 tensor.
+"""
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import abi, lib
+from .exceptions import UpkieRuntimeError
+from .model.default_model import default_model
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchedSim:
+    """B robots stepped by one HIP kernel launch per ``env.step()``."""
+
+    def __init__(
+        self,
+        config: abi.UpkieSimConfig,
+        model: Optional[abi.UpkieModel] = None,
+        device: str = "cuda:0",
+    ):
+        if not torch.cuda.is_available():
+            raise UpkieRuntimeError(
+                "no HIP device visible: the batched simulation only runs on "
+                "a GPU (there is no CPU fallback)"
+            )
+        self._lib = lib.load()
+        self.device = torch.device(device)
+        self.config = config
+        self.model = model if model is not None else default_model()
+        self.num_envs = int(config.num_envs)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            status = self._lib.upkie_sim_create(
+                C.byref(self.config), C.byref(self.model), C.byref(self._handle)
+            )
+        lib.check(status, None)
+        B = self.num_envs
+        nbytes = self._lib.upkie_sim_state_bytes(self._handle)
+        assert nbytes == abi.STATE_WORDS * B * 4
+        self.state = torch.zeros(
+            (abi.STATE_WORDS, B), dtype=torch.float32, device=self.device
+        )
+        self.state[abi.S_QUAT] = 1.0
+        self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self.truncated = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self.obs4 = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
+        self.obs6 = torch.zeros((B, 6), dtype=torch.float32, device=self.device)
+        self.obs_servos = None
+        self.inertia_scale = None
+        self.ext_force = None
+        self._ext_point = (C.c_double * 3)(0.0, 0.0, 0.0)
+
+    # ------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.upkie_sim_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, status: int) -> None:
+        lib.check(status, self._handle)
+
+    # ---------------------------------------------------------- randomise
+    def randomize_inertias(self, inertia_variation: float) -> torch.Tensor:
+        """Per-env, per-body mass/inertia scales 1 + U(-v, v)
+        (pybullet_backend.py:571-601)."""
+        if self.inertia_scale is None:
+            self.inertia_scale = torch.ones(
+                (abi.NB, self.num_envs), dtype=torch.float32, device=self.device
+            )
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_sample_inertia_scales(
+                    self._handle,
+                    _ptr(self.inertia_scale),
+                    float(inertia_variation),
+                    self._stream(),
+                )
+            )
+        self._push_randomization()
+        return self.inertia_scale
+
+    def set_external_force(self, force: Optional[torch.Tensor], point=(0.0, 0.0, 0.0)):
+        """World-frame force ``[3, B]`` on the trunk at base-frame ``point``,
+        held until overwritten (pybullet_backend.py:603-658)."""
+        if force is not None:
+            if tuple(force.shape) != (3, self.num_envs):
+                raise ValueError(  # external_force.py:38-41
+                    f"force must have shape (3, {self.num_envs})"
+                )
+            force = force.to(self.device, torch.float32).contiguous()
+        self.ext_force = force
+        self._ext_point = (C.c_double * 3)(*[float(x) for x in point])
+        self._push_randomization()
+
+    def _push_randomization(self):
+        self._check(
+            self._lib.upkie_sim_set_randomization(
+                self._handle,
+                _ptr(self.inertia_scale),
+                _ptr(self.ext_force),
+                self._ext_point,
+            )
+        )
+
+    # ---------------------------------------------------------------- API
+    def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reset masked envs (all if None); returns the Gyropod obs [B, 6]."""
+        if mask is not None:
+            mask = mask.to(self.device, torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_reset(
+                    self._handle,
+                    _ptr(self.state),
+                    _ptr(mask),
+                    _ptr(self.obs6),
+                    self._stream(),
+                )
+            )
+        return self.obs6
+
+    def _step(self, fn, act, obs):
+        with torch.cuda.device(self.device):
+            self._check(
+                fn(
+                    self._handle,
+                    _ptr(self.state),
+                    _ptr(act),
+                    _ptr(obs),
+                    _ptr(self.reward),
+                    _ptr(self.terminated),
+                    _ptr(self.truncated),
+                    self._stream(),
+                )
+            )
+        return obs, self.reward, self.terminated, self.truncated
+
+    def _as_action(self, act, shape):
+        act = torch.as_tensor(act, dtype=torch.float32, device=self.device)
+        if tuple(act.shape) != shape:
+            act = act.reshape(shape)
+        return act.contiguous()
+
+    def step_pendulum(self, act):
+        act = self._as_action(act, (self.num_envs,))
+        return self._step(self._lib.upkie_sim_step_pendulum, act, self.obs4)
+
+    def step_gyropod(self, act):
+        act = self._as_action(act, (self.num_envs, 2))
+        return self._step(self._lib.upkie_sim_step_gyropod, act, self.obs6)
+
+    def step_servos(self, act):
+        act = self._as_action(act, (self.num_envs, 6, 6))
+        if self.obs_servos is None:
+            self.obs_servos = torch.zeros(
+                (self.num_envs, 6, 5), dtype=torch.float32, device=self.device
+            )
+        return self._step(self._lib.upkie_sim_step_servos, act, self.obs_servos)
+
+    def step_pendulum_agent(self):
+        """Pendulum step with the README's linear agent evaluated on-device
+        from the observation currently held in ``self.obs4``."""
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_step_pendulum_agent(
+                    self._handle,
+                    _ptr(self.state),
+                    _ptr(self.obs4),
+                    _ptr(self.reward),
+                    _ptr(self.terminated),
+                    _ptr(self.truncated),
+                    self._stream(),
+                )
+            )
+        return self.obs4, self.reward, self.terminated, self.truncated
+
+    def observe(self, update_imu: bool = True) -> dict:
+        """Full spine observation as ``[B, ...]`` tensors
+        (pybullet_backend.py:313-331), materialised on request only."""
+        B, dev = self.num_envs, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {
+            "pitch": torch.empty(B, **f32),
+            "angular_velocity": torch.empty((B, 3), **f32),
+            "linear_velocity": torch.empty((B, 3), **f32),
+            "rotation_base_to_world": torch.empty((B, 9), **f32),
+            "floor_contact": torch.empty(B, dtype=torch.uint8, device=dev),
+            "imu_orientation": torch.empty((B, 4), **f32),
+            "imu_angular_velocity": torch.empty((B, 3), **f32),
+            "imu_linear_acceleration": torch.empty((B, 3), **f32),
+            "imu_raw_linear_acceleration": torch.empty((B, 3), **f32),
+            "servo": torch.empty((B, 6, 5), **f32),
+            "wheel_odometry": torch.empty((B, 2), **f32),
+        }
+        so = abi.UpkieSpineObservation()
+        for name, t in out.items():
+            setattr(so, name, t.data_ptr())
+        with torch.cuda.device(dev):
+            self._check(
+                self._lib.upkie_sim_observe(
+                    self._handle,
+                    _ptr(self.state),
+                    C.byref(so),
+                    1 if update_imu else 0,
+                    self._stream(),
+                )
+            )
+        return out
+
+    def state_numpy(self) -> np.ndarray:
+        return self.state.detach().cpu().numpy()
