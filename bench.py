@@ -1,0 +1,172 @@
+"""Headline benchmark: env-steps/s of the batched Upkie-Pendulum env.step().
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): Upkie-Pendulum,
+4096 envs per GPU, 200 Hz control (5 x 1 ms physics substeps), fp32, the
+README's PD-gain balancer evaluated on-device, init-state randomisation pitch
++-0.1 rad, x +-0.05 m, omega_y +-0.1 rad/s, v_x +-0.05 m/s, fall_pitch 1.0,
+NEXT_STEP autoreset. One "step" = one env.step() of every env = ONE kernel
+launch per GPU; for N > 1 ranks each step also gathers the packed
+(obs, reward, terminated, truncated) records to rank 0 over RCCL.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+"roofline" (algorithmic bytes / measured kernel time vs HBM peak) and
+"cpu_baseline" (the fp64 oracle timed on the host cores, rank 0, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+# 29 fp32 state words read + written (232 B), action 4,
+# obs 16, reward 4, terminated 1, truncated 1.
+ALGORITHMIC_BYTES_PER_ENV_STEP = 258
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def make_config(num_envs: int, env_id_offset: int = 0, seed: int = 0):
+    from upkie_amd import abi
+
+    cfg = abi.default_sim_config(num_envs, frequency=200.0, seed=seed)
+    cfg.rand_pitch = 0.1
+    cfg.rand_x = 0.05
+    cfg.rand_omega_y = 0.1
+    cfg.rand_linvel[0] = 0.05
+    cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+    cfg.env_id_offset = env_id_offset
+    return cfg
+
+
+def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
+    """Time the fp64 oracle (a port: the reference's PyBullet path cannot run
+    here) on the host cores with the same workload, bounded to ~budget_s."""
+    from oracle import oracle as O
+    from upkie_amd.model.default_model import default_model
+
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ref = O.Oracle(default_model(), make_config(envs))
+    obs = ref.reset()[:, [1, 0, 4, 3]]
+    obs, *_ = ref.step_pendulum_agent(obs)  # warm up
+    t0 = time.perf_counter()
+    obs, *_ = ref.step_pendulum_agent(obs)
+    one = time.perf_counter() - t0
+    steps = max(2, min(5000, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, *_ = ref.step_pendulum_agent(obs)
+    elapsed = time.perf_counter() - t0
+    return {
+        "value": envs * steps / elapsed,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} env.step() of {envs} envs, fp64 C oracle, OpenMP over envs ({elapsed:.1f} s)",
+    }
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=2000)
+    parser.add_argument("--warmup", type=int, default=200)
+    parser.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+
+    from upkie_amd.distributed import ShardedPendulum, init_distributed
+
+    rank, world, local_rank = init_distributed(args.gpus)
+    B = args.envs_per_gpu
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world)
+    env.reset()
+
+    for _ in range(args.warmup):
+        env.step_agent()
+    env.barrier()
+    torch.cuda.synchronize()
+    start_evt = torch.cuda.Event(enable_timing=True)
+    stop_evt = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    start_evt.record()  # same stream the kernels are launched on
+    for _ in range(args.steps):
+        env.step_agent()
+    stop_evt.record()
+    env.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = env.max_over_ranks(elapsed)
+    device_ms = start_evt.elapsed_time(stop_evt)
+    resets = env.total_resets()
+
+    if rank != 0:
+        env.shutdown()
+        return
+
+    total_envs = B * world
+    value = total_envs * args.steps / elapsed
+    launch_us = device_ms * 1e3 / args.steps  # avg per-launch device time, this rank
+    achieved = ALGORITHMIC_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+    traffic = None
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    line = {
+        "metric": "env-steps/sec (batched Upkie-Pendulum, 200 Hz)",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset",
+            "envs_per_gpu": B,
+            "total_envs": total_envs,
+            "gather": "RCCL gather of packed obs/reward/done to rank 0 every step" if world > 1 else "none (single GPU)",
+            "episode_resets_in_timed_region": resets,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel": "step_kernel<MODE_PENDULUM_AGENT>",
+            "avg_launch_us": launch_us,
+            "algorithmic_bytes_per_env_step": ALGORITHMIC_BYTES_PER_ENV_STEP,
+            "note": "the step is fp32-VALU/latency bound (~5e4 flop vs 258 B per env-step), not HBM bound: see DESIGN.md",
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(B)
+    else:
+        line["cpu_baseline"] = None
+    env.shutdown()
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

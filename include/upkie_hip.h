@@ -197,6 +197,17 @@ int upkie_sim_step_pendulum_agent(UpkieSim* sim, float* state, float* obs,
                                   float* reward, uint8_t* terminated,
                                   uint8_t* truncated, void* stream);
 
+/* Packed-record variants for rollout collection across GPUs: instead of four
+ * output arrays each env gets one 32-byte record records[B][8] =
+ * [obs(4) | reward, terminated, truncated, 0] (two 16-byte stores per lane),
+ * which is what one RCCL gather per step ships to rank 0. The agent variant
+ * reads the previous observation from the record. */
+int upkie_sim_step_pendulum_packed(UpkieSim* sim, float* state,
+                                   const float* act, float* records,
+                                   void* stream);
+int upkie_sim_step_pendulum_agent_packed(UpkieSim* sim, float* state,
+                                         float* records, void* stream);
+
 /* One env.step() of UpkieGyropod (upkie_gyropod.py:354-392):
  * act[B][2] -> obs[B][6]. */
 int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act,

@@ -209,7 +209,7 @@ def default_mpc_config(num_envs: int = 1, nb_timesteps: int = 50):
     cfg = UpkieMpcConfig()
     cfg.num_envs = num_envs
     cfg.nb_timesteps = nb_timesteps
-    cfg.admm_iterations = 60
+    cfg.admm_iterations = 30
     cfg.sampling_period = 0.02
     cfg.leg_length = 0.58
     cfg.max_ground_accel = 10.0
@@ -218,5 +218,5 @@ def default_mpc_config(num_envs: int = 1, nb_timesteps: int = 50):
     cfg.stage_input_cost_weight = 1e-3
     cfg.stage_state_cost_weight = 1e-3
     cfg.terminal_cost_weight = 1.0
-    cfg.admm_rho = 0.05
+    cfg.admm_rho = 1e-3
     return cfg

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ inertia_scale,
-                                                   const float* __restrict__ ext_force) {
+                                                   const float* __restrict__ ext_force, int packed) {
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
       a0 = act[e];  // upkie_pendulum.py:139: [action[0], 0.0]
     } else if (MODE == MODE_PENDULUM_AGENT) {
       // README.md:62-64: action = gains . observation, clipped
-      const float4 o = reinterpret_cast<const float4*>(obs)[e];
+      const float4 o = reinterpret_cast<const float4*>(obs)[packed ? 2 * (size_t)e : (size_t)e];
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
     } else {
@@ -357,7 +357,16 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
   }
   if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
     // _PENDULUM_OBS_INDICES = [1, 0, 4, 3], upkie_pendulum.py:17
-    reinterpret_cast<float4*>(obs)[e] = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    if (packed) {
+      // one 32-byte record per env for the rollout gather:
+      // [obs(4) | reward, terminated, truncated, 0]
+      float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
+      rec[0] = o4;
+      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      return;
+    }
+    reinterpret_cast<float4*>(obs)[e] = o4;
   } else if (MODE == MODE_GYROPOD) {
     float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
     o2[0] = make_float2(obs6[0], obs6[1]);
@@ -734,9 +743,9 @@ extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_sca
 
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
-                       uint8_t* truncated, const uint8_t* mask, void* stream) {
+                       uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  if (MODE != MODE_RESET && (!obs || !reward || !terminated || !truncated))
+  if (MODE != MODE_RESET && (!obs || (!packed && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
   if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS) && !act)
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
@@ -744,10 +753,10 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   dim3 grid = grid_for(sim->config.num_envs), block(64);
   if (rnd) {
     hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
-                       reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force);
+                       reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed);
   } else {
     hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
-                       reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr);
+                       reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr, packed);
   }
   return check_hip(sim, hipGetLastError(), "step_kernel");
 }
@@ -764,6 +773,14 @@ extern "C" int upkie_sim_step_pendulum(UpkieSim* sim, float* state, const float*
 extern "C" int upkie_sim_step_pendulum_agent(UpkieSim* sim, float* state, float* obs, float* reward, uint8_t* terminated,
                                              uint8_t* truncated, void* stream) {
   return launch_step<MODE_PENDULUM_AGENT>(sim, state, nullptr, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_step_pendulum_packed(UpkieSim* sim, float* state, const float* act, float* records, void* stream) {
+  return launch_step<MODE_PENDULUM>(sim, state, act, records, nullptr, nullptr, nullptr, nullptr, stream, 1);
+}
+
+extern "C" int upkie_sim_step_pendulum_agent_packed(UpkieSim* sim, float* state, float* records, void* stream) {
+  return launch_step<MODE_PENDULUM_AGENT>(sim, state, nullptr, records, nullptr, nullptr, nullptr, nullptr, stream, 1);
 }
 
 extern "C" int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,

@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_reset",
     "upkie_sim_step_pendulum",
     "upkie_sim_step_pendulum_agent",
+    "upkie_sim_step_pendulum_packed",
+    "upkie_sim_step_pendulum_agent_packed",
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
     "upkie_sim_observe",
@@ -97,6 +99,11 @@ def load() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback"
         )
+    # PyTorch owns the device memory and streams handed to the library, so both
+    # must run on ONE HIP runtime instance: load torch's first and let the
+    # dynamic loader resolve libupkie_hip.so's libamdhip64 dependency to it.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.upkie_hip_device_count.restype = C.c_int
@@ -128,6 +135,10 @@ def load() -> C.CDLL:
         fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.upkie_sim_step_pendulum_agent.restype = C.c_int
     lib.upkie_sim_step_pendulum_agent.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.upkie_sim_step_pendulum_packed.restype = C.c_int
+    lib.upkie_sim_step_pendulum_packed.argtypes = [vp, vp, vp, vp, vp]
+    lib.upkie_sim_step_pendulum_agent_packed.restype = C.c_int
+    lib.upkie_sim_step_pendulum_agent_packed.argtypes = [vp, vp, vp, vp]
     lib.upkie_sim_observe.restype = C.c_int
     lib.upkie_sim_observe.argtypes = [
         vp,

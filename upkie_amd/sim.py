@@ -196,6 +196,24 @@ class BatchedSim:
             )
         return self.obs4, self.reward, self.terminated, self.truncated
 
+    def step_pendulum_packed(self, records: torch.Tensor, act=None) -> torch.Tensor:
+        """Pendulum step writing one ``[obs(4) | reward, terminated,
+        truncated, 0]`` record per env into ``records[B, 8]``; with
+        ``act=None`` the on-device linear agent acts on the previous record."""
+        assert records.shape == (self.num_envs, 8) and records.is_contiguous()
+        with torch.cuda.device(self.device):
+            if act is None:
+                status = self._lib.upkie_sim_step_pendulum_agent_packed(
+                    self._handle, _ptr(self.state), _ptr(records), self._stream()
+                )
+            else:
+                act = self._as_action(act, (self.num_envs,))
+                status = self._lib.upkie_sim_step_pendulum_packed(
+                    self._handle, _ptr(self.state), _ptr(act), _ptr(records), self._stream()
+                )
+        self._check(status)
+        return records
+
     def observe(self, update_imu: bool = True) -> dict:
         """Full spine observation as ``[B, ...]`` tensors
         (pybullet_backend.py:313-331), materialised on request only."""
