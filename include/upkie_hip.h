@@ -99,6 +99,9 @@ typedef struct UpkieModel {
   double contact_stiffness;        /* tire <contact> stiffness              */
   double contact_damping;          /* tire <contact> damping                */
   double friction_mu;              /* tire x plane lateral friction         */
+  double friction_cfm;             /* compliance added to friction rows, 1/kg:
+                                      the two tires' lateral rows coincide in a
+                                      symmetric stance (singular otherwise)  */
   double contact_breaking_threshold; /* floor_contact flag distance         */
   double base_linear_damping;      /* Bullet default 0.04                   */
   double base_angular_damping;     /* Bullet default 0.04                   */
@@ -157,6 +160,12 @@ int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* model,
                      UpkieSim** out);
 int upkie_sim_destroy(UpkieSim* sim);
 const char* upkie_sim_last_error(const UpkieSim* sim);
+
+/* Replace the configuration of an existing handle (same num_envs): lets a
+ * caller change init state, randomisation magnitudes, seed, gains, fall pitch
+ * ... between resets, as the reference's mutable env attributes allow
+ * (upkie_env.py:244-251 update_init_rand, upkie_gyropod.py:176-184). */
+int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config);
 
 /* Size in bytes the caller must allocate for the state buffer. */
 int64_t upkie_sim_state_bytes(const UpkieSim* sim);

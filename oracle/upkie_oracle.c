@@ -495,7 +495,7 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
       } else {
         kind[nrows] = 1;
         normal_row[nrows] = nrows - r_;
-        cfm[nrows] = 0.0;
+        cfm[nrows] = model->friction_cfm;
         rhs_c[nrows] = -v;
       }
       ++nrows;
@@ -537,7 +537,33 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
         W[a][b] = s_;
       }
     double mu = model->friction_mu;
-    for (int it = 0; it < model->pgs_iterations; ++it) {
+    /* Direct solve first: in the usual regime (tires loaded, no slip) the
+     * unconstrained solution of (W + CFM) lam = rhs already satisfies
+     * lam_n >= 0 and |lam_t| <= mu lam_n and IS the solution. Otherwise it is
+     * projected and used as the warm start of the projected Gauss-Seidel
+     * sweeps (continuous at the stick/slip and lift-off boundaries). */
+    int need_pgs = 1;
+    {
+      double A[MAXROWS * MAXROWS], La[MAXROWS * MAXROWS];
+      for (int a = 0; a < nrows; ++a)
+        for (int b = 0; b < nrows; ++b) A[a * nrows + b] = W[a][b] + (a == b ? cfm[a] : 0.0);
+      if (cholesky(nrows, A, La) == 0) {
+        cholesky_solve(nrows, La, rhs_c, lam);
+        need_pgs = 0;
+        for (int r_ = 0; r_ < nrows; ++r_)
+          if (kind[r_] != 1 && lam[r_] < 0.0) {
+            lam[r_] = 0.0;
+            need_pgs = 1;
+          }
+        for (int r_ = 0; r_ < nrows; ++r_)
+          if (kind[r_] == 1) {
+            double lim = mu * lam[normal_row[r_]];
+            if (lam[r_] < -lim) { lam[r_] = -lim; need_pgs = 1; }
+            if (lam[r_] > lim) { lam[r_] = lim; need_pgs = 1; }
+          }
+      }
+    }
+    for (int it = 0; need_pgs && it < model->pgs_iterations; ++it) {
       for (int pass = 0; pass < 3; ++pass) { /* normals, friction, limits */
         for (int r_ = 0; r_ < nrows; ++r_) {
           if (kind[r_] != pass) continue;

@@ -1,0 +1,115 @@
+"""Test doubles with the interface of `BatchedSim` / `BatchedMpc` but driven by
+the fp64 oracle on the CPU, so the env wrappers (`upkie_amd.envs`) can be
+tested without a GPU -- the counterpart of the reference's mock-the-simulator
+tests (tests/envs/backends/test_pybullet_backend_mock.py, upkie/envs/
+testing.py). TEST INFRASTRUCTURE ONLY: the product never falls back to this."""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+from upkie_amd import abi
+
+
+class OracleSim:
+    def __init__(self, config, model_struct, device="cpu"):
+        self.config = config
+        self.model = model_struct
+        self.device = torch.device("cpu")
+        self.num_envs = int(config.num_envs)
+        self._o = O.Oracle(model_struct, config)
+        self._o.state[abi.S_QUAT] = 1.0
+        B = self.num_envs
+        self.obs4 = torch.zeros((B, 4))
+        self.obs6 = torch.zeros((B, 6))
+        self.obs_servos = torch.zeros((B, 6, 5))
+        self.reward = torch.zeros(B)
+        self.terminated = torch.zeros(B, dtype=torch.uint8)
+        self.truncated = torch.zeros(B, dtype=torch.uint8)
+        self.inertia_scale = None
+        self.ext_force = None
+
+    @property
+    def state(self):
+        return torch.from_numpy(self._o.state.astype(np.float32))
+
+    def close(self):
+        pass
+
+    def push_config(self):
+        self._o.config = self.config
+
+    def randomize_inertias(self, variation):
+        self._o.inertia_scale = self._o.sample_inertia_scales(variation)
+        self.inertia_scale = torch.from_numpy(self._o.inertia_scale.astype(np.float32))
+        return self.inertia_scale
+
+    def set_external_force(self, force, point=(0.0, 0.0, 0.0)):
+        self.ext_force = force
+        self._o.ext_force = None if force is None else np.ascontiguousarray(force.double().numpy())
+        self._o.ext_point = np.array(point, dtype=np.float64)
+
+    def reset(self, mask=None):
+        m = None if mask is None else mask.to(torch.uint8).numpy()
+        self.obs6 = torch.from_numpy(self._o.reset(m).astype(np.float32))
+        return self.obs6
+
+    def _out(self, obs, rew, term, trunc, holder):
+        obs = torch.from_numpy(np.asarray(obs, dtype=np.float32))
+        getattr(self, holder).copy_(obs)
+        self.reward = torch.from_numpy(rew.astype(np.float32))
+        self.terminated = torch.from_numpy(term)
+        self.truncated = torch.from_numpy(trunc)
+        return getattr(self, holder), self.reward, self.terminated, self.truncated
+
+    def step_pendulum(self, act):
+        return self._out(*self._o.step_pendulum(torch.as_tensor(act).double().numpy().reshape(-1)), "obs4")
+
+    def step_gyropod(self, act):
+        return self._out(*self._o.step_gyropod(torch.as_tensor(act).double().numpy().reshape(-1, 2)), "obs6")
+
+    def step_servos(self, act):
+        return self._out(*self._o.step_servos(torch.as_tensor(act).double().numpy().reshape(-1, 6, 6)), "obs_servos")
+
+    def step_pendulum_agent(self):
+        return self._out(*self._o.step_pendulum_agent(self.obs4.double().numpy()), "obs4")
+
+    def observe(self, update_imu=True):
+        out = self._o.observe(update_imu)
+        return {k: torch.from_numpy(v if v.dtype == np.uint8 else v.astype(np.float32)) for k, v in out.items()}
+
+
+def oracle_sim_factory(config, model_struct, device):
+    return OracleSim(config, model_struct, device)
+
+
+class OracleMpc:
+    def __init__(self, config, device="cpu"):
+        self.config = config
+        self.num_envs = int(config.num_envs)
+        N, B = config.nb_timesteps, self.num_envs
+        self._ws = np.zeros((2 * N, B))
+        self._v = np.zeros(B)
+        self._first = np.zeros(B)
+
+    @property
+    def commanded_velocity(self):
+        return torch.from_numpy(self._v.astype(np.float32))
+
+    def reset(self, mask=None):
+        sel = slice(None) if mask is None else mask.bool().numpy()
+        self._ws[:, sel] = 0.0
+        self._v[sel] = 0.0
+
+    def step(self, x0, target_velocity, contact, dt):
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        x = np.ascontiguousarray(x0.double().numpy())
+        vt = np.ascontiguousarray(target_velocity.double().numpy())
+        ct = np.ascontiguousarray(contact.to(torch.uint8).numpy())
+        O.lib().oracle_mpc_step(C.byref(self.config), p(self._ws), p(x), p(vt), p(ct), C.c_double(dt), p(self._v), p(self._first))
+        return torch.from_numpy(self._v.astype(np.float32)), torch.from_numpy(self._first.astype(np.float32))
+
+    def close(self):
+        pass

@@ -1,0 +1,220 @@
+"""Environment wrappers (upkie_amd.envs) against the reference's own wrapper
+tests, restated: tests/envs/test_upkie_{pendulum,gyropod,servos,base_velocity}.py
+and tests/envs/test_entry_points.py. Runs on the CPU through oracle-backed
+test doubles (tests/fake_sim.py); tests/test_envs_gpu.py repeats the key ones
+on the real HIP path."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import upkie_amd.envs as envs
+from upkie_amd import abi
+from upkie_amd.exceptions import UpkieException, UpkieRuntimeError
+from upkie_amd.utils.robot_state import RobotState
+from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+from .fake_sim import OracleMpc, oracle_sim_factory
+
+KW = dict(sim_factory=oracle_sim_factory)
+
+
+def test_ids_follow_the_reference_scheme():
+    """upkie/envs/__init__.py:24-44: <Robot>-<Backend>-<Action>."""
+    for action in ("Servos", "Gyropod", "Pendulum", "BaseVelocity"):
+        assert f"Upkie-HIP-{action}" in envs.REGISTRY
+        assert f"Upkie-HIP-{action}-Vec" in envs.REGISTRY
+        assert f"Upkie-PyBullet-{action}" in envs.REGISTRY  # resolves here when pybullet is absent
+    with pytest.raises(KeyError):
+        envs.make("Upkie-Nope-Pendulum")
+
+
+def test_readme_agent_loop_single_env():
+    """README.md:53-68: the documented balancing loop runs unchanged."""
+    env = envs.make("Upkie-HIP-Pendulum", frequency=200.0, **KW)
+    observation, _ = env.reset()
+    gain = np.array([10.0, 1.0, 0.0, 0.1])
+    for _ in range(100):
+        action = gain.dot(observation).reshape((1,))
+        observation, reward, terminated, truncated, _ = env.step(action)
+        assert reward == 0.0 and not truncated
+        assert not terminated
+    assert observation.dtype == np.float32 and observation.shape == (4,)
+    assert abs(observation[0]) < 0.1
+
+
+def test_pendulum_observation_layout_and_dtypes():
+    """tests/envs/test_upkie_pendulum.py:34-40,75-87."""
+    env = envs.make("Upkie-HIP-Pendulum", frequency=100.0, **KW)
+    obs, info = env.reset()
+    assert obs.dtype == np.float32 and env.observation_space.shape == (4,) and env.action_space.shape == (1,)
+    obs, _, _, _, info = env.step(np.array([0.2], dtype=np.float32))
+    spine = info["spine_observation"]
+    assert obs[1] == pytest.approx(spine["wheel_odometry"]["position"], abs=1e-6)
+    assert obs[0] == pytest.approx(spine["base_orientation"]["pitch"], abs=1e-6)
+    assert obs[2] == pytest.approx(spine["base_orientation"]["angular_velocity"][1], abs=1e-6)
+    assert obs[3] == pytest.approx(spine["wheel_odometry"]["velocity"], abs=1e-6)
+    assert set(spine) == {"base_orientation", "floor_contact", "imu", "servo", "wheel_odometry"}
+    assert set(spine["servo"]) == set(abi.JOINT_NAMES)
+    assert spine["servo"]["left_hip"]["temperature"] == 42.0 and spine["servo"]["left_hip"]["voltage"] == 18.0
+
+
+def test_pendulum_clamps_huge_actions_and_caps_torques():
+    """tests/envs/test_upkie_pendulum.py:48-73: |wheel velocity * radius| <=
+    max_ground_velocity after a huge action; torques < 20 / < 2 N.m."""
+    env = envs.make("Upkie-HIP-Pendulum", frequency=200.0, max_ground_velocity=1.0, **KW)
+    env.reset()
+    _, _, _, _, info = env.step(np.array([1e6], dtype=np.float32))
+    servo = info["spine_observation"]["servo"]
+    for name in abi.JOINT_NAMES:
+        limit = 2.0 if "wheel" in name else 20.0
+        assert abs(servo[name]["torque"]) < limit
+    assert abs(servo["left_wheel"]["torque"]) == pytest.approx(1.7)  # saturated towards 1.0 / 0.05 rad/s
+
+
+def test_gyropod_yaw_integration_and_reset():
+    """tests/envs/test_upkie_gyropod.py:57-72."""
+    env = envs.make("Upkie-HIP-Gyropod", frequency=100.0, **KW)
+    env.reset()
+    obs, *_ = env.step(np.array([0.0, 0.5], dtype=np.float32))
+    assert obs[2] == pytest.approx(0.5 * env.dt, abs=1e-7)
+    assert obs[5] == pytest.approx(0.5)
+    obs, *_ = env.step(np.array([0.0, 5.0], dtype=np.float32))  # yaw integrates the UNCLAMPED action (:383-385)
+    assert obs[2] == pytest.approx(0.5 * env.dt + 5.0 * env.dt, abs=1e-6)
+    obs, _ = env.reset()
+    assert obs[2] == 0.0 and obs[5] == 0.0
+
+
+def test_gyropod_wheel_velocity_commands():
+    """tests/envs/test_upkie_gyropod.py:74-86: a pure yaw command turns both
+    wheel servos the same way; a pure forward command in opposite ways."""
+    env = envs.make("Upkie-HIP-Gyropod-Vec", num_envs=2, frequency=1000.0, nb_substeps=1, autoreset=False, **KW)
+    env.reset()
+    act = torch.tensor([[0.0, 1.0], [1.0, 0.0]])
+    env.step(act)
+    tau = env.sim.state[abi.S_TORQUE : abi.S_TORQUE + 6].t()
+    assert tau[0, 2] * tau[0, 5] > 0  # yaw: same sign
+    assert tau[1, 2] * tau[1, 5] < 0  # forward: opposite signs
+    # omega_wheel = v / r = 20 rad/s -> kd * 20 = 20 N.m, clipped to the 1.7 N.m wheel effort
+    assert tau[1, 2] == pytest.approx(1.7) and tau[1, 5] == pytest.approx(-1.7)
+
+
+def test_leg_gain_scale_is_applied():
+    """tests/envs/test_upkie_gyropod.py:102-113."""
+    env = envs.make("Upkie-HIP-Gyropod", frequency=1000.0, nb_substeps=1, leg_gain_scale=2.0,
+                    init_state=RobotState(joint_configuration=np.array([0.1, 0, 0, 0, 0, 0]), position_base_in_world=np.array([0, 0, 2.0])), **KW)
+    env.reset()
+    _, _, _, _, info = env.step(np.zeros(2, dtype=np.float32))
+    servo = info["spine_observation"]["servo"]["left_hip"]
+    env2 = envs.make("Upkie-HIP-Gyropod", frequency=1000.0, nb_substeps=1, leg_gain_scale=1.0,
+                     init_state=RobotState(joint_configuration=np.array([0.1, 0, 0, 0, 0, 0]), position_base_in_world=np.array([0, 0, 2.0])), **KW)
+    env2.reset()
+    _, _, _, _, info2 = env2.step(np.zeros(2, dtype=np.float32))
+    assert servo["torque"] == pytest.approx(2.0 * info2["spine_observation"]["servo"]["left_hip"]["torque"], rel=1e-3)
+    assert env.leg_gain_scale == 2.0
+    env.set_leg_gain_scale(0.5)
+    assert env.leg_gain_scale == 0.5
+
+
+def test_servos_neutral_action_and_dict_api():
+    """tests/envs/test_upkie_servos.py:157-200,242-275."""
+    env = envs.make("Upkie-HIP-Servos", frequency=200.0, **KW)
+    obs, info = env.reset()
+    neutral = env.get_neutral_action()
+    assert set(neutral) == set(abi.JOINT_NAMES)
+    for name in abi.JOINT_NAMES:
+        assert math.isnan(neutral[name]["position"]) and neutral[name]["velocity"] == 0.0
+        assert neutral[name]["kp_scale"] == 1.0 and neutral[name]["kd_scale"] == 1.0
+        assert neutral[name]["maximum_torque"] == pytest.approx(1.7 if "wheel" in name else 16.0)
+        assert set(obs[name]) == set(abi.SERVO_OBS_KEYS)
+        assert obs[name]["position"].dtype == np.float32 and obs[name]["position"].shape == (1,)
+    # partial action: missing keys come from the neutral action (:326-330)
+    action = {name: {"position": np.array([0.05], dtype=np.float32), "velocity": 0.0} for name in abi.JOINT_NAMES}
+    action["left_wheel"] = {"position": float("nan"), "velocity": 500.0}  # clamped to 111 rad/s
+    obs, reward, terminated, truncated, info = env.step(action)
+    assert reward == 0.0 and not terminated and not truncated
+    assert abs(obs["left_wheel"]["torque"][0]) == pytest.approx(1.7)
+    assert env.action_space["left_hip"]["position"].low[0] == pytest.approx(-1.26)
+    assert env.action_space["left_wheel"]["velocity"].high[0] == pytest.approx(111.0)
+
+
+def test_base_velocity_dead_reckoning_and_mpc():
+    """tests/envs/test_upkie_base_velocity.py:55-107."""
+    env = envs.make("Upkie-HIP-BaseVelocity", frequency=200.0, mpc_factory=OracleMpc, **KW)
+    obs, _ = env.reset()
+    np.testing.assert_array_equal(obs, np.zeros(3, dtype=np.float32))
+    x = y = yaw = 0.0
+    for _ in range(20):
+        obs, reward, terminated, truncated, info = env.step(np.array([0.3, 0.4], dtype=np.float32))
+        yaw += 0.4 * env.dt
+        x += 0.3 * math.cos(yaw) * env.dt
+        y += 0.3 * math.sin(yaw) * env.dt
+        assert not terminated
+    np.testing.assert_allclose(obs, [x, y, yaw], atol=1e-5)
+    v = float(env.mpc_balancer.commanded_velocity[0])
+    assert math.isfinite(v) and abs(v) <= 3.0 and v != 0.0
+    obs, _ = env.reset()
+    np.testing.assert_array_equal(obs, np.zeros(3, dtype=np.float32))
+    assert float(env.mpc_balancer.commanded_velocity[0]) == 0.0
+
+
+def test_vector_env_api_and_autoreset():
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=8, frequency=200.0, fall_pitch=0.12,
+                    init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1)), **KW)
+    assert env.observation_space.shape == (8, 4) and env.action_space.shape == (8, 1)
+    assert env.single_observation_space.shape == (4,)
+    obs, info = env.reset(seed=3)
+    assert obs.shape == (8, 4) and obs.dtype == torch.float32
+    episodes_before = env.sim.state[abi.S_EPISODE].clone()
+    fell = torch.zeros(8, dtype=torch.bool)
+    for _ in range(600):
+        obs, reward, terminated, truncated, info = env.step(torch.zeros(8, 1))
+        assert reward.shape == (8,) and terminated.dtype == torch.bool and not truncated.any()
+        fell |= terminated
+    assert fell.sum() >= 6  # passive wheels: (nearly) everyone tips over past 0.12 rad
+    assert (env.sim.state[abi.S_EPISODE] > episodes_before)[fell].all()  # ... and was reset by the next step
+    assert (obs[:, 0].abs() <= 0.12 + 0.2).all()
+    spine = info["spine_observation"]
+    assert spine["base_orientation"]["pitch"].shape == (8,)
+    assert spine["servo"]["right_knee"]["position"].shape == (8,)
+    assert spine["floor_contact"]["contact"].dtype == torch.bool
+    # same seed, same episodes
+    env2 = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=8, frequency=200.0, fall_pitch=0.12,
+                     init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1)), **KW)
+    obs2, _ = env2.reset(seed=3)
+    obs1, _ = env.reset(seed=3)
+    # episode counters differ (env was used), so compare a fresh pair instead
+    env3 = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=8, frequency=200.0, fall_pitch=0.12,
+                     init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1)), **KW)
+    obs3, _ = env3.reset(seed=3)
+    assert torch.equal(obs2, obs3)
+
+
+def test_invalid_configurations_raise_the_reference_exceptions():
+    with pytest.raises(UpkieException):  # upkie_gyropod.py:123-124
+        envs.make("Upkie-HIP-Gyropod", frequency=None, **KW)
+    with pytest.raises(UpkieException):  # real-time regulation makes no sense here
+        envs.make("Upkie-HIP-Pendulum", regulate_frequency=True, **KW)
+    with pytest.raises(UpkieRuntimeError):  # upkie_servos.py:144-145
+        envs.make("Upkie-HIP-Servos", max_gain_scale=12.0, **KW)
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, **KW)
+    with pytest.raises(UpkieRuntimeError):  # pybullet_backend.py:614-617
+        env.set_external_forces("no_such_link", torch.zeros(3))
+    with pytest.raises(ValueError):  # external_force.py:38-41
+        env.set_external_forces("torso", torch.zeros(4))
+
+
+def test_external_force_pushes_the_robot():
+    """examples/pybullet/apply_external_forces.py: a forward push on the torso
+    moves the base forward."""
+    pushed = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=1, autoreset=False, **KW)
+    free = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=1, autoreset=False, **KW)
+    pushed.reset()
+    free.reset()
+    pushed.set_external_forces("torso", torch.tensor([5.0, 0.0, 0.0]))
+    for _ in range(20):
+        pushed.step(torch.zeros(1, 1))
+        free.step(torch.zeros(1, 1))
+    assert float(pushed.sim.state[abi.S_POS, 0]) > float(free.sim.state[abi.S_POS, 0]) + 1e-3

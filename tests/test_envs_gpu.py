@@ -1,0 +1,84 @@
+"""Environment wrappers on the real HIP path (one MI355X)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import upkie_amd.envs as envs
+from upkie_amd import abi
+from upkie_amd.utils.robot_state import RobotState
+from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+from .fake_sim import OracleMpc, oracle_sim_factory
+
+pytestmark = pytest.mark.gpu
+
+
+def test_readme_agent_loop_on_gpu_matches_cpu_double():
+    """README.md:53-68 loop on "Upkie-HIP-Pendulum" vs the same env on the
+    oracle-backed double: observations within the closed-loop tolerance."""
+    gpu = envs.make("Upkie-HIP-Pendulum", frequency=200.0)
+    cpu = envs.make("Upkie-HIP-Pendulum", frequency=200.0, sim_factory=oracle_sim_factory)
+    og, _ = gpu.reset(seed=1)
+    oc, _ = cpu.reset(seed=1)
+    gain = np.array([10.0, 1.0, 0.0, 0.1])
+    for _ in range(200):
+        og, rg, tg, ug, ig = gpu.step(gain.dot(og).reshape((1,)))
+        oc, rc, tc, uc, ic = cpu.step(gain.dot(oc).reshape((1,)))
+        assert (rg, tg, ug) == (rc, tc, uc)
+    assert abs(og[0] - oc[0]) < 1e-3 and abs(og[1] - oc[1]) < 1e-3
+    sg, sc = ig["spine_observation"], ic["spine_observation"]
+    assert sg["floor_contact"]["contact"] == sc["floor_contact"]["contact"]
+    assert sg["base_orientation"]["pitch"] == pytest.approx(sc["base_orientation"]["pitch"], abs=1e-3)
+    np.testing.assert_allclose(sg["imu"]["orientation"], sc["imu"]["orientation"], atol=1e-3)
+    for name in abi.JOINT_NAMES:
+        assert sg["servo"][name]["position"] == pytest.approx(sc["servo"][name]["position"], abs=2e-3)
+
+
+def test_pybullet_id_alias_runs_on_hip():
+    env = envs.make("Upkie-PyBullet-Pendulum", frequency=200.0, regulate_frequency=False)
+    obs, info = env.reset()
+    assert obs.shape == (4,) and "spine_observation" in info
+    obs, reward, terminated, truncated, info = env.step(np.array([0.1], dtype=np.float32))
+    assert reward == 0.0 and not terminated and not truncated
+
+
+def test_vector_env_4096_throughput_path():
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=4096, frequency=200.0,
+                    init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0]))))
+    obs, info = env.reset(seed=0)
+    assert obs.is_cuda and obs.shape == (4096, 4)
+    gains = torch.tensor([10.0, 1.0, 0.0, 0.1], device=obs.device)
+    for _ in range(50):
+        action = (obs @ gains).clamp(-0.99, 0.99)[:, None]
+        obs, reward, terminated, truncated, info = env.step(action)
+    assert not terminated.any() and float(obs[:, 0].abs().max()) < 0.3
+    spine = info["spine_observation"]  # materialised lazily by one extra launch
+    assert spine["base_orientation"]["pitch"].shape == (4096,)
+    assert torch.allclose(spine["base_orientation"]["pitch"], obs[:, 0], atol=1e-6)
+    assert bool(spine["floor_contact"]["contact"].all())
+
+
+def test_base_velocity_env_gpu_matches_cpu_double():
+    """UpkieBaseVelocity (MPC balancer in the loop, upkie_base_velocity.py:164-202)."""
+    gpu = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=64, frequency=200.0, nb_timesteps=16, autoreset=False)
+    cpu = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=64, frequency=200.0, nb_timesteps=16, autoreset=False,
+                    sim_factory=oracle_sim_factory, mpc_factory=OracleMpc)
+    gpu.reset(seed=5)
+    cpu.reset(seed=5)
+    act = torch.zeros(64, 2)
+    act[:, 0] = torch.linspace(-0.3, 0.3, 64)
+    act[:, 1] = 0.2
+    for _ in range(100):
+        og, _, tg, _, _ = gpu.step(act)
+        oc, _, tc, _, _ = cpu.step(act)
+    assert torch.equal(tg.cpu(), tc)
+    np.testing.assert_allclose(og.cpu().numpy(), oc.numpy(), atol=1e-5)  # dead-reckoned pose
+    vg, vc = gpu.mpc_balancer.commanded_velocity.cpu().numpy(), cpu.mpc_balancer.commanded_velocity.numpy()
+    assert np.max(np.abs(vg - vc)) < 5e-3
+    pg = gpu.sim.state[abi.S_POS].cpu().numpy()
+    pc = cpu.sim.state[abi.S_POS].numpy()
+    assert np.max(np.abs(pg - pc)) < 2e-3
+    assert not bool(tg.any())  # the MPC keeps everyone upright

@@ -1,0 +1,68 @@
+"""Model layer: URDF -> merged rigid-body structure (upkie_amd/model), with
+the constants the reference pins (tests/model/*.py)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from upkie_amd.exceptions import ModelError
+from upkie_amd.model.default_model import default_model
+from upkie_amd.model.model import Model
+from upkie_amd.model.synthetic_urdf import synthetic_urdf
+from upkie_amd.model.urdf import UrdfTree, load_urdf_model
+
+
+def test_shipped_urdf_is_the_generated_one():
+    path = os.path.join(os.path.dirname(__import__("upkie_amd.model").model.__file__), "upkie_synthetic.urdf")
+    with open(path) as f:
+        assert f.read() == synthetic_urdf()
+
+
+def test_urdf_reduces_to_the_default_model():
+    m = Model()
+    d = default_model()
+    for name, _ in d._fields_:
+        a, b = getattr(m.struct, name), getattr(d, name)
+        a = np.array(a, dtype=float).ravel() if hasattr(b, "__len__") else np.array([float(a)])
+        b = np.array(b, dtype=float).ravel() if hasattr(b, "__len__") else np.array([float(b)])
+        np.testing.assert_allclose(np.nan_to_num(a, posinf=1e30, neginf=-1e30), np.nan_to_num(b, posinf=1e30, neginf=-1e30), atol=1e-12, err_msg=name)
+
+
+def test_reference_model_constants():
+    """tests/model/test_model.py:31-89, tests/model/test_kinematic_tree.py:31-36."""
+    m = Model()
+    assert m.wheel_radius == pytest.approx(0.05)
+    assert m.wheel_base == pytest.approx(0.3048, abs=0.005)
+    assert m.left_wheeled is True
+    np.testing.assert_allclose(m.rotation_base_to_imu, np.diag([-1.0, 1.0, -1.0]), atol=1e-12)
+    np.testing.assert_allclose(m.rotation_ars_to_world, np.diag([1.0, -1.0, -1.0]))
+    np.testing.assert_allclose(m.link_position_in_base("torso"), [0.0, 0.0, -0.1])
+    for frame in ("base", "torso", "imu", "left_hip_qdd100_stator", "left_wheel_tire", "left_wheel_hub", "right_wheel_tire"):
+        assert frame in m.link_names
+    assert [j.name for j in m.joints] == ["left_hip", "left_knee", "left_wheel", "right_hip", "right_knee", "right_wheel"]
+    assert [j.name for j in m.upper_leg_joints] == ["left_hip", "left_knee", "right_hip", "right_knee"]
+    assert [j.name for j in m.wheel_joints] == ["left_wheel", "right_wheel"]
+    hip, knee, wheel = m.joints[0].limit, m.joints[1].limit, m.joints[2].limit
+    assert (hip.lower, hip.upper, hip.effort, hip.velocity) == (-1.26, 1.26, 16.0, 28.8)
+    assert (knee.lower, knee.upper) == (-2.51, 2.51)
+    assert (wheel.effort, wheel.velocity) == (1.7, 111.0) and np.isinf(wheel.upper)
+    # mass and centre of mass survive the merge (BulletInterfaceTest.cpp:328, utils_test.cpp:93-98)
+    assert O.total_mass(m.struct) == pytest.approx(5.3382, abs=1e-4)
+    np.testing.assert_allclose(O.center_of_mass(m.struct), [-0.0059, 0.0, -0.2455], atol=1e-4)
+    # virtual links are not massless (docs/kinematics.md:77)
+    tree = UrdfTree(m.urdf_path)
+    assert tree.links["torso"].mass == pytest.approx(1e-3) and tree.links["imu"].mass > 0
+
+
+def test_urdf_errors(tmp_path):
+    text = synthetic_urdf()
+    bad = tmp_path / "no_imu.urdf"
+    bad.write_text(text.replace('name="imu"', 'name="not_imu"').replace('link="imu"', 'link="not_imu"'))
+    with pytest.raises(ModelError):  # pybullet_backend.py:153-154
+        load_urdf_model(str(bad))
+    bad2 = tmp_path / "sphere_tire.urdf"
+    bad2.write_text(text.replace("<cylinder", "<sphere"))
+    with pytest.raises(ModelError):  # model.py:137-143
+        load_urdf_model(str(bad2))

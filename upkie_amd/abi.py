@@ -86,6 +86,7 @@ class UpkieModel(C.Structure):
         ("contact_stiffness", C.c_double),
         ("contact_damping", C.c_double),
         ("friction_mu", C.c_double),
+        ("friction_cfm", C.c_double),
         ("contact_breaking_threshold", C.c_double),
         ("base_linear_damping", C.c_double),
         ("base_angular_damping", C.c_double),

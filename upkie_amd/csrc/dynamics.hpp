@@ -92,6 +92,7 @@ struct DevModel {
   float contact_stiffness;
   float contact_damping;
   float friction_mu;
+  float friction_cfm;
   float contact_breaking_threshold;
   float base_linear_damping;
   float base_angular_damping;
@@ -459,8 +460,7 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
   // ---- tire / floor contacts -------------------------------------------
   // Rows 3w+0..2 = (normal, t1, t2) of wheel w. Row r of wheel w only touches
   // the base and leg w: J = [d ; P x d ; leg part (3)].
-  float Jb[6][6], Jl[6][3];     // Jacobian rows
-  float Xb[6][6], Xl[6][3], Xo[6][3];  // M^-1 J' : base, own leg, other leg
+  float Jb[6][6], Jl[6][3];  // Jacobian rows
   float rhs[6];
   bool active[2];
   bool any_contact = false;
@@ -474,7 +474,7 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
     const Leg& G = S.leg[w];
     float sa = G.sgn[2];  // wheel axis = sa * y
     V3 wc = v3(M.wheel_center[w][0], M.wheel_center[w][1], M.wheel_center[w][2]);
-    V3 center = G.o[2] + wc;  // wheel_center must lie on the axis unless the wheel angle is tracked
+    V3 center = G.o[2] + wc;  // the tire centre lies on the wheel axis (checked at create)
     // lowest point of the tire circle: P = center - r * u / |u|, u = n - (n.a) a
     V3 dlow = v3(-nB.x * iun, 0.f, -nB.z * iun);
     V3 P = center + M.wheel_radius * dlow;
@@ -505,83 +505,121 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
       for (int j = 0; j < 3; ++j) v = fmaf(Jl[r][j], nu[6 + 3 * w + j], v);
       // penetration is pushed out with ERP; a separated point may only close
       // its gap within the step (continuous at dist = 0)
-      rhs[r] = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) / h : -v - dist / h) : -v;
-      // X = M^-1 J'
-      float xb[6], xl[3], xr[3];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) xb[c] = Jb[r][c];
-      if (w == 0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { xl[j] = Jl[r][j]; xr[j] = 0.f; }
-        system_solve<true, false>(S, xb, xl, xr);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Xl[r][j] = xl[j]; Xo[r][j] = xr[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { xl[j] = 0.f; xr[j] = Jl[r][j]; }
-        system_solve<false, true>(S, xb, xl, xr);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Xl[r][j] = xr[j]; Xo[r][j] = xl[j]; }
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) Xb[r][c] = xb[c];
+      float b = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) / h : -v - dist / h) : -v;
+      rhs[r] = active[w] ? b : 0.f;
     }
   }
   if (active[0] || active[1]) {
-    // Delassus matrix W = J M^-1 J' (symmetric)
-    float W[6][6];
+    // A = J M^-1 J' + CFM (symmetric, packed lower by rows), built one column
+    // of M^-1 J' at a time so that only J stays live; rows of a wheel without
+    // a contact point are replaced by identity rows with zero rhs.
+    float A[21];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int b = 0; b < 6; ++b) {
+      float xb[6], xl[3], xr[3];
 #pragma unroll
-      for (int b = a; b < 6; ++b) {
+      for (int c = 0; c < 6; ++c) xb[c] = Jb[b][c];
+      if (b < 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xl[j] = Jl[b][j]; xr[j] = 0.f; }
+        system_solve<true, false>(S, xb, xl, xr);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xl[j] = 0.f; xr[j] = Jl[b][j]; }
+        system_solve<false, true>(S, xb, xl, xr);
+      }
+#pragma unroll
+      for (int a = b; a < 6; ++a) {
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc = fmaf(Jb[a][c], Xb[b][c], acc);
-        bool same = (a / 3) == (b / 3);
+        for (int c = 0; c < 6; ++c) acc = fmaf(Jb[a][c], xb[c], acc);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc = fmaf(Jl[a][j], same ? Xl[b][j] : Xo[b][j], acc);
-        W[a][b] = acc;
-        W[b][a] = acc;
+        for (int j = 0; j < 3; ++j) acc = fmaf(Jl[a][j], a < 3 ? xl[j] : xr[j], acc);
+        if (a == b) acc += (a % 3) == 0 ? cfm : M.friction_cfm;
+        const bool live = active[a / 3] && active[b / 3];
+        A[a * (a + 1) / 2 + b] = live ? acc : (a == b ? 1.f : 0.f);
       }
     }
-    float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float idiag[6];
+    // Direct solve first: with both tires loaded and no slip the unconstrained
+    // solution already satisfies lam_n >= 0, |lam_t| <= mu lam_n and IS the
+    // solution. Otherwise it is projected and warm-starts the projected
+    // Gauss-Seidel sweeps (continuous at the stick/slip / lift-off boundaries).
+    float lam[6];
+    const float mu = M.friction_mu;
+    bool need_pgs = false;
+    {
+      Ldl6 fac;
+      ldl6_factor(A, fac);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) idiag[r] = 1.f / (W[r][r] + ((r % 3) == 0 ? cfm : 0.f));
-    float mu = M.friction_mu;
-    for (int it = 0; it < M.pgs_iterations; ++it) {
-      // normals of both wheels first, then friction rows
+      for (int r = 0; r < 6; ++r) lam[r] = rhs[r];
+      ldl6_solve(fac, lam);
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
+      for (int w = 0; w < 2; ++w) {
+        if (lam[3 * w] < 0.f) {
+          lam[3 * w] = 0.f;
+          need_pgs = true;
+        }
+      }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          bool is_normal = (r % 3) == 0;
-          if (is_normal != (pass == 0)) continue;
-          float wl = 0.f;
+      for (int r = 0; r < 6; ++r) {
+        if ((r % 3) == 0) continue;
+        const float lim = mu * lam[3 * (r / 3)];
+        if (lam[r] < -lim) { lam[r] = -lim; need_pgs = true; }
+        if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
+      }
+    }
+    if (need_pgs) {
+      float idiag[6];
+      idiag[0] = 1.f / A[0]; idiag[1] = 1.f / A[2]; idiag[2] = 1.f / A[5];
+      idiag[3] = 1.f / A[9]; idiag[4] = 1.f / A[14]; idiag[5] = 1.f / A[20];
+      for (int it = 0; it < M.pgs_iterations; ++it) {
+        // normals of both wheels first, then friction rows
 #pragma unroll
-          for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
-          float x;
-          if (is_normal) {
-            x = lam[r] + (rhs[r] - wl - cfm * lam[r]) * idiag[r];
-            x = fmaxf(x, 0.f);
-          } else {
-            x = lam[r] + (rhs[r] - wl) * idiag[r];
-            float lim = mu * lam[3 * (r / 3)];
-            x = fminf(fmaxf(x, -lim), lim);
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const bool is_normal = (r % 3) == 0;
+            if (is_normal != (pass == 0)) continue;
+            float al = 0.f;  // (W + CFM) lam, row r
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              const int hi = r > b ? r : b, lo = r > b ? b : r;
+              al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
+            }
+            float x = lam[r] + (rhs[r] - al) * idiag[r];
+            if (is_normal) {
+              x = fmaxf(x, 0.f);
+            } else {
+              const float lim = mu * lam[3 * (r / 3)];
+              x = fminf(fmaxf(x, -lim), lim);
+            }
+            lam[r] = x;
           }
-          lam[r] = active[r / 3] ? x : 0.f;
         }
       }
     }
+    // velocity jump M^-1 J' lam with one more solve
+    {
+      float gb[6], gl[3], gr[3];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      int w = r / 3;
+      for (int c = 0; c < 6; ++c) {
+        float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) nu[c] = fmaf(Xb[r][c], lam[r], nu[c]);
+        for (int r = 0; r < 6; ++r) acc = fmaf(Jb[r][c], lam[r], acc);
+        gb[c] = acc;
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        nu[6 + 3 * w + j] = fmaf(Xl[r][j], lam[r], nu[6 + 3 * w + j]);
-        nu[6 + 3 * (1 - w) + j] = fmaf(Xo[r][j], lam[r], nu[6 + 3 * (1 - w) + j]);
+        gl[j] = Jl[0][j] * lam[0] + Jl[1][j] * lam[1] + Jl[2][j] * lam[2];
+        gr[j] = Jl[3][j] * lam[3] + Jl[4][j] * lam[4] + Jl[5][j] * lam[5];
+      }
+      system_solve<true, true>(S, gb, gl, gr);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) nu[c] += gb[c];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        nu[6 + j] += gl[j];
+        nu[9 + j] += gr[j];
       }
     }
   }

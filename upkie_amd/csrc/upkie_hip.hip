@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -620,6 +621,7 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   d->contact_stiffness = (float)m->contact_stiffness;
   d->contact_damping = (float)m->contact_damping;
   d->friction_mu = (float)m->friction_mu;
+  d->friction_cfm = (float)m->friction_cfm;
   d->contact_breaking_threshold = (float)m->contact_breaking_threshold;
   d->base_linear_damping = (float)m->base_linear_damping;
   d->base_angular_damping = (float)m->base_angular_damping;
@@ -710,6 +712,17 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
   return UPKIE_OK;
 }
 
+extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config) {
+  if (!sim || !config) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (config->num_envs != sim->config.num_envs) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "num_envs cannot change");
+  DevConfig next;
+  std::string why;
+  if (!convert_config(config, &next, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);
+  for (int k = 0; k < 3; ++k) next.ext_point[k] = sim->config.ext_point[k];
+  sim->config = next;
+  return UPKIE_OK;
+}
+
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   delete sim;
   return UPKIE_OK;
@@ -732,11 +745,12 @@ extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_s
   return UPKIE_OK;
 }
 
-static dim3 grid_for(int B) { return dim3((unsigned)((B + 63) / 64)); }
+static int block_lanes() { return 64; }  // one wavefront per block
+static dim3 grid_for(int B) { return dim3((unsigned)((B + block_lanes() - 1) / block_lanes())); }
 
 extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale, double inertia_variation, void* stream) {
   if (!sim || !inertia_scale) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  hipLaunchKernelGGL(inertia_scale_kernel, grid_for(sim->config.num_envs), dim3(64), 0, (hipStream_t)stream, sim->config,
+  hipLaunchKernelGGL(inertia_scale_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config,
                      inertia_scale, (float)inertia_variation);
   return check_hip(sim, hipGetLastError(), "inertia_scale_kernel");
 }
@@ -750,7 +764,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS) && !act)
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
   const bool rnd = sim->inertia_scale || sim->ext_force;
-  dim3 grid = grid_for(sim->config.num_envs), block(64);
+  dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   if (rnd) {
     hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
                        reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed);
@@ -807,7 +821,7 @@ extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineOb
   p.imu_raw_linear_acceleration = out->imu_raw_linear_acceleration;
   p.servo = out->servo;
   p.wheel_odometry = out->wheel_odometry;
-  hipLaunchKernelGGL(observe_kernel, grid_for(sim->config.num_envs), dim3(64), 0, (hipStream_t)stream, sim->model, sim->config,
+  hipLaunchKernelGGL(observe_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->model, sim->config,
                      state, p, update_imu);
   return check_hip(sim, hipGetLastError(), "observe_kernel");
 }
@@ -888,7 +902,7 @@ extern "C" int64_t upkie_mpc_workspace_bytes(const UpkieMpc* mpc) {
 
 extern "C" int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded_velocity, const uint8_t* mask, void* stream) {
   if (!mpc || !workspace || !commanded_velocity) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  hipLaunchKernelGGL(mpc_reset_kernel, grid_for(mpc->dev.num_envs), dim3(64), 0, (hipStream_t)stream, mpc->dev.num_envs,
+  hipLaunchKernelGGL(mpc_reset_kernel, grid_for(mpc->dev.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, mpc->dev.num_envs,
                      mpc->dev.n, workspace, commanded_velocity, mask);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));

@@ -1,0 +1,373 @@
+"""Batched Upkie environments (gymnasium.vector semantics, torch tensors).
+
+Same kwargs, observation/action layouts and arithmetic as the reference's
+single-robot envs -- ``UpkieServos`` (upkie/envs/upkie_servos.py),
+``UpkieGyropod`` (upkie_gyropod.py), ``UpkiePendulum`` (upkie_pendulum.py),
+``UpkieBaseVelocity`` (upkie_base_velocity.py) on a ``PyBulletBackend`` --
+but for ``num_envs`` independent robots stepped by one kernel launch:
+
+    env = UpkiePendulumVecEnv(num_envs=4096, frequency=200.0)
+    obs, info = env.reset(seed=0)                  # obs: [B, 4] on the GPU
+    obs, reward, terminated, truncated, info = env.step(actions)   # [B, 1]
+
+Terminated envs are reset by the next step() (gymnasium's NEXT_STEP autoreset),
+which ignores their action and returns their reset observation.
+"""
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import abi
+from ..exceptions import UpkieException, UpkieRuntimeError
+from ..model.joint_properties import JointProperties
+from ..model.model import Model
+from ..utils.robot_state import RobotState
+from .spaces import Box, Dict as DictSpace, batch_box
+from .spine_observation import LazySpineObservation
+
+
+def _default_sim_factory(config, model_struct, device):
+    from ..sim import BatchedSim
+
+    return BatchedSim(config, model_struct, device=device)
+
+
+class UpkieVecEnv:
+    """Common part of the batched envs: owns the simulation handle, the model
+    and the configuration (the role of UpkieEnv + PyBulletBackend,
+    upkie_env.py:19-251 / pybullet_backend.py:55-197)."""
+
+    def __init__(
+        self,
+        num_envs: int = 1,
+        device: str = "cuda:0",
+        frequency: Optional[float] = 200.0,
+        frequency_checks: bool = True,
+        init_state: Optional[RobotState] = None,
+        regulate_frequency: bool = False,
+        max_gain_scale: float = 5.0,
+        model: Optional[Model] = None,
+        gui: bool = False,
+        inertia_variation: float = 0.0,
+        joint_properties: Optional[Dict[str, JointProperties]] = None,
+        nb_substeps: Optional[int] = None,
+        torque_control_kd: float = 1.0,
+        torque_control_kp: float = 20.0,
+        seed: int = 0,
+        autoreset: bool = True,
+        env_id_offset: int = 0,
+        eager_spine_observation: bool = False,
+        sim_factory=None,
+    ):
+        if frequency is None:  # upkie_gyropod.py:123-124, upkie_env.py:85-86
+            raise UpkieException("This environment needs a loop frequency")
+        if regulate_frequency:
+            raise UpkieException(
+                "regulate_frequency=True sleeps to real time (upkie_env.py:220-221); "
+                "a batched simulation is stepped as fast as possible"
+            )
+        if gui:
+            raise UpkieException("the batched simulation has no GUI")
+        if not (0.0 < max_gain_scale < 10.0):  # upkie_servos.py:144-145
+            raise UpkieRuntimeError(f"Invalid value {max_gain_scale=}")
+        self.num_envs = int(num_envs)
+        self.model = model if model is not None else Model()
+        self.init_state = init_state if init_state is not None else RobotState(
+            position_base_in_world=np.array([0.0, 0.0, 0.6])  # upkie_env.py:87-90
+        )
+        self.frequency = float(frequency)
+        self.inertia_variation = float(inertia_variation)
+        self.eager_spine_observation = eager_spine_observation
+        cfg = abi.default_sim_config(self.num_envs, frequency=self.frequency, nb_substeps=nb_substeps, seed=seed)
+        cfg.torque_control_kp = torque_control_kp
+        cfg.torque_control_kd = torque_control_kd
+        cfg.max_gain_scale = max_gain_scale
+        cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP if autoreset else abi.AUTORESET_DISABLED
+        cfg.env_id_offset = env_id_offset
+        for idx, name in enumerate(abi.JOINT_NAMES):
+            props = (joint_properties or {}).get(name, JointProperties())
+            cfg.joint_friction[idx] = props.friction
+            cfg.torque_control_noise[idx] = props.torque_control_noise
+            cfg.torque_measurement_noise[idx] = props.torque_measurement_noise
+        self.init_state.write_to_config(cfg)
+        self.config = cfg
+        self._configure(cfg)  # wrapper-specific fields
+        factory = sim_factory if sim_factory is not None else _default_sim_factory
+        self.sim = factory(cfg, self.model.struct, device)
+        self.device = self.sim.device
+        if abs(self.inertia_variation) > 1e-10:  # pybullet_backend.py:178-179
+            self.sim.randomize_inertias(self.inertia_variation)
+        self._spine = LazySpineObservation(self.sim)
+        self._external_forces: Dict[str, object] = {}
+
+    # hooks ------------------------------------------------------------
+    def _configure(self, cfg) -> None:
+        pass
+
+    # gymnasium.Env-like attributes -------------------------------------
+    @property
+    def dt(self) -> float:
+        """Control period in seconds (upkie_env.py:113-119)."""
+        return 1.0 / self.frequency
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def close(self) -> None:
+        self.sim.close()
+
+    def _info(self) -> dict:
+        self._spine.invalidate()
+        if self.eager_spine_observation:
+            self._spine.materialize()
+        return {"spine_observation": self._spine}
+
+    def update_init_rand(self, **kwargs) -> None:
+        """upkie_env.py:244-251."""
+        self.init_state.randomization.update(**kwargs)
+        self.init_state.write_to_config(self.config)
+        self.sim.push_config()
+
+    def set_external_forces(self, link_name: str, forces: Optional[torch.Tensor]) -> None:
+        """World-frame force ``[B, 3]`` (or ``[3]``) applied at the origin of
+        `link_name`'s frame every substep until overwritten
+        (pybullet_backend.py:603-658). Links rigidly part of the trunk only."""
+        if link_name not in self.model.link_names:
+            raise UpkieRuntimeError(f"Robot does not have a link named '{link_name}'")
+        if self.model.body_of_link(link_name) != 0:
+            raise UpkieRuntimeError(f"external forces on '{link_name}': only trunk links are supported")
+        if forces is None:
+            self.sim.set_external_force(None)
+            return
+        forces = torch.as_tensor(forces, dtype=torch.float32)
+        if forces.shape == (3,):
+            forces = forces.expand(self.num_envs, 3)
+        if tuple(forces.shape) != (self.num_envs, 3):
+            raise ValueError(f"Force must be a 3D vector per env, got shape {tuple(forces.shape)}")
+        point = self.model.link_position_in_base(link_name)
+        self.sim.set_external_force(forces.t().contiguous(), point=tuple(point))
+
+    def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
+        if seed is not None:
+            self.config.seed = int(seed)
+            self.sim.push_config()
+        return self.sim.reset(mask)
+
+
+class UpkiePendulumVecEnv(UpkieVecEnv):
+    """Batched ``UpkiePendulum``: action [ground velocity], observation
+    [pitch, ground position, pitch rate, ground velocity]
+    (upkie_pendulum.py:20-60)."""
+
+    def __init__(self, num_envs: int = 1, fall_pitch: float = 1.0, max_ground_velocity: float = 3.0, **kwargs):
+        self.fall_pitch = fall_pitch
+        self.max_ground_velocity = max_ground_velocity
+        super().__init__(num_envs=num_envs, **kwargs)
+        # upkie_gyropod.py:126-142 limits, permuted by _PENDULUM_OBS_INDICES = [1, 0, 4, 3]
+        obs_limit = np.array([np.pi, np.inf, 1000.0, max_ground_velocity], dtype=np.float32)
+        act_limit = np.array([max_ground_velocity], dtype=np.float32)
+        self.single_observation_space = Box(-obs_limit, +obs_limit, shape=obs_limit.shape, dtype=np.float32)
+        self.single_action_space = Box(-act_limit, +act_limit, shape=act_limit.shape, dtype=np.float32)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        self.action_space = batch_box(self.single_action_space, self.num_envs)
+
+    def _configure(self, cfg) -> None:
+        cfg.fall_pitch = self.fall_pitch
+        cfg.max_ground_velocity = self.max_ground_velocity
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
+        obs6 = self._reset_sim(seed, mask)
+        obs = obs6[:, [1, 0, 4, 3]].contiguous()  # upkie_pendulum.py:17,122
+        self.sim.obs4.copy_(obs)
+        return obs, self._info()
+
+    def step(self, action):
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs)
+        obs, reward, terminated, truncated = self.sim.step_pendulum(act)
+        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+
+
+class UpkieGyropodVecEnv(UpkieVecEnv):
+    """Batched ``UpkieGyropod``: action [ground velocity, yaw velocity],
+    observation [ground position, pitch, yaw, ground velocity, pitch rate,
+    yaw velocity] (upkie_gyropod.py:20-98)."""
+
+    def __init__(
+        self,
+        num_envs: int = 1,
+        fall_pitch: float = 1.0,
+        leg_gain_scale: float = 1.0,
+        max_ground_velocity: float = 3.0,
+        max_yaw_velocity: float = 1.0,
+        **kwargs,
+    ):
+        self.fall_pitch = fall_pitch
+        self._leg_gain_scale = leg_gain_scale
+        self.max_ground_velocity = max_ground_velocity
+        self.max_yaw_velocity = max_yaw_velocity
+        super().__init__(num_envs=num_envs, **kwargs)
+        obs_limit = np.array(  # upkie_gyropod.py:126-142
+            [np.inf, np.pi, np.inf, max_ground_velocity, 1000.0, max_yaw_velocity], dtype=np.float32
+        )
+        act_limit = np.array([max_ground_velocity, max_yaw_velocity], dtype=np.float32)
+        self.single_observation_space = Box(-obs_limit, +obs_limit, shape=obs_limit.shape, dtype=np.float32)
+        self.single_action_space = Box(-act_limit, +act_limit, shape=act_limit.shape, dtype=np.float32)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        self.action_space = batch_box(self.single_action_space, self.num_envs)
+
+    def _configure(self, cfg) -> None:
+        cfg.fall_pitch = self.fall_pitch
+        cfg.leg_gain_scale = self._leg_gain_scale
+        cfg.max_ground_velocity = self.max_ground_velocity
+        cfg.max_yaw_velocity = self.max_yaw_velocity
+
+    @property
+    def leg_gain_scale(self) -> float:
+        return self._leg_gain_scale
+
+    def set_leg_gain_scale(self, leg_gain_scale: float) -> None:
+        """upkie_gyropod.py:178-184."""
+        self._leg_gain_scale = leg_gain_scale
+        self.config.leg_gain_scale = leg_gain_scale
+        self.sim.push_config()
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
+        obs6 = self._reset_sim(seed, mask)
+        return obs6, self._info()
+
+    def step(self, action):
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2)
+        obs, reward, terminated, truncated = self.sim.step_gyropod(act)
+        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+
+
+class UpkieServosVecEnv(UpkieVecEnv):
+    """Batched ``UpkieServos``: action ``[B, 6, 6]`` = joints x ACTION_KEYS
+    (position, velocity, feedforward_torque, kp_scale, kd_scale,
+    maximum_torque), observation ``[B, 6, 5]`` = joints x (position, velocity,
+    torque, temperature, voltage) (upkie_servos.py:20-306). Never terminates
+    on its own (upkie_env.py:231-238)."""
+
+    def __init__(self, num_envs: int = 1, **kwargs):
+        super().__init__(num_envs=num_envs, **kwargs)
+        m = self.model.struct
+        lo = np.zeros((6, 6), dtype=np.float32)
+        hi = np.zeros((6, 6), dtype=np.float32)
+        olo = np.zeros((6, 5), dtype=np.float32)
+        ohi = np.zeros((6, 5), dtype=np.float32)
+        neutral = np.zeros((6, 6), dtype=np.float32)
+        for j in range(6):  # upkie_servos.py:173-278
+            eff, vel = m.joint_effort[j], m.joint_velocity[j]
+            lo[j] = [m.joint_lower[j], -vel, -eff, 0.0, 0.0, 0.0]
+            hi[j] = [m.joint_upper[j], vel, eff, self.config.max_gain_scale, self.config.max_gain_scale, eff]
+            olo[j] = [m.joint_lower[j], -vel, -eff, 0.0, 10.0]
+            ohi[j] = [m.joint_upper[j], vel, eff, 100.0, 44.0]
+            neutral[j] = [np.nan, 0.0, 0.0, 1.0, 1.0, eff]  # upkie_servos.py:255-262
+        self._neutral = neutral
+        self.single_action_space = Box(lo, hi, shape=(6, 6), dtype=np.float32)
+        self.single_observation_space = Box(olo, ohi, shape=(6, 5), dtype=np.float32)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        self.action_space = batch_box(self.single_action_space, self.num_envs)
+
+    def get_neutral_action(self) -> torch.Tensor:
+        """``[B, 6, 6]`` action where servos do not move (upkie_servos.py:308-314)."""
+        return torch.from_numpy(self._neutral).to(self.device).expand(self.num_envs, 6, 6).clone()
+
+    def _servo_obs(self) -> torch.Tensor:
+        obs = torch.empty((self.num_envs, 6, 5), dtype=torch.float32, device=self.device)
+        st = self.sim.state
+        obs[:, :, 0] = st[abi.S_Q : abi.S_Q + 6].t()
+        obs[:, :, 1] = st[abi.S_QD : abi.S_QD + 6].t()
+        obs[:, :, 2] = st[abi.S_TORQUE : abi.S_TORQUE + 6].t()
+        obs[:, :, 3] = 42.0
+        obs[:, :, 4] = 18.0
+        return obs
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
+        self._reset_sim(seed, mask)
+        return self._servo_obs(), self._info()
+
+    def step(self, action):
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 6, 6)
+        obs, reward, terminated, truncated = self.sim.step_servos(act)
+        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+
+
+class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
+    """Batched ``UpkieBaseVelocity``: action [linear velocity, yaw velocity]
+    goes through the MPC balancer, observation is the dead-reckoned SE(2) pose
+    [x, y, yaw] (upkie_base_velocity.py:21-202)."""
+
+    def __init__(
+        self,
+        num_envs: int = 1,
+        fall_pitch: float = 1.0,
+        max_ground_velocity: float = 3.0,
+        max_yaw_velocity: float = 1.0,
+        leg_length: float = 0.58,
+        max_ground_accel: float = 10.0,
+        nb_timesteps: int = 50,
+        mpc_factory=None,
+        **kwargs,
+    ):
+        super().__init__(
+            num_envs=num_envs,
+            fall_pitch=fall_pitch,
+            max_ground_velocity=max_ground_velocity,
+            max_yaw_velocity=max_yaw_velocity,
+            **kwargs,
+        )
+        obs_limit = np.full(3, np.inf, dtype=np.float32)
+        self.single_observation_space = Box(-obs_limit, +obs_limit, shape=(3,), dtype=np.float32)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        mpc_cfg = abi.default_mpc_config(self.num_envs, nb_timesteps)
+        mpc_cfg.fall_pitch = fall_pitch
+        mpc_cfg.leg_length = leg_length
+        mpc_cfg.max_ground_accel = max_ground_accel
+        mpc_cfg.max_ground_velocity = max_ground_velocity
+        if mpc_factory is None:
+            from ..mpc import BatchedMpc
+
+            mpc_factory = BatchedMpc
+        self.mpc_balancer = mpc_factory(mpc_cfg, device=str(self.device))
+        B = self.num_envs
+        self._x0 = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
+        self._contact = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self._xy = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
+
+    def _remember(self, obs6: torch.Tensor) -> None:
+        # MPC state [ground position, pitch, ground velocity, pitch rate] of the
+        # LAST observation (upkie_base_velocity.py:185-187,195)
+        self._x0.copy_(obs6[:, [0, 1, 3, 4]])
+        self._contact.copy_((self.sim.state[abi.S_CONTACT] != 0).to(torch.uint8))
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
+        obs6, info = super().reset(seed=seed, options=options, mask=mask)
+        self._remember(obs6)
+        self.mpc_balancer.reset(mask)  # upkie_base_velocity.py:158
+        if mask is None:
+            self._xy.zero_()
+        else:
+            self._xy[mask.to(self.device).bool()] = 0.0
+        obs = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)
+        return obs, info
+
+    def step(self, action):
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2)
+        linear_velocity, yaw_velocity = act[:, 0].contiguous(), act[:, 1]
+        autoreset = (self.sim.state[abi.S_DONE] != 0) if self.config.autoreset_mode else None
+        ground_velocity, _ = self.mpc_balancer.step(self._x0, linear_velocity, self._contact, self.dt)
+        gyropod_action = torch.stack([ground_velocity, yaw_velocity], dim=1)
+        obs6, reward, terminated, truncated, info = super().step(gyropod_action)
+        self._remember(obs6)
+        yaw = obs6[:, 2]
+        self._xy[:, 0] += linear_velocity * torch.cos(yaw) * self.dt  # :197-199
+        self._xy[:, 1] += linear_velocity * torch.sin(yaw) * self.dt
+        if autoreset is not None and bool(autoreset.any()):
+            self.mpc_balancer.reset(autoreset.to(torch.uint8))
+            self._xy[autoreset] = 0.0
+        obs = torch.cat([self._xy, yaw[:, None]], dim=1)
+        return obs, reward, terminated, truncated, info

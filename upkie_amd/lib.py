@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "upkie_hip_device_count",
     "upkie_sim_create",
     "upkie_sim_destroy",
+    "upkie_sim_set_config",
     "upkie_sim_last_error",
     "upkie_sim_state_bytes",
     "upkie_sim_set_randomization",
@@ -113,6 +114,8 @@ def load() -> C.CDLL:
         C.POINTER(abi.UpkieModel),
         C.POINTER(vp),
     ]
+    lib.upkie_sim_set_config.restype = C.c_int
+    lib.upkie_sim_set_config.argtypes = [vp, C.POINTER(abi.UpkieSimConfig)]
     lib.upkie_sim_destroy.restype = C.c_int
     lib.upkie_sim_destroy.argtypes = [vp]
     lib.upkie_sim_last_error.restype = C.c_char_p

@@ -116,6 +116,7 @@ def default_model() -> UpkieModel:
     m.contact_stiffness = 30000.0
     m.contact_damping = 1000.0
     m.friction_mu = 1.0
+    m.friction_cfm = 0.01
     m.contact_breaking_threshold = 0.02
     m.base_linear_damping = 0.04
     m.base_angular_damping = 0.04

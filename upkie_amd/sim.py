@@ -81,6 +81,10 @@ class BatchedSim:
     def _check(self, status: int) -> None:
         lib.check(status, self._handle)
 
+    def push_config(self) -> None:
+        """Hand the (mutated) ``self.config`` to the library."""
+        self._check(self._lib.upkie_sim_set_config(self._handle, C.byref(self.config)))
+
     # ---------------------------------------------------------- randomise
     def randomize_inertias(self, inertia_variation: float) -> torch.Tensor:
         """Per-env, per-body mass/inertia scales 1 + U(-v, v)

@@ -1,0 +1,60 @@
+"""Initial robot state (upkie/utils/robot_state.py:52-120).
+
+The reference stores the base orientation as a scipy Rotation; here it is a
+unit quaternion ``[w, x, y, z]`` (a scipy Rotation is accepted and converted).
+"""
+
+from typing import Optional
+
+import numpy as np
+
+from .robot_state_randomization import RobotStateRandomization
+
+
+def _as_quat_wxyz(orientation) -> np.ndarray:
+    if orientation is None:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    if hasattr(orientation, "as_quat"):  # scipy Rotation: [x, y, z, w]
+        x, y, z, w = orientation.as_quat()
+        return np.array([w, x, y, z], dtype=np.float64)
+    quat = np.array(orientation, dtype=np.float64)
+    if quat.shape != (4,):
+        raise ValueError("orientation must be a scipy Rotation or [w, x, y, z]")
+    return quat
+
+
+class RobotState:
+    def __init__(
+        self,
+        angular_velocity_base_in_base: Optional[np.ndarray] = None,
+        joint_configuration: Optional[np.ndarray] = None,
+        joint_velocity: Optional[np.ndarray] = None,
+        linear_velocity_base_to_world_in_world: Optional[np.ndarray] = None,
+        orientation_base_in_world=None,
+        position_base_in_world: Optional[np.ndarray] = None,
+        randomization: Optional[RobotStateRandomization] = None,
+    ):
+        def vec(value, default):
+            return np.array(value, dtype=np.float64) if value is not None else default
+
+        self.angular_velocity_base_in_base = vec(angular_velocity_base_in_base, np.zeros(3))
+        self.joint_configuration = vec(joint_configuration, np.zeros(6))
+        self.joint_velocity = vec(joint_velocity, np.zeros(6))  # never used, :261-267
+        self.linear_velocity_base_to_world_in_world = vec(linear_velocity_base_to_world_in_world, np.zeros(3))
+        self.orientation_base_in_world = _as_quat_wxyz(orientation_base_in_world)
+        # Upkie above the horizontal plane, robot_state.py:112
+        self.position_base_in_world = vec(position_base_in_world, np.array([0.0, 0.0, 0.6]))
+        self.randomization = randomization if randomization is not None else RobotStateRandomization()
+
+    def write_to_config(self, cfg) -> None:
+        """Fill the init-state and randomisation fields of an UpkieSimConfig."""
+        cfg.init_pos[:] = list(self.position_base_in_world)
+        cfg.init_quat[:] = list(self.orientation_base_in_world)
+        cfg.init_linvel[:] = list(self.linear_velocity_base_to_world_in_world)
+        cfg.init_angvel[:] = list(self.angular_velocity_base_in_base)
+        cfg.init_joint[:] = list(self.joint_configuration)
+        r = self.randomization
+        cfg.rand_roll, cfg.rand_pitch = r.roll, r.pitch
+        cfg.rand_x, cfg.rand_z = r.x, r.z
+        cfg.rand_omega_x, cfg.rand_omega_y = r.omega_x, r.omega_y
+        cfg.rand_linvel[:] = list(r.linear_velocity)
