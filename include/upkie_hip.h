@@ -50,6 +50,7 @@ enum UpkieStateWord {
   UPKIE_S_SE2_X = 43,   /* 1: dead-reckoned x, upkie_base_velocity.py:197   */
   UPKIE_S_SE2_Y = 44,   /* 1: dead-reckoned y                               */
   UPKIE_S_CONTACT = 45, /* 1: floor contact flag after the last substep     */
+  UPKIE_S_STEP = 46,    /* 1: env.step() calls so far (torque-noise stream)  */
   UPKIE_STATE_WORDS = 48
 };
 

@@ -151,8 +151,8 @@ static void philox_uniform4(uint64_t seed, int64_t env, uint32_t episode,
 
 /* ------------------------------------------------------------ servo law */
 /* pybullet_backend.py:492-553 (noise handled by the caller). */
-double oracle_joint_torque(double q, double qd, const OracleServoCommand* cmd,
-                           double kp_gain, double kd_gain, double friction) {
+static double joint_torque_with_noise(double q, double qd, const OracleServoCommand* cmd,
+                                      double kp_gain, double kd_gain, double friction, double noise) {
   double kp = cmd->kp_scale * kp_gain;                 /* :526 */
   double kd = cmd->kd_scale * kd_gain;                 /* :527 */
   double torque = cmd->feedforward_torque;             /* :530 */
@@ -162,10 +162,37 @@ double oracle_joint_torque(double q, double qd, const OracleServoCommand* cmd,
     double sign = qd > 0.0 ? 1.0 : -1.0;
     torque += -friction * sign;
   }
+  torque += noise; /* :545-550, drawn by the caller when sigma > 1e-10 */
   /* np.clip, :552 */
   if (torque < -cmd->maximum_torque) torque = -cmd->maximum_torque;
   if (torque > cmd->maximum_torque) torque = cmd->maximum_torque;
   return torque;
+}
+
+double oracle_joint_torque(double q, double qd, const OracleServoCommand* cmd,
+                           double kp_gain, double kd_gain, double friction) {
+  return joint_torque_with_noise(q, qd, cmd, kp_gain, kd_gain, friction, 0.0);
+}
+
+/* Six standard normals for (env, step, slot): Box-Muller on two Philox blocks.
+ * slot = substep index for control noise, NOISE_SLOT_MEASUREMENT for the
+ * measurement noise of the observation that follows step `step`. */
+#define NOISE_SLOT_MEASUREMENT 0x7fffu
+static void philox_normal6(uint64_t seed, int64_t env, uint32_t step, uint32_t slot, double z[6]) {
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  uint32_t r[8];
+  for (uint32_t k = 0; k < 2; ++k) {
+    uint32_t ctr[4] = {(uint32_t)((uint64_t)env & 0xffffffffu), (uint32_t)((uint64_t)env >> 32), step,
+                       ((uint32_t)STREAM_NOISE << 24) | (slot * 2u + k)};
+    oracle_philox4x32_10(ctr, key, r + 4 * k);
+  }
+  for (int p = 0; p < 3; ++p) {
+    double u1 = ((double)(r[2 * p] >> 8) + 1.0) * (1.0 / 16777216.0); /* (0, 1] */
+    double u2 = (double)(r[2 * p + 1] >> 8) * (1.0 / 16777216.0);
+    double radius = sqrt(-2.0 * log(u1));
+    z[2 * p] = radius * cos(6.283185307179586 * u2);
+    z[2 * p + 1] = radius * sin(6.283185307179586 * u2);
+  }
 }
 
 /* ------------------------------------------------------------ kinematics */
@@ -793,21 +820,34 @@ static void clamp_servo_commands(const UpkieModel* model,
 }
 
 /* PyBulletBackend.step, pybullet_backend.py:269-311 */
+static int has_noise(const double sigma[NJ]) {
+  for (int j = 0; j < NJ; ++j)
+    if (sigma[j] > 1e-10) return 1;
+  return 0;
+}
+
 static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
-                         double s[NW], const OracleServoCommand cmd[NJ],
+                         double s[NW], int64_t env_global,
+                         const OracleServoCommand cmd[NJ],
                          const double* scale, const double* force,
                          const double* point) {
   double h = cfg->dt / cfg->nb_substeps;
+  int noisy = has_noise(cfg->torque_control_noise);
+  uint32_t step = (uint32_t)s[UPKIE_S_STEP];
   for (int sub = 0; sub < cfg->nb_substeps; ++sub) {
-    double tau[NJ];
+    double tau[NJ], z[6] = {0, 0, 0, 0, 0, 0};
+    /* control noise: one draw per joint per substep, :545-550 */
+    if (noisy) philox_normal6(cfg->seed, env_global, step, (uint32_t)sub, z);
     for (int j = 0; j < NJ; ++j) {
-      tau[j] = oracle_joint_torque(s[UPKIE_S_Q + j], s[UPKIE_S_QD + j], &cmd[j],
-                                   cfg->torque_control_kp, cfg->torque_control_kd,
-                                   cfg->joint_friction[j]);
+      double sigma = cfg->torque_control_noise[j];
+      tau[j] = joint_torque_with_noise(s[UPKIE_S_Q + j], s[UPKIE_S_QD + j], &cmd[j],
+                                       cfg->torque_control_kp, cfg->torque_control_kd,
+                                       cfg->joint_friction[j], sigma > 1e-10 ? sigma * z[j] : 0.0);
       s[UPKIE_S_TORQUE + j] = tau[j]; /* :293 */
     }
     oracle_substep(model, s, tau, h, scale, force, point);
   }
+  s[UPKIE_S_STEP] = (double)(step + 1u);
 }
 
 /* UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331 */
@@ -876,7 +916,7 @@ static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   OracleServoCommand cmd[NJ];
   gyropod_commands(model, cfg, s, a0, a1, cmd);
   clamp_servo_commands(model, cfg, cmd);
-  backend_step(model, cfg, s, cmd, sp, fp, pp);
+  backend_step(model, cfg, s, env_global, cmd, sp, fp, pp);
   s[UPKIE_S_YAW] += a1 * cfg->dt; /* upkie_gyropod.py:383-385, unclamped */
   s[UPKIE_S_YAWVEL] = a1;
   gyropod_observation(model, s, obs6);
@@ -954,11 +994,17 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
 }
 
 /* upkie_servos.py:288-306 with pybullet_backend.py:448-474 */
-static void servo_observation(const double s[NW], double obs[30]) {
+static void servo_observation(const UpkieSimConfig* cfg, int64_t env_global,
+                              const double s[NW], double obs[30]) {
+  double z[6] = {0, 0, 0, 0, 0, 0};
+  /* measurement noise: one draw per joint per observation, :461-466 */
+  if (has_noise(cfg->torque_measurement_noise))
+    philox_normal6(cfg->seed, env_global, (uint32_t)s[UPKIE_S_STEP], NOISE_SLOT_MEASUREMENT, z);
   for (int j = 0; j < NJ; ++j) {
+    double sigma = cfg->torque_measurement_noise[j];
     obs[5 * j + 0] = s[UPKIE_S_Q + j];
     obs[5 * j + 1] = s[UPKIE_S_QD + j];
-    obs[5 * j + 2] = s[UPKIE_S_TORQUE + j];
+    obs[5 * j + 2] = s[UPKIE_S_TORQUE + j] + (sigma > 1e-10 ? sigma * z[j] : 0.0);
     obs[5 * j + 3] = 42.0;
     obs[5 * j + 4] = 18.0;
   }
@@ -989,9 +1035,9 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
         cmd[j].maximum_torque = a[6 * j + 5];
       }
       clamp_servo_commands(model, cfg, cmd);
-      backend_step(model, cfg, s, cmd, sp, fp, pp);
+      backend_step(model, cfg, s, cfg->env_id_offset + e, cmd, sp, fp, pp);
     }
-    servo_observation(s, obs + 30 * (int64_t)e);
+    servo_observation(cfg, cfg->env_id_offset + e, s, obs + 30 * (int64_t)e);
     reward[e] = 0.0;
     terminated[e] = 0; /* upkie_env.py:231-238: only the joystick ends it */
     truncated[e] = 0;
@@ -1046,7 +1092,7 @@ void oracle_observe(const UpkieModel* model, const UpkieSimConfig* cfg,
         if (out->imu_raw_linear_acceleration) out->imu_raw_linear_acceleration[3 * e + d] = proper_i[d];
       }
     }
-    if (out->servo) servo_observation(s, out->servo + 30 * (int64_t)e);
+    if (out->servo) servo_observation(cfg, cfg->env_id_offset + e, s, out->servo + 30 * (int64_t)e);
     if (out->wheel_odometry)
       wheel_odometry(model, s, &out->wheel_odometry[2 * e], &out->wheel_odometry[2 * e + 1]);
     if (update_imu) store_env(state, B, e, s);

@@ -342,3 +342,35 @@ def test_sharded_results_do_not_depend_on_the_shard():
         o_full, *_ = full.step_pendulum(act_full)
         o_part, *_ = part.step_pendulum(act_full[100:164])
     assert torch.equal(o_full[100:164], o_part)
+
+
+def test_torque_noise_matches_oracle():
+    """Same Philox streams on both sides: the noisy torques agree draw by
+    draw (fp32 Box-Muller vs fp64), and the statistics match the reference's
+    checks (test_pybullet_backend_mock.py:404-417)."""
+    cfg = abi.default_sim_config(128, frequency=1000.0, nb_substeps=1, seed=4)
+    cfg.init_pos[2] = 3.0
+    for j in range(6):
+        cfg.torque_control_noise[j] = 0.1
+    cfg.torque_measurement_noise[2] = 0.05
+    oracle, sim = make_pair(128, cfg=cfg)
+    oracle.reset()
+    sim.reset()
+    act = np.zeros((128, 6, 6), dtype=np.float32)
+    act[:, :, 0] = np.nan
+    act[:, :, 2] = 1.0
+    act[:, :, 5] = 16.0
+    samples = []
+    for _ in range(60):
+        obs_o, *_ = oracle.step_servos(act.astype(np.float64))
+        obs_h, *_ = sim.step_servos(torch.from_numpy(act))
+        obs_h = obs_h.cpu().numpy()
+        np.testing.assert_allclose(obs_h[:, :, 2], obs_o[:, :, 2], atol=2e-5)
+        samples.append(obs_h[:, :, 2] - 1.0)
+    x = np.stack(samples)
+    assert abs(x[:, :, 0].mean()) < 0.01 and 0.09 < x[:, :, 0].std() < 0.11
+    assert 0.105 < x[:, :, 2].std() < 0.12  # control 0.1 and measurement 0.05 add in quadrature
+    spine = sim.observe(update_imu=False)["servo"].cpu().numpy()
+    np.testing.assert_allclose(spine[:, :, 2], obs_h[:, :, 2], atol=1e-7)  # same measurement draw
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 1e-5 and err["q"] < 1e-4, err

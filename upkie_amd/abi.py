@@ -51,6 +51,7 @@ S_MPC_V = 42
 S_SE2_X = 43
 S_SE2_Y = 44
 S_CONTACT = 45
+S_STEP = 46
 STATE_WORDS = 48
 PENDULUM_STATE_WORDS = 29
 

@@ -27,6 +27,9 @@ struct DevConfig {
   float h;  // dt / nb_substeps
   float kp, kd;
   float joint_friction[UPKIE_NJ];
+  float control_noise[UPKIE_NJ];      // torque_control_noise std dev
+  float measurement_noise[UPKIE_NJ];  // torque_measurement_noise std dev
+  int any_control_noise, any_measurement_noise;
   float fall_pitch, max_ground_velocity, max_yaw_velocity, leg_gain_scale, max_gain_scale;
   float init_pos[3], init_quat[4], init_linvel[3], init_angvel[3], init_joint[UPKIE_NJ];
   float rand_roll, rand_pitch, rand_x, rand_z, rand_omega_x, rand_omega_y, rand_linvel[3];
@@ -69,6 +72,31 @@ __device__ __forceinline__ void philox_uniform4(const DevConfig& C, unsigned env
   for (int i = 0; i < 4; ++i) u[i] = (float)(r[i] >> 8) * (1.0f / 16777216.0f);
 }
 
+// Six standard normals for (env, step, slot): Box-Muller on two Philox blocks.
+// slot = substep index (control noise) or NOISE_SLOT_MEASUREMENT.
+#define NOISE_SLOT_MEASUREMENT 0x7fffu
+__device__ __forceinline__ void philox_normal6(const DevConfig& C, unsigned env_local, unsigned step, unsigned slot, float (&z)[6]) {
+  unsigned lo = C.env_lo + env_local;
+  unsigned hi = C.env_hi + (lo < C.env_lo ? 1u : 0u);
+  unsigned r[8];
+#pragma unroll
+  for (unsigned k = 0; k < 2; ++k) {
+    unsigned q[4];
+    philox4x32_10(lo, hi, step, ((unsigned)STREAM_NOISE << 24) | (slot * 2u + k), C.seed_lo, C.seed_hi, q);
+    r[4 * k] = q[0]; r[4 * k + 1] = q[1]; r[4 * k + 2] = q[2]; r[4 * k + 3] = q[3];
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    float u1 = ((float)(r[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    float u2 = (float)(r[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+    float radius = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * p] = radius * cs;
+    z[2 * p + 1] = radius * sn;
+  }
+}
+
 __device__ __forceinline__ float uniform(float low, float high, float u) { return fmaf(high - low, u, low); }
 
 // clamp_and_warn (upkie/utils/clamp.py:42-58): NaN passes through.
@@ -79,13 +107,15 @@ struct Servo {
 };
 
 // moteus-like torque law, pybullet_backend.py:492-553.
-__device__ __forceinline__ float joint_torque(float q, float qd, const Servo& c, float kp_gain, float kd_gain, float friction) {
+__device__ __forceinline__ float joint_torque(float q, float qd, const Servo& c, float kp_gain, float kd_gain, float friction,
+                                              float noise) {
   float kp = c.kp_scale * kp_gain;
   float kd = c.kd_scale * kd_gain;
   float torque = c.feedforward_torque;
   torque += kd * (c.velocity - qd);
   if (!isnan(c.position)) torque += kp * (c.position - q);
   if (fabsf(qd) > 1e-3f) torque += qd > 0.f ? -friction : friction;
+  torque += noise;  // pybullet_backend.py:545-550
   torque = torque < -c.maximum_torque ? -c.maximum_torque : torque;
   torque = torque > c.maximum_torque ? c.maximum_torque : torque;
   return torque;
@@ -293,11 +323,17 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
   // ---- PyBulletBackend.step: substeps of {torques; stepSimulation} -------
   float tau[UPKIE_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool contact = false;
+  const bool any_noise = C.any_control_noise || C.any_measurement_noise;
+  unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
   const int nsub = do_reset ? 1 : C.nb_substeps;
   for (int sub = 0; sub < C.nb_substeps; ++sub) {
     if (sub >= nsub) break;
+    float zn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // control noise: one draw per joint per substep (uniform branch)
+    if (C.any_control_noise && !do_reset) philox_normal6(C, (unsigned)e, step_count, (unsigned)sub, zn);
 #pragma unroll
-    for (int j = 0; j < UPKIE_NJ; ++j) tau[j] = joint_torque(s.q[j], s.qd[j], cmd[j], C.kp, C.kd, C.joint_friction[j]);
+    for (int j = 0; j < UPKIE_NJ; ++j)
+      tau[j] = joint_torque(s.q[j], s.qd[j], cmd[j], C.kp, C.kd, C.joint_friction[j], C.control_noise[j] * zn[j]);
     contact = physics_substep(M, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
   }
 
@@ -331,6 +367,10 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
     }
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) SW(UPKIE_S_TORQUE + j) = tau[j];  // pybullet_backend.py:293
+    if (any_noise) {
+      step_count += 1u;
+      SW(UPKIE_S_STEP) = (float)step_count;
+    }
   }
 
   // ---- store -------------------------------------------------------------
@@ -376,11 +416,14 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
   } else {
     // upkie_servos.py:288-306 / pybullet_backend.py:448-474
     float* o = obs + (size_t)30 * e;
+    float zm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // measurement noise: one draw per joint per observation, :461-466
+    if (C.any_measurement_noise) philox_normal6(C, (unsigned)e, step_count, NOISE_SLOT_MEASUREMENT, zm);
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) {
       o[5 * j + 0] = s.q[j];
       o[5 * j + 1] = s.qd[j];
-      o[5 * j + 2] = do_reset ? SW(UPKIE_S_TORQUE + j) : tau[j];
+      o[5 * j + 2] = (do_reset ? SW(UPKIE_S_TORQUE + j) : tau[j]) + C.measurement_noise[j] * zm[j];
       o[5 * j + 3] = 42.0f;
       o[5 * j + 4] = 18.0f;
     }
@@ -503,12 +546,14 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
   }
   float ql = SW(UPKIE_S_Q + 2), qr = SW(UPKIE_S_Q + 5), qdl = SW(UPKIE_S_QD + 2), qdr = SW(UPKIE_S_QD + 5);
   if (out.servo) {
+    float zm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (C.any_measurement_noise) philox_normal6(C, (unsigned)e, (unsigned)SW(UPKIE_S_STEP), NOISE_SLOT_MEASUREMENT, zm);
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) {
       float* o = out.servo + 30 * (size_t)e + 5 * j;
       o[0] = SW(UPKIE_S_Q + j);
       o[1] = SW(UPKIE_S_QD + j);
-      o[2] = SW(UPKIE_S_TORQUE + j);
+      o[2] = SW(UPKIE_S_TORQUE + j) + C.measurement_noise[j] * zm[j];
       o[3] = 42.0f;
       o[4] = 18.0f;
     }
@@ -646,10 +691,11 @@ static bool convert_config(const UpkieSimConfig* c, DevConfig* d, std::string* w
     return false;
   }
   for (int j = 0; j < UPKIE_NJ; ++j) {
-    if (c->torque_control_noise[j] > 1e-10 || c->torque_measurement_noise[j] > 1e-10) {
-      *why = "torque noise is not supported by the HIP path yet";
-      return false;
-    }
+    // noise is only applied above 1e-10, pybullet_backend.py:463,547
+    d->control_noise[j] = c->torque_control_noise[j] > 1e-10 ? (float)c->torque_control_noise[j] : 0.f;
+    d->measurement_noise[j] = c->torque_measurement_noise[j] > 1e-10 ? (float)c->torque_measurement_noise[j] : 0.f;
+    if (d->control_noise[j] > 0.f) d->any_control_noise = 1;
+    if (d->measurement_noise[j] > 0.f) d->any_measurement_noise = 1;
     d->joint_friction[j] = (float)c->joint_friction[j];
     d->init_joint[j] = (float)c->init_joint[j];
   }
