@@ -107,6 +107,8 @@ typedef struct UpkieModel {
   double base_linear_damping;      /* Bullet default 0.04                   */
   double base_angular_damping;     /* Bullet default 0.04                   */
   double max_joint_velocity;       /* Bullet maxCoordinateVelocity, 100     */
+  double pgs_tolerance;            /* sweeps stop once no impulse moved by more
+                                      than this fraction of the largest one  */
   int32_t pgs_iterations;          /* Bullet numSolverIterations, 50        */
   int32_t enforce_joint_limits;    /* hip/knee limit rows in the solver     */
 } UpkieModel;

@@ -20,6 +20,8 @@
 #define NW UPKIE_STATE_WORDS
 #define MAXROWS 10
 
+long oracle_debug_sweeps = 0, oracle_debug_fallbacks = 0, oracle_debug_substeps = 0;
+
 /* ------------------------------------------------------------------ vec3 */
 static void v3_cross(const double a[3], const double b[3], double c[3]) {
   double x = a[1] * b[2] - a[2] * b[1];
@@ -426,6 +428,7 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
   double* q = s + UPKIE_S_Q;
   double* qd = s + UPKIE_S_QD;
 
+  oracle_debug_substeps += 1;
   Kin k;
   kinematics(model, inertia_scale, pos, quat, q, &k);
   double M[NV * NV], bias[NV], L[NV * NV];
@@ -591,6 +594,7 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
       }
     }
     for (int it = 0; need_pgs && it < model->pgs_iterations; ++it) {
+      double change = 0.0, scale = 0.0;
       for (int pass = 0; pass < 3; ++pass) { /* normals, friction, limits */
         for (int r_ = 0; r_ < nrows; ++r_) {
           if (kind[r_] != pass) continue;
@@ -605,10 +609,17 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
           } else if (x < 0.0) {
             x = 0.0;
           }
+          if (fabs(x - lam[r_]) > change) change = fabs(x - lam[r_]);
+          if (fabs(x) > scale) scale = fabs(x);
           lam[r_] = x;
         }
       }
+      oracle_debug_sweeps += 1;
+      /* converged: the sweep moved no impulse by more than pgs_tolerance of
+       * the largest one (each env stops on its own criterion) */
+      if (change <= model->pgs_tolerance * scale) break;
     }
+    if (need_pgs) oracle_debug_fallbacks += 1;
     for (int r_ = 0; r_ < nrows; ++r_)
       for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
   }

@@ -92,6 +92,7 @@ class UpkieModel(C.Structure):
         ("base_linear_damping", C.c_double),
         ("base_angular_damping", C.c_double),
         ("max_joint_velocity", C.c_double),
+        ("pgs_tolerance", C.c_double),
         ("pgs_iterations", C.c_int32),
         ("enforce_joint_limits", C.c_int32),
     ]

@@ -28,6 +28,29 @@
 
 namespace upkie {
 
+// Hardware-rate elementary functions (v_rcp_f32, v_sqrt_f32, v_rsq_f32,
+// about 1 ulp) in kernels; libm when the same code is compiled for the host harness.
+UPKIE_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.f / x;
+#endif
+}
+UPKIE_HD float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+UPKIE_HD float fast_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.f / sqrtf(x);
+#endif
+}
 struct V3 {
   float x, y, z;
 };
@@ -97,6 +120,7 @@ struct DevModel {
   float base_linear_damping;
   float base_angular_damping;
   float max_joint_velocity;
+  float pgs_tolerance;
   int pgs_iterations;
   int wheel_axisymmetric;  // wheel inertia invariant under its own rotation
 };
@@ -120,29 +144,29 @@ struct Ldl6 {
 UPKIE_HD void ldl6_factor(const float (&A)[21], Ldl6& f) {
   // A packed lower by rows: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) ...
   float d0 = A[0];
-  f.i0 = 1.f / d0;
+  f.i0 = fast_rcp(d0);
   float a10 = A[1], a20 = A[3], a30 = A[6], a40 = A[10], a50 = A[15];
   f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0; f.l40 = a40 * f.i0; f.l50 = a50 * f.i0;
   float d1 = A[2] - f.l10 * a10;
-  f.i1 = 1.f / d1;
+  f.i1 = fast_rcp(d1);
   float a21 = A[4] - f.l20 * a10, a31 = A[7] - f.l30 * a10, a41 = A[11] - f.l40 * a10, a51 = A[16] - f.l50 * a10;
   f.l21 = a21 * f.i1; f.l31 = a31 * f.i1; f.l41 = a41 * f.i1; f.l51 = a51 * f.i1;
   float d2 = A[5] - f.l20 * a20 - f.l21 * a21;
-  f.i2 = 1.f / d2;
+  f.i2 = fast_rcp(d2);
   float a32 = A[8] - f.l30 * a20 - f.l31 * a21, a42 = A[12] - f.l40 * a20 - f.l41 * a21,
         a52 = A[17] - f.l50 * a20 - f.l51 * a21;
   f.l32 = a32 * f.i2; f.l42 = a42 * f.i2; f.l52 = a52 * f.i2;
   float d3 = A[9] - f.l30 * a30 - f.l31 * a31 - f.l32 * a32;
-  f.i3 = 1.f / d3;
+  f.i3 = fast_rcp(d3);
   float a43 = A[13] - f.l40 * a30 - f.l41 * a31 - f.l42 * a32,
         a53 = A[18] - f.l50 * a30 - f.l51 * a31 - f.l52 * a32;
   f.l43 = a43 * f.i3; f.l53 = a53 * f.i3;
   float d4 = A[14] - f.l40 * a40 - f.l41 * a41 - f.l42 * a42 - f.l43 * a43;
-  f.i4 = 1.f / d4;
+  f.i4 = fast_rcp(d4);
   float a54 = A[19] - f.l50 * a40 - f.l51 * a41 - f.l52 * a42 - f.l53 * a43;
   f.l54 = a54 * f.i4;
   float d5 = A[20] - f.l50 * a50 - f.l51 * a51 - f.l52 * a52 - f.l53 * a53 - f.l54 * a54;
-  f.i5 = 1.f / d5;
+  f.i5 = fast_rcp(d5);
 }
 
 UPKIE_HD void ldl6_solve(const Ldl6& f, float (&x)[6]) {
@@ -277,14 +301,11 @@ UPKIE_HD void leg_pass(const DevModel& M, const float* scale, int body0, int joi
   }
   // inverse of the SPD 3x3 block through its Cholesky factor
   {
-    float l00 = sqrtf(H[0][0]);
-    float i00 = 1.f / l00;
+    float i00 = fast_rsqrt(H[0][0]);
     float l10 = H[1][0] * i00, l20 = H[2][0] * i00;
-    float l11 = sqrtf(H[1][1] - l10 * l10);
-    float i11 = 1.f / l11;
+    float i11 = fast_rsqrt(H[1][1] - l10 * l10);
     float l21 = (H[2][1] - l20 * l10) * i11;
-    float l22 = sqrtf(H[2][2] - l20 * l20 - l21 * l21);
-    float i22 = 1.f / l22;
+    float i22 = fast_rsqrt(H[2][2] - l20 * l20 - l21 * l21);
     // Linv (lower): m00 m10 m11 m20 m21 m22
     float m00 = i00, m11 = i11, m22 = i22;
     float m10 = -l10 * m00 * i11;
@@ -427,7 +448,7 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
   {
     // Bullet-style base damping on the trunk: F = -m v (k + k|v|) at its com
     V3 vc = vB + cross(wB, c0);
-    float vn = sqrtf(dot(vc, vc)), wn = sqrtf(dot(wB, wB));
+    float vn = fast_sqrt(dot(vc, vc)), wn = fast_sqrt(dot(wB, wB));
     float kl = M.base_linear_damping, ka = M.base_angular_damping;
     V3 F = (-m0 * (kl + kl * vn)) * vc;
     V3 T = (-(ka + ka * wn)) * I0w;
@@ -464,11 +485,12 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
   float rhs[6];
   bool active[2];
   bool any_contact = false;
-  float un = sqrtf(nB.x * nB.x + nB.z * nB.z);
-  float iun = 1.f / fmaxf(un, 1e-12f);
+  float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
+  float iun = fast_rcp(fmaxf(un, 1e-12f));
   float denom = h * M.contact_stiffness + M.contact_damping;
-  float erp = denom > 0.f ? h * M.contact_stiffness / denom : 0.2f;
-  float cfm = denom > 0.f ? 1.f / (denom * h) : 0.f;
+  float ih = fast_rcp(h);
+  float erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
+  float cfm = denom > 0.f ? fast_rcp(denom * h) : 0.f;
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
     const Leg& G = S.leg[w];
@@ -505,7 +527,7 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
       for (int j = 0; j < 3; ++j) v = fmaf(Jl[r][j], nu[6 + 3 * w + j], v);
       // penetration is pushed out with ERP; a separated point may only close
       // its gap within the step (continuous at dist = 0)
-      float b = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) / h : -v - dist / h) : -v;
+      float b = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) * ih : -v - dist * ih) : -v;
       rhs[r] = active[w] ? b : 0.f;
     }
   }
@@ -570,9 +592,10 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
     }
     if (need_pgs) {
       float idiag[6];
-      idiag[0] = 1.f / A[0]; idiag[1] = 1.f / A[2]; idiag[2] = 1.f / A[5];
-      idiag[3] = 1.f / A[9]; idiag[4] = 1.f / A[14]; idiag[5] = 1.f / A[20];
+      idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
+      idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
       for (int it = 0; it < M.pgs_iterations; ++it) {
+        float change = 0.f, scale = 0.f;
         // normals of both wheels first, then friction rows
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -593,9 +616,13 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
               const float lim = mu * lam[3 * (r / 3)];
               x = fminf(fmaxf(x, -lim), lim);
             }
+            change = fmaxf(change, fabsf(x - lam[r]));
+            scale = fmaxf(scale, fabsf(x));
             lam[r] = x;
           }
         }
+        // each env stops on its own criterion: lanes leave the loop one by one
+        if (change <= M.pgs_tolerance * scale) break;
       }
     }
     // velocity jump M^-1 J' lam with one more solve
@@ -635,18 +662,28 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
   s.angvel = v3(r00 * nu[3] + r01 * nu[4] + r02 * nu[5], r10 * nu[3] + r11 * nu[4] + r12 * nu[5], r20 * nu[3] + r21 * nu[4] + r22 * nu[5]);
   s.pos = s.pos + h * s.linvel;
   {
-    float wn = sqrtf(dot(s.angvel, s.angvel));
+    float wn = fast_sqrt(dot(s.angvel, s.angvel));
     float half = 0.5f * h * wn;
-    float sh, ch;
-    sincosf(half, &sh, &ch);
-    float k = wn > 1e-9f ? sh / wn : 0.5f * h;
+    // dq = (cos(half), sin(half) w / |w|) with sin(half) / |w| = h/2 sinc(half);
+    // half is a few 1e-3 at most in practice: series to x^8 (exact to fp32
+    // below 0.5 rad), libm beyond
+    float ch, k;
+    if (half < 0.5f) {
+      float x2 = half * half;
+      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+    } else {
+      float sh;
+      sincosf(half, &sh, &ch);
+      k = sh * fast_rcp(wn);
+    }
     float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
     // q <- dq * q (world-frame angular velocity)
     float nw = dw * qw - dx * qx - dy * qy - dz * qz;
     float nx = dw * qx + dx * qw + dy * qz - dz * qy;
     float ny = dw * qy - dx * qz + dy * qw + dz * qx;
     float nz = dw * qz + dx * qy - dy * qx + dz * qw;
-    float inv = 1.f / sqrtf(nw * nw + nx * nx + ny * ny + nz * nz);
+    float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
     s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
   }
   return any_contact;

@@ -186,12 +186,13 @@ __device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phy
 }
 
 template <int MODE, bool RAND>
-__global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float* __restrict__ state,
+__global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ Mp, DevConfig C, float* __restrict__ state,
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ inertia_scale,
                                                    const float* __restrict__ ext_force, int packed) {
+  const DevModel& M = *Mp;
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
@@ -290,9 +291,10 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
     // UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
-    float wheel_velocity = v / M.wheel_radius;
+    float inv_radius = fast_rcp(M.wheel_radius);
+    float wheel_velocity = v * inv_radius;
     float left = M.left_sign * wheel_velocity, right = -M.left_sign * wheel_velocity;
-    float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) / M.wheel_radius;
+    float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) * inv_radius;
     left = fmaf(yaw_to_wheel, yawd, left);
     right = fmaf(yaw_to_wheel, yawd, right);
     const float alpha = C.dt / 1.0f;  // filters.py:77, cutoff_period = 1 s
@@ -334,7 +336,14 @@ __global__ __launch_bounds__(64) void step_kernel(DevModel M, DevConfig C, float
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j)
       tau[j] = joint_torque(s.q[j], s.qd[j], cmd[j], C.kp, C.kd, C.joint_friction[j], C.control_noise[j] * zn[j]);
-    contact = physics_substep(M, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
+    {
+      // Re-derive the model pointer every substep: the ~150 model constants are
+      // then re-fetched by scalar loads when needed instead of being hoisted
+      // out of the loop and spilled to VGPR lanes.
+      const DevModel* mp = Mp;
+      asm volatile("" : "+s"(mp));
+      contact = physics_substep(*mp, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
+    }
   }
 
   // ---- wrapper post-processing -----------------------------------------
@@ -588,6 +597,7 @@ using namespace upkie;
 
 struct UpkieSim {
   DevModel model;
+  DevModel* d_model = nullptr;  // device copy read through scalar loads
   DevConfig config;
   const float* inertia_scale = nullptr;
   const float* ext_force = nullptr;
@@ -672,6 +682,7 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   d->base_angular_damping = (float)m->base_angular_damping;
   d->max_joint_velocity = (float)m->max_joint_velocity;
   d->pgs_iterations = m->pgs_iterations;
+  d->pgs_tolerance = (float)m->pgs_tolerance;
   if (m->enforce_joint_limits) {
     *why = "enforce_joint_limits is not supported by the HIP path yet";
     return false;
@@ -754,6 +765,14 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
     delete sim;
     return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
+  hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
+  if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    std::string msg = std::string("hipMalloc/hipMemcpy(model): ") + hipGetErrorString(err);
+    if (sim->d_model) (void)hipFree(sim->d_model);
+    delete sim;
+    return fail(nullptr, UPKIE_ERR_HIP, msg);
+  }
   *out = sim;
   return UPKIE_OK;
 }
@@ -770,6 +789,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
 }
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
+  if (sim && sim->d_model) (void)hipFree(sim->d_model);
   delete sim;
   return UPKIE_OK;
 }
@@ -812,10 +832,10 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const bool rnd = sim->inertia_scale || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   if (rnd) {
-    hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
+    hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
                        reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed);
   } else {
-    hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->model, sim->config, state, act, obs,
+    hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
                        reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr, packed);
   }
   return check_hip(sim, hipGetLastError(), "step_kernel");

@@ -71,6 +71,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             "--offload-arch=gfx950",
             "-O3",
             "-std=c++17",
+            # SLP-packing scalar fp32 chains into v_pk_* costs ~1700 v_mov and
+            # 180 extra registers in the step kernel (tools/isa_stats.sh)
+            "-fno-slp-vectorize",
             "-shared",
             "-fPIC",
             SOURCES[0],

@@ -122,6 +122,7 @@ def default_model() -> UpkieModel:
     m.base_angular_damping = 0.04
     m.max_joint_velocity = 100.0
     m.pgs_iterations = 50
+    m.pgs_tolerance = 1e-6
     m.enforce_joint_limits = 0
     return m
 

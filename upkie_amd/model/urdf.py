@@ -158,6 +158,7 @@ def load_urdf_model(urdf_path: str, template: Optional[UpkieModel] = None) -> Up
         "base_angular_damping",
         "max_joint_velocity",
         "pgs_iterations",
+        "pgs_tolerance",
         "enforce_joint_limits",
         "contact_stiffness",
         "contact_damping",
