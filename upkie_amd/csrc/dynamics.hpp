@@ -209,7 +209,8 @@ struct Composite {
 // `body0` is the index of the thigh body, `joint0` of the hip joint.
 // Adds the leg's composite inertia to `total` and its bias wrench about the
 // base origin to (bias_f, bias_n).
-UPKIE_HD void leg_pass(const DevModel& M, const float* scale, int body0, int joint0,
+template <class ModelT>
+UPKIE_HD void leg_pass(const ModelT& M, const float* scale, int body0, int joint0,
                                          const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ], V3 w0, V3 gn,
                                          Leg& L, Composite& total, V3& bias_f, V3& bias_n) {
   float cs[3], sn[3];
@@ -381,7 +382,8 @@ UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], floa
 // scale: per-body inertia scales of this env or nullptr. ext_force (world
 // frame) acts on the trunk at base-frame point ext_point when has_ext.
 // Returns the floor-contact flag.
-UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPKIE_NJ], float h,
+template <class ModelT>
+UPKIE_HD bool physics_substep(const ModelT& M, Phys& s, const float (&tau)[UPKIE_NJ], float h,
                                                 const float* scale, bool has_ext, V3 ext_force, V3 ext_point) {
   // rotation base -> world (upkie/utils/rotations.py:52-71)
   float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
@@ -467,22 +469,30 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
       br[k] = tau[3 + k] - M.joint_damping[3 + k] * s.qd[3 + k] - S.leg[1].bias[k];
     }
   }
-  system_solve<true, true>(S, bb, bl, br);
-  // free velocity nu = [vB, wB, qd] + h * acc
-  float nu[12];
-  nu[0] = fmaf(h, bb[0], vB.x); nu[1] = fmaf(h, bb[1], vB.y); nu[2] = fmaf(h, bb[2], vB.z);
-  nu[3] = fmaf(h, bb[3], wB.x); nu[4] = fmaf(h, bb[4], wB.y); nu[5] = fmaf(h, bb[5], wB.z);
+  // Generalised impulse so far: t = h (applied - bias). The contact impulses
+  // J' lam are added below and ONE solve nu+ = nu + M^-1 t ends the substep.
+  // Reduced base right-hand side rt = t_b - D_L t_L - D_R t_R: with the legs
+  // eliminated, J M^-1 t = Jt . A^-1 rt + J_leg . Hinv t_leg where
+  // Jt = J_b - D_w J_leg is the contact row reduced onto the base (6-vector).
+  float tb[6], tl[3], tr[3], rt[6];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    nu[6 + k] = fmaf(h, bl[k], s.qd[k]);
-    nu[9 + k] = fmaf(h, br[k], s.qd[3 + k]);
+  for (int c = 0; c < 6; ++c) tb[c] = h * bb[c];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    tl[j] = h * bl[j];
+    tr[j] = h * br[j];
   }
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+    rt[c] = tb[c] - (S.leg[0].D[c][0] * tl[0] + S.leg[0].D[c][1] * tl[1] + S.leg[0].D[c][2] * tl[2]) -
+            (S.leg[1].D[c][0] * tr[0] + S.leg[1].D[c][1] * tr[1] + S.leg[1].D[c][2] * tr[2]);
 
   // ---- tire / floor contacts -------------------------------------------
   // Rows 3w+0..2 = (normal, t1, t2) of wheel w. Row r of wheel w only touches
   // the base and leg w: J = [d ; P x d ; leg part (3)].
   float Jb[6][6], Jl[6][3];  // Jacobian rows
-  float rhs[6];
+  float Jt[6][6];            // rows reduced onto the base
+  float rhs[6], vnow[6], dists[2];
   bool active[2];
   bool any_contact = false;
   float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
@@ -501,6 +511,7 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
     V3 dlow = v3(-nB.x * iun, 0.f, -nB.z * iun);
     V3 P = center + M.wheel_radius * dlow;
     float dist = s.pos.z + dot(nB, P);
+    dists[w] = dist;
     // a contact point exists below the manifold breaking threshold
     active[w] = un >= 1e-6f && dist <= M.contact_breaking_threshold;
     any_contact = any_contact || active[w];
@@ -520,45 +531,53 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
         // (a x rr) . d, a = s*y : y x rr = (rr.z, 0, -rr.x)
         Jl[r][j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
       }
-      float v = 0.f;
+      // velocity of the contact point before this substep's impulses
+      float v = Jb[r][0] * vB.x + Jb[r][1] * vB.y + Jb[r][2] * vB.z + Jb[r][3] * wB.x + Jb[r][4] * wB.y + Jb[r][5] * wB.z;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v = fmaf(Jb[r][c], nu[c], v);
+      for (int j = 0; j < 3; ++j) v = fmaf(Jl[r][j], s.qd[3 * w + j], v);
+      vnow[r] = v;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) v = fmaf(Jl[r][j], nu[6 + 3 * w + j], v);
-      // penetration is pushed out with ERP; a separated point may only close
-      // its gap within the step (continuous at dist = 0)
-      float b = (k == 0) ? (dist <= 0.f ? -v + erp * (-dist) * ih : -v - dist * ih) : -v;
-      rhs[r] = active[w] ? b : 0.f;
+      for (int c = 0; c < 6; ++c) Jt[r][c] = Jb[r][c] - (G.D[c][0] * Jl[r][0] + G.D[c][1] * Jl[r][1] + G.D[c][2] * Jl[r][2]);
     }
   }
+  float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (active[0] || active[1]) {
-    // A = J M^-1 J' + CFM (symmetric, packed lower by rows), built one column
-    // of M^-1 J' at a time so that only J stays live; rows of a wheel without
-    // a contact point are replaced by identity rows with zero rhs.
+    // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
+    // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors
+    // give the free velocity of row b. Rows of a wheel without a contact point
+    // are replaced by identity rows with zero rhs.
     float A[21];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-      float xb[6], xl[3], xr[3];
+      const int wb_ = b / 3;
+      const Leg& G = S.leg[wb_];
+      const float* hv = G.Hinv;
+      float Y[6], K[3];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) xb[c] = Jb[b][c];
-      if (b < 3) {
+      for (int c = 0; c < 6; ++c) Y[c] = Jt[b][c];
+      ldl6_solve(S.A, Y);
+      K[0] = hv[0] * Jl[b][0] + hv[3] * Jl[b][1] + hv[4] * Jl[b][2];
+      K[1] = hv[3] * Jl[b][0] + hv[1] * Jl[b][1] + hv[5] * Jl[b][2];
+      K[2] = hv[4] * Jl[b][0] + hv[5] * Jl[b][1] + hv[2] * Jl[b][2];
+      // free velocity of row b: v + J M^-1 t
+      float vf = vnow[b];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { xl[j] = Jl[b][j]; xr[j] = 0.f; }
-        system_solve<true, false>(S, xb, xl, xr);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { xl[j] = 0.f; xr[j] = Jl[b][j]; }
-        system_solve<false, true>(S, xb, xl, xr);
-      }
+      for (int c = 0; c < 6; ++c) vf = fmaf(Y[c], rt[c], vf);
+      const float(&tw)[3] = wb_ == 0 ? tl : tr;
+      vf += K[0] * tw[0] + K[1] * tw[1] + K[2] * tw[2];
+      // penetration is pushed out with ERP; a separated point may only close
+      // its gap within the step (continuous at dist = 0)
+      const float dist = dists[wb_];
+      const float rb = (b % 3 == 0) ? (dist <= 0.f ? -vf + erp * (-dist) * ih : -vf - dist * ih) : -vf;
+      rhs[b] = active[wb_] ? rb : 0.f;
 #pragma unroll
       for (int a = b; a < 6; ++a) {
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc = fmaf(Jb[a][c], xb[c], acc);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc = fmaf(Jl[a][j], a < 3 ? xl[j] : xr[j], acc);
+        for (int c = 0; c < 6; ++c) acc = fmaf(Jt[a][c], Y[c], acc);
+        if (a / 3 == wb_) acc += Jl[a][0] * K[0] + Jl[a][1] * K[1] + Jl[a][2] * K[2];
         if (a == b) acc += (a % 3) == 0 ? cfm : M.friction_cfm;
-        const bool live = active[a / 3] && active[b / 3];
+        const bool live = active[a / 3] && active[wb_];
         A[a * (a + 1) / 2 + b] = live ? acc : (a == b ? 1.f : 0.f);
       }
     }
@@ -566,7 +585,6 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
     // solution already satisfies lam_n >= 0, |lam_t| <= mu lam_n and IS the
     // solution. Otherwise it is projected and warm-starts the projected
     // Gauss-Seidel sweeps (continuous at the stick/slip / lift-off boundaries).
-    float lam[6];
     const float mu = M.friction_mu;
     bool need_pgs = false;
     {
@@ -625,30 +643,29 @@ UPKIE_HD bool physics_substep(const DevModel& M, Phys& s, const float (&tau)[UPK
         if (change <= M.pgs_tolerance * scale) break;
       }
     }
-    // velocity jump M^-1 J' lam with one more solve
-    {
-      float gb[6], gl[3], gr[3];
+    // t += J' lam
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        float acc = 0.f;
+    for (int c = 0; c < 6; ++c) {
+      float acc = tb[c];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc = fmaf(Jb[r][c], lam[r], acc);
-        gb[c] = acc;
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        gl[j] = Jl[0][j] * lam[0] + Jl[1][j] * lam[1] + Jl[2][j] * lam[2];
-        gr[j] = Jl[3][j] * lam[3] + Jl[4][j] * lam[4] + Jl[5][j] * lam[5];
-      }
-      system_solve<true, true>(S, gb, gl, gr);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) nu[c] += gb[c];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        nu[6 + j] += gl[j];
-        nu[9 + j] += gr[j];
-      }
+      for (int r = 0; r < 6; ++r) acc = fmaf(Jb[r][c], lam[r], acc);
+      tb[c] = acc;
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      tl[j] += Jl[0][j] * lam[0] + Jl[1][j] * lam[1] + Jl[2][j] * lam[2];
+      tr[j] += Jl[3][j] * lam[3] + Jl[4][j] * lam[4] + Jl[5][j] * lam[5];
+    }
+  }
+  // nu+ = nu + M^-1 t
+  system_solve<true, true>(S, tb, tl, tr);
+  float nu[12];
+  nu[0] = vB.x + tb[0]; nu[1] = vB.y + tb[1]; nu[2] = vB.z + tb[2];
+  nu[3] = wB.x + tb[3]; nu[4] = wB.y + tb[4]; nu[5] = wB.z + tb[5];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    nu[6 + j] = s.qd[j] + tl[j];
+    nu[9 + j] = s.qd[3 + j] + tr[j];
   }
 
   // ---- integrate (semi-implicit Euler: new velocities move positions) ----

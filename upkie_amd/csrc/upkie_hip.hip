@@ -340,7 +340,9 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
       // Re-derive the model pointer every substep: the ~150 model constants are
       // then re-fetched by scalar loads when needed instead of being hoisted
       // out of the loop and spilled to VGPR lanes.
-      const DevModel* mp = Mp;
+      // (constant address space: uniform loads become s_load, not flat vector loads)
+      typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
+      ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
       contact = physics_substep(*mp, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
     }
