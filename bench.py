@@ -59,14 +59,14 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     ref = O.Oracle(default_model(), make_config(envs))
     obs = ref.reset()[:, [1, 0, 4, 3]]
     obs, *_ = ref.step_pendulum_agent(obs)  # warm up
+    steps = 0
     t0 = time.perf_counter()
-    obs, *_ = ref.step_pendulum_agent(obs)
-    one = time.perf_counter() - t0
-    steps = max(2, min(5000, int(budget_s / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    while True:
         obs, *_ = ref.step_pendulum_agent(obs)
-    elapsed = time.perf_counter() - t0
+        steps += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s or steps >= 5000:
+            break
     return {
         "value": envs * steps / elapsed,
         "unit": "env-steps/s",
