@@ -51,6 +51,24 @@ UPKIE_HD float fast_rsqrt(float x) {
   return 1.f / sqrtf(x);
 #endif
 }
+// sin and cos of a joint angle: one Cody-Waite reduction step by pi/2 and the
+// Cephes single-precision kernels on [-pi/4, pi/4] (about 1 ulp for the
+// |x| < 8 rad a hip + knee angle can reach; the absolute error grows like
+// 4e-8 |x| beyond, i.e. stays below the fp32 resolution of x itself).
+UPKIE_HD void joint_sincos(float x, float* sn, float* cs) {
+  const float kf = rintf(x * 0.63661977236758134f);
+  float r = fmaf(kf, -1.5707963705062866f, x);
+  r = fmaf(kf, 4.3711390001862426e-08f, r);
+  const float r2 = r * r;
+  const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+  const float cp = 1.f - 0.5f * r2 + r2 * r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
+  const int q = (int)kf & 3;
+  const float s0 = (q & 1) ? cp : sp;
+  const float c0 = (q & 1) ? sp : cp;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 struct V3 {
   float x, y, z;
 };
@@ -223,7 +241,7 @@ UPKIE_HD void leg_pass(const ModelT& M, const float* scale, int body0, int joint
       cs[k] = 1.f;
       sn[k] = 0.f;
     } else {
-      sincosf(psi, &sn[k], &cs[k]);
+      joint_sincos(psi, &sn[k], &cs[k]);
     }
   }
   // joint origins
