@@ -226,6 +226,18 @@ int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act,
                            float* obs, float* reward, uint8_t* terminated,
                            uint8_t* truncated, void* stream);
 
+/* One env.step() of UpkieBaseVelocity (upkie_base_velocity.py:164-202) after
+ * upkie_mpc_step_env(): act[B][2] = [linear velocity, yaw velocity]; the
+ * ground velocity commanded to the Gyropod layer is commanded_velocity[B]
+ * (the MPC balancer's output). obs[B][3] = dead-reckoned [x, y, yaw]. Also
+ * writes what the balancer reads at the next step: mpc_x0[B][4] = [ground
+ * position, pitch, ground velocity, pitch rate], mpc_contact[B]. */
+int upkie_sim_step_base_velocity(UpkieSim* sim, float* state, const float* act,
+                                 const float* commanded_velocity, float* obs,
+                                 float* mpc_x0, uint8_t* mpc_contact,
+                                 float* reward, uint8_t* terminated,
+                                 uint8_t* truncated, void* stream);
+
 /* One env.step() of UpkieServos (upkie_servos.py:316-344 + upkie_env.py:
  * 196-242): act[B][6][6] in ACTION_KEYS order (position, velocity,
  * feedforward_torque, kp_scale, kd_scale, maximum_torque) -> obs[B][6][5]
@@ -291,6 +303,16 @@ int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0,
                    const float* target_velocity, const uint8_t* contact,
                    double dt, float* commanded_velocity, float* first_input,
                    void* stream);
+
+/* MPCBalancer.step as the first half of a fused UpkieBaseVelocity env.step():
+ * the target velocity of env e is act[2 e] (act is the env's [B][2] action),
+ * and envs whose `done` word (row UPKIE_S_DONE of the state, may be NULL) is
+ * set get MPCBalancer.reset() instead of a solve, because the env step that
+ * follows resets them (NEXT_STEP autoreset). */
+int upkie_mpc_step_env(UpkieMpc* mpc, float* workspace, const float* x0,
+                       const float* act, const uint8_t* contact,
+                       const float* done, double dt, float* commanded_velocity,
+                       void* stream);
 
 #ifdef __cplusplus
 }

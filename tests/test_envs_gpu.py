@@ -82,3 +82,33 @@ def test_base_velocity_env_gpu_matches_cpu_double():
     pc = cpu.sim.state[abi.S_POS].numpy()
     assert np.max(np.abs(pg - pc)) < 2e-3
     assert not bool(tg.any())  # the MPC keeps everyone upright
+
+
+def test_base_velocity_fused_path_with_autoreset():
+    """Fused MPC + Gyropod launches (the GPU path) vs the generic composition
+    on the CPU doubles, with falls and NEXT_STEP autoresets in the loop."""
+    kw = dict(num_envs=48, frequency=200.0, nb_timesteps=16, fall_pitch=0.12, seed=3,
+              init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1)))
+    gpu = envs.make("Upkie-HIP-BaseVelocity-Vec", **kw)
+    cpu = envs.make("Upkie-HIP-BaseVelocity-Vec", sim_factory=oracle_sim_factory, mpc_factory=OracleMpc, **kw)
+    assert hasattr(gpu.sim, "step_base_velocity") and not hasattr(cpu.sim, "step_base_velocity")
+    gpu.reset()
+    cpu.reset()
+    act = torch.zeros(48, 2)
+    act[:, 0] = torch.linspace(-1.0, 1.0, 48)  # hard velocity steps tip some robots past 0.12 rad
+    act[:, 1] = 0.3
+    in_sync = np.ones(48, dtype=bool)
+    falls = 0
+    for _ in range(150):
+        og, _, tg, _, _ = gpu.step(act)
+        oc, _, tc, _, _ = cpu.step(act)
+        in_sync &= tg.cpu().numpy() == tc.numpy()
+        falls += int(tc.sum())
+    assert falls > 0 and in_sync.mean() > 0.8
+    np.testing.assert_allclose(og.cpu().numpy()[in_sync], oc.numpy()[in_sync], atol=1e-4)
+    vg = gpu.mpc_balancer.commanded_velocity.cpu().numpy()[in_sync]
+    vc = cpu.mpc_balancer.commanded_velocity.numpy()[in_sync]
+    assert np.max(np.abs(vg - vc)) < 2e-2
+    eg = gpu.sim.state[abi.S_EPISODE].cpu().numpy()[in_sync]
+    ec = cpu.sim.state[abi.S_EPISODE].numpy()[in_sync]
+    assert np.array_equal(eg, ec)

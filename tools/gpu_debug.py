@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from tests.helpers import randomized_config
 from upkie_amd.sim import BatchedSim

@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from bench import make_config
 from upkie_amd.model.default_model import default_model

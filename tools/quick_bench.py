@@ -1,7 +1,8 @@
 """Throughput probe of the fused Pendulum step at several batch sizes."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from tests.helpers import randomized_config
 from upkie_amd.sim import BatchedSim
 

@@ -45,8 +45,9 @@ __device__ __forceinline__ int mpc_index(int t, int g, int r) { return 16 * t + 
 
 template <int T>
 __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
-                                                       const float* __restrict__ v_target,
-                                                       const uint8_t* __restrict__ contact, float dt,
+                                                       const float* __restrict__ v_target, int v_target_stride,
+                                                       const uint8_t* __restrict__ contact,
+                                                       const float* __restrict__ done, float dt,
                                                        float* __restrict__ commanded, float* __restrict__ first_input) {
   constexpr int NP = 16 * T;
   const int lane = threadIdx.x;
@@ -64,7 +65,10 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
     for (int s = 0; s < 4 * T; ++s) a[t][s] = P.minv[(size_t)(16 * t + col) * NP + 4 * s + g];
 
   float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
-  float vt = live ? v_target[env] : 0.f;
+  float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
+  // envs that the coming env.step() will reset: MPCBalancer.reset() instead of
+  // a solve (upkie_base_velocity.py:158): zero warm start, zero velocity
+  const bool resetting = live && done != nullptr && done[env] != 0.f;
   float q[T][4], z[T][4], y[T][4];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
       const int n = mpc_index(t, g, r);
       const float4 k = reinterpret_cast<const float4*>(P.kx)[n];
       q[t][r] = k.x * x.x + k.y * x.y + k.z * x.z + k.w * x.w + P.kv[n] * vt;
-      const bool in = live && n < N;
+      const bool in = live && n < N && !resetting;
       z[t][r] = in ? ws[(size_t)n * B + env] : 0.f;
       y[t][r] = in ? ws[(size_t)(N + n) * B + env] : 0.f;
     }
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
     for (int r = 0; r < 4; ++r) {
       const int n = mpc_index(t, g, r);
       if (live && n < N) {
-        ws[(size_t)n * B + env] = z[t][r];
-        ws[(size_t)(N + n) * B + env] = y[t][r];
+        ws[(size_t)n * B + env] = resetting ? 0.f : z[t][r];
+        ws[(size_t)(N + n) * B + env] = resetting ? 0.f : y[t][r];
       }
     }
   if (live && g == 0) {
@@ -119,7 +123,9 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
     if (first_input) first_input[env] = u0;
     const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
     float v = commanded[env];
-    if (fallen || !contact[env]) {
+    if (resetting) {
+      v = 0.f;  // mpc_balancer.py:232
+    } else if (fallen || !contact[env]) {
       v = v + (dt / 0.1f) * (0.f - v);  // :295-301
     } else {
       v = v + u0 * dt / 2.0f;  // :305-311

@@ -41,7 +41,14 @@ struct DevConfig {
   float ext_point[3];
 };
 
-enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4 };
+enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4, MODE_BASE_VELOCITY = 5 };
+
+// Extra buffers of the fused UpkieBaseVelocity step (upkie_base_velocity.py:164-202).
+struct BaseVelocityPtrs {
+  const float* commanded;  // [B] ground velocity out of the MPC balancer
+  float* x0;               // [B][4] next MPC state: position, pitch, velocity, pitch rate
+  uint8_t* contact;        // [B] next MPC floor-contact flag
+};
 
 // ------------------------------------------------------------------ Philox
 // Philox4x32-10 (Salmon et al., SC'11): counter = (env id lo/hi, episode,
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ inertia_scale,
-                                                   const float* __restrict__ ext_force, int packed) {
+                                                   const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv) {
   const DevModel& M = *Mp;
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,8 +220,9 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
   float legref[4];
 #pragma unroll
   for (int l = 0; l < 4; ++l) legref[l] = SW(UPKIE_S_LEGREF + l);
+  constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
   float yaw = 0.f, yawvel = 0.f;
-  if (MODE == MODE_GYROPOD) {
+  if (YAWING) {
     yaw = SW(UPKIE_S_YAW);
     yawvel = SW(UPKIE_S_YAWVEL);
   }
@@ -284,6 +292,9 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
       const float4 o = reinterpret_cast<const float4*>(obs)[packed ? 2 * (size_t)e : (size_t)e];
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
+    } else if (MODE == MODE_BASE_VELOCITY) {
+      a0 = bv.commanded[e];  // MPCBalancer output, upkie_base_velocity.py:185-192
+      a1 = act[2 * (size_t)e + 1];
     } else {
       a0 = act[2 * (size_t)e];
       a1 = act[2 * (size_t)e + 1];
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
     SW(UPKIE_S_DONE) = 0.f;
     gyropod_observation(M, s, yaw, yawvel, obs6);
   } else {
-    if (MODE == MODE_GYROPOD) {
+    if (YAWING) {
       yaw = fmaf(a1, C.dt, yaw);  // upkie_gyropod.py:383-385 (unclamped action)
       yawvel = a1;
       SW(UPKIE_S_YAW) = yaw;
@@ -419,6 +430,24 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
       return;
     }
     reinterpret_cast<float4*>(obs)[e] = o4;
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    // dead reckoning with the TARGET linear velocity and the new yaw, :197-199
+    float x = 0.f, y = 0.f;
+    if (!do_reset) {
+      const float lin = act[2 * (size_t)e];
+      float sy, cy;
+      sincosf(yaw, &sy, &cy);
+      x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
+      y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
+      SW(UPKIE_S_SE2_X) = x;
+      SW(UPKIE_S_SE2_Y) = y;
+    }
+    obs[(size_t)3 * e] = x;
+    obs[(size_t)3 * e + 1] = y;
+    obs[(size_t)3 * e + 2] = yaw;
+    // what MPCBalancer.step reads from the spine observation next time, :253-273
+    reinterpret_cast<float4*>(bv.x0)[e] = make_float4(obs6[0], obs6[1], obs6[3], obs6[4]);
+    bv.contact[e] = contact ? 1 : 0;
   } else if (MODE == MODE_GYROPOD) {
     float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
     o2[0] = make_float2(obs6[0], obs6[1]);
@@ -825,20 +854,21 @@ extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_sca
 
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
-                       uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0) {
+                       uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
+                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (MODE != MODE_RESET && (!obs || (!packed && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
-  if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS) && !act)
+  if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS || MODE == MODE_BASE_VELOCITY) && !act)
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
   const bool rnd = sim->inertia_scale || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   if (rnd) {
     hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
-                       reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed);
+                       reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed, bv);
   } else {
     hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
-                       reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr, packed);
+                       reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr, packed, bv);
   }
   return check_hip(sim, hipGetLastError(), "step_kernel");
 }
@@ -868,6 +898,14 @@ extern "C" int upkie_sim_step_pendulum_agent_packed(UpkieSim* sim, float* state,
 extern "C" int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
                                       uint8_t* terminated, uint8_t* truncated, void* stream) {
   return launch_step<MODE_GYROPOD>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_step_base_velocity(UpkieSim* sim, float* state, const float* act, const float* commanded_velocity,
+                                            float* obs, float* mpc_x0, uint8_t* mpc_contact, float* reward,
+                                            uint8_t* terminated, uint8_t* truncated, void* stream) {
+  if (!commanded_velocity || !mpc_x0 || !mpc_contact) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null MPC buffer");
+  return launch_step<MODE_BASE_VELOCITY>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream, 0,
+                                         BaseVelocityPtrs{commanded_velocity, mpc_x0, mpc_contact});
 }
 
 extern "C" int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
@@ -976,19 +1014,30 @@ extern "C" int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded
   return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));
 }
 
-extern "C" int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0, const float* target_velocity,
-                              const uint8_t* contact, double dt, float* commanded_velocity, float* first_input, void* stream) {
+static int mpc_launch(UpkieMpc* mpc, float* workspace, const float* x0, const float* target_velocity, int target_stride,
+                      const uint8_t* contact, const float* done, double dt, float* commanded_velocity, float* first_input,
+                      void* stream) {
   if (!mpc || !workspace || !x0 || !target_velocity || !contact || !commanded_velocity)
     return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (!(dt / 0.1 < 0.5)) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
   dim3 grid((unsigned)((mpc->dev.num_envs + 15) / 16)), block(64);
   hipStream_t st = (hipStream_t)stream;
   switch (mpc->tiles) {
-    case 1: hipLaunchKernelGGL(mpc_step_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
-    case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
-    case 3: hipLaunchKernelGGL(mpc_step_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
-    default: hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, contact, (float)dt, commanded_velocity, first_input); break;
+    case 1: hipLaunchKernelGGL(mpc_step_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+    case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+    case 3: hipLaunchKernelGGL(mpc_step_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+    default: hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
   }
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));
+}
+
+extern "C" int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0, const float* target_velocity,
+                              const uint8_t* contact, double dt, float* commanded_velocity, float* first_input, void* stream) {
+  return mpc_launch(mpc, workspace, x0, target_velocity, 1, contact, nullptr, dt, commanded_velocity, first_input, stream);
+}
+
+extern "C" int upkie_mpc_step_env(UpkieMpc* mpc, float* workspace, const float* x0, const float* act, const uint8_t* contact,
+                                  const float* done, double dt, float* commanded_velocity, void* stream) {
+  return mpc_launch(mpc, workspace, x0, act, 2, contact, done, dt, commanded_velocity, nullptr, stream);
 }

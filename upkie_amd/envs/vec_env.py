@@ -356,7 +356,14 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         return obs, info
 
     def step(self, action):
-        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2)
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2).contiguous()
+        if hasattr(self.sim, "step_base_velocity") and hasattr(self.mpc_balancer, "step_env"):
+            # fused path: two launches per env.step(), everything stays on device
+            done = self.sim.state[abi.S_DONE] if self.config.autoreset_mode else None
+            commanded = self.mpc_balancer.step_env(self._x0, act, self._contact, done, self.dt)
+            obs, reward, terminated, truncated = self.sim.step_base_velocity(act, commanded, self._x0, self._contact)
+            return obs, reward, terminated.bool(), truncated.bool(), self._info()
+        # generic composition (used with the CPU test doubles)
         linear_velocity, yaw_velocity = act[:, 0].contiguous(), act[:, 1]
         autoreset = (self.sim.state[abi.S_DONE] != 0) if self.config.autoreset_mode else None
         ground_velocity, _ = self.mpc_balancer.step(self._x0, linear_velocity, self._contact, self.dt)
@@ -364,10 +371,14 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         obs6, reward, terminated, truncated, info = super().step(gyropod_action)
         self._remember(obs6)
         yaw = obs6[:, 2]
-        self._xy[:, 0] += linear_velocity * torch.cos(yaw) * self.dt  # :197-199
-        self._xy[:, 1] += linear_velocity * torch.sin(yaw) * self.dt
         if autoreset is not None and bool(autoreset.any()):
             self.mpc_balancer.reset(autoreset.to(torch.uint8))
             self._xy[autoreset] = 0.0
+            live = ~autoreset
+            self._xy[live, 0] += (linear_velocity * torch.cos(yaw) * self.dt)[live]  # :197-199
+            self._xy[live, 1] += (linear_velocity * torch.sin(yaw) * self.dt)[live]
+        else:
+            self._xy[:, 0] += linear_velocity * torch.cos(yaw) * self.dt  # :197-199
+            self._xy[:, 1] += linear_velocity * torch.sin(yaw) * self.dt
         obs = torch.cat([self._xy, yaw[:, None]], dim=1)
         return obs, reward, terminated, truncated, info

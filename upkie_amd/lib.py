@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_pendulum_agent_packed",
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
+    "upkie_sim_step_base_velocity",
     "upkie_sim_observe",
     "upkie_mpc_create",
     "upkie_mpc_destroy",
@@ -45,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "upkie_mpc_workspace_bytes",
     "upkie_mpc_reset",
     "upkie_mpc_step",
+    "upkie_mpc_step_env",
 )
 
 
@@ -145,6 +147,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_step_pendulum_packed.argtypes = [vp, vp, vp, vp, vp]
     lib.upkie_sim_step_pendulum_agent_packed.restype = C.c_int
     lib.upkie_sim_step_pendulum_agent_packed.argtypes = [vp, vp, vp, vp]
+    lib.upkie_sim_step_base_velocity.restype = C.c_int
+    lib.upkie_sim_step_base_velocity.argtypes = [vp] * 11
     lib.upkie_sim_observe.restype = C.c_int
     lib.upkie_sim_observe.argtypes = [
         vp,
@@ -165,6 +169,8 @@ def load() -> C.CDLL:
     lib.upkie_mpc_reset.argtypes = [vp, vp, vp, vp, vp]
     lib.upkie_mpc_step.restype = C.c_int
     lib.upkie_mpc_step.argtypes = [vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
+    lib.upkie_mpc_step_env.restype = C.c_int
+    lib.upkie_mpc_step_env.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, vp, vp]
     _lib = lib
     return lib
 

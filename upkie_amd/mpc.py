@@ -61,6 +61,25 @@ class BatchedMpc:
             )
         lib.check(status, self._handle, what="mpc")
 
+    def step_env(self, x0: torch.Tensor, act: torch.Tensor, contact: torch.Tensor, done: Optional[torch.Tensor], dt: float):
+        """First half of the fused UpkieBaseVelocity step: target velocity of
+        env e is ``act[e, 0]``; envs flagged in ``done`` (a float row of the
+        simulation state) are reset instead of solved."""
+        with torch.cuda.device(self.device):
+            status = self._lib.upkie_mpc_step_env(
+                self._handle,
+                _ptr(self.workspace),
+                _ptr(x0),
+                _ptr(act),
+                _ptr(contact),
+                _ptr(done),
+                float(dt),
+                _ptr(self.commanded_velocity),
+                self._stream(),
+            )
+        lib.check(status, self._handle, what="mpc")
+        return self.commanded_velocity
+
     def step(self, x0: torch.Tensor, target_velocity: torch.Tensor, contact: torch.Tensor, dt: float):
         """MPCBalancer.step (mpc_balancer.py:237-312): ``x0[B, 4]`` = ground
         position, pitch, ground velocity, pitch rate. Returns the commanded

@@ -183,6 +183,32 @@ class BatchedSim:
             )
         return self._step(self._lib.upkie_sim_step_servos, act, self.obs_servos)
 
+    def step_base_velocity(self, act, commanded_velocity, mpc_x0, mpc_contact):
+        """Second half of the fused UpkieBaseVelocity step: ``act[B, 2]`` =
+        [linear velocity, yaw velocity], ground velocity from the MPC
+        balancer; returns the SE(2) observation ``[B, 3]`` and refreshes the
+        balancer's next inputs in place."""
+        act = self._as_action(act, (self.num_envs, 2))
+        if getattr(self, "obs3", None) is None:
+            self.obs3 = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_step_base_velocity(
+                    self._handle,
+                    _ptr(self.state),
+                    _ptr(act),
+                    _ptr(commanded_velocity),
+                    _ptr(self.obs3),
+                    _ptr(mpc_x0),
+                    _ptr(mpc_contact),
+                    _ptr(self.reward),
+                    _ptr(self.terminated),
+                    _ptr(self.truncated),
+                    self._stream(),
+                )
+            )
+        return self.obs3, self.reward, self.terminated, self.truncated
+
     def step_pendulum_agent(self):
         """Pendulum step with the README's linear agent evaluated on-device
         from the observation currently held in ``self.obs4``."""
