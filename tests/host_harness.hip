@@ -17,7 +17,9 @@ extern "C" int harness_substep(const UpkieModel* model, float* st, const float* 
   for (int j = 0; j < 6; ++j) t[j] = tau[j];
   V3 f = ext_force ? v3(ext_force[0], ext_force[1], ext_force[2]) : v3(0, 0, 0);
   V3 p = ext_point ? v3(ext_point[0], ext_point[1], ext_point[2]) : v3(0, 0, 0);
-  bool c = physics_substep(M, s, t, h, scale, ext_force != nullptr, f, p);
+  DevLimits Lm;
+  model_limits(M, &Lm);
+  bool c = physics_substep(M, Lm, s, t, h, scale, ext_force != nullptr, f, p);
   st[UPKIE_S_POS] = s.pos.x; st[UPKIE_S_POS + 1] = s.pos.y; st[UPKIE_S_POS + 2] = s.pos.z;
   st[UPKIE_S_QUAT] = s.qw; st[UPKIE_S_QUAT + 1] = s.qx; st[UPKIE_S_QUAT + 2] = s.qy; st[UPKIE_S_QUAT + 3] = s.qz;
   st[UPKIE_S_LINVEL] = s.linvel.x; st[UPKIE_S_LINVEL + 1] = s.linvel.y; st[UPKIE_S_LINVEL + 2] = s.linvel.z;

@@ -110,3 +110,26 @@ def test_free_fall_semi_implicit_euler_in_fp32(harness):
         harness.harness_substep(C.byref(model), s.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p), C.c_float(1e-3), None, None, None)
     assert float(s[abi.S_POS + 2]) - 1.0 == pytest.approx(-3 * 9.81e-6, abs=2e-7)
     assert float(s[abi.S_LINVEL + 2]) == pytest.approx(-2 * 9.81e-3, abs=1e-7)
+
+
+def test_substep_with_joint_limits(harness):
+    """Hip/knee limit rows (general constraint path) vs the oracle's coupled
+    solve: states with joints at or beyond their limits, in the air and on the
+    floor."""
+    rng = np.random.default_rng(8)
+    model = default_model()
+    model.enforce_joint_limits = 1
+    hits = 0
+    for trial in range(120):
+        s = random_state(rng, on_floor=trial % 2 == 0)
+        for j, lim in ((0, 1.26), (1, 2.51), (3, 1.26), (4, 2.51)):
+            if rng.uniform() < 0.5:
+                s[abi.S_Q + j] = rng.choice([-1, 1]) * (lim + rng.uniform(0.0, 0.01))
+                s[abi.S_QD + j] = rng.uniform(-3, 3)
+                hits += 1
+        so, sh = run_both(harness, model, s, rng.uniform(-3.0, 3.0, 6))
+        assert np.abs(so[0:7] - sh[0:7]).max() < 1e-6
+        assert np.abs(so[7:10] - sh[7:10]).max() < 5e-4
+        assert np.abs(so[10:13] - sh[10:13]).max() < 3e-3
+        assert np.abs(so[19:25] - sh[19:25]).max() < 5e-2
+    assert hits > 100

@@ -141,6 +141,16 @@ struct DevModel {
   float pgs_tolerance;
   int pgs_iterations;
   int wheel_axisymmetric;  // wheel inertia invariant under its own rotation
+  int enforce_joint_limits;  // hip/knee limit rows in the constraint solve
+};
+
+// Joint position limits, passed by value as a kernel argument (loaded once,
+// SGPR-resident for the whole launch) rather than re-read every substep.
+struct DevLimits {
+  float lower[UPKIE_NJ];
+  float upper[UPKIE_NJ];
+  int bounded[UPKIE_NJ];  // finite lower and upper
+  int enforce;
 };
 
 // Physics state of one env held in registers.
@@ -396,13 +406,151 @@ UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], floa
   }
 }
 
+// General constraint solve (contacts + active hip/knee limits, up to 10 rows),
+// the rare path: taken only by envs with a joint at its limit. Same rows,
+// ordering and numerics as the 6-row path: rows = per touching wheel (normal,
+// rolling, lateral), then one row per limited joint; direct Cholesky solve,
+// projected Gauss-Seidel warm-started from its projection when infeasible.
+// Row data come reduced onto the base: Jt (6), leg index, leg part (3).
+// On return (tb, tl, tr) += J' lam. Arrays are indexed dynamically (scratch).
+struct GeneralRows {
+  float Jt[10][6];
+  float Jb[10][6];
+  float Jl[10][3];
+  float vnow[10];
+  float cfm[10];
+  float bias[10];  // positional term of the rhs (ERP push / gap closing / limit error)
+  int leg[10];
+  int kind[10];  // 0 contact normal, 1 friction, 2 joint limit
+  int normal_row[10];
+  int n;
+};
+
+template <class ModelT>
+UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const GeneralRows& R, const float (&rt)[6], float (&tb)[6],
+                                       float (&tl)[3], float (&tr)[3]) {
+  const int n = R.n;
+  float A[10][10], Y[10][6], K[10][3], rhs[10], lam[10];
+  for (int b = 0; b < n; ++b) {
+    float y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) y[c] = R.Jt[b][c];
+    ldl6_solve(S.A, y);
+    const float* hv = R.leg[b] == 0 ? S.leg[0].Hinv : S.leg[1].Hinv;
+    const float k0 = hv[0] * R.Jl[b][0] + hv[3] * R.Jl[b][1] + hv[4] * R.Jl[b][2];
+    const float k1 = hv[3] * R.Jl[b][0] + hv[1] * R.Jl[b][1] + hv[5] * R.Jl[b][2];
+    const float k2 = hv[4] * R.Jl[b][0] + hv[5] * R.Jl[b][1] + hv[2] * R.Jl[b][2];
+    float vf = R.vnow[b];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      Y[b][c] = y[c];
+      vf = fmaf(y[c], rt[c], vf);
+    }
+    K[b][0] = k0; K[b][1] = k1; K[b][2] = k2;
+    if (R.leg[b] == 0)
+      vf += k0 * tl[0] + k1 * tl[1] + k2 * tl[2];
+    else
+      vf += k0 * tr[0] + k1 * tr[1] + k2 * tr[2];
+    rhs[b] = -vf + R.bias[b];
+  }
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc = fmaf(R.Jt[a][c], Y[b][c], acc);
+      if (R.leg[a] == R.leg[b]) acc += R.Jl[a][0] * K[b][0] + R.Jl[a][1] * K[b][1] + R.Jl[a][2] * K[b][2];
+      if (a == b) acc += R.cfm[a];
+      A[a][b] = acc;
+    }
+  // Cholesky A = L L' in place of a copy, then two triangular solves
+  float L[10][10];
+  bool spd = true;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      float s = A[i][j];
+      for (int c = 0; c < j; ++c) s -= L[i][c] * L[j][c];
+      if (i == j) {
+        if (!(s > 0.f)) spd = false;
+        L[i][i] = fast_sqrt(fmaxf(s, 1e-30f));
+      } else {
+        L[i][j] = s * fast_rcp(L[j][j]);
+      }
+    }
+  const float mu = M.friction_mu;
+  bool need_pgs = !spd;
+  for (int i = 0; i < n; ++i) lam[i] = 0.f;
+  if (spd) {
+    float yv[10];
+    for (int i = 0; i < n; ++i) {
+      float s = rhs[i];
+      for (int c = 0; c < i; ++c) s -= L[i][c] * yv[c];
+      yv[i] = s * fast_rcp(L[i][i]);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      float s = yv[i];
+      for (int c = i + 1; c < n; ++c) s -= L[c][i] * lam[c];
+      lam[i] = s * fast_rcp(L[i][i]);
+    }
+    for (int r = 0; r < n; ++r)
+      if (R.kind[r] != 1 && lam[r] < 0.f) {
+        lam[r] = 0.f;
+        need_pgs = true;
+      }
+    for (int r = 0; r < n; ++r)
+      if (R.kind[r] == 1) {
+        const float lim = mu * lam[R.normal_row[r]];
+        if (lam[r] < -lim) { lam[r] = -lim; need_pgs = true; }
+        if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
+      }
+  }
+  for (int it = 0; need_pgs && it < M.pgs_iterations; ++it) {
+    float change = 0.f, scale = 0.f;
+    for (int pass = 0; pass < 3; ++pass)
+      for (int r = 0; r < n; ++r) {
+        if (R.kind[r] != pass) continue;
+        float al = 0.f;
+        for (int b = 0; b < n; ++b) al = fmaf(A[r][b], lam[b], al);
+        float x = lam[r] + (rhs[r] - al) * fast_rcp(A[r][r]);
+        if (R.kind[r] == 1) {
+          const float lim = mu * lam[R.normal_row[r]];
+          x = fminf(fmaxf(x, -lim), lim);
+        } else {
+          x = fmaxf(x, 0.f);
+        }
+        change = fmaxf(change, fabsf(x - lam[r]));
+        scale = fmaxf(scale, fabsf(x));
+        lam[r] = x;
+      }
+    if (change <= M.pgs_tolerance * scale) break;
+  }
+  for (int r = 0; r < n; ++r) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tb[c] = fmaf(R.Jb[r][c], lam[r], tb[c]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (R.leg[r] == 0)
+        tl[j] = fmaf(R.Jl[r][j], lam[r], tl[j]);
+      else
+        tr[j] = fmaf(R.Jl[r][j], lam[r], tr[j]);
+    }
+  }
+}
+
 // One physics substep of duration h. tau: commanded joint torques.
 // scale: per-body inertia scales of this env or nullptr. ext_force (world
 // frame) acts on the trunk at base-frame point ext_point when has_ext.
 // Returns the floor-contact flag.
 template <class ModelT>
-UPKIE_HD bool physics_substep(const ModelT& M, Phys& s, const float (&tau)[UPKIE_NJ], float h,
+UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
                                                 const float* scale, bool has_ext, V3 ext_force, V3 ext_point) {
+  // hip / knee position limits (URDF revolute limits, enforced by Bullet as
+  // unilateral rows with ERP 0.2): rare, handled by the general solver
+  bool any_limit = false;
+  if (Lm.enforce) {
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j)
+      any_limit = any_limit || (Lm.bounded[j] && (s.q[j] <= Lm.lower[j] || s.q[j] >= Lm.upper[j]));
+  }
   // rotation base -> world (upkie/utils/rotations.py:52-71)
   float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
   float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
@@ -559,7 +707,63 @@ UPKIE_HD bool physics_substep(const ModelT& M, Phys& s, const float (&tau)[UPKIE
     }
   }
   float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (active[0] || active[1]) {
+  if (any_limit) {
+    GeneralRows R;
+    R.n = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      if (!active[w]) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int r = 3 * w + k, i = R.n;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          R.Jt[i][c] = Jt[r][c];
+          R.Jb[i][c] = Jb[r][c];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R.Jl[i][j] = Jl[r][j];
+        R.vnow[i] = vnow[r];
+        R.leg[i] = w;
+        R.kind[i] = k == 0 ? 0 : 1;
+        R.normal_row[i] = i - k;
+        R.cfm[i] = k == 0 ? cfm : M.friction_cfm;
+        R.bias[i] = k == 0 ? (dists[w] <= 0.f ? erp * (-dists[w]) * ih : -dists[w] * ih) : 0.f;
+        R.n = i + 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      float sign = 0.f, err = 0.f;
+      if (Lm.bounded[j] && s.q[j] <= Lm.lower[j]) {
+        sign = 1.f;
+        err = Lm.lower[j] - s.q[j];
+      } else if (Lm.bounded[j] && s.q[j] >= Lm.upper[j]) {
+        sign = -1.f;
+        err = s.q[j] - Lm.upper[j];
+      }
+      if (sign != 0.f) {
+        const int i = R.n, w = j / 3, kk = j % 3;
+        const Leg& G = S.leg[w];
+        // J = sign * e_j: no base part, reduced row = -D_w J_leg
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          R.Jb[i][c] = 0.f;
+          R.Jt[i][c] = -sign * G.D[c][kk];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) R.Jl[i][jj] = jj == kk ? sign : 0.f;
+        R.vnow[i] = sign * s.qd[j];
+        R.leg[i] = w;
+        R.kind[i] = 2;
+        R.normal_row[i] = i;
+        R.cfm[i] = 0.f;
+        R.bias[i] = 0.2f * err * ih;
+        R.n = i + 1;
+      }
+    }
+    general_constraint_solve(M, S, R, rt, tb, tl, tr);
+  } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors
     // give the free velocity of row b. Rows of a wheel without a contact point

@@ -193,7 +193,7 @@ __device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phy
 }
 
 template <int MODE, bool RAND>
-__global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ Mp, DevConfig C, float* __restrict__ state,
+__global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C, float* __restrict__ state,
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void step_kernel(const DevModel* __restrict__ M
       typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep(*mp, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
+      contact = physics_substep(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
     }
   }
 
@@ -628,6 +628,7 @@ using namespace upkie;
 
 struct UpkieSim {
   DevModel model;
+  DevLimits limits;
   DevModel* d_model = nullptr;  // device copy read through scalar loads
   DevConfig config;
   const float* inertia_scale = nullptr;
@@ -714,11 +715,17 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   d->max_joint_velocity = (float)m->max_joint_velocity;
   d->pgs_iterations = m->pgs_iterations;
   d->pgs_tolerance = (float)m->pgs_tolerance;
-  if (m->enforce_joint_limits) {
-    *why = "enforce_joint_limits is not supported by the HIP path yet";
-    return false;
-  }
+  d->enforce_joint_limits = m->enforce_joint_limits ? 1 : 0;
   return true;
+}
+
+static void model_limits(const DevModel& m, DevLimits* l) {
+  l->enforce = m.enforce_joint_limits;
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    l->lower[j] = m.joint_lower[j];
+    l->upper[j] = m.joint_upper[j];
+    l->bounded[j] = (m.joint_lower[j] > -1e30f && m.joint_upper[j] < 1e30f) ? 1 : 0;
+  }
 }
 
 static bool convert_config(const UpkieSimConfig* c, DevConfig* d, std::string* why) {
@@ -796,6 +803,7 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
     delete sim;
     return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
+  model_limits(sim->model, &sim->limits);
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
   if (err != hipSuccess) {
@@ -864,10 +872,10 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const bool rnd = sim->inertia_scale || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   if (rnd) {
-    hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
+    hipLaunchKernelGGL((step_kernel<MODE, true>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->limits, sim->config, state, act, obs,
                        reward, terminated, truncated, mask, sim->inertia_scale, sim->ext_force, packed, bv);
   } else {
-    hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->config, state, act, obs,
+    hipLaunchKernelGGL((step_kernel<MODE, false>), grid, block, 0, (hipStream_t)stream, sim->d_model, sim->limits, sim->config, state, act, obs,
                        reward, terminated, truncated, mask, (const float*)nullptr, (const float*)nullptr, packed, bv);
   }
   return check_hip(sim, hipGetLastError(), "step_kernel");

@@ -123,7 +123,7 @@ def default_model() -> UpkieModel:
     m.max_joint_velocity = 100.0
     m.pgs_iterations = 50
     m.pgs_tolerance = 1e-6
-    m.enforce_joint_limits = 0
+    m.enforce_joint_limits = 1  # Bullet enforces URDF revolute limits
     return m
 
 
