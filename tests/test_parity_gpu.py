@@ -408,3 +408,22 @@ def test_joint_limits_match_oracle():
     for _ in range(60):
         obs_h2, *_ = sim2.step_servos(torch.from_numpy(act))
     assert float(obs_h2[:, 1, 0].min()) > 3.0
+
+
+def test_dense_batch_variant_matches_small_batch_variant():
+    """Batches >= 131072 run the register-capped (2 waves/SIMD) build of the
+    same kernel: env i of a big batch must equal env i of a small one."""
+    from upkie_amd.sim import BatchedSim
+
+    big = BatchedSim(randomized_config(131072, seed=21, autoreset=True))
+    small = BatchedSim(randomized_config(512, seed=21, autoreset=True))
+    big.reset()
+    small.reset()
+    big.obs4.copy_(big.obs6[:, [1, 0, 4, 3]])
+    small.obs4.copy_(small.obs6[:, [1, 0, 4, 3]])
+    for _ in range(30):
+        ob, *_ = big.step_pendulum_agent()
+        os_, *_ = small.step_pendulum_agent()
+    # different register allocation may reorder fp32 operations: tolerance, not bits
+    assert float((ob[:512] - os_).abs().max()) < 1e-4
+    assert float((big.state[:25, :512] - small.state[:25]).abs().max()) < 5e-3

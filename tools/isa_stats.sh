@@ -9,7 +9,7 @@ grep -A10 "step_kernelILi2ELb0" remarks.txt | grep -E "VGPRs:|AGPRs|Scratch|Spil
 python3 - <<'PY'
 import re, collections
 txt = open('upkie_hip-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-m = re.search(r'^_ZN5upkie11step_kernelILi2ELb0EEE.*?:\n(.*?)\.Lfunc_end', txt, re.S | re.M)
+m = re.search(r'^_ZN5upkie11step_kernelILi2ELb0ELi1EEE.*?:\n(.*?)\.Lfunc_end', txt, re.S | re.M)
 ops = collections.Counter()
 for line in m.group(1).split('\n'):
     line = line.strip()
