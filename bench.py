@@ -106,6 +106,7 @@ def main() -> None:
     start_evt.record()  # same stream the kernels are launched on
     for _ in range(args.steps):
         env.step_agent()
+    env.flush()  # records of the last steps must have reached rank 0
     stop_evt.record()
     env.barrier()
     torch.cuda.synchronize()
@@ -144,7 +145,7 @@ def main() -> None:
             "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset",
             "envs_per_gpu": B,
             "total_envs": total_envs,
-            "gather": "RCCL gather of packed obs/reward/done to rank 0 every step" if world > 1 else "none (single GPU)",
+            "gather": "RCCL gather of packed obs/reward/done records into rank 0's rollout ring buffer every step, overlapped with the next step" if world > 1 else "none (single GPU): records written straight into the rollout ring buffer",
             "episode_resets_in_timed_region": resets,
         },
         "roofline": {

@@ -219,6 +219,12 @@ int upkie_sim_step_pendulum_packed(UpkieSim* sim, float* state,
                                    void* stream);
 int upkie_sim_step_pendulum_agent_packed(UpkieSim* sim, float* state,
                                          float* records, void* stream);
+/* Double-buffered form: the agent reads the previous observation from
+ * prev_records (a different buffer) so that a gather of prev_records can still
+ * be in flight while this step runs. */
+int upkie_sim_step_pendulum_agent_records(UpkieSim* sim, float* state,
+                                          const float* prev_records,
+                                          float* records, void* stream);
 
 /* One env.step() of UpkieGyropod (upkie_gyropod.py:354-392):
  * act[B][2] -> obs[B][6]. */

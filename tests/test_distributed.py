@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size 2 over gloo (the GPU path uses the same
+"""Multi-rank path on CPU: world_size 2 over gloo (the GPU path runs the same
 code with backend "nccl" = RCCL)."""
 
 import os
@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from upkie_amd.distributed import RECORD_WORDS, RecordGather, init_distributed, shard_range
+from upkie_amd.distributed import RECORD_WORDS, RolloutGather, init_distributed, shard_range
 
 
 def free_port() -> int:
@@ -28,24 +28,38 @@ def test_shard_range_partitions_the_batch():
         assert covered == list(range(total))
 
 
-def _worker(rank: int, world: int, port: int, envs: int, steps: int, out_path: str):
+def record_pattern(step: int, lo: int, hi: int) -> torch.Tensor:
+    """Record of global env g at step s: word w = 1000 s + g + w / 10."""
+    g = torch.arange(lo, hi, dtype=torch.float32)[:, None]
+    return 1000.0 * step + g + torch.arange(RECORD_WORDS)[None, :] / 10.0
+
+
+def produce(gather: RolloutGather, steps: int, lo: int, hi: int) -> bool:
+    ok = True
+    for step in range(steps):
+        out = gather.begin_step()
+        if step > 0:  # the agent's input: last step's records are still intact
+            ok = ok and torch.equal(gather.previous, record_pattern(step - 1, lo, hi))
+        out.copy_(record_pattern(step, lo, hi))
+        gather.end_step()
+    gather.flush()
+    return ok
+
+
+def _worker(rank: int, world: int, port: int, envs: int, steps: int, horizon: int, out_path: str):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r, w, _ = init_distributed(world, backend="gloo")
     assert (r, w) == (rank, world)
-    gather = RecordGather(envs, rank, world, device="cpu")
+    gather = RolloutGather(envs, rank, world, device="cpu", horizon=horizon)
     lo, hi = shard_range(rank, world, envs * world)
-    ok = True
-    for step in range(steps):
-        # record of global env g at step s: every word = 1000 s + g + word / 10
-        g = torch.arange(lo, hi, dtype=torch.float32)[:, None]
-        gather.local.copy_(1000.0 * step + g + torch.arange(RECORD_WORDS)[None, :] / 10.0)
-        out = gather.gather()
-        if rank == 0:
-            flat = out.reshape(world * envs, RECORD_WORDS)
-            expect = 1000.0 * step + torch.arange(world * envs, dtype=torch.float32)[:, None] + torch.arange(RECORD_WORDS)[None, :] / 10.0
-            ok = ok and torch.equal(flat, expect)
-        else:
-            ok = ok and out is None
+    ok = produce(gather, steps, lo, hi)
+    if rank == 0:
+        for step in range(max(0, steps - horizon), steps):  # the ring keeps the last `horizon` steps
+            flat = gather.rollout[step % horizon].reshape(world * envs, RECORD_WORDS)
+            ok = ok and torch.equal(flat, record_pattern(step, 0, world * envs))
+        ok = ok and torch.equal(gather.last(), gather.rollout[(steps - 1) % horizon])
+    else:
+        ok = ok and gather.rollout is None and gather.last() is None
     # max-over-ranks reduction used for the timing contract
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -59,17 +73,19 @@ def _worker(rank: int, world: int, port: int, envs: int, steps: int, out_path: s
         raise SystemExit(1)
 
 
-def test_record_gather_world_size_2_gloo(tmp_path):
+@pytest.mark.parametrize("steps,horizon", [(7, 16), (21, 8)])
+def test_pipelined_gather_world_size_2_gloo(tmp_path, steps, horizon):
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(2, free_port(), 33, 3, str(out)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, free_port(), 33, steps, horizon, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
 
 
-def test_record_gather_single_rank():
-    gather = RecordGather(5, 0, 1, device="cpu")
-    gather.local.copy_(torch.arange(5 * RECORD_WORDS, dtype=torch.float32).reshape(5, RECORD_WORDS))
-    out = gather.gather()
-    assert out.shape == (1, 5, RECORD_WORDS) and torch.equal(out[0], gather.local)
+def test_single_rank_writes_straight_into_the_ring():
+    gather = RolloutGather(5, 0, 1, device="cpu", horizon=4)
+    assert produce(gather, 6, 0, 5)
+    for step in (2, 3, 4, 5):
+        assert torch.equal(gather.rollout[step % 4, 0], record_pattern(step, 0, 5))
+    assert gather.current.data_ptr() == gather.rollout[6 % 4, 0].data_ptr()  # no staging copy
 
 
 def test_world_size_mismatch_is_an_error(monkeypatch):

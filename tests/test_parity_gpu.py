@@ -427,3 +427,29 @@ def test_dense_batch_variant_matches_small_batch_variant():
     # different register allocation may reorder fp32 operations: tolerance, not bits
     assert float((ob[:512] - os_).abs().max()) < 1e-4
     assert float((big.state[:25, :512] - small.state[:25]).abs().max()) < 5e-3
+
+
+def test_sharded_pendulum_single_rank_rollout():
+    """The bench's driver object: records land in the rollout ring buffer and
+    equal what the four-array agent step produces."""
+    from upkie_amd.distributed import ShardedPendulum
+    from upkie_amd.sim import BatchedSim
+
+    cfg = randomized_config(200, seed=14, autoreset=True)
+    env = ShardedPendulum(cfg, device="cuda:0", horizon=8)
+    ref = BatchedSim(cfg)
+    env.reset()
+    ref.reset()
+    ref.obs4.copy_(ref.obs6[:, [1, 0, 4, 3]])
+    history = []
+    for _ in range(20):
+        env.step_agent()
+        obs, rew, term, trunc = ref.step_pendulum_agent()
+        history.append((obs.clone(), term.clone()))
+    env.flush()
+    for back in range(8):  # the ring keeps the last 8 steps
+        rec = env.gather.last(back)[0]
+        obs, term = history[-1 - back]
+        assert torch.equal(rec[:, :4], obs) and torch.equal(rec[:, 5], term.float())
+    assert torch.equal(env.sim.state, ref.state)
+    env.shutdown()

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       a0 = act[e];  // upkie_pendulum.py:139: [action[0], 0.0]
     } else if (MODE == MODE_PENDULUM_AGENT) {
       // README.md:62-64: action = gains . observation, clipped
-      const float4 o = reinterpret_cast<const float4*>(obs)[packed ? 2 * (size_t)e : (size_t)e];
+      // previous observation: from `act` when the caller double-buffers its records
+      const float* prev = act ? act : obs;
+      const float4 o = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
     } else if (MODE == MODE_BASE_VELOCITY) {
@@ -914,6 +916,12 @@ extern "C" int upkie_sim_step_pendulum_packed(UpkieSim* sim, float* state, const
 
 extern "C" int upkie_sim_step_pendulum_agent_packed(UpkieSim* sim, float* state, float* records, void* stream) {
   return launch_step<MODE_PENDULUM_AGENT>(sim, state, nullptr, records, nullptr, nullptr, nullptr, nullptr, stream, 1);
+}
+
+extern "C" int upkie_sim_step_pendulum_agent_records(UpkieSim* sim, float* state, const float* prev_records, float* records,
+                                                    void* stream) {
+  if (!prev_records) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  return launch_step<MODE_PENDULUM_AGENT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1);
 }
 
 extern "C" int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,

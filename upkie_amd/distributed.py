@@ -7,6 +7,14 @@ The reference has nothing to mirror here: every PyBulletBackend is its own
 world (pybullet_backend.py:100-125), so envs are independent units and the
 random streams are keyed by the GLOBAL env index (results do not depend on the
 number of ranks).
+
+xGMI is point-to-point and the message is tiny (32 B/env: 128 KB per rank at
+4096 envs), so the gather is latency bound, not bandwidth bound. It is
+therefore taken off the critical path: records are double-buffered, the
+gather of step t is issued asynchronously and overlaps the kernel of step
+t + 1, and rank 0 receives straight into the slot of a rollout ring buffer
+``[T, world, B, 8]`` (the "PPO rollout consumer" of BASELINE.json configs[3]),
+so there is no extra copy on the consumer side either.
 """
 
 import os
@@ -52,61 +60,112 @@ def init_distributed(expected_world: Optional[int] = None, backend: Optional[str
     return rank, world, local_rank
 
 
-class RecordGather:
-    """Gathers fixed-size per-env records from every rank to rank 0.
+class RolloutGather:
+    """Double-buffered per-env records on every rank + a rollout ring buffer on
+    rank 0 that the gathers write into directly.
 
-    Works on any device / backend (RCCL for GPU tensors, gloo for CPU tests);
-    buffers are allocated once, so the per-step cost is one collective."""
+    Usage per step ``t`` on every rank::
 
-    def __init__(self, local_envs: int, rank: int, world_size: int, device, words: int = RECORD_WORDS):
-        self.rank, self.world_size = rank, world_size
-        self.local = torch.zeros((local_envs, words), dtype=torch.float32, device=device)
-        self.gathered: Optional[torch.Tensor] = None
-        self._gather_list: Optional[List[torch.Tensor]] = None
+        out = g.begin_step()          # buffer this step's kernel writes
+        prev = g.previous             # buffer holding step t-1 (agent input)
+        ... launch the step writing `out` ...
+        g.end_step()                  # async gather of `out` to rank 0
+
+    `begin_step` first waits (stream-level) for the gather that last used the
+    buffer about to be overwritten, i.e. the one issued two steps earlier: the
+    gather of step t-1 is still free to run during step t's kernel.
+    Works on any device / backend (RCCL for GPU tensors, gloo for CPU tests).
+    """
+
+    def __init__(self, local_envs: int, rank: int, world_size: int, device, horizon: int = 128, words: int = RECORD_WORDS):
+        self.rank, self.world_size, self.horizon = rank, world_size, horizon
+        self.buffers = [torch.zeros((local_envs, words), dtype=torch.float32, device=device) for _ in range(2)]
+        self._work = [None, None]
+        self._step = 0  # index of the step being produced
+        self.rollout: Optional[torch.Tensor] = None
         if rank == 0:
-            self.gathered = torch.zeros((world_size, local_envs, words), dtype=torch.float32, device=device)
-            self._gather_list = list(self.gathered.unbind(0))
+            # [T, world, B, words]: slot t % T holds step t of every env (rank-major = global env order)
+            self.rollout = torch.zeros((horizon, world_size, local_envs, words), dtype=torch.float32, device=device)
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Rank 0 returns ``[world, local_envs, words]`` (rank-major = global
-        env order), other ranks return None."""
+    @property
+    def current(self) -> torch.Tensor:
+        if self.world_size == 1:  # single rank: produce straight into the ring slot
+            return self.rollout[self._step % self.horizon, 0]
+        return self.buffers[self._step % 2]
+
+    @property
+    def previous(self) -> torch.Tensor:
         if self.world_size == 1:
-            self.gathered[0].copy_(self.local)
-            return self.gathered
-        dist.gather(self.local, self._gather_list, dst=0)
-        return self.gathered
+            return self.rollout[(self._step - 1) % self.horizon, 0]
+        return self.buffers[(self._step + 1) % 2]
+
+    def begin_step(self) -> torch.Tensor:
+        work = self._work[self._step % 2]
+        if work is not None:
+            work.wait()  # the gather issued two steps ago has read this buffer
+            self._work[self._step % 2] = None
+        return self.current
+
+    def end_step(self) -> None:
+        slot = self._step % self.horizon
+        out = self.current
+        if self.world_size > 1:
+            gather_list: Optional[List[torch.Tensor]] = None
+            if self.rank == 0:
+                gather_list = list(self.rollout[slot].unbind(0))
+            self._work[self._step % 2] = dist.gather(out, gather_list, dst=0, async_op=True)
+        self._step += 1
+
+    def flush(self) -> None:
+        """Wait for every gather in flight (end of a rollout / of the bench)."""
+        for i, work in enumerate(self._work):
+            if work is not None:
+                work.wait()
+                self._work[i] = None
+
+    def last(self, steps_back: int = 0) -> Optional[torch.Tensor]:
+        """Rank 0: records ``[world, B, words]`` of the step issued
+        `steps_back` steps before the latest one (after `flush`)."""
+        if self.rollout is None:
+            return None
+        return self.rollout[(self._step - 1 - steps_back) % self.horizon]
 
 
 class ShardedPendulum:
-    """This rank's shard of a batch of Upkie-Pendulum envs plus the per-step
-    gather of records to rank 0."""
+    """This rank's shard of a batch of Upkie-Pendulum envs plus the pipelined
+    gather of per-step records into rank 0's rollout buffer."""
 
-    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None):
+    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128):
         from .sim import BatchedSim
 
         self.rank, self.world_size = rank, world_size
         self.sim = BatchedSim(config, model, device=device)
-        self.records = RecordGather(self.sim.num_envs, rank, world_size, self.sim.device)
+        self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon)
         self._device = self.sim.device
 
     def reset(self) -> None:
         obs6 = self.sim.reset()
-        self.records.local.zero_()
-        self.records.local[:, :4] = obs6[:, [1, 0, 4, 3]]  # upkie_pendulum.py:17
+        self.gather.flush()
+        for buf in self.gather.buffers:
+            buf.zero_()
+        self.gather.previous.zero_()
+        # the agent's first input: the reset observation, upkie_pendulum.py:17
+        self.gather.previous[:, :4] = obs6[:, [1, 0, 4, 3]]
 
-    def step_agent(self) -> Optional[torch.Tensor]:
-        """One env.step() of every local env with the on-device linear agent,
-        then (world_size > 1) the gather to rank 0."""
-        self.sim.step_pendulum_packed(self.records.local)
-        if self.world_size > 1:
-            return self.records.gather()
-        return self.records.local
+    def step_agent(self) -> None:
+        """One env.step() of every local env with the on-device linear agent;
+        the records of this step travel to rank 0 while the next step runs."""
+        out = self.gather.begin_step()
+        self.sim.step_pendulum_records(self.gather.previous, out)
+        self.gather.end_step()
 
-    def step(self, act: torch.Tensor) -> Optional[torch.Tensor]:
-        self.sim.step_pendulum_packed(self.records.local, act)
-        if self.world_size > 1:
-            return self.records.gather()
-        return self.records.local
+    def step(self, act: torch.Tensor) -> None:
+        out = self.gather.begin_step()
+        self.sim.step_pendulum_packed(out, act)
+        self.gather.end_step()
+
+    def flush(self) -> None:
+        self.gather.flush()
 
     def barrier(self) -> None:
         if self.world_size > 1:
@@ -129,6 +188,7 @@ class ShardedPendulum:
         return int(n.item())
 
     def shutdown(self) -> None:
+        self.gather.flush()
         self.sim.close()
         if self.world_size > 1 and dist.is_initialized():
             dist.destroy_process_group()

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_pendulum_agent",
     "upkie_sim_step_pendulum_packed",
     "upkie_sim_step_pendulum_agent_packed",
+    "upkie_sim_step_pendulum_agent_records",
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
     "upkie_sim_step_base_velocity",
@@ -147,6 +148,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_step_pendulum_packed.argtypes = [vp, vp, vp, vp, vp]
     lib.upkie_sim_step_pendulum_agent_packed.restype = C.c_int
     lib.upkie_sim_step_pendulum_agent_packed.argtypes = [vp, vp, vp, vp]
+    lib.upkie_sim_step_pendulum_agent_records.restype = C.c_int
+    lib.upkie_sim_step_pendulum_agent_records.argtypes = [vp, vp, vp, vp, vp]
     lib.upkie_sim_step_base_velocity.restype = C.c_int
     lib.upkie_sim_step_base_velocity.argtypes = [vp] * 11
     lib.upkie_sim_observe.restype = C.c_int

@@ -226,6 +226,19 @@ class BatchedSim:
             )
         return self.obs4, self.reward, self.terminated, self.truncated
 
+    def step_pendulum_records(self, prev_records: torch.Tensor, records: torch.Tensor) -> torch.Tensor:
+        """On-device agent step reading the previous observation from
+        ``prev_records`` and writing this step's records to ``records``."""
+        assert records.shape == (self.num_envs, 8) and prev_records.shape == (self.num_envs, 8)
+        assert records.is_contiguous() and prev_records.is_contiguous()
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_step_pendulum_agent_records(
+                    self._handle, _ptr(self.state), _ptr(prev_records), _ptr(records), self._stream()
+                )
+            )
+        return records
+
     def step_pendulum_packed(self, records: torch.Tensor, act=None) -> torch.Tensor:
         """Pendulum step writing one ``[obs(4) | reward, terminated,
         truncated, 0]`` record per env into ``records[B, 8]``; with
