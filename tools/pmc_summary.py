@@ -8,7 +8,7 @@ for path in sorted(glob.glob(os.path.join(root, "pass*", "pmc_counter_collection
     sums, counts = defaultdict(float), defaultdict(int)
     with open(path) as f:
         for row in csv.DictReader(f):
-            if "step_kernel<2" not in row["Kernel_Name"]:
+            if "step_kernel<2, false" not in row["Kernel_Name"]:
                 continue
             sums[row["Counter_Name"]] += float(row["Counter_Value"])
             counts[row["Counter_Name"]] += 1
