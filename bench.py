@@ -155,10 +155,10 @@ def main() -> None:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "kernel": "step_kernel<MODE_PENDULUM_AGENT>",
+            "kernel": "step_kernel_pair<MODE_PENDULUM_AGENT> (two lanes per env; step_kernel<...> above 32768 envs per GPU)" if B <= 32768 else "step_kernel<MODE_PENDULUM_AGENT>",
             "avg_launch_us": launch_us,
             "algorithmic_bytes_per_env_step": ALGORITHMIC_BYTES_PER_ENV_STEP,
-            "note": "the step is fp32-VALU/latency bound (~5e4 flop vs 258 B per env-step), not HBM bound: see DESIGN.md",
+            "note": "the step is fp32-VALU/latency bound (~2e4 VALU instructions vs 258 B per env-step), not HBM bound: see DESIGN.md section 6",
         },
     }
     if world == 1 and not args.no_cpu_baseline:

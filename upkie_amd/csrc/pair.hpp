@@ -1,0 +1,746 @@
+// pair.hpp -- two lanes per env: each lane owns one leg (left = even lane,
+// right = odd lane) and a redundant copy of the base.
+//
+// Small batches are latency bound: at 4096 envs the one-env-per-lane kernel
+// puts 64 wavefronts on a chip with 1024 SIMDs and the launch lasts as long as
+// ONE wave's instruction stream. Almost half of that stream is per-leg work
+// (kinematics, Newton-Euler, composite inertias, the 3x3 leg block, the tire's
+// contact rows), which two lanes can do side by side. Everything that couples
+// the legs goes through the 6x6 base system, so the lanes only meet in a few
+// sums and in the contact matrix: ~100 DPP swaps (quad_perm [1,0,3,2], one VALU
+// instruction each, no LDS) per substep. Sums are formed as own + partner,
+// which is commutative in IEEE arithmetic, and the one non-symmetric product
+// (the left/right block of the contact matrix) is computed by the right lane
+// and copied, so both lanes hold bit-identical base quantities throughout.
+//
+// Included by upkie_hip.hip inside namespace upkie, after the one-lane kernel
+// (it reuses DevConfig, Servo, joint_torque, sample_init_state, philox_*).
+#pragma once
+
+// value held by the partner lane (lane ^ 1)
+__device__ __forceinline__ float xchg(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pair_sum(float x) { return x + xchg(x); }
+__device__ __forceinline__ V3 pair_sum(V3 a) { return V3{pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)}; }
+__device__ __forceinline__ bool pair_any(bool b) { return b || xchg(b ? 1.f : 0.f) != 0.f; }
+template <class T>
+__device__ __forceinline__ T pick(int leg, T left, T right) {
+  return leg ? right : left;
+}
+
+// Per-lane constants of the leg a lane owns.
+struct PairLeg {
+  LegRegs regs;
+  float damping[3], lower[3], upper[3], effort[3], velocity[3], friction[3], control_noise[3], measurement_noise[3];
+  int bounded[3];
+  float wheel_center[3];
+};
+
+template <class ModelT>
+__device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int leg, const float* scale3) {
+  PairLeg P;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int bl = 1 + k, br = 4 + k, jl = k, jr = 3 + k;
+    P.regs.m[k] = pick(leg, M.mass[bl], M.mass[br]);
+    P.regs.sc[k] = scale3 ? scale3[k] : 1.f;
+    P.regs.sg[k] = pick(leg, M.joint_sign[jl], M.joint_sign[jr]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      P.regs.c[k][d] = pick(leg, M.com[bl][d], M.com[br][d]);
+      P.regs.p[k][d] = pick(leg, M.joint_pos[jl][d], M.joint_pos[jr][d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) P.regs.I[k][d] = pick(leg, M.inertia[bl][d], M.inertia[br][d]);
+    P.damping[k] = pick(leg, M.joint_damping[jl], M.joint_damping[jr]);
+    P.lower[k] = pick(leg, Lm.lower[jl], Lm.lower[jr]);
+    P.upper[k] = pick(leg, Lm.upper[jl], Lm.upper[jr]);
+    P.bounded[k] = pick(leg, Lm.bounded[jl], Lm.bounded[jr]);
+    P.effort[k] = pick(leg, M.joint_effort[jl], M.joint_effort[jr]);
+    P.velocity[k] = pick(leg, M.joint_velocity[jl], M.joint_velocity[jr]);
+    P.friction[k] = pick(leg, C.joint_friction[jl], C.joint_friction[jr]);
+    P.control_noise[k] = pick(leg, C.control_noise[jl], C.control_noise[jr]);
+    P.measurement_noise[k] = pick(leg, C.measurement_noise[jl], C.measurement_noise[jr]);
+    P.wheel_center[k] = pick(leg, M.wheel_center[0][k], M.wheel_center[1][k]);
+  }
+  return P;
+}
+
+struct PhysPair {
+  V3 pos;
+  float qw, qx, qy, qz;
+  V3 linvel, angvel;
+  float q[3], qd[3];  // the owned leg
+};
+
+// One physics substep, two lanes per env. Mirrors physics_substep() step by
+// step; comments there apply. `leg` = 0 (left) / 1 (right) is the leg this lane
+// owns. Returns the floor-contact flag (identical in both lanes).
+template <class ModelT>
+__device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
+                                                     const float (&tau)[3], float h, float scale0, bool has_ext, V3 ext_force,
+                                                     V3 ext_point) {
+  bool own_limit = false;
+  if (Lm.enforce) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) own_limit = own_limit || (PL.bounded[k] && (s.q[k] <= PL.lower[k] || s.q[k] >= PL.upper[k]));
+  }
+  const bool any_limit = Lm.enforce ? pair_any(own_limit) : false;
+
+  float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+  float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
+  float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+  float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+  V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
+             r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
+  V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
+             r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
+  V3 nB = v3(r20, r21, r22);
+  V3 gn = M.gravity * nB;
+
+  // trunk (both lanes, identical)
+  float m0 = M.mass[0] * scale0;
+  V3 c0 = v3(M.com[0][0], M.com[0][1], M.com[0][2]);
+  S3 I0 = S3{scale0 * M.inertia[0][0], scale0 * M.inertia[0][1], scale0 * M.inertia[0][2],
+             scale0 * M.inertia[0][3], scale0 * M.inertia[0][4], scale0 * M.inertia[0][5]};
+  V3 I0w = mul(I0, wB);
+  V3 bias_f, bias_n;
+  {
+    V3 ac = cross(wB, cross(wB, c0));
+    V3 f = m0 * (ac + gn);
+    V3 n = cross(wB, I0w);
+    bias_f = f;
+    bias_n = n + cross(c0, f);
+  }
+  Composite total{m0, m0 * c0, shift_to_origin(I0, m0, c0)};
+
+  // own leg, then legs' totals as own + partner
+  Leg G;
+  Composite legs{0.f, v3(0.f, 0.f, 0.f), S3{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+  V3 lf = v3(0.f, 0.f, 0.f), ln = v3(0.f, 0.f, 0.f);
+  leg_pass(PL.regs, M.wheel_axisymmetric != 0, s.q, s.qd, wB, gn, G, legs, lf, ln);
+  total.m += pair_sum(legs.m);
+  total.h = total.h + pair_sum(legs.h);
+  total.I = total.I + S3{pair_sum(legs.I.xx), pair_sum(legs.I.yy), pair_sum(legs.I.zz),
+                         pair_sum(legs.I.xy), pair_sum(legs.I.xz), pair_sum(legs.I.yz)};
+  bias_f = bias_f + pair_sum(lf);
+  bias_n = bias_n + pair_sum(ln);
+
+  Ldl6 fac;
+  {
+    float A[21];
+    V3 hh = total.h;
+    A[0] = total.m;
+    A[1] = 0.f; A[2] = total.m;
+    A[3] = 0.f; A[4] = 0.f; A[5] = total.m;
+    A[6] = 0.f;   A[7] = -hh.z; A[8] = hh.y;  A[9] = total.I.xx;
+    A[10] = hh.z; A[11] = 0.f;  A[12] = -hh.x; A[13] = total.I.xy; A[14] = total.I.yy;
+    A[15] = -hh.y; A[16] = hh.x; A[17] = 0.f;  A[18] = total.I.xz; A[19] = total.I.yz; A[20] = total.I.zz;
+    int idx = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const float own = G.D[r][0] * G.F[0][c] + G.D[r][1] * G.F[1][c] + G.D[r][2] * G.F[2][c];
+        A[idx] -= pair_sum(own);
+        ++idx;
+      }
+    }
+    ldl6_factor(A, fac);
+  }
+
+  // impulses so far: t = h (applied - bias)
+  float tb[6], tl[3], rt[6];
+  {
+    V3 vc = vB + cross(wB, c0);
+    float vn = fast_sqrt(dot(vc, vc)), wn = fast_sqrt(dot(wB, wB));
+    float kl = M.base_linear_damping, ka = M.base_angular_damping;
+    V3 F = (-m0 * (kl + kl * vn)) * vc;
+    V3 T = (-(ka + ka * wn)) * I0w;
+    V3 Ntot = T + cross(c0, F);
+    if (has_ext) {
+      V3 Fe = v3(r00 * ext_force.x + r10 * ext_force.y + r20 * ext_force.z, r01 * ext_force.x + r11 * ext_force.y + r21 * ext_force.z,
+                 r02 * ext_force.x + r12 * ext_force.y + r22 * ext_force.z);
+      F = F + Fe;
+      Ntot = Ntot + cross(ext_point, Fe);
+    }
+    tb[0] = h * (F.x - bias_f.x); tb[1] = h * (F.y - bias_f.y); tb[2] = h * (F.z - bias_f.z);
+    tb[3] = h * (Ntot.x - bias_n.x); tb[4] = h * (Ntot.y - bias_n.y); tb[5] = h * (Ntot.z - bias_n.z);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tl[k] = h * (tau[k] - PL.damping[k] * s.qd[k] - G.bias[k]);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) rt[c] = tb[c] - pair_sum(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
+
+  // ---- contact rows of the owned tire ------------------------------------
+  float Jb[3][6], Jl[3][3], Jt[3][6], vnow[3];
+  float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
+  float iun = fast_rcp(fmaxf(un, 1e-12f));
+  float denom = h * M.contact_stiffness + M.contact_damping;
+  float ih = fast_rcp(h);
+  float erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
+  float cfm = denom > 0.f ? fast_rcp(denom * h) : 0.f;
+  float dist;
+  bool active_own;
+  {
+    float sa = G.sgn[2];
+    V3 center = G.o[2] + v3(PL.wheel_center[0], PL.wheel_center[1], PL.wheel_center[2]);
+    V3 dlow = v3(-nB.x * iun, 0.f, -nB.z * iun);
+    V3 P = center + M.wheel_radius * dlow;
+    dist = s.pos.z + dot(nB, P);
+    active_own = un >= 1e-6f && dist <= M.contact_breaking_threshold;
+    V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
+    V3 t2 = cross(nB, t1);
+    V3 dirs[3] = {nB, t1, t2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      V3 d = dirs[k];
+      V3 Pxd = cross(P, d);
+      Jb[k][0] = d.x; Jb[k][1] = d.y; Jb[k][2] = d.z;
+      Jb[k][3] = Pxd.x; Jb[k][4] = Pxd.y; Jb[k][5] = Pxd.z;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        V3 rr = P - G.o[j];
+        Jl[k][j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
+      }
+      float v = Jb[k][0] * vB.x + Jb[k][1] * vB.y + Jb[k][2] * vB.z + Jb[k][3] * wB.x + Jb[k][4] * wB.y + Jb[k][5] * wB.z;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v = fmaf(Jl[k][j], s.qd[j], v);
+      vnow[k] = v;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Jt[k][c] = Jb[k][c] - (G.D[c][0] * Jl[k][0] + G.D[c][1] * Jl[k][1] + G.D[c][2] * Jl[k][2]);
+    }
+  }
+  const bool active_partner = xchg(active_own ? 1.f : 0.f) != 0.f;
+  const bool active_l = pick(leg, active_own, active_partner), active_r = pick(leg, active_partner, active_own);
+  const bool any_contact = active_own || active_partner;
+
+  if (any_limit) {
+    // rare: rebuild both legs' data in both lanes and run the shared path
+    System S2;
+    S2.A = fac;
+    Leg Gp = G;  // only Hinv and D of the partner are needed
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Gp.Hinv[i] = xchg(G.Hinv[i]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Gp.D[r][c] = xchg(G.D[r][c]);
+    S2.leg[0] = pick(leg, G, Gp);
+    S2.leg[1] = pick(leg, Gp, G);
+    float lo6[6], up6[6], q6[6], qd6[6], vn6[6], Jt6[6][6], Jb6[6][6], Jl6[6][3], d2[2], tl2[3], tr2[3];
+    int bd6[6];
+    bool act2[2] = {active_l, active_r};
+    const float pdist = xchg(dist);
+    d2[0] = pick(leg, dist, pdist);
+    d2[1] = pick(leg, pdist, dist);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float plo = xchg(PL.lower[k]), pup = xchg(PL.upper[k]), pq = xchg(s.q[k]), pqd = xchg(s.qd[k]), pvn = xchg(vnow[k]);
+      const float pb = xchg(PL.bounded[k] ? 1.f : 0.f), ptl = xchg(tl[k]);
+      lo6[k] = pick(leg, PL.lower[k], plo); lo6[3 + k] = pick(leg, plo, PL.lower[k]);
+      up6[k] = pick(leg, PL.upper[k], pup); up6[3 + k] = pick(leg, pup, PL.upper[k]);
+      bd6[k] = pick(leg, PL.bounded[k], (int)(pb != 0.f)); bd6[3 + k] = pick(leg, (int)(pb != 0.f), PL.bounded[k]);
+      q6[k] = pick(leg, s.q[k], pq); q6[3 + k] = pick(leg, pq, s.q[k]);
+      qd6[k] = pick(leg, s.qd[k], pqd); qd6[3 + k] = pick(leg, pqd, s.qd[k]);
+      vn6[k] = pick(leg, vnow[k], pvn); vn6[3 + k] = pick(leg, pvn, vnow[k]);
+      tl2[k] = pick(leg, tl[k], ptl); tr2[k] = pick(leg, ptl, tl[k]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float pjt = xchg(Jt[k][c]), pjb = xchg(Jb[k][c]);
+        Jt6[k][c] = pick(leg, Jt[k][c], pjt); Jt6[3 + k][c] = pick(leg, pjt, Jt[k][c]);
+        Jb6[k][c] = pick(leg, Jb[k][c], pjb); Jb6[3 + k][c] = pick(leg, pjb, Jb[k][c]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float pjl = xchg(Jl[k][j]);
+        Jl6[k][j] = pick(leg, Jl[k][j], pjl); Jl6[3 + k][j] = pick(leg, pjl, Jl[k][j]);
+      }
+    }
+    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl2, tr2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tl[k] = pick(leg, tl2[k], tr2[k]);
+  } else if (any_contact) {
+    // own rows: Y = A^-1 Jt, K = Hinv J_leg, free velocity, own diagonal block
+    float Y[3][6], K[3][3], rhs_own[3], Dg[6];
+    const float* hv = G.Hinv;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Y[b][c] = Jt[b][c];
+      ldl6_solve(fac, Y[b]);
+      K[b][0] = hv[0] * Jl[b][0] + hv[3] * Jl[b][1] + hv[4] * Jl[b][2];
+      K[b][1] = hv[3] * Jl[b][0] + hv[1] * Jl[b][1] + hv[5] * Jl[b][2];
+      K[b][2] = hv[4] * Jl[b][0] + hv[5] * Jl[b][1] + hv[2] * Jl[b][2];
+      float vf = vnow[b];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) vf = fmaf(Y[b][c], rt[c], vf);
+      vf += K[b][0] * tl[0] + K[b][1] * tl[1] + K[b][2] * tl[2];
+      const float rb = (b == 0) ? (dist <= 0.f ? -vf + erp * (-dist) * ih : -vf - dist * ih) : -vf;
+      rhs_own[b] = active_own ? rb : 0.f;
+#pragma unroll
+      for (int a = b; a < 3; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc = fmaf(Jt[a][c], Y[b][c], acc);
+        acc += Jl[a][0] * K[b][0] + Jl[a][1] * K[b][1] + Jl[a][2] * K[b][2];
+        if (a == b) acc += a == 0 ? cfm : M.friction_cfm;
+        Dg[a * (a + 1) / 2 + b] = acc;
+      }
+    }
+    // cross block: rows of the RIGHT tire against columns of the LEFT tire,
+    // X[a][b] = Jt_R[a] . Y_L[b]; computed by the right lane, copied to the left
+    float X[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float pY[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pY[c] = xchg(Y[b][c]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc = fmaf(Jt[a][c], pY[c], acc);
+        X[a][b] = acc;
+      }
+    }
+    float A[21], rhs[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float px = xchg(X[a][b]);
+        const float v = pick(leg, px, X[a][b]);  // the right lane's product
+        A[(3 + a) * (4 + a) / 2 + b] = (active_l && active_r) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float pd = xchg(Dg[i]);
+      // packed index i of a 3x3 lower triangle: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+      const int a = i < 1 ? 0 : (i < 3 ? 1 : 2), b = i - a * (a + 1) / 2;
+      const float dl = pick(leg, Dg[i], pd), dr = pick(leg, pd, Dg[i]);
+      A[a * (a + 1) / 2 + b] = active_l ? dl : (a == b ? 1.f : 0.f);
+      A[(3 + a) * (4 + a) / 2 + 3 + b] = active_r ? dr : (a == b ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float pr = xchg(rhs_own[k]);
+      rhs[k] = pick(leg, rhs_own[k], pr);
+      rhs[3 + k] = pick(leg, pr, rhs_own[k]);
+    }
+    float lam[6];
+    const float mu = M.friction_mu;
+    bool need_pgs = false;
+    {
+      Ldl6 cf;
+      ldl6_factor(A, cf);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) lam[r] = rhs[r];
+      ldl6_solve(cf, lam);
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        if (lam[3 * w] < 0.f) {
+          lam[3 * w] = 0.f;
+          need_pgs = true;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if ((r % 3) == 0) continue;
+        const float lim = mu * lam[3 * (r / 3)];
+        if (lam[r] < -lim) { lam[r] = -lim; need_pgs = true; }
+        if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
+      }
+    }
+    if (need_pgs) {  // identical data in both lanes: they iterate in lockstep
+      float idiag[6];
+      idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
+      idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+      for (int it = 0; it < M.pgs_iterations; ++it) {
+        float change = 0.f, scale = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const bool is_normal = (r % 3) == 0;
+            if (is_normal != (pass == 0)) continue;
+            float al = 0.f;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              const int hi = r > b ? r : b, lo = r > b ? b : r;
+              al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
+            }
+            float x = lam[r] + (rhs[r] - al) * idiag[r];
+            if (is_normal) {
+              x = fmaxf(x, 0.f);
+            } else {
+              const float lim = mu * lam[3 * (r / 3)];
+              x = fminf(fmaxf(x, -lim), lim);
+            }
+            change = fmaxf(change, fabsf(x - lam[r]));
+            scale = fmaxf(scale, fabsf(x));
+            lam[r] = x;
+          }
+        }
+        if (change <= M.pgs_tolerance * scale) break;
+      }
+    }
+    // t += J' lam: own rows locally, base part as own + partner
+    float lo_[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lo_[k] = pick(leg, lam[k], lam[3 + k]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tb[c] += pair_sum(Jb[0][c] * lo_[0] + Jb[1][c] * lo_[1] + Jb[2][c] * lo_[2]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tl[j] += Jl[0][j] * lo_[0] + Jl[1][j] * lo_[1] + Jl[2][j] * lo_[2];
+  }
+
+  // nu+ = nu + M^-1 t
+  float xb[6], xl[3];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xb[c] = tb[c] - pair_sum(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
+  ldl6_solve(fac, xb);
+  {
+    const float* hv = G.Hinv;
+    xl[0] = hv[0] * tl[0] + hv[3] * tl[1] + hv[4] * tl[2];
+    xl[1] = hv[3] * tl[0] + hv[1] * tl[1] + hv[5] * tl[2];
+    xl[2] = hv[4] * tl[0] + hv[5] * tl[1] + hv[2] * tl[2];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      xl[0] -= G.D[r][0] * xb[r];
+      xl[1] -= G.D[r][1] * xb[r];
+      xl[2] -= G.D[r][2] * xb[r];
+    }
+  }
+  const float n0 = vB.x + xb[0], n1 = vB.y + xb[1], n2 = vB.z + xb[2];
+  const float n3 = wB.x + xb[3], n4 = wB.y + xb[4], n5 = wB.z + xb[5];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float v = fminf(fmaxf(s.qd[j] + xl[j], -M.max_joint_velocity), M.max_joint_velocity);
+    s.qd[j] = v;
+    s.q[j] = fmaf(h, v, s.q[j]);
+  }
+  s.linvel = v3(r00 * n0 + r01 * n1 + r02 * n2, r10 * n0 + r11 * n1 + r12 * n2, r20 * n0 + r21 * n1 + r22 * n2);
+  s.angvel = v3(r00 * n3 + r01 * n4 + r02 * n5, r10 * n3 + r11 * n4 + r12 * n5, r20 * n3 + r21 * n4 + r22 * n5);
+  s.pos = s.pos + h * s.linvel;
+  {
+    float wn = fast_sqrt(dot(s.angvel, s.angvel));
+    float half = 0.5f * h * wn;
+    float ch, k;
+    if (half < 0.5f) {
+      float x2 = half * half;
+      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+    } else {
+      float sh;
+      sincosf(half, &sh, &ch);
+      k = sh * fast_rcp(wn);
+    }
+    float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
+    float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+    float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+    float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+    float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+    float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
+    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
+  }
+  return any_contact;
+}
+
+// One env.step() of B envs on 2 B lanes. Same contract as step_kernel.
+template <int MODE, bool RAND>
+__global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
+                                                        float* __restrict__ state, const float* __restrict__ act,
+                                                        float* __restrict__ obs, float* __restrict__ reward,
+                                                        uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                                                        const uint8_t* __restrict__ mask, const float* __restrict__ inertia_scale,
+                                                        const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv) {
+  typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
+  const int B = C.num_envs;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = tid >> 1, leg = tid & 1;
+  if (e >= B) return;  // both lanes of a pair leave together
+  const bool lead = leg == 0;  // the lane that writes per-env (not per-leg) words
+  float* st = state + e;
+#define SW(w) st[(size_t)(w) * B]
+
+  // ---- load ----------------------------------------------------------
+  PhysPair s;
+  s.pos = v3(SW(UPKIE_S_POS), SW(UPKIE_S_POS + 1), SW(UPKIE_S_POS + 2));
+  s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
+  s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
+  s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    s.q[k] = SW(UPKIE_S_Q + 3 * leg + k);
+    s.qd[k] = SW(UPKIE_S_QD + 3 * leg + k);
+  }
+  float legref[2] = {SW(UPKIE_S_LEGREF + 2 * leg), SW(UPKIE_S_LEGREF + 2 * leg + 1)};
+  constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
+  float yaw = 0.f, yawvel = 0.f;
+  if (YAWING) {
+    yaw = SW(UPKIE_S_YAW);
+    yawvel = SW(UPKIE_S_YAWVEL);
+  }
+  float scale0 = 1.f, scale3[3] = {1.f, 1.f, 1.f};
+  V3 fext = v3(0.f, 0.f, 0.f);
+  bool has_ext = false;
+  if (RAND) {
+    if (inertia_scale) {
+      scale0 = inertia_scale[e];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) scale3[k] = inertia_scale[(size_t)(1 + 3 * leg + k) * B + e];
+    }
+    if (ext_force) {
+      has_ext = true;
+      fext = v3(ext_force[e], ext_force[(size_t)B + e], ext_force[(size_t)2 * B + e]);
+    }
+  }
+  const V3 ext_point = v3(C.ext_point[0], C.ext_point[1], C.ext_point[2]);
+  // the owned leg's constants: selected once, kept in registers for the launch
+  const PairLeg PL = load_pair_leg(*(ConstModelPtr)Mp, Lm, C, leg, RAND ? scale3 : nullptr);
+  const DevModel& M = *Mp;
+
+  bool do_reset;
+  if (MODE == MODE_RESET) {
+    do_reset = mask ? mask[e] != 0 : true;
+  } else {
+    do_reset = C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && SW(UPKIE_S_DONE) != 0.f;
+  }
+  const float signed_radius = M.left_sign * M.wheel_radius;
+
+  // Gyropod observation from the pair (upkie_gyropod.py:186-214)
+  auto observe6 = [&](float yaw_, float yawvel_, float (&o6)[6]) {
+    const float qp = xchg(s.q[2]), qdp = xchg(s.qd[2]);
+    const float ql = pick(leg, s.q[2], qp), qr = pick(leg, qp, s.q[2]);
+    const float qdl = pick(leg, s.qd[2], qdp), qdr = pick(leg, qdp, s.qd[2]);
+    float r01 = 2.f * (s.qx * s.qy - s.qz * s.qw), r11 = 1.f - 2.f * (s.qx * s.qx + s.qz * s.qz), r21 = 2.f * (s.qy * s.qz + s.qx * s.qw);
+    float x = fminf(fmaxf(2.f * (s.qw * s.qy - s.qz * s.qx), -1.f), 1.f);
+    o6[0] = 0.5f * (ql - qr) * signed_radius;
+    o6[1] = asinf(x);
+    o6[2] = yaw_;
+    o6[3] = 0.5f * (qdl - qdr) * signed_radius;
+    o6[4] = r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z;
+    o6[5] = yawvel_;
+  };
+
+  if (MODE == MODE_RESET && !do_reset) {
+    if (obs) {
+      float o6[6];
+      observe6(SW(UPKIE_S_YAW), SW(UPKIE_S_YAWVEL), o6);
+      if (lead) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = o6[i];
+      }
+    }
+    return;
+  }
+
+  // ---- action map (the owned hip, knee and wheel) --------------------------
+  Servo cmd[3];
+  float a0 = 0.f, a1 = 0.f;
+  unsigned episode = 0;
+  if (do_reset) {
+    episode = (unsigned)SW(UPKIE_S_EPISODE);
+    Phys full;
+    sample_init_state(C, (unsigned)e, episode, full);  // same draws in both lanes
+    s.pos = full.pos; s.qw = full.qw; s.qx = full.qx; s.qy = full.qy; s.qz = full.qz;
+    s.linvel = full.linvel; s.angvel = full.angvel;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s.q[k] = pick(leg, full.q[k], full.q[3 + k]);
+      s.qd[k] = 0.f;
+      cmd[k] = Servo{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+  } else if (MODE == MODE_SERVOS) {
+    const float* a = act + (size_t)36 * e + 18 * leg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float eff = PL.effort[k], vel = PL.velocity[k];
+      cmd[k].position = clamp_ref(a[6 * k + 0], PL.lower[k], PL.upper[k]);
+      cmd[k].velocity = clamp_ref(a[6 * k + 1], -vel, vel);
+      cmd[k].feedforward_torque = clamp_ref(a[6 * k + 2], -eff, eff);
+      cmd[k].kp_scale = clamp_ref(a[6 * k + 3], 0.f, C.max_gain_scale);
+      cmd[k].kd_scale = clamp_ref(a[6 * k + 4], 0.f, C.max_gain_scale);
+      cmd[k].maximum_torque = clamp_ref(a[6 * k + 5], 0.f, eff);
+    }
+  } else if (MODE != MODE_RESET) {
+    if (MODE == MODE_PENDULUM) {
+      a0 = act[e];
+    } else if (MODE == MODE_PENDULUM_AGENT) {
+      const float* prev = act ? act : obs;
+      const float4 o = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+      a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
+      a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
+    } else if (MODE == MODE_BASE_VELOCITY) {
+      a0 = bv.commanded[e];
+      a1 = act[2 * (size_t)e + 1];
+    } else {
+      a0 = act[2 * (size_t)e];
+      a1 = act[2 * (size_t)e + 1];
+    }
+    float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
+    float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
+    float inv_radius = fast_rcp(M.wheel_radius);
+    float wheel_velocity = v * inv_radius;
+    float left = M.left_sign * wheel_velocity, right = -M.left_sign * wheel_velocity;
+    float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) * inv_radius;
+    left = fmaf(yaw_to_wheel, yawd, left);
+    right = fmaf(yaw_to_wheel, yawd, right);
+    const float alpha = C.dt / 1.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      legref[k] = legref[k] + alpha * (0.f - legref[k]);
+      cmd[k].position = clamp_ref(legref[k], PL.lower[k], PL.upper[k]);
+      cmd[k].velocity = 0.f;
+      cmd[k].feedforward_torque = 0.f;
+      cmd[k].kp_scale = clamp_ref(C.leg_gain_scale, 0.f, C.max_gain_scale);
+      cmd[k].kd_scale = cmd[k].kp_scale;
+      cmd[k].maximum_torque = PL.effort[k];
+    }
+    cmd[2].position = NAN;
+    cmd[2].velocity = clamp_ref(pick(leg, left, right), -PL.velocity[2], PL.velocity[2]);
+    cmd[2].feedforward_torque = 0.f;
+    cmd[2].kp_scale = 1.f;
+    cmd[2].kd_scale = 1.f;
+    cmd[2].maximum_torque = PL.effort[2];
+  }
+
+  // ---- substeps ------------------------------------------------------------
+  float tau[3] = {0.f, 0.f, 0.f};
+  bool contact = false;
+  const bool any_noise = C.any_control_noise || C.any_measurement_noise;
+  unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
+  const int nsub = do_reset ? 1 : C.nb_substeps;
+  for (int sub = 0; sub < C.nb_substeps; ++sub) {
+    if (sub >= nsub) break;
+    float zn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (C.any_control_noise && !do_reset) philox_normal6(C, (unsigned)e, step_count, (unsigned)sub, zn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      tau[k] = joint_torque(s.q[k], s.qd[k], cmd[k], C.kp, C.kd, PL.friction[k], PL.control_noise[k] * pick(leg, zn[k], zn[3 + k]));
+    {
+      ConstModelPtr mp = (ConstModelPtr)Mp;
+      asm volatile("" : "+s"(mp));
+      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, scale0, has_ext, fext, ext_point);
+    }
+  }
+
+  // ---- wrapper post-processing ---------------------------------------------
+  bool fallen = false;
+  float obs6[6];
+  if (do_reset) {
+    legref[0] = s.q[0];
+    legref[1] = s.q[1];
+    yaw = 0.f;
+    yawvel = 0.f;
+    if (lead) {
+      SW(UPKIE_S_YAW) = 0.f;
+      SW(UPKIE_S_YAWVEL) = 0.f;
+      SW(UPKIE_S_MPC_V) = 0.f;
+      SW(UPKIE_S_SE2_X) = 0.f;
+      SW(UPKIE_S_SE2_Y) = 0.f;
+      SW(UPKIE_S_EPISODE) = (float)(episode + 1);
+      SW(UPKIE_S_DONE) = 0.f;
+    }
+    observe6(yaw, yawvel, obs6);
+  } else {
+    if (YAWING) {
+      yaw = fmaf(a1, C.dt, yaw);
+      yawvel = a1;
+      if (lead) {
+        SW(UPKIE_S_YAW) = yaw;
+        SW(UPKIE_S_YAWVEL) = yawvel;
+      }
+    }
+    observe6(yaw, yawvel, obs6);
+    if (MODE != MODE_SERVOS) {
+      fallen = fabsf(obs6[1]) > C.fall_pitch;
+      if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) SW(UPKIE_S_TORQUE + 3 * leg + k) = tau[k];
+    if (any_noise) {
+      step_count += 1u;
+      if (lead) SW(UPKIE_S_STEP) = (float)step_count;
+    }
+  }
+
+  // ---- store -----------------------------------------------------------------
+  if (lead) {
+    SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
+    SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
+    SW(UPKIE_S_LINVEL) = s.linvel.x; SW(UPKIE_S_LINVEL + 1) = s.linvel.y; SW(UPKIE_S_LINVEL + 2) = s.linvel.z;
+    SW(UPKIE_S_ANGVEL) = s.angvel.x; SW(UPKIE_S_ANGVEL + 1) = s.angvel.y; SW(UPKIE_S_ANGVEL + 2) = s.angvel.z;
+    SW(UPKIE_S_CONTACT) = contact ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    SW(UPKIE_S_Q + 3 * leg + k) = s.q[k];
+    SW(UPKIE_S_QD + 3 * leg + k) = s.qd[k];
+  }
+  if (MODE != MODE_SERVOS) {
+    SW(UPKIE_S_LEGREF + 2 * leg) = legref[0];
+    SW(UPKIE_S_LEGREF + 2 * leg + 1) = legref[1];
+  }
+
+  if (MODE == MODE_RESET) {
+    if (obs && lead) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = obs6[i];
+    }
+    return;
+  }
+  if (MODE == MODE_SERVOS) {
+    // each lane reports its own three servos (upkie_servos.py:288-306)
+    float* o = obs + (size_t)30 * e + 15 * leg;
+    float zm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (C.any_measurement_noise) philox_normal6(C, (unsigned)e, step_count, NOISE_SLOT_MEASUREMENT, zm);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      o[5 * k + 0] = s.q[k];
+      o[5 * k + 1] = s.qd[k];
+      o[5 * k + 2] = (do_reset ? SW(UPKIE_S_TORQUE + 3 * leg + k) : tau[k]) + PL.measurement_noise[k] * pick(leg, zm[k], zm[3 + k]);
+      o[5 * k + 3] = 42.0f;
+      o[5 * k + 4] = 18.0f;
+    }
+  }
+  if (!lead) return;
+  if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
+    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    if (packed) {
+      float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
+      rec[0] = o4;
+      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      return;
+    }
+    reinterpret_cast<float4*>(obs)[e] = o4;
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    float x = 0.f, y = 0.f;
+    if (!do_reset) {
+      const float lin = act[2 * (size_t)e];
+      float sy, cy;
+      sincosf(yaw, &sy, &cy);
+      x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
+      y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
+      SW(UPKIE_S_SE2_X) = x;
+      SW(UPKIE_S_SE2_Y) = y;
+    }
+    obs[(size_t)3 * e] = x;
+    obs[(size_t)3 * e + 1] = y;
+    obs[(size_t)3 * e + 2] = yaw;
+    reinterpret_cast<float4*>(bv.x0)[e] = make_float4(obs6[0], obs6[1], obs6[3], obs6[4]);
+    bv.contact[e] = contact ? 1 : 0;
+  } else if (MODE == MODE_GYROPOD) {
+    float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
+    o2[0] = make_float2(obs6[0], obs6[1]);
+    o2[1] = make_float2(obs6[2], obs6[3]);
+    o2[2] = make_float2(obs6[4], obs6[5]);
+  }
+  reward[e] = 0.f;
+  terminated[e] = fallen ? 1 : 0;
+  truncated[e] = 0;
+#undef SW
+}

@@ -479,6 +479,8 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
 #undef SW
 }
 
+#include "pair.hpp"
+
 // Full spine observation, pybullet_backend.py:313-490.
 struct ObsPtrs {
   float* pitch;
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(64) void inertia_scale_kernel(DevConfig C, float* _
 using namespace upkie;
 
 struct UpkieSim {
+  int lanes_per_env = 0;  // 0 = choose by batch size, 1 / 2 = forced (tests, experiments)
   DevModel model;
   DevLimits limits;
   DevModel* d_model = nullptr;  // device copy read through scalar loads
@@ -809,6 +812,7 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
     return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
   model_limits(sim->model, &sim->limits);
+  if (const char* forced = std::getenv("UPKIE_LANES_PER_ENV")) sim->lanes_per_env = std::atoi(forced);
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
   if (err != hipSuccess) {
@@ -867,6 +871,8 @@ extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_sca
 
 // 256 CUs x 4 SIMDs x 64 lanes x 2 waves
 static const int kDenseBatch = 131072;
+// up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
+static const int kPairBatch = 32768;
 
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
@@ -882,16 +888,24 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const float* scale = rnd ? sim->inertia_scale : nullptr;
   const float* force = rnd ? sim->ext_force : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  // more than two waves per SIMD in flight: favour occupancy over registers
+  // more than two waves per SIMD in flight: favour occupancy over registers;
+  // fewer lanes than SIMD slots: split every env over two lanes (pair.hpp)
   const bool dense = sim->config.num_envs >= kDenseBatch;
+  const bool paired = sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
 #define UPKIE_LAUNCH(R, W)                                                                                          \
   hipLaunchKernelGGL((step_kernel<MODE, R, W>), grid, block, 0, st, sim->d_model, sim->limits, sim->config, state, act, obs, \
                      reward, terminated, truncated, mask, scale, force, packed, bv)
-  if (rnd) {
+#define UPKIE_LAUNCH_PAIR(R)                                                                                               \
+  hipLaunchKernelGGL((step_kernel_pair<MODE, R>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
+                     sim->config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv)
+  if (paired) {
+    if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
+  } else if (rnd) {
     if (dense) UPKIE_LAUNCH(true, 2); else UPKIE_LAUNCH(true, 1);
   } else {
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
+#undef UPKIE_LAUNCH_PAIR
 #undef UPKIE_LAUNCH
   return check_hip(sim, hipGetLastError(), "step_kernel");
 }
