@@ -8,7 +8,8 @@ for path in sorted(glob.glob(os.path.join(root, "pass*", "pmc_counter_collection
     sums, counts = defaultdict(float), defaultdict(int)
     with open(path) as f:
         for row in csv.DictReader(f):
-            if "step_kernel<2, false" not in row["Kernel_Name"]:
+            name = row["Kernel_Name"]
+            if "step_kernel_pair<2, false" not in name and "step_kernel<2, false" not in name:
                 continue
             sums[row["Counter_Name"]] += float(row["Counter_Value"])
             counts[row["Counter_Name"]] += 1

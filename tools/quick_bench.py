@@ -1,23 +1,23 @@
-"""Throughput probe of the fused Pendulum step at several batch sizes."""
-import sys, time
-import torch
-import os
+"""Throughput probe of the fused Pendulum step at several batch sizes (and,
+with UPKIE_LANES_PER_ENV=1/2, of a forced lane mapping)."""
+import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
 from tests.helpers import randomized_config
 from upkie_amd.sim import BatchedSim
 
-for B in (4096, 16384, 65536, 262144, 1048576):
+for B in (1024, 4096, 16384, 32768, 65536, 262144, 1048576):
     cfg = randomized_config(B, seed=0, autoreset=True)
     sim = BatchedSim(cfg)
     sim.reset()
     sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
-    for _ in range(20):
+    for _ in range(50):
         sim.step_pendulum_agent()
     torch.cuda.synchronize()
-    K = 200
+    K = 300
     t0 = time.perf_counter()
     for _ in range(K):
         sim.step_pendulum_agent()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"B={B:8d}  {dt / K * 1e6:9.1f} us/step  {B * K / dt:12.4e} env-steps/s  terminated={int(sim.terminated.sum())}", flush=True)
+    print(f"B={B:8d}  {dt / K * 1e6:9.1f} us/step  {B * K / dt:12.4e} env-steps/s  lanes/env={os.environ.get('UPKIE_LANES_PER_ENV', 'auto')}", flush=True)
