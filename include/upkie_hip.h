@@ -320,6 +320,82 @@ int upkie_mpc_step_env(UpkieMpc* mpc, float* workspace, const float* x0,
                        const float* done, double dt, float* commanded_velocity,
                        void* stream);
 
+/* ---- Spine observer pipeline ---------------------
+ * Device restatement of the observers the real spine runs after every cycle
+ * (spines/common/observers.h:22-42): BaseOrientation
+ * (upkie/cpp/observers/BaseOrientation.{h,cpp}), FloorContact
+ * (FloorContact.cpp:37-104) with its two WheelContact estimators
+ * (WheelContact.cpp:19-48) and the velocity-integrating WheelOdometry
+ * (WheelOdometry.cpp:16-54), in that order, for every env of a batch. Sim
+ * observations then carry what an agent sees on the real robot. */
+typedef struct UpkieObserverConfig {
+  int32_t num_envs;
+  int32_t reserved0;
+  double dt; /* spine period, FloorContact::Parameters::dt / WheelOdometry::Parameters::dt */
+  double upper_leg_torque_threshold; /* 10.0  (FloorContact.h:82)            */
+  double wheel_cutoff_period;        /* 0.2   (spine_backend.py:93); < 1e-6 =
+                                        "not configured": wheel observers idle
+                                        (WheelContact.cpp:21-24)             */
+  double liftoff_inertia;            /* 0.001 */
+  double min_touchdown_acceleration; /* 2.0   */
+  double min_touchdown_torque;       /* 0.015 */
+  double touchdown_inertia;          /* 0.004 */
+  double signed_radius[2];           /* left, right: +0.05, -0.05 (spine_backend.py:99-104) */
+  double rotation_base_to_imu[9];    /* row-major, diag(-1, 1, -1) (BaseOrientation.h:161-162) */
+  double rotation_ars_to_world[9];   /* row-major, diag(1, -1, -1) (BaseOrientation.h:163-164) */
+} UpkieObserverConfig;
+
+/* Observer memory, struct-of-arrays [UPKIE_OBSERVER_STATE_WORDS][B] fp32,
+ * allocated by the caller. */
+enum UpkieObserverStateWord {
+  UPKIE_O_WHEEL = 0, /* 2 wheels x (velocity, abs_acceleration, abs_torque, inertia, contact) */
+  UPKIE_O_UPPER_LEG_TORQUE = 10,
+  UPKIE_O_CONTACT = 11,
+  UPKIE_O_ODOMETRY_POSITION = 12,
+  UPKIE_O_ODOMETRY_VELOCITY = 13,
+  UPKIE_OBSERVER_STATE_WORDS = 16
+};
+
+/* What the observers read from the spine observation (device pointers, the
+ * layouts of UpkieSpineObservation). imu_orientation == NULL skips
+ * BaseOrientation (no "imu" key, BaseOrientation.cpp:17-19); cross_button
+ * may be NULL. */
+typedef struct UpkieObserverInput {
+  const float* servo;                /* [B][6][5]                             */
+  const float* imu_orientation;      /* [B][4] w x y z, IMU in ARS            */
+  const float* imu_angular_velocity; /* [B][3]                                */
+  const uint8_t* cross_button;       /* [B] joystick.cross_button             */
+} UpkieObserverInput;
+
+/* What they write (any pointer may be NULL). */
+typedef struct UpkieObserverOutput {
+  float* base_pitch;             /* [B]    base_orientation.pitch             */
+  float* base_angular_velocity;  /* [B][3] base in base                       */
+  float* rotation_base_to_world; /* [B][9] row-major                          */
+  uint8_t* floor_contact;        /* [B]    floor_contact.contact              */
+  float* upper_leg_torque;       /* [B]    floor_contact.upper_leg_torque     */
+  float* wheel_contact;          /* [B][2][4] per wheel: abs_acceleration,
+                                    abs_torque, contact (0/1), inertia
+                                    (FloorContact.cpp:96-103)                 */
+  float* wheel_odometry;         /* [B][2] position, velocity                 */
+} UpkieObserverOutput;
+
+typedef struct UpkieObservers UpkieObservers;
+
+/* Fails with UPKIE_ERR_INVALID_ARGUMENT where the reference throws:
+ * cutoff period <= 2 dt (FilterError, low_pass_filter.h:22-30) for the wheel
+ * filters or for the 0.01 s upper-leg torque filter (FloorContact.cpp:87). */
+int upkie_observers_create(const UpkieObserverConfig* config, UpkieObservers** out);
+int upkie_observers_destroy(UpkieObservers* observers);
+const char* upkie_observers_last_error(const UpkieObservers* observers);
+int64_t upkie_observers_state_bytes(const UpkieObservers* observers);
+/* Observer::reset for masked envs (all when mask is NULL): filters, contacts
+ * and odometry back to zero (FloorContact.cpp:26-35, WheelOdometry.cpp:10-14). */
+int upkie_observers_reset(UpkieObservers* observers, float* state, const uint8_t* mask, void* stream);
+/* One ObserverPipeline::run (read + write of the three observers). */
+int upkie_observers_step(UpkieObservers* observers, float* state, const UpkieObserverInput* in,
+                         const UpkieObserverOutput* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

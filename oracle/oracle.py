@@ -46,7 +46,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no-op when the .so is up to date)."""
     sources = [
         os.path.join(_HERE, name)
-        for name in ("upkie_oracle.c", "upkie_oracle_mpc.c", "upkie_oracle.h")
+        for name in ("upkie_oracle.c", "upkie_oracle_mpc.c", "upkie_oracle_observers.c", "upkie_oracle.h")
     ] + [os.path.join(_HERE, "..", "include", "upkie_hip.h")]
     stale = force or not os.path.exists(_LIB_PATH)
     if not stale:
@@ -81,6 +81,8 @@ def lib():
         _lib.oracle_energy.restype = C.c_double
         _lib.oracle_substep.restype = C.c_int
         _lib.oracle_mpc_solve_exact.restype = C.c_int
+        _lib.oracle_observers_check.restype = C.c_int
+        _lib.oracle_pitch_frame_in_parent.restype = C.c_double
     return _lib
 
 
@@ -276,3 +278,59 @@ def center_of_mass(model, q=None):
 def energy(model, pos, quat, linvel, angvel, q, qd) -> float:
     args = [np.ascontiguousarray(a, dtype=np.float64) for a in (pos, quat, linvel, angvel, q, qd)]
     return lib().oracle_energy(C.byref(model), *[_ptr(a) for a in args])
+
+
+class ObserverOracle:
+    """fp64 observer pipeline for B envs (upkie_oracle_observers.c)."""
+
+    def __init__(self, config: abi.UpkieObserverConfig):
+        self.config = config
+        self.B = config.num_envs
+        if lib().oracle_observers_check(C.byref(config)) != 0:
+            raise ValueError("observer filters need cutoff period > 2 dt (FilterError in the reference)")
+        self.state = np.zeros((abi.OBSERVER_STATE_WORDS, self.B))
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.state[:] = 0.0
+        else:
+            self.state[:, np.asarray(mask, dtype=bool)] = 0.0
+
+    def step(self, servo, imu_orientation=None, imu_angular_velocity=None, cross_button=None) -> dict:
+        B = self.B
+        servo = np.ascontiguousarray(servo, dtype=np.float64).reshape(B, 6, 5)
+        q = None if imu_orientation is None else np.ascontiguousarray(imu_orientation, dtype=np.float64).reshape(B, 4)
+        w = None if imu_angular_velocity is None else np.ascontiguousarray(imu_angular_velocity, dtype=np.float64).reshape(B, 3)
+        cb = None if cross_button is None else np.ascontiguousarray(cross_button, dtype=np.uint8).reshape(B)
+        out = dict(
+            base_pitch=np.zeros(B),
+            base_angular_velocity=np.zeros((B, 3)),
+            rotation_base_to_world=np.zeros((B, 9)),
+            floor_contact=np.zeros(B, dtype=np.uint8),
+            upper_leg_torque=np.zeros(B),
+            wheel_contact=np.zeros((B, 2, 4)),
+            wheel_odometry=np.zeros((B, 2)),
+        )
+        lib().oracle_observers_step(
+            C.byref(self.config), _ptr(self.state), _ptr(servo), _ptr(q), _ptr(w), _ptr(cb),
+            _ptr(out["base_pitch"]), _ptr(out["base_angular_velocity"]), _ptr(out["rotation_base_to_world"]),
+            _ptr(out["floor_contact"]), _ptr(out["upper_leg_torque"]), _ptr(out["wheel_contact"]), _ptr(out["wheel_odometry"]),
+        )
+        if q is None:
+            for k in ("base_pitch", "base_angular_velocity", "rotation_base_to_world"):
+                out.pop(k)
+        return out
+
+
+def pitch_frame_in_parent(R) -> float:
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    return float(lib().oracle_pitch_frame_in_parent(_ptr(R)))
+
+
+def base_orientation_from_imu(q_wxyz, base_to_imu, ars_to_world):
+    q = np.ascontiguousarray(q_wxyz, dtype=np.float64).reshape(4)
+    a = np.ascontiguousarray(base_to_imu, dtype=np.float64).reshape(9)
+    b = np.ascontiguousarray(ars_to_world, dtype=np.float64).reshape(9)
+    R = np.zeros(9)
+    lib().oracle_base_orientation_from_imu(_ptr(q), _ptr(a), _ptr(b), _ptr(R))
+    return R.reshape(3, 3)

@@ -155,6 +155,19 @@ void oracle_mpc_step(const UpkieMpcConfig* cfg, double* workspace,
                      const uint8_t* contact, double dt, double* commanded,
                      double* first_input);
 
+
+/* ---- observer pipeline (upkie_oracle_observers.c) ---- */
+int oracle_observers_check(const UpkieObserverConfig* c);
+double oracle_pitch_frame_in_parent(const double R[9]);
+void oracle_base_orientation_from_imu(const double q[4], const double base_to_imu[9],
+                                      const double ars_to_world[9], double R[9]);
+void oracle_observers_step(const UpkieObserverConfig* p, double* state, const double* servo,
+                           const double* imu_orientation, const double* imu_angular_velocity,
+                           const uint8_t* cross_button, double* base_pitch,
+                           double* base_angular_velocity, double* rotation_base_to_world,
+                           uint8_t* floor_contact, double* upper_leg_torque,
+                           double* wheel_contact_out, double* wheel_odometry);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,35 @@ class OracleMpc:
 
     def close(self):
         pass
+
+
+class OracleObservers:
+    """`BatchedObservers` double on the fp64 observer oracle."""
+
+    def __init__(self, config, device="cpu"):
+        self.config = config
+        self.num_envs = int(config.num_envs)
+        self.device = torch.device("cpu")
+        self._o = O.ObserverOracle(config)
+
+    @property
+    def state(self):
+        return torch.from_numpy(self._o.state.astype(np.float32))
+
+    def reset(self, mask=None):
+        self._o.reset(None if mask is None else mask.bool().numpy())
+
+    def step(self, servo, imu_orientation=None, imu_angular_velocity=None, cross_button=None):
+        from upkie_amd.observers import observer_blocks
+
+        n = lambda t: None if t is None else t.double().numpy()
+        out = self._o.step(n(servo), n(imu_orientation), n(imu_angular_velocity), None if cross_button is None else cross_button.numpy())
+        tensors = {k: torch.from_numpy(np.asarray(v, dtype=np.uint8 if v.dtype == np.uint8 else np.float32)) for k, v in out.items()}
+        return observer_blocks(tensors)
+
+    def step_from_sim(self, sim, update_imu=False, cross_button=None):
+        obs = sim.observe(update_imu=update_imu)
+        return self.step(obs["servo"], obs["imu_orientation"], obs["imu_angular_velocity"], cross_button)
+
+    def close(self):
+        pass

@@ -218,3 +218,48 @@ def test_external_force_pushes_the_robot():
         pushed.step(torch.zeros(1, 1))
         free.step(torch.zeros(1, 1))
     assert float(pushed.sim.state[abi.S_POS, 0]) > float(free.sim.state[abi.S_POS, 0]) + 1e-3
+
+
+def test_spine_observers_in_the_vector_env():
+    """`spine_observers=True` appends what the C++ spine's observer pipeline
+    writes (spines/common/observers.h:22-42) to info["spine_observation"] and
+    restarts the observers of envs that were reset."""
+    from .fake_sim import OracleObservers
+
+    kw = dict(KW, observers_factory=OracleObservers)
+    with pytest.raises(ValueError):  # 200 Hz: the 0.01 s torque filter is <= 2 dt (FilterError in the reference)
+        envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, frequency=200.0, spine_observers=True, **kw)
+    env = envs.make(
+        "Upkie-HIP-Pendulum-Vec",
+        num_envs=4,
+        frequency=500.0,
+        fall_pitch=0.25,
+        init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58]), randomization=RobotStateRandomization(pitch=0.05)),
+        spine_observers=True,
+        **kw,
+    )
+    obs, info = env.reset(seed=1)
+    spine = info["spine_observation"]
+    assert set(spine["floor_contact"]) >= {"contact", "upper_leg_torque", "left_wheel", "right_wheel"}
+    assert spine["base_orientation"]["linear_velocity"].shape == (4, 3)  # the backend's block is kept, the observer's merged in
+    odometry = []
+    restarted = torch.zeros(4, dtype=torch.bool)
+    episodes = env.sim.state[abi.S_EPISODE].clone()
+    for k in range(700):
+        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.02 * k)
+        if k > 400:
+            act[0] = 3.0  # env 0 is driven into a fall and autoresets
+        obs, _, terminated, _, info = env.step(act.reshape(4, 1))
+        now = env.sim.state[abi.S_EPISODE]
+        if (now != episodes)[0] and not restarted[0]:
+            restarted[0] = True
+            # observers of a restarted env start from zero and have seen exactly one observation
+            assert abs(float(info["spine_observation"]["wheel_odometry"]["position"][0])) < 1e-3
+        episodes = now.clone()
+        odometry.append(info["spine_observation"]["wheel_odometry"]["position"].clone())
+    spine = info["spine_observation"]
+    assert restarted[0]
+    # the spine's pitch estimate agrees with the backend's (same frames by default)
+    assert spine["floor_contact"]["contact"][1:].all()
+    assert torch.stack(odometry)[:, 1:].abs().max() > 1e-3  # the integrator moved
+    assert spine["floor_contact"]["left_wheel"]["inertia"].shape == (4,)

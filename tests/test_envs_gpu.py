@@ -112,3 +112,38 @@ def test_base_velocity_fused_path_with_autoreset():
     eg = gpu.sim.state[abi.S_EPISODE].cpu().numpy()[in_sync]
     ec = cpu.sim.state[abi.S_EPISODE].numpy()[in_sync]
     assert np.array_equal(eg, ec)
+
+
+def test_spine_observers_in_the_vector_env_on_device():
+    """spine_observers=True on the HIP path: estimator blocks appear in
+    info["spine_observation"], balancing robots are seen in contact and the
+    observers of autoreset envs restart."""
+    import math
+
+    B = 512
+    env = envs.make(
+        "Upkie-HIP-Pendulum-Vec",
+        num_envs=B,
+        frequency=500.0,
+        fall_pitch=0.25,
+        init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58]), randomization=RobotStateRandomization(pitch=0.05)),
+        spine_observers=True,
+    )
+    obs, info = env.reset(seed=1)
+    first_episode = env.sim.state[abi.S_EPISODE].clone()
+    for k in range(700):
+        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.02 * k)
+        if k > 400:
+            act[:16] = 3.0  # the first 16 envs are driven into a fall
+        obs, _, terminated, _, info = env.step(act.reshape(B, 1))
+    spine = info["spine_observation"]
+    restarted = env.sim.state[abi.S_EPISODE] != first_episode
+    assert restarted[:16].all()
+    alive = ~restarted
+    assert alive.float().mean() > 0.9
+    assert spine["floor_contact"]["contact"][alive].float().mean() > 0.95
+    assert spine["floor_contact"]["upper_leg_torque"].shape == (B,)
+    assert spine["base_orientation"]["linear_velocity"].shape == (B, 3)
+    truth = env.sim.observe(update_imu=False)
+    assert torch.allclose(spine["base_orientation"]["pitch"], truth["pitch"], atol=1e-5)
+    env.close()

@@ -168,6 +168,53 @@ class UpkieMpcConfig(C.Structure):
     ]
 
 
+class UpkieObserverConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("dt", C.c_double),
+        ("upper_leg_torque_threshold", C.c_double),
+        ("wheel_cutoff_period", C.c_double),
+        ("liftoff_inertia", C.c_double),
+        ("min_touchdown_acceleration", C.c_double),
+        ("min_touchdown_torque", C.c_double),
+        ("touchdown_inertia", C.c_double),
+        ("signed_radius", C.c_double * 2),
+        ("rotation_base_to_imu", C.c_double * 9),
+        ("rotation_ars_to_world", C.c_double * 9),
+    ]
+
+
+class UpkieObserverInput(C.Structure):
+    _fields_ = [
+        ("servo", C.c_void_p),
+        ("imu_orientation", C.c_void_p),
+        ("imu_angular_velocity", C.c_void_p),
+        ("cross_button", C.c_void_p),
+    ]
+
+
+class UpkieObserverOutput(C.Structure):
+    _fields_ = [
+        ("base_pitch", C.c_void_p),
+        ("base_angular_velocity", C.c_void_p),
+        ("rotation_base_to_world", C.c_void_p),
+        ("floor_contact", C.c_void_p),
+        ("upper_leg_torque", C.c_void_p),
+        ("wheel_contact", C.c_void_p),
+        ("wheel_odometry", C.c_void_p),
+    ]
+
+
+# observer memory words (enum UpkieObserverStateWord)
+O_WHEEL = 0
+O_UPPER_LEG_TORQUE = 10
+O_CONTACT = 11
+O_ODOMETRY_POSITION = 12
+O_ODOMETRY_VELOCITY = 13
+OBSERVER_STATE_WORDS = 16
+
+
 def default_sim_config(
     num_envs: int = 1,
     frequency: float = 200.0,
@@ -222,4 +269,29 @@ def default_mpc_config(num_envs: int = 1, nb_timesteps: int = 50):
     cfg.stage_state_cost_weight = 1e-3
     cfg.terminal_cost_weight = 1.0
     cfg.admm_rho = 1e-3
+    return cfg
+
+
+def default_observer_config(num_envs: int = 1, dt: float = 1e-3) -> UpkieObserverConfig:
+    """The spine's observer defaults (spine_backend.py:89-105,
+    FloorContact.h:82, BaseOrientation.h:161-164); `dt` is the spine period
+    (spines/common/observers.h:31-38)."""
+    cfg = UpkieObserverConfig()
+    cfg.num_envs = num_envs
+    cfg.dt = dt
+    cfg.upper_leg_torque_threshold = 10.0
+    cfg.wheel_cutoff_period = 0.2
+    cfg.liftoff_inertia = 0.001
+    cfg.min_touchdown_acceleration = 2.0
+    cfg.min_touchdown_torque = 0.015
+    cfg.touchdown_inertia = 0.004
+    cfg.signed_radius[0] = +0.05
+    cfg.signed_radius[1] = -0.05
+    for i in range(9):
+        cfg.rotation_base_to_imu[i] = 0.0
+        cfg.rotation_ars_to_world[i] = 0.0
+    for i, v in enumerate((-1.0, 1.0, -1.0)):
+        cfg.rotation_base_to_imu[4 * i] = v
+    for i, v in enumerate((1.0, -1.0, -1.0)):
+        cfg.rotation_ars_to_world[4 * i] = v
     return cfg

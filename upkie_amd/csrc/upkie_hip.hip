@@ -17,6 +17,7 @@
 
 #include "dynamics.hpp"
 #include "mpc.hpp"
+#include "observers.hpp"
 
 namespace upkie {
 
@@ -1083,4 +1084,89 @@ extern "C" int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0, 
 extern "C" int upkie_mpc_step_env(UpkieMpc* mpc, float* workspace, const float* x0, const float* act, const uint8_t* contact,
                                   const float* done, double dt, float* commanded_velocity, void* stream) {
   return mpc_launch(mpc, workspace, x0, act, 2, contact, done, dt, commanded_velocity, nullptr, stream);
+}
+
+// =========================================================== observer pipeline
+struct UpkieObservers {
+  upkie::ObserverDev dev;
+  std::string error;
+};
+
+static int observers_fail(UpkieObservers* h, int status, const std::string& msg) {
+  if (h) h->error = msg;
+  g_create_error = msg;
+  return status;
+}
+
+extern "C" int upkie_observers_create(const UpkieObserverConfig* c, UpkieObservers** out) {
+  if (!c || !out) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (c->num_envs <= 0) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "num_envs must be positive");
+  if (!(c->dt > 0.0) || !std::isfinite(c->dt))
+    return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "observers are not configured: dt must be a positive number");
+  const bool wheels = c->wheel_cutoff_period >= 1e-6;  // WheelContact.cpp:21
+  auto nyquist = [&](double cutoff, const char* what) {
+    if (cutoff <= 2.0 * c->dt) {  // low_pass_filter.h:22-30
+      observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT,
+                     std::string("[low_pass_filter] ") + what + " cutoff period " + std::to_string(cutoff) +
+                         " s is less than 2 * dt = " + std::to_string(2.0 * c->dt) + " s, causing information loss");
+      return false;
+    }
+    return true;
+  };
+  if (wheels && !nyquist(c->wheel_cutoff_period, "wheel contact")) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (!nyquist(0.01, "upper-leg torque")) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (upkie_hip_device_count() <= 0) return observers_fail(nullptr, UPKIE_ERR_NO_DEVICE, "no HIP device visible");
+  UpkieObservers* h = new (std::nothrow) UpkieObservers();
+  if (!h) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "out of host memory");
+  upkie::ObserverDev& d = h->dev;
+  d.num_envs = c->num_envs;
+  d.wheels_configured = wheels ? 1 : 0;
+  d.dt = (float)c->dt;
+  d.inv_dt = (float)(1.0 / c->dt);
+  d.wheel_alpha = wheels ? (float)(c->dt / c->wheel_cutoff_period) : 0.f;
+  d.leg_alpha = (float)(c->dt / 0.01);
+  d.upper_leg_torque_threshold = (float)c->upper_leg_torque_threshold;
+  d.liftoff_inertia = (float)c->liftoff_inertia;
+  d.min_touchdown_acceleration = (float)c->min_touchdown_acceleration;
+  d.min_touchdown_torque = (float)c->min_touchdown_torque;
+  d.touchdown_inertia = (float)c->touchdown_inertia;
+  for (int i = 0; i < 2; ++i) d.signed_radius[i] = (float)c->signed_radius[i];
+  for (int i = 0; i < 9; ++i) {
+    d.base_to_imu[i] = (float)c->rotation_base_to_imu[i];
+    d.ars_to_world[i] = (float)c->rotation_ars_to_world[i];
+  }
+  *out = h;
+  return UPKIE_OK;
+}
+
+extern "C" int upkie_observers_destroy(UpkieObservers* h) {
+  delete h;
+  return UPKIE_OK;
+}
+
+extern "C" const char* upkie_observers_last_error(const UpkieObservers* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+extern "C" int64_t upkie_observers_state_bytes(const UpkieObservers* h) {
+  return h ? (int64_t)UPKIE_OBSERVER_STATE_WORDS * h->dev.num_envs * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int upkie_observers_reset(UpkieObservers* h, float* state, const uint8_t* mask, void* stream) {
+  if (!h || !state) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(upkie::observers_reset_kernel, grid_for(h->dev.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream,
+                     h->dev.num_envs, state, mask);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? UPKIE_OK : observers_fail(h, UPKIE_ERR_HIP, hipGetErrorString(err));
+}
+
+extern "C" int upkie_observers_step(UpkieObservers* h, float* state, const UpkieObserverInput* in, const UpkieObserverOutput* out,
+                                    void* stream) {
+  if (!h || !state || !in || !out) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (!in->servo) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "observation has no \"servo\" block");
+  if (in->imu_orientation && !in->imu_angular_velocity)  // KeyError in BaseOrientation::read, BaseOrientationTest.cpp:93-98
+    return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "imu observation has an orientation but no angular_velocity");
+  hipLaunchKernelGGL(upkie::observers_step_kernel, grid_for(h->dev.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, h->dev, state,
+                     *in, *out);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? UPKIE_OK : observers_fail(h, UPKIE_ERR_HIP, hipGetErrorString(err));
 }

@@ -57,14 +57,27 @@ class LazySpineObservation(dict):
         super().__init__()
         self._sim = sim
         self._fresh = False
+        self._overrides: Dict = {}
 
     def invalidate(self) -> None:
+        self._fresh = False
+
+    def set_overrides(self, blocks: Dict) -> None:
+        """Blocks written by the spine observer pipeline (upkie_amd.observers):
+        merged over the backend's blocks of the same name, as the spine's
+        observers write over / next to what the interface reported."""
+        self._overrides = blocks
         self._fresh = False
 
     def materialize(self) -> "LazySpineObservation":
         if not self._fresh:
             super().clear()
             super().update(spine_observation_dict(self._sim.observe(update_imu=True)))
+            for key, block in self._overrides.items():
+                if super().__contains__(key):
+                    super().__getitem__(key).update(block)
+                else:
+                    super().__setitem__(key, dict(block))
             self._fresh = True
         return self
 

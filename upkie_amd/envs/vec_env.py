@@ -59,7 +59,9 @@ class UpkieVecEnv:
         autoreset: bool = True,
         env_id_offset: int = 0,
         eager_spine_observation: bool = False,
+        spine_observers=None,
         sim_factory=None,
+        observers_factory=None,
     ):
         if frequency is None:  # upkie_gyropod.py:123-124, upkie_env.py:85-86
             raise UpkieException("This environment needs a loop frequency")
@@ -101,6 +103,21 @@ class UpkieVecEnv:
             self.sim.randomize_inertias(self.inertia_variation)
         self._spine = LazySpineObservation(self.sim)
         self._external_forces: Dict[str, object] = {}
+        # Optional spine observer pipeline (FloorContact, WheelOdometry,
+        # BaseOrientation of upkie/cpp/observers), run once per env step with
+        # the env period as spine period; `spine_observers` is True or a spine
+        # configuration dictionary (spine_backend.py:77-105). The reference's
+        # filters refuse cutoff periods <= 2 dt: frequencies above 200 Hz only.
+        self._observers = None
+        if spine_observers:
+            from ..observers import BatchedObservers, observer_config_from_spine_config
+
+            spine_config = spine_observers if isinstance(spine_observers, dict) else None
+            obs_cfg = observer_config_from_spine_config(self.num_envs, self.dt, spine_config)
+            make = observers_factory if observers_factory is not None else BatchedObservers
+            self._observers = make(obs_cfg, device)
+            self._observers.reset()
+            self._episodes = self.sim.state[abi.S_EPISODE].clone()
 
     # hooks ------------------------------------------------------------
     def _configure(self, cfg) -> None:
@@ -117,10 +134,19 @@ class UpkieVecEnv:
         return self
 
     def close(self) -> None:
+        if self._observers is not None:
+            self._observers.close()
         self.sim.close()
 
     def _info(self) -> dict:
         self._spine.invalidate()
+        if self._observers is not None:
+            # envs that (auto)reset during this call start from fresh observers
+            episodes = self.sim.state[abi.S_EPISODE]
+            restarted = episodes != self._episodes
+            self._episodes = episodes.clone()
+            self._observers.reset(restarted)
+            self._spine.set_overrides(self._observers.step_from_sim(self.sim))
         if self.eager_spine_observation:
             self._spine.materialize()
         return {"spine_observation": self._spine}

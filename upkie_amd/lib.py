@@ -18,6 +18,8 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "upkie_hip.hip"),
     os.path.join(_HERE, "csrc", "dynamics.hpp"),
     os.path.join(_HERE, "csrc", "mpc.hpp"),
+    os.path.join(_HERE, "csrc", "pair.hpp"),
+    os.path.join(_HERE, "csrc", "observers.hpp"),
     os.path.join(_HERE, "..", "include", "upkie_hip.h"),
 ]
 
@@ -48,6 +50,12 @@ EXPORTED_SYMBOLS = (
     "upkie_mpc_reset",
     "upkie_mpc_step",
     "upkie_mpc_step_env",
+    "upkie_observers_create",
+    "upkie_observers_destroy",
+    "upkie_observers_last_error",
+    "upkie_observers_state_bytes",
+    "upkie_observers_reset",
+    "upkie_observers_step",
 )
 
 
@@ -174,6 +182,24 @@ def load() -> C.CDLL:
     lib.upkie_mpc_step.argtypes = [vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
     lib.upkie_mpc_step_env.restype = C.c_int
     lib.upkie_mpc_step_env.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, vp, vp]
+    lib.upkie_observers_create.restype = C.c_int
+    lib.upkie_observers_create.argtypes = [C.POINTER(abi.UpkieObserverConfig), C.POINTER(vp)]
+    lib.upkie_observers_destroy.restype = C.c_int
+    lib.upkie_observers_destroy.argtypes = [vp]
+    lib.upkie_observers_last_error.restype = C.c_char_p
+    lib.upkie_observers_last_error.argtypes = [vp]
+    lib.upkie_observers_state_bytes.restype = C.c_int64
+    lib.upkie_observers_state_bytes.argtypes = [vp]
+    lib.upkie_observers_reset.restype = C.c_int
+    lib.upkie_observers_reset.argtypes = [vp, vp, vp, vp]
+    lib.upkie_observers_step.restype = C.c_int
+    lib.upkie_observers_step.argtypes = [
+        vp,
+        vp,
+        C.POINTER(abi.UpkieObserverInput),
+        C.POINTER(abi.UpkieObserverOutput),
+        vp,
+    ]
     _lib = lib
     return lib
 
@@ -185,6 +211,8 @@ def check(status: int, handle=None, what: str = "sim") -> None:
     lib = load()
     if what == "mpc":
         msg = lib.upkie_mpc_last_error(handle)
+    elif what == "observers":
+        msg = lib.upkie_observers_last_error(handle)
     else:
         msg = lib.upkie_sim_last_error(handle)
     raise UpkieHipError(status, msg.decode() if msg else "")
