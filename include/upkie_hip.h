@@ -396,6 +396,18 @@ int upkie_observers_reset(UpkieObservers* observers, float* state, const uint8_t
 int upkie_observers_step(UpkieObservers* observers, float* state, const UpkieObserverInput* in,
                          const UpkieObserverOutput* out, void* stream);
 
+/* ---- Rollout consumer (BASELINE.json configs[3]) ---
+ * Generalized advantage estimation over a rollout resident in HBM: rewards,
+ * values, episode_starts, advantages, returns are [num_steps][num_envs]
+ * (episode_starts[t][n] != 0 when step t is the first of an episode),
+ * last_values / last_dones [num_envs] describe the state after the last step.
+ * The reference has no learner (README.md:107-109 points to external RL
+ * playgrounds); the recurrence is the published one (Schulman et al. 2016).
+ * Errors are reported through upkie_sim_last_error(NULL). */
+int upkie_rollout_gae(int32_t num_steps, int32_t num_envs, const float* rewards, const float* values,
+                      const uint8_t* episode_starts, const float* last_values, const uint8_t* last_dones,
+                      double gamma, double gae_lambda, float* advantages, float* returns, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

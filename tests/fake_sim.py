@@ -38,6 +38,9 @@ class OracleSim:
     def close(self):
         pass
 
+    def flag_done(self, done):
+        self._o.state[abi.S_DONE] = done.double().numpy()
+
     def push_config(self):
         self._o.config = self.config
 

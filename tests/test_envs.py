@@ -263,3 +263,113 @@ def test_spine_observers_in_the_vector_env():
     assert spine["floor_contact"]["contact"][1:].all()
     assert torch.stack(odometry)[:, 1:].abs().max() > 1e-3  # the integrator moved
     assert spine["floor_contact"]["left_wheel"]["inertia"].shape == (4,)
+
+
+@pytest.mark.parametrize("env_id", ["Upkie-HIP-Pendulum-Vec", "Upkie-HIP-Gyropod-Vec"])
+def test_same_step_autoreset_reports_final_observation(env_id):
+    """gymnasium.vector AutoresetMode.SAME_STEP: the step that ends an episode
+    returns the next episode's first observation and the last one of the old
+    episode in info["final_obs"] (mask info["_final_obs"])."""
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.1))
+    env = envs.make(env_id, num_envs=6, frequency=200.0, fall_pitch=0.15, init_state=init, autoreset_mode="same_step", **KW)
+    obs, _ = env.reset(seed=5)
+    pitch_index = 0 if "Pendulum" in env_id else 1
+    act_dim = env.single_action_space.shape[0]
+    seen = 0
+    episodes = env.sim.state[abi.S_EPISODE].clone()
+    for _ in range(400):
+        obs, reward, terminated, truncated, info = env.step(torch.zeros(6, act_dim))
+        if "final_obs" in info and info["_final_obs"].any():
+            m = info["_final_obs"]
+            assert torch.equal(m, terminated | truncated)
+            assert (info["final_obs"][m][:, pitch_index].abs() > 0.15).all()  # the observation that terminated the episode
+            assert (obs[m][:, pitch_index].abs() <= 0.1 + 1e-6).all()  # a freshly sampled initial state
+            now = env.sim.state[abi.S_EPISODE]
+            assert ((now - episodes)[m] == 1).all() and ((now - episodes)[~m] == 0).all()
+            episodes = now.clone()
+            seen += int(m.sum())
+    assert seen >= 6
+    with pytest.raises(UpkieException):
+        envs.make(env_id, num_envs=2, autoreset_mode="sometimes", **KW)
+
+
+def test_base_velocity_masked_reset_keeps_the_pose_of_other_envs():
+    env = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=3, frequency=200.0, nb_timesteps=12, mpc_factory=OracleMpc, **KW)
+    env.reset(seed=0)
+    for _ in range(40):
+        obs, *_ = env.step(torch.tensor([[0.3, 0.2]] * 3))
+    assert (obs[:, 0] > 0.01).all()
+    mask = torch.tensor([1, 0, 0], dtype=torch.uint8)
+    obs2, _ = env.reset(mask=mask)
+    assert torch.all(obs2[0] == 0.0)
+    assert torch.allclose(obs2[1:], obs[1:])
+
+
+@pytest.mark.parametrize("mode", ["next_step", "same_step", "disabled"])
+def test_time_limit_truncates_and_autoresets(mode):
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=3, frequency=200.0, max_episode_steps=7, autoreset_mode=mode, **KW)
+    obs, _ = env.reset(seed=0)
+    start = env.sim.state[abi.S_EPISODE].clone()
+    agent = lambda o: (10.0 * o[:, 0] + o[:, 1] + 0.1 * o[:, 3]).clamp(-0.99, 0.99).reshape(3, 1)
+    trunc_steps = []
+    for k in range(1, 25):
+        obs, _, terminated, truncated, info = env.step(agent(obs))
+        assert not terminated.any()
+        if truncated.any():
+            assert truncated.all()
+            trunc_steps.append(k)
+            if mode == "disabled":
+                obs, _ = env.reset(mask=truncated)
+    if mode == "next_step":  # 7 steps, then the reset step, then 7 steps ...
+        assert trunc_steps == [7, 15, 23]
+    else:
+        assert trunc_steps == [7, 14, 21]
+    assert ((env.sim.state[abi.S_EPISODE] - start) == 3).all()
+
+
+def test_numpy_vector_env_and_sb3_adapter():
+    from upkie_amd.envs.adapters import NumpyVectorEnv, Sb3VecEnv
+
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.1))
+    kw = dict(num_envs=5, frequency=200.0, fall_pitch=0.15, init_state=init, max_episode_steps=40, autoreset_mode="same_step", **KW)
+    venv = NumpyVectorEnv(envs.make("Upkie-HIP-Pendulum-Vec", **kw))
+    obs, info = venv.reset(seed=2)
+    assert isinstance(obs, np.ndarray) and obs.shape == (5, 4) and obs.dtype == np.float32
+    assert venv.metadata["autoreset_mode"] == "same_step" and venv.single_action_space.shape == (1,)
+    obs2, rew, term, trunc, info = venv.step(np.zeros((5, 1), dtype=np.float32))
+    assert rew.shape == (5,) and term.dtype == np.bool_ and trunc.dtype == np.bool_
+    assert isinstance(info["final_obs"], np.ndarray) and not info["_final_obs"].any()
+    venv.close()
+
+    with pytest.raises(ValueError):
+        Sb3VecEnv(envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, **KW))
+    sb3 = Sb3VecEnv(envs.make("Upkie-HIP-Pendulum-Vec", **kw))
+    assert sb3.seed(2) == [2] * 5
+    obs = sb3.reset()
+    assert np.array_equal(obs, venv_first_obs(kw)) and sb3.observation_space.shape == (4,)
+    falls = limits = 0
+    for k in range(120):
+        obs, rewards, dones, infos = sb3.step(np.zeros((5, 1), dtype=np.float32))
+        assert obs.shape == (5, 4) and dones.dtype == np.bool_ and len(infos) == 5
+        for i in np.nonzero(dones)[0]:
+            final = infos[i]["terminal_observation"]
+            assert final.shape == (4,)
+            if infos[i]["TimeLimit.truncated"]:
+                limits += 1
+                assert abs(final[0]) <= 0.15
+            else:
+                falls += 1
+                assert abs(final[0]) > 0.15 and abs(obs[i, 0]) <= 0.1 + 1e-6
+        for i in np.nonzero(~dones)[0]:
+            assert len(infos[i]) == 0
+    assert falls >= 5 and limits == 0 or falls + limits >= 5
+    assert sb3.get_attr("num_envs") == [5] * 5 and sb3.get_attr("dt", indices=[1, 3]) == [1.0 / 200.0] * 2
+    assert sb3.env_is_wrapped(object) == [False] * 5
+    assert sb3.env_method("update_init_rand", pitch=0.05, indices=0) == [None]
+    sb3.close()
+
+
+def venv_first_obs(kw):
+    env = envs.make("Upkie-HIP-Pendulum-Vec", **kw)
+    obs, _ = env.reset(seed=2)
+    return obs.numpy()

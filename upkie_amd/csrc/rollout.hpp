@@ -1,0 +1,40 @@
+// rollout.hpp -- consumer side of a rollout (BASELINE.json configs[3] names a
+// "PPO rollout consumer"): generalized advantage
+// estimation over a [T][N] rollout that already sits in HBM, one env column per
+// lane, walking the T steps backwards. Pure streaming: 3 words read and 2
+// written per (step, env), coalesced over envs -> HBM bound.
+//
+// Recurrence (Schulman et al. 2016, as every PPO implementation states it):
+//   delta_t = r_t + gamma * V_{t+1} * (1 - start_{t+1}) - V_t
+//   A_t     = delta_t + gamma * lambda * (1 - start_{t+1}) * A_{t+1}
+//   R_t     = A_t + V_t
+// with V_T = last_values, start_T = last_dones; start_t = 1 when step t is the
+// first of an episode.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace upkie {
+
+__global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float* __restrict__ rewards, const float* __restrict__ values,
+                                                  const uint8_t* __restrict__ episode_starts, const float* __restrict__ last_values,
+                                                  const uint8_t* __restrict__ last_dones, float gamma, float lambda,
+                                                  float* __restrict__ advantages, float* __restrict__ returns) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float next_value = last_values[n];
+  float next_non_terminal = last_dones[n] ? 0.f : 1.f;
+  float gae = 0.f;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * N + n;
+    const float v = values[i];
+    const float delta = rewards[i] + gamma * next_value * next_non_terminal - v;
+    gae = delta + gamma * lambda * next_non_terminal * gae;
+    advantages[i] = gae;
+    returns[i] = gae + v;
+    next_value = v;
+    next_non_terminal = episode_starts[i] ? 0.f : 1.f;
+  }
+}
+
+}  // namespace upkie

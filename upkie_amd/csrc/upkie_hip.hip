@@ -18,6 +18,7 @@
 #include "dynamics.hpp"
 #include "mpc.hpp"
 #include "observers.hpp"
+#include "rollout.hpp"
 
 namespace upkie {
 
@@ -1169,4 +1170,30 @@ extern "C" int upkie_observers_step(UpkieObservers* h, float* state, const Upkie
                      *in, *out);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? UPKIE_OK : observers_fail(h, UPKIE_ERR_HIP, hipGetErrorString(err));
+}
+
+// ============================================================ rollout consumer
+extern "C" int upkie_rollout_gae(int32_t num_steps, int32_t num_envs, const float* rewards, const float* values,
+                                 const uint8_t* episode_starts, const float* last_values, const uint8_t* last_dones, double gamma,
+                                 double gae_lambda, float* advantages, float* returns, void* stream) {
+  if (num_steps <= 0 || num_envs <= 0) {
+    g_create_error = "num_steps and num_envs must be positive";
+    return UPKIE_ERR_INVALID_ARGUMENT;
+  }
+  if (!rewards || !values || !episode_starts || !last_values || !last_dones || !advantages || !returns) {
+    g_create_error = "null argument";
+    return UPKIE_ERR_INVALID_ARGUMENT;
+  }
+  if (upkie_hip_device_count() <= 0) {
+    g_create_error = "no HIP device visible";
+    return UPKIE_ERR_NO_DEVICE;
+  }
+  hipLaunchKernelGGL(upkie::gae_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, num_steps, num_envs,
+                     rewards, values, episode_starts, last_values, last_dones, (float)gamma, (float)gae_lambda, advantages, returns);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_create_error = hipGetErrorString(err);
+    return UPKIE_ERR_HIP;
+  }
+  return UPKIE_OK;
 }

@@ -57,6 +57,8 @@ class UpkieVecEnv:
         torque_control_kp: float = 20.0,
         seed: int = 0,
         autoreset: bool = True,
+        autoreset_mode: Optional[str] = None,
+        max_episode_steps: Optional[int] = None,
         env_id_offset: int = 0,
         eager_spine_observation: bool = False,
         spine_observers=None,
@@ -86,7 +88,20 @@ class UpkieVecEnv:
         cfg.torque_control_kp = torque_control_kp
         cfg.torque_control_kd = torque_control_kd
         cfg.max_gain_scale = max_gain_scale
-        cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP if autoreset else abi.AUTORESET_DISABLED
+        # gymnasium.vector.AutoresetMode: "next_step" (in-kernel: an env flagged
+        # done is re-initialised by its next step() and returns the reset
+        # observation), "same_step" (the step that ends an episode returns the
+        # first observation of the next one, the last observation of the old
+        # one in info["final_obs"]), "disabled" (reset(mask=...) by hand)
+        if autoreset_mode is None:
+            autoreset_mode = "next_step" if autoreset else "disabled"
+        if autoreset_mode not in ("next_step", "same_step", "disabled"):
+            raise UpkieException(f"unknown autoreset_mode '{autoreset_mode}'")
+        self.autoreset_mode = autoreset_mode
+        # gymnasium's TimeLimit for a batch: `truncated` after this many steps
+        # of an episode (the reference registers no limit, envs/__init__.py:38-44)
+        self.max_episode_steps = None if max_episode_steps is None else int(max_episode_steps)
+        cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP if autoreset_mode == "next_step" else abi.AUTORESET_DISABLED
         cfg.env_id_offset = env_id_offset
         for idx, name in enumerate(abi.JOINT_NAMES):
             props = (joint_properties or {}).get(name, JointProperties())
@@ -103,6 +118,8 @@ class UpkieVecEnv:
             self.sim.randomize_inertias(self.inertia_variation)
         self._spine = LazySpineObservation(self.sim)
         self._external_forces: Dict[str, object] = {}
+        self._elapsed = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self._pending_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         # Optional spine observer pipeline (FloorContact, WheelOdometry,
         # BaseOrientation of upkie/cpp/observers), run once per env step with
         # the env period as spine period; `spine_observers` is True or a spine
@@ -151,6 +168,26 @@ class UpkieVecEnv:
             self._spine.materialize()
         return {"spine_observation": self._spine}
 
+    def _finish_step(self, obs, reward, terminated, truncated):
+        terminated, truncated = terminated.bool(), truncated.bool()
+        if self.max_episode_steps is not None:
+            # a NEXT_STEP autoreset step is not a step of the new episode
+            self._elapsed = torch.where(self._pending_reset, torch.zeros_like(self._elapsed), self._elapsed + 1)
+            timeout = (self._elapsed >= self.max_episode_steps) & ~terminated
+            truncated = truncated | timeout
+            if self.autoreset_mode == "next_step":
+                self._pending_reset = terminated | truncated
+                self.sim.flag_done(self._pending_reset)  # the kernel's autoreset flag
+        if self.autoreset_mode != "same_step":
+            return obs, reward, terminated, truncated, self._info()
+        done = terminated | truncated
+        final_obs = obs.clone()
+        obs, info = self.reset(mask=done)  # untouched envs report their current observation
+        info = dict(info)
+        info["final_obs"] = final_obs
+        info["_final_obs"] = done
+        return obs, reward, terminated, truncated, info
+
     def update_init_rand(self, **kwargs) -> None:
         """upkie_env.py:244-251."""
         self.init_state.randomization.update(**kwargs)
@@ -177,6 +214,13 @@ class UpkieVecEnv:
         self.sim.set_external_force(forces.t().contiguous(), point=tuple(point))
 
     def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
+        if mask is None:
+            self._elapsed.zero_()
+            self._pending_reset.zero_()
+        else:
+            m = torch.as_tensor(mask).to(self.device).bool()
+            self._elapsed[m] = 0
+            self._pending_reset[m] = False
         if seed is not None:
             self.config.seed = int(seed)
             self.sim.push_config()
@@ -213,7 +257,7 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
     def step(self, action):
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs)
         obs, reward, terminated, truncated = self.sim.step_pendulum(act)
-        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+        return self._finish_step(obs, reward, terminated, truncated)
 
 
 class UpkieGyropodVecEnv(UpkieVecEnv):
@@ -264,10 +308,12 @@ class UpkieGyropodVecEnv(UpkieVecEnv):
         obs6 = self._reset_sim(seed, mask)
         return obs6, self._info()
 
-    def step(self, action):
+    def _gyropod_step(self, action):
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2)
-        obs, reward, terminated, truncated = self.sim.step_gyropod(act)
-        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+        return self.sim.step_gyropod(act)
+
+    def step(self, action):
+        return self._finish_step(*self._gyropod_step(action))
 
 
 class UpkieServosVecEnv(UpkieVecEnv):
@@ -319,7 +365,7 @@ class UpkieServosVecEnv(UpkieVecEnv):
     def step(self, action):
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 6, 6)
         obs, reward, terminated, truncated = self.sim.step_servos(act)
-        return obs, reward, terminated.bool(), truncated.bool(), self._info()
+        return self._finish_step(obs, reward, terminated, truncated)
 
 
 class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
@@ -378,7 +424,9 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
             self._xy.zero_()
         else:
             self._xy[mask.to(self.device).bool()] = 0.0
-        obs = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)
+        # reset envs start at the origin (upkie_base_velocity.py:160-162);
+        # untouched ones report their current dead-reckoned pose
+        obs = torch.cat([self._xy, obs6[:, 2:3].to(self._xy.dtype)], dim=1)
         return obs, info
 
     def step(self, action):
@@ -388,13 +436,13 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
             done = self.sim.state[abi.S_DONE] if self.config.autoreset_mode else None
             commanded = self.mpc_balancer.step_env(self._x0, act, self._contact, done, self.dt)
             obs, reward, terminated, truncated = self.sim.step_base_velocity(act, commanded, self._x0, self._contact)
-            return obs, reward, terminated.bool(), truncated.bool(), self._info()
+            return self._finish_step(obs, reward, terminated, truncated)
         # generic composition (used with the CPU test doubles)
         linear_velocity, yaw_velocity = act[:, 0].contiguous(), act[:, 1]
         autoreset = (self.sim.state[abi.S_DONE] != 0) if self.config.autoreset_mode else None
         ground_velocity, _ = self.mpc_balancer.step(self._x0, linear_velocity, self._contact, self.dt)
         gyropod_action = torch.stack([ground_velocity, yaw_velocity], dim=1)
-        obs6, reward, terminated, truncated, info = super().step(gyropod_action)
+        obs6, reward, terminated, truncated = self._gyropod_step(gyropod_action)
         self._remember(obs6)
         yaw = obs6[:, 2]
         if autoreset is not None and bool(autoreset.any()):
@@ -407,4 +455,4 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
             self._xy[:, 0] += linear_velocity * torch.cos(yaw) * self.dt  # :197-199
             self._xy[:, 1] += linear_velocity * torch.sin(yaw) * self.dt
         obs = torch.cat([self._xy, yaw[:, None]], dim=1)
-        return obs, reward, terminated, truncated, info
+        return self._finish_step(obs, reward, terminated, truncated)

@@ -20,6 +20,7 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "mpc.hpp"),
     os.path.join(_HERE, "csrc", "pair.hpp"),
     os.path.join(_HERE, "csrc", "observers.hpp"),
+    os.path.join(_HERE, "csrc", "rollout.hpp"),
     os.path.join(_HERE, "..", "include", "upkie_hip.h"),
 ]
 
@@ -56,6 +57,7 @@ EXPORTED_SYMBOLS = (
     "upkie_observers_state_bytes",
     "upkie_observers_reset",
     "upkie_observers_step",
+    "upkie_rollout_gae",
 )
 
 
@@ -200,6 +202,8 @@ def load() -> C.CDLL:
         C.POINTER(abi.UpkieObserverOutput),
         vp,
     ]
+    lib.upkie_rollout_gae.restype = C.c_int
+    lib.upkie_rollout_gae.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -290,5 +290,11 @@ class BatchedSim:
             )
         return out
 
+    def flag_done(self, done: torch.Tensor) -> None:
+        """Overwrite the per-env `done` word the NEXT_STEP autoreset reads: envs
+        flagged here are re-initialised by their next step (used by the
+        envs' time limit, which the kernel knows nothing about)."""
+        self.state[abi.S_DONE] = done.to(self.device, torch.float32)
+
     def state_numpy(self) -> np.ndarray:
         return self.state.detach().cpu().numpy()
