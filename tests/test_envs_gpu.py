@@ -147,3 +147,53 @@ def test_spine_observers_in_the_vector_env_on_device():
     truth = env.sim.observe(update_imu=False)
     assert torch.allclose(spine["base_orientation"]["pitch"], truth["pitch"], atol=1e-5)
     env.close()
+
+
+def test_hip_spine_serves_one_env_of_a_gpu_batch():
+    """An agent attached through the spine's shared memory to env #5 of a GPU
+    batch while a device-side policy balances the other envs."""
+    import os
+    import threading
+    import uuid
+
+    from upkie_amd.envs.backends.spine_backend import SpineBackend
+    from upkie_amd.spine import HipSpine, State
+
+    B = 64
+    name = f"/upkie_gpu_test_{os.getpid()}_{uuid.uuid4().hex[:6]}"
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=B, frequency=200.0, autoreset_mode="disabled")
+    env.reset(seed=0)
+    neutral = env.get_neutral_action()
+    radius = float(env.sim.model.wheel_radius)
+
+    def batch_policy(servo_obs):
+        spine = env.sim.observe(update_imu=False)
+        v = (10.0 * spine["pitch"] + spine["wheel_odometry"][:, 0] + 0.1 * spine["wheel_odometry"][:, 1]).clamp(-0.99, 0.99)
+        act = neutral.clone()
+        for j, sign in ((2, 1.0), (5, -1.0)):
+            act[:, j, 1] = sign * v / radius
+        act[:, [0, 1, 3, 4], 0] = 0.0  # legs held straight
+        return act
+
+    spine = HipSpine(env, shm_name=name, env_index=5, batch_policy=batch_policy)
+    thread = threading.Thread(target=spine.run, kwargs=dict(idle_sleep=1e-4), daemon=True)
+    thread.start()
+    backend = SpineBackend(shm_name=name, retries=1)
+    obs = backend.reset(RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58])))
+    for _ in range(100):
+        v = 10.0 * obs["base_orientation"]["pitch"] + obs["wheel_odometry"]["position"] + 0.1 * obs["wheel_odometry"]["velocity"]
+        w = max(-0.99, min(0.99, v)) / radius
+        legs = {"position": 0.0, "velocity": 0.0}
+        obs = backend.step({"servo": {
+            "left_wheel": {"position": float("nan"), "velocity": +w}, "right_wheel": {"position": float("nan"), "velocity": -w},
+            "left_hip": legs, "left_knee": legs, "right_hip": legs, "right_knee": legs}})
+    assert abs(obs["base_orientation"]["pitch"]) < 0.1 and obs["floor_contact"]["contact"] is True
+    assert obs["time"] == pytest.approx(0.5)
+    pitch = env.sim.observe(update_imu=False)["pitch"]
+    assert pitch.abs().max() < 0.2  # the device-side policy kept the rest of the batch up
+    backend.close()
+    spine.interrupt()
+    thread.join(timeout=10.0)
+    assert spine.state_machine.state == State.kOver
+    spine.close()
+    env.close()

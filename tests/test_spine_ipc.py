@@ -1,0 +1,220 @@
+"""Spine IPC: the state machine against the reference's
+own StateMachineTest.cpp, the shared-memory wire format, and an agent driving
+one env of a batch through `HipSpine` exactly as it drives a bullet spine
+(client = our SpineInterface / SpineBackend, same protocol as
+upkie/envs/backends/spine/spine_interface.py). CPU: the batch is backed by the
+oracle test double."""
+
+import os
+import sys
+import threading
+import uuid
+
+import msgpack
+import numpy as np
+import pytest
+import torch
+
+import upkie_amd.envs as envs
+from upkie_amd.envs.backends.spine_backend import SpineBackend
+from upkie_amd.exceptions import SpineError, UpkieRuntimeError, UpkieTimeoutError
+from upkie_amd.spine import AgentInterface, Event, HipSpine, Request, SpineInterface, State, StateMachine
+from upkie_amd.spine.state_machine import kNbStopCycles
+from upkie_amd.utils.robot_state import RobotState
+
+from .fake_sim import oracle_sim_factory
+
+
+def shm_name():
+    return f"/upkie_test_{os.getpid()}_{uuid.uuid4().hex[:8]}"
+
+
+@pytest.fixture
+def machine():
+    interface = AgentInterface(shm_name(), 4096)
+    yield interface, StateMachine(interface)
+    interface.close()
+
+
+# ---- upkie/cpp/spine/tests/StateMachineTest.cpp ------------------------------------
+
+
+def test_starts_in_stop_state(machine):  # :34-37
+    interface, sm = machine
+    assert sm.state == State.kSendStops and interface.request() == Request.kNone
+
+
+def test_restops_work(machine):  # :39-49
+    interface, sm = machine
+    interface.set_request(Request.kStop)
+    sm.process_event(Event.kCycleBeginning)
+    assert interface.request() == Request.kNone and sm.state == State.kSendStops
+    sm.process_event(Event.kCycleEnd)
+    assert interface.request() == Request.kNone and sm.state == State.kSendStops
+
+
+def test_startup(machine):  # :51-76
+    interface, sm = machine
+    interface.set_request(Request.kStart)
+    for _ in range(kNbStopCycles):
+        sm.process_event(Event.kCycleBeginning)
+        assert sm.state == State.kSendStops
+        sm.process_event(Event.kCycleEnd)
+        assert sm.state == State.kSendStops
+    sm.process_event(Event.kCycleBeginning)
+    assert sm.state == State.kReset
+    sm.process_event(Event.kCycleEnd)
+    assert sm.state == State.kIdle and interface.request() == Request.kNone
+    interface.set_request(Request.kStart)  # invalid from idle: request is reset, state stays
+    sm.process_event(Event.kCycleBeginning)
+    assert interface.request() == Request.kNone and sm.state == State.kIdle
+    sm.process_event(Event.kCycleEnd)
+    assert sm.state == State.kIdle and interface.request() == Request.kNone
+
+
+def test_acting_when_sending_stops_fails(machine):  # :78-85
+    interface, sm = machine
+    interface.set_request(Request.kAction)
+    sm.process_event(Event.kCycleBeginning)
+    assert sm.state == State.kSendStops and interface.request() == Request.kError
+
+
+def test_step_stop_and_shutdown(machine):  # StateMachine.cpp:39-135
+    interface, sm = machine
+    interface.set_request(Request.kStart)
+    for _ in range(kNbStopCycles + 1):
+        sm.process_event(Event.kCycleBeginning)
+        sm.process_event(Event.kCycleEnd)
+    assert sm.state == State.kIdle
+    interface.set_request(Request.kAction)
+    sm.process_event(Event.kCycleBeginning)
+    assert sm.state == State.kStep and interface.request() == Request.kAction  # held until the observation is written
+    sm.process_event(Event.kCycleEnd)
+    assert sm.state == State.kIdle and interface.request() == Request.kNone
+    interface.set_request(Request.kStop)
+    sm.process_event(Event.kCycleBeginning)
+    assert sm.state == State.kSendStops
+    interface.set_request(17)
+    sm.process_event(Event.kCycleBeginning)
+    assert interface.request() == Request.kError
+    sm.process_event(Event.kInterrupt)
+    assert sm.state == State.kShutdown
+    for k in range(kNbStopCycles):
+        assert sm.is_over_after_this_cycle() == (k == kNbStopCycles - 1)
+        sm.process_event(Event.kCycleEnd)
+    assert sm.state == State.kOver
+
+
+# ---- wire format ---------------------------------------------------------------------
+
+
+def test_shared_memory_layout_and_exclusivity():
+    name = shm_name()
+    spine_side = AgentInterface(name, 4096)
+    with pytest.raises(UpkieRuntimeError):  # "file already exists. Is a spine already running?"
+        AgentInterface(name, 4096)
+    payload = msgpack.packb({"servo": {"left_wheel": {"velocity": 1.5}}})
+    spine_side.write(payload)
+    with open(f"/dev/shm{name}", "rb") as f:  # AgentInterface.cpp:71-73: request, size, data
+        raw = f.read(8 + len(payload))
+    assert int.from_bytes(raw[0:4], sys.byteorder) == Request.kNone
+    assert int.from_bytes(raw[4:8], sys.byteorder) == len(payload)
+    assert raw[8:] == payload
+    with pytest.raises(UpkieRuntimeError):  # buffer overflow, AgentInterface.cpp:91-97
+        spine_side.write(b"x" * 4090)
+    agent_side = SpineInterface(name, retries=1)
+    assert agent_side._read_dict() == {"servo": {"left_wheel": {"velocity": 1.5}}}
+    agent_side._write_dict({"a": np.arange(3)})  # numpy goes through serialize()
+    assert msgpack.unpackb(spine_side.data()) == {"a": [0, 1, 2]}
+    agent_side.close()
+    spine_side.close()
+    assert not os.path.exists(f"/dev/shm{name}")  # unlinked by the spine, AgentInterface.cpp:81-83
+    with pytest.raises(SpineError):
+        SpineInterface(name, retries=1)
+
+
+# ---- an agent attached to env #1 of a batch ---------------------------------------------
+
+
+@pytest.fixture
+def served_batch():
+    name = shm_name()
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=3, frequency=200.0, autoreset_mode="disabled", sim_factory=oracle_sim_factory)
+    env.reset(seed=0)
+    spine = HipSpine(env, shm_name=name, shm_size=1 << 16, env_index=1)
+    thread = threading.Thread(target=spine.run, kwargs=dict(idle_sleep=1e-4), daemon=True)
+    thread.start()
+    yield name, env, spine
+    spine.interrupt()
+    thread.join(timeout=10.0)
+    assert spine.state_machine.state == State.kOver
+    spine.close()
+
+
+def test_agent_drives_one_env_of_the_batch(served_batch):
+    name, env, spine = served_batch
+    backend = SpineBackend(shm_name=name, retries=1)
+    init = RobotState(position_base_in_world=np.array([0.1, 0.0, 0.58]), joint_configuration=np.array([0.1, -0.2, 0.0, 0.1, -0.2, 0.0]))
+    with pytest.raises(SpineError):  # acting before start: Request.kError, StateMachine.cpp:83-85
+        backend._spine.set_action({"servo": {}})
+    obs = backend.reset(init)
+    assert set(obs) >= {"servo", "imu", "base_orientation", "floor_contact", "wheel_odometry", "time"}
+    assert obs["time"] == 0.0
+    assert obs["servo"]["left_hip"]["position"] == pytest.approx(0.1, abs=2e-3)
+    assert obs["servo"]["right_knee"]["position"] == pytest.approx(-0.2, abs=2e-3)
+    state = env.sim.state
+    assert float(state[abi_pos(0), 1]) == pytest.approx(0.1, abs=1e-3)  # env #1 was put where the agent asked ...
+    assert float(state[abi_pos(0), 0]) == pytest.approx(0.0, abs=1e-6)  # ... env #0 was not touched
+    # PD balancing through the spine, as examples/pybullet/servos do with a real spine
+    pitch0 = obs["base_orientation"]["pitch"]
+    for k in range(60):
+        pitch = obs["base_orientation"]["pitch"]
+        ground_velocity = 10.0 * pitch + 1.0 * obs["wheel_odometry"]["position"] + 0.1 * obs["wheel_odometry"]["velocity"]
+        wheel = ground_velocity / 0.05
+        action = {
+            "servo": {
+                "left_wheel": {"position": float("nan"), "velocity": +wheel, "kp_scale": 0.0, "kd_scale": 1.0},
+                "right_wheel": {"position": float("nan"), "velocity": -wheel, "kp_scale": 0.0, "kd_scale": 1.0},
+                "left_hip": {"position": 0.1, "velocity": 0.0},
+                "left_knee": {"position": -0.2, "velocity": 0.0},
+                "right_hip": {"position": 0.1, "velocity": 0.0},
+                "right_knee": {"position": -0.2, "velocity": 0.0},
+            }
+        }
+        obs = backend.step(action)
+    assert obs["time"] == pytest.approx(60 * env.dt)
+    assert abs(obs["base_orientation"]["pitch"]) < 0.2 and obs["floor_contact"]["contact"] is True
+    assert obs["servo"]["left_hip"]["position"] == pytest.approx(0.1, abs=0.05)
+    assert abs(obs["servo"]["left_wheel"]["velocity"]) > 1e-3 or abs(pitch0) < 1e-6
+    # the other envs were stepped alongside with the neutral action: passive wheels, the robot tips over
+    assert abs(float(env.sim.observe(update_imu=False)["pitch"][0])) > abs(obs["base_orientation"]["pitch"])
+    # a second start without stopping first is ignored from idle; stop + start works
+    obs2 = backend.reset(init)
+    assert obs2["time"] == 0.0 and obs2["servo"]["left_hip"]["position"] == pytest.approx(0.1, abs=2e-3)
+    backend.close()
+
+
+def test_agent_times_out_when_the_spine_is_gone():
+    name = shm_name()
+    interface = AgentInterface(name, 4096)
+    agent = SpineInterface(name, retries=1, timeout_ns=20_000_000)
+    interface.set_request(Request.kAction)  # nobody is serving
+    with pytest.raises(UpkieTimeoutError):
+        agent.stop()
+    agent.close()
+    interface.close()
+
+
+def test_hip_spine_refuses_unsuitable_envs():
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=2, sim_factory=oracle_sim_factory)  # next_step autoreset
+    with pytest.raises(UpkieRuntimeError):
+        HipSpine(env, shm_name=shm_name())
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, autoreset_mode="disabled", sim_factory=oracle_sim_factory)
+    with pytest.raises(UpkieRuntimeError):
+        HipSpine(env, shm_name=shm_name())
+
+
+def abi_pos(axis):
+    from upkie_amd import abi
+
+    return abi.S_POS + axis

@@ -169,7 +169,9 @@ class UpkieVecEnv:
         return {"spine_observation": self._spine}
 
     def _finish_step(self, obs, reward, terminated, truncated):
-        terminated, truncated = terminated.bool(), truncated.bool()
+        # the kernels write 0/1 bytes: reinterpreting them as bool launches nothing
+        terminated = terminated.view(torch.bool) if terminated.dtype == torch.uint8 else terminated.bool()
+        truncated = truncated.view(torch.bool) if truncated.dtype == torch.uint8 else truncated.bool()
         if self.max_episode_steps is not None:
             # a NEXT_STEP autoreset step is not a step of the new episode
             self._elapsed = torch.where(self._pending_reset, torch.zeros_like(self._elapsed), self._elapsed + 1)
@@ -219,8 +221,8 @@ class UpkieVecEnv:
             self._pending_reset.zero_()
         else:
             m = torch.as_tensor(mask).to(self.device).bool()
-            self._elapsed[m] = 0
-            self._pending_reset[m] = False
+            self._elapsed.masked_fill_(m, 0)  # (boolean indexing would synchronise with the device)
+            self._pending_reset.masked_fill_(m, False)
         if seed is not None:
             self.config.seed = int(seed)
             self.sim.push_config()
@@ -236,6 +238,7 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
         self.fall_pitch = fall_pitch
         self.max_ground_velocity = max_ground_velocity
         super().__init__(num_envs=num_envs, **kwargs)
+        self._pendulum_obs_indices = torch.tensor([1, 0, 4, 3], device=self.device)  # _PENDULUM_OBS_INDICES, upkie_pendulum.py:17
         # upkie_gyropod.py:126-142 limits, permuted by _PENDULUM_OBS_INDICES = [1, 0, 4, 3]
         obs_limit = np.array([np.pi, np.inf, 1000.0, max_ground_velocity], dtype=np.float32)
         act_limit = np.array([max_ground_velocity], dtype=np.float32)
@@ -250,7 +253,7 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
         obs6 = self._reset_sim(seed, mask)
-        obs = obs6[:, [1, 0, 4, 3]].contiguous()  # upkie_pendulum.py:17,122
+        obs = obs6.index_select(1, self._pendulum_obs_indices)  # upkie_pendulum.py:17,122
         self.sim.obs4.copy_(obs)
         return obs, self._info()
 
@@ -423,7 +426,7 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         if mask is None:
             self._xy.zero_()
         else:
-            self._xy[mask.to(self.device).bool()] = 0.0
+            self._xy.masked_fill_(mask.to(self.device).bool()[:, None], 0.0)
         # reset envs start at the origin (upkie_base_velocity.py:160-162);
         # untouched ones report their current dead-reckoned pose
         obs = torch.cat([self._xy, obs6[:, 2:3].to(self._xy.dtype)], dim=1)

@@ -21,6 +21,14 @@ class ModelError(UpkieException):
     """Something is wrong in the robot model."""
 
 
+class PerformanceIssue(UpkieException):
+    """A performance issue was detected (upkie/exceptions.py:31-34)."""
+
+
+class SpineError(UpkieException):
+    """A spine did not answer or refused a request (upkie/exceptions.py:37-42)."""
+
+
 class UpkieRuntimeError(UpkieException, RuntimeError):
     """Runtime error, for instance an invalid call to a library function."""
 
