@@ -182,6 +182,27 @@ int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_scale,
                                 const float* ext_force,
                                 const double ext_point[3]);
 
+/* External forces on any link, PyBulletBackend.set_external_forces /
+ * __apply_external_forces (pybullet_backend.py:603-658): up to
+ * UPKIE_MAX_EXTERNAL_FORCES forces act at the same time, each on one composite
+ * body (0 trunk, 1-3 left thigh / calf / wheel, 4-6 right) at `point` given in
+ * that body's frame (Bullet applies the force at the link's centre of mass),
+ * expressed in the world frame (pybullet.WORLD_FRAME) or, with `local`, in the
+ * body frame (pybullet.LINK_FRAME). forces[count][3][B] is a device buffer
+ * read at every substep until replaced; NULL or count = 0 removes all forces.
+ * Replaces whatever upkie_sim_set_randomization installed as ext_force. */
+#define UPKIE_MAX_EXTERNAL_FORCES 4
+typedef struct UpkieExternalForces {
+  int32_t count;
+  int32_t body[UPKIE_MAX_EXTERNAL_FORCES];
+  int32_t local[UPKIE_MAX_EXTERNAL_FORCES];
+  int32_t reserved0;
+  double point[UPKIE_MAX_EXTERNAL_FORCES][3];
+} UpkieExternalForces;
+
+int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
+                                  const UpkieExternalForces* slots);
+
 /* Fill inertia_scale[UPKIE_NB][B] with 1 + U(-v, v), one draw per body and
  * env (pybullet_backend.py:571-601). */
 int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale,

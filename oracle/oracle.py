@@ -35,6 +35,7 @@ class Randomization(C.Structure):
         ("inertia_scale", C.c_void_p),
         ("ext_force", C.c_void_p),
         ("ext_point", C.c_double * 3),
+        ("ext_slots", C.c_void_p),
     ]
 
 
@@ -80,6 +81,7 @@ def lib():
         _lib.oracle_total_mass.restype = C.c_double
         _lib.oracle_energy.restype = C.c_double
         _lib.oracle_substep.restype = C.c_int
+        _lib.oracle_substep_ext.restype = C.c_int
         _lib.oracle_mpc_solve_exact.restype = C.c_int
         _lib.oracle_observers_check.restype = C.c_int
         _lib.oracle_pitch_frame_in_parent.restype = C.c_double
@@ -119,8 +121,9 @@ class Oracle:
         self.B = config.num_envs
         self.state = np.zeros((abi.STATE_WORDS, self.B), dtype=np.float64)
         self.inertia_scale = None
-        self.ext_force = None
+        self.ext_force = None  # [3, B] (legacy: trunk, world frame) or [count, 3, B] with ext_slots
         self.ext_point = np.zeros(3)
+        self.ext_slots = None  # abi.UpkieExternalForces
         self._lib = lib()
 
     # -- randomisation -----------------------------------------------------
@@ -131,6 +134,7 @@ class Oracle:
         r.inertia_scale = _ptr(self.inertia_scale)
         r.ext_force = _ptr(self.ext_force)
         r.ext_point[:] = list(self.ext_point)
+        r.ext_slots = C.cast(C.pointer(self.ext_slots), C.c_void_p) if (self.ext_slots is not None and self.ext_force is not None) else None
         self._rnd_keepalive = r
         return C.byref(r)
 
@@ -237,21 +241,17 @@ class Oracle:
             if self.inertia_scale is not None
             else None
         )
-        force = (
-            np.ascontiguousarray(self.ext_force[:, env])
-            if self.ext_force is not None
-            else None
-        )
-        point = np.ascontiguousarray(self.ext_point, dtype=np.float64)
-        contact = self._lib.oracle_substep(
-            C.byref(self.model),
-            _ptr(s),
-            _ptr(tau),
-            C.c_double(h),
-            _ptr(scale),
-            _ptr(force),
-            _ptr(point),
-        )
+        if self.ext_force is not None and self.ext_slots is not None:
+            force = np.ascontiguousarray(self.ext_force[:, :, env])
+            contact = self._lib.oracle_substep_ext(
+                C.byref(self.model), _ptr(s), _ptr(tau), C.c_double(h), _ptr(scale), _ptr(force), C.byref(self.ext_slots)
+            )
+        else:
+            force = np.ascontiguousarray(self.ext_force[:, env]) if self.ext_force is not None else None
+            point = np.ascontiguousarray(self.ext_point, dtype=np.float64)
+            contact = self._lib.oracle_substep(
+                C.byref(self.model), _ptr(s), _ptr(tau), C.c_double(h), _ptr(scale), _ptr(force), _ptr(point)
+            )
         self.state[:, env] = s
         return contact
 

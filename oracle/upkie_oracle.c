@@ -418,9 +418,9 @@ double oracle_energy(const UpkieModel* model, const double pos[3],
  * free acceleration -> contact/limit rows -> PGS -> velocity update ->
  * position integration (semi-implicit Euler, pinned by
  * upkie/cpp/interfaces/tests/BulletInterfaceTest.cpp:263-285). */
-int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
-                   double h, const double* inertia_scale,
-                   const double* ext_force, const double* ext_point) {
+int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
+                       double h, const double* inertia_scale,
+                       const double* ext_forces, const UpkieExternalForces* ext_slots) {
   double* pos = s + UPKIE_S_POS;
   double* quat = s + UPKIE_S_QUAT;
   double* linvel = s + UPKIE_S_LINVEL;
@@ -455,14 +455,24 @@ int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
     for (int a = 0; a < NV; ++a)
       for (int d = 0; d < 3; ++d) Q[a] += Jv[d][a] * F[d] + Jw[d][a] * T[d];
   }
-  if (ext_force) {
-    /* world-frame force at a trunk point, pybullet_backend.py:625-658 */
-    double Jv[3][NV], Jw[3][NV], r[3], P[3];
-    m3_mulv(k.R[0], ext_point, r);
-    for (int d = 0; d < 3; ++d) P[d] = k.o[0][d] + r[d];
-    point_jacobian(&k, 0, P, Jv, Jw);
-    for (int a = 0; a < NV; ++a)
-      for (int d = 0; d < 3; ++d) Q[a] += Jv[d][a] * ext_force[d];
+  if (ext_forces && ext_slots) {
+    /* __apply_external_forces, pybullet_backend.py:625-658: each force acts on
+     * one link at a point of that link, given in the world frame
+     * (WORLD_FRAME) or in the link frame (LINK_FRAME) */
+    for (int i = 0; i < ext_slots->count; ++i) {
+      const int b = ext_slots->body[i];
+      double Jv[3][NV], Jw[3][NV], r[3], P[3], F[3];
+      m3_mulv(k.R[b], ext_slots->point[i], r);
+      for (int d = 0; d < 3; ++d) P[d] = k.o[b][d] + r[d];
+      if (ext_slots->local[i]) {
+        m3_mulv(k.R[b], ext_forces + 3 * i, F);
+      } else {
+        for (int d = 0; d < 3; ++d) F[d] = ext_forces[3 * i + d];
+      }
+      point_jacobian(&k, b, P, Jv, Jw);
+      for (int a = 0; a < NV; ++a)
+        for (int d = 0; d < 3; ++d) Q[a] += Jv[d][a] * F[d];
+    }
   }
 
   cholesky(NV, M, L);
@@ -662,21 +672,30 @@ static void store_env(double* state, int B, int e, const double s[NW]) {
   for (int w = 0; w < NW; ++w) state[(int64_t)w * B + e] = s[w];
 }
 static void env_randomization(const OracleRandomization* rnd, int B, int e,
-                              double scale[NB], double force[3],
+                              double scale[NB], double force[3 * UPKIE_MAX_EXTERNAL_FORCES],
+                              UpkieExternalForces* slots,
                               const double** scale_p, const double** force_p,
-                              const double** point_p) {
+                              const UpkieExternalForces** slots_p) {
   *scale_p = NULL;
   *force_p = NULL;
-  *point_p = NULL;
+  *slots_p = NULL;
   if (!rnd) return;
   if (rnd->inertia_scale) {
     for (int i = 0; i < NB; ++i) scale[i] = rnd->inertia_scale[(int64_t)i * B + e];
     *scale_p = scale;
   }
   if (rnd->ext_force) {
-    for (int d = 0; d < 3; ++d) force[d] = rnd->ext_force[(int64_t)d * B + e];
+    if (rnd->ext_slots) {
+      *slots = *rnd->ext_slots;
+    } else { /* one world-frame force on the trunk at ext_point */
+      memset(slots, 0, sizeof(*slots));
+      slots->count = 1;
+      for (int d = 0; d < 3; ++d) slots->point[0][d] = rnd->ext_point[d];
+    }
+    for (int i = 0; i < slots->count; ++i)
+      for (int d = 0; d < 3; ++d) force[3 * i + d] = rnd->ext_force[(int64_t)(3 * i + d) * B + e];
     *force_p = force;
-    *point_p = rnd->ext_point;
+    *slots_p = slots;
   }
 }
 
@@ -721,7 +740,7 @@ static double uniform(double low, double high, double u) { return low + (high - 
 
 static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
                       double s[NW], int64_t env_global, const double* scale,
-                      const double* force, const double* point) {
+                      const double* force, const UpkieExternalForces* point) {
   uint32_t episode = (uint32_t)s[UPKIE_S_EPISODE];
   double u0[4], u1[4], u2[4];
   philox_uniform4(cfg->seed, env_global, episode, STREAM_RESET, 0, u0);
@@ -759,7 +778,7 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   }
   /* pybullet_backend.py:228: one stepSimulation() with no motor torque */
   const double zero_tau[6] = {0, 0, 0, 0, 0, 0};
-  oracle_substep(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, force, point);
+  oracle_substep_ext(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, force, point);
   /* upkie_gyropod.py:236-240 */
   s[UPKIE_S_LEGREF + 0] = s[UPKIE_S_Q + 0];
   s[UPKIE_S_LEGREF + 1] = s[UPKIE_S_Q + 1];
@@ -795,11 +814,13 @@ void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3];
-    const double *sp, *fp, *pp;
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
     load_env(state, B, e, s);
     if (!mask || mask[e]) {
-      env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+      env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
       reset_env(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp);
       store_env(state, B, e, s);
     }
@@ -841,7 +862,7 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
                          double s[NW], int64_t env_global,
                          const OracleServoCommand cmd[NJ],
                          const double* scale, const double* force,
-                         const double* point) {
+                         const UpkieExternalForces* point) {
   double h = cfg->dt / cfg->nb_substeps;
   int noisy = has_noise(cfg->torque_control_noise);
   uint32_t step = (uint32_t)s[UPKIE_S_STEP];
@@ -856,7 +877,7 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
                                        cfg->joint_friction[j], sigma > 1e-10 ? sigma * z[j] : 0.0);
       s[UPKIE_S_TORQUE + j] = tau[j]; /* :293 */
     }
-    oracle_substep(model, s, tau, h, scale, force, point);
+    oracle_substep_ext(model, s, tau, h, scale, force, point);
   }
   s[UPKIE_S_STEP] = (double)(step + 1u);
 }
@@ -905,7 +926,7 @@ static void gyropod_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
 
 static void autoreset_or_null(const UpkieModel* model, const UpkieSimConfig* cfg,
                               double s[NW], int64_t env_global, const double* sp,
-                              const double* fp, const double* pp, int* did_reset) {
+                              const double* fp, const UpkieExternalForces* pp, int* did_reset) {
   *did_reset = 0;
   if (cfg->autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && s[UPKIE_S_DONE] != 0.0) {
     reset_env(model, cfg, s, env_global, sp, fp, pp);
@@ -916,7 +937,7 @@ static void autoreset_or_null(const UpkieModel* model, const UpkieSimConfig* cfg
 static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
                              double s[NW], int64_t env_global, double a0,
                              double a1, double obs6[6], uint8_t* terminated,
-                             const double* sp, const double* fp, const double* pp) {
+                             const double* sp, const double* fp, const UpkieExternalForces* pp) {
   int did_reset;
   autoreset_or_null(model, cfg, s, env_global, sp, fp, pp, &did_reset);
   if (did_reset) {
@@ -943,10 +964,12 @@ void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3];
-    const double *sp, *fp, *pp;
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
     load_env(state, B, e, s);
-    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[2 * e], act[2 * e + 1],
                      obs + 6 * (int64_t)e, &terminated[e], sp, fp, pp);
     reward[e] = 0.0; /* upkie_env.py:230 */
@@ -965,10 +988,12 @@ void oracle_step_pendulum(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3], obs6[6];
-    const double *sp, *fp, *pp;
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
     load_env(state, B, e, s);
-    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
     /* upkie_pendulum.py:139: action_2d = [action[0], 0.0] */
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[e], 0.0, obs6,
                      &terminated[e], sp, fp, pp);
@@ -987,10 +1012,12 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3], obs6[6];
-    const double *sp, *fp, *pp;
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
     load_env(state, B, e, s);
-    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
     /* README.md:62-64 / examples/pybullet/pd_balancing.py:23-31 */
     double a = 0.0;
     for (int i = 0; i < 4; ++i) a += cfg->agent_gains[i] * obs[4 * (int64_t)e + i];
@@ -1028,11 +1055,13 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3];
-    const double *sp, *fp, *pp;
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
     int did_reset;
     load_env(state, B, e, s);
-    env_randomization(rnd, B, e, scale, force, &sp, &fp, &pp);
+    env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
     autoreset_or_null(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp, &did_reset);
     if (!did_reset) {
       OracleServoCommand cmd[NJ];
@@ -1125,3 +1154,16 @@ double oracle_low_pass_filter(double prev_output, double cutoff_period, double n
   return prev_output + alpha * (new_input - prev_output);
 }
 double oracle_pitch_from_quat(const double quat_wxyz[4]) { return pitch_from_quat(quat_wxyz); }
+
+
+/* One world-frame force at a trunk point (the original entry point). */
+int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
+                   double h, const double* inertia_scale,
+                   const double* ext_force, const double* ext_point) {
+  UpkieExternalForces slots;
+  memset(&slots, 0, sizeof(slots));
+  slots.count = 1;
+  if (ext_point)
+    for (int d = 0; d < 3; ++d) slots.point[0][d] = ext_point[d];
+  return oracle_substep_ext(model, s, tau, h, inertia_scale, ext_force, ext_force ? &slots : NULL);
+}

@@ -42,8 +42,9 @@ typedef struct OracleServoCommand {
 /* Optional per-env randomisation inputs (any pointer may be NULL). */
 typedef struct OracleRandomization {
   const double* inertia_scale; /* [UPKIE_NB][B] */
-  const double* ext_force;     /* [3][B] world frame, on the trunk */
-  double ext_point[3];         /* application point in base frame */
+  const double* ext_force;     /* [count][3][B] (count = 1 without ext_slots) */
+  double ext_point[3];         /* without ext_slots: application point on the trunk, base frame */
+  const UpkieExternalForces* ext_slots; /* bodies / points / frames of the forces, or NULL */
 } OracleRandomization;
 
 /* Philox4x32-10 counter-based generator (Salmon et al., SC'11). */
@@ -89,6 +90,10 @@ double oracle_energy(const UpkieModel* model, const double pos[3],
 int oracle_substep(const UpkieModel* model, double* state, const double tau[6],
                    double h, const double* inertia_scale,
                    const double* ext_force, const double* ext_point);
+/* Same with forces on any link: ext_forces[count][3], pybullet_backend.py:603-658. */
+int oracle_substep_ext(const UpkieModel* model, double* state, const double tau[6],
+                       double h, const double* inertia_scale,
+                       const double* ext_forces, const UpkieExternalForces* ext_slots);
 
 /* Batched entry points mirroring the HIP C-ABI (state is [WORDS][B]). */
 void oracle_sample_inertia_scales(const UpkieSimConfig* cfg,

@@ -51,8 +51,24 @@ class OracleSim:
 
     def set_external_force(self, force, point=(0.0, 0.0, 0.0)):
         self.ext_force = force
+        self._o.ext_slots = None
         self._o.ext_force = None if force is None else np.ascontiguousarray(force.double().numpy())
         self._o.ext_point = np.array(point, dtype=np.float64)
+
+    def set_external_forces(self, forces, bodies=(), points=(), local=()):
+        self.ext_force = forces
+        if forces is None:
+            self._o.ext_force, self._o.ext_slots = None, None
+            return
+        slots = abi.UpkieExternalForces()
+        slots.count = len(bodies)
+        for i in range(len(bodies)):
+            slots.body[i] = int(bodies[i])
+            slots.local[i] = 1 if local[i] else 0
+            for k in range(3):
+                slots.point[i][k] = float(points[i][k])
+        self._o.ext_slots = slots
+        self._o.ext_force = np.ascontiguousarray(forces.double().numpy())
 
     def reset(self, mask=None):
         m = None if mask is None else mask.to(torch.uint8).numpy()

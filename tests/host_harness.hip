@@ -3,7 +3,7 @@
 #include "../upkie_amd/csrc/upkie_hip.hip"
 
 extern "C" int harness_substep(const UpkieModel* model, float* st, const float* tau, float h, const float* scale,
-                               const float* ext_force, const float* ext_point) {
+                               const float* ext_forces, const UpkieExternalForces* ext_slots) {
   DevModel M;
   std::string why;
   if (!convert_model(model, &M, &why)) return -1;
@@ -15,11 +15,19 @@ extern "C" int harness_substep(const UpkieModel* model, float* st, const float* 
   for (int j = 0; j < 6; ++j) { s.q[j] = st[UPKIE_S_Q + j]; s.qd[j] = st[UPKIE_S_QD + j]; }
   float t[6];
   for (int j = 0; j < 6; ++j) t[j] = tau[j];
-  V3 f = ext_force ? v3(ext_force[0], ext_force[1], ext_force[2]) : v3(0, 0, 0);
-  V3 p = ext_point ? v3(ext_point[0], ext_point[1], ext_point[2]) : v3(0, 0, 0);
+  ExtSlots x{};
+  if (ext_forces && ext_slots) {
+    x.count = ext_slots->count;
+    for (int i = 0; i < x.count; ++i) {
+      x.body[i] = ext_slots->body[i];
+      x.local[i] = ext_slots->local[i];
+      for (int k = 0; k < 3; ++k) x.point[i][k] = (float)ext_slots->point[i][k];
+    }
+  }
+  const ExtForces ext{ext_forces && ext_slots ? ext_forces : nullptr, 1, &x};  // [count][3], one env
   DevLimits Lm;
   model_limits(M, &Lm);
-  bool c = physics_substep(M, Lm, s, t, h, scale, ext_force != nullptr, f, p);
+  bool c = physics_substep(M, Lm, s, t, h, scale, ext);
   st[UPKIE_S_POS] = s.pos.x; st[UPKIE_S_POS + 1] = s.pos.y; st[UPKIE_S_POS + 2] = s.pos.z;
   st[UPKIE_S_QUAT] = s.qw; st[UPKIE_S_QUAT + 1] = s.qx; st[UPKIE_S_QUAT + 2] = s.qy; st[UPKIE_S_QUAT + 3] = s.qz;
   st[UPKIE_S_LINVEL] = s.linvel.x; st[UPKIE_S_LINVEL + 1] = s.linvel.y; st[UPKIE_S_LINVEL + 2] = s.linvel.z;

@@ -49,15 +49,31 @@ def random_state(rng, on_floor: bool):
     return s
 
 
-def run_both(harness, model, s64, tau, h=1e-3, scale=None, force=None, point=None):
+def make_slots(bodies, points, local):
+    slots = abi.UpkieExternalForces()
+    slots.count = len(bodies)
+    for i in range(len(bodies)):
+        slots.body[i] = bodies[i]
+        slots.local[i] = 1 if local[i] else 0
+        for k in range(3):
+            slots.point[i][k] = points[i][k]
+    return slots
+
+
+def run_both(harness, model, s64, tau, h=1e-3, scale=None, force=None, point=None, slots=None):
+    """`force` [3] with `point` (trunk, world frame) or `force` [count, 3] with `slots`."""
     so = s64.copy()
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-    O.lib().oracle_substep(C.byref(model), p(so), p(tau), C.c_double(h), p(scale), p(force), p(point))
+    if force is not None and slots is None:
+        slots = make_slots([0], [point], [False])
+        force = np.asarray(force, dtype=np.float64).reshape(1, 3)
+    force = None if force is None else np.ascontiguousarray(force, dtype=np.float64)
+    O.lib().oracle_substep_ext(C.byref(model), p(so), p(tau), C.c_double(h), p(scale), p(force), C.byref(slots) if slots is not None else None)
     s32 = s64.astype(np.float32)
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32) if a is not None else None
-    t32, sc32, fo32, po32 = f32(tau), f32(scale), f32(force), f32(point)
+    t32, sc32, fo32 = f32(tau), f32(scale), f32(force)
     harness.harness_substep.restype = C.c_int
-    rc = harness.harness_substep(C.byref(model), p(s32), p(t32), C.c_float(h), p(sc32), p(fo32), p(po32))
+    rc = harness.harness_substep(C.byref(model), p(s32), p(t32), C.c_float(h), p(sc32), p(fo32), C.byref(slots) if slots is not None else None)
     assert rc >= 0
     return so, s32.astype(np.float64)
 
@@ -133,3 +149,29 @@ def test_substep_with_joint_limits(harness):
         assert np.abs(so[10:13] - sh[10:13]).max() < 3e-3
         assert np.abs(so[19:25] - sh[19:25]).max() < 5e-2
     assert hits > 100
+
+
+def test_substep_with_external_forces_on_any_link(harness):
+    """World- and link-frame forces on trunk, thigh, calf and wheel links
+    (pybullet_backend.py:603-658), several at a time: device arithmetic vs the
+    oracle's Jacobian-transpose formulation."""
+    rng = np.random.default_rng(8)
+    model = default_model()
+    for trial in range(120):
+        s = random_state(rng, trial % 2 == 0)
+        count = 1 + trial % 4
+        bodies = [int(b) for b in rng.integers(0, 7, count)]
+        local = [bool(v) for v in rng.integers(0, 2, count)]
+        points = rng.uniform(-0.05, 0.05, (count, 3))
+        force = rng.uniform(-15, 15, (count, 3))
+        so, sh = run_both(harness, model, s, rng.uniform(-1, 1, 6), force=force, slots=make_slots(bodies, points, local))
+        assert np.abs(so[0:7] - sh[0:7]).max() < 5e-7
+        assert np.abs(so[7:10] - sh[7:10]).max() < 3e-4
+        assert np.abs(so[10:13] - sh[10:13]).max() < 2e-3
+        assert np.abs(so[13:19] - sh[13:19]).max() < 1e-6
+        # a force really does something to the joints of the link it acts on
+    s = random_state(rng, False)
+    free, _ = run_both(harness, model, s, np.zeros(6))
+    pushed, pushed32 = run_both(harness, model, s, np.zeros(6), force=np.array([[0.0, 0.0, 5.0]]), slots=make_slots([5], [[0.0, 0.0, -0.1]], [False]))
+    assert np.abs(pushed[19 + 3 : 19 + 5] - free[19 + 3 : 19 + 5]).max() > 1e-3  # right hip / knee accelerate
+    assert np.abs(pushed[19:25] - pushed32[19:25]).max() < 2e-2

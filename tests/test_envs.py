@@ -373,3 +373,50 @@ def venv_first_obs(kw):
     env = envs.make("Upkie-HIP-Pendulum-Vec", **kw)
     obs, _ = env.reset(seed=2)
     return obs.numpy()
+
+
+def test_external_forces_on_leg_links_and_link_frames():
+    """set_external_forces with the reference's dictionary form
+    (pybullet_backend.py:603-623, tests/envs/backends/test_pybullet_backend_mock.py:
+    several links at once, world and link frames, forces persist until the
+    link is given another one)."""
+    from upkie_amd.utils.external_force import ExternalForce
+
+    def run(forces, steps=10):
+        env = envs.make("Upkie-HIP-Servos-Vec", num_envs=2, autoreset=False,
+                        init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 1.5])), **KW)  # in the air
+        env.reset()
+        if forces:
+            env.set_external_forces(forces)
+        act = env.get_neutral_action()
+        act[:, :, 3] = 0.0  # kp scale 0: free joints apart from damping
+        act[:, :, 4] = 0.0
+        for _ in range(steps):
+            env.step(act)
+        return env
+
+    free = run({})
+    q = lambda env: env.sim.state[abi.S_Q : abi.S_Q + 6, 0]
+    # a world-frame force on the right calf swings the right leg, not the left one
+    pushed = run({"right_calf": ExternalForce([4.0, 0.0, 0.0], local=False)})
+    dq = (q(pushed) - q(free)).abs()
+    assert dq[3:5].max() > 5e-3 and dq[0:3].max() < 0.2 * dq[3:5].max()  # (the left leg only feels the base reacting)
+    # upward force equal to the weight on the torso + per-env forces on a wheel tire
+    weight = 9.81 * sum(free.model.struct.mass[:])
+    per_env = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 3.0]])
+    held = run({"torso": ExternalForce([0.0, 0.0, weight]), "left_wheel_tire": (per_env, True)})
+    z = held.sim.state[abi.S_POS + 2]
+    assert abs(float(z[0]) - 1.5) < 2e-3 and float(free.sim.state[abi.S_POS + 2, 0]) < 1.5 - 5e-3  # held vs falling
+    # the tire's link z-axis is the wheel axis (model.py:92-104): env 1's link-frame force is lateral in the world
+    y = held.sim.state[abi.S_POS + 1]
+    assert abs(float(y[1]) - float(y[0])) > 1e-4 and abs(float(z[1]) - float(z[0])) < 1e-4
+    # forces persist: updating one link leaves the other in place (pybullet_backend.py:619-623)
+    held.set_external_forces({"left_wheel_tire": ExternalForce([0.0, 0.0, 0.0])})
+    z_before = float(held.sim.state[abi.S_POS + 2, 0])
+    for _ in range(10):
+        held.step(held.get_neutral_action())
+    assert abs(float(held.sim.state[abi.S_POS + 2, 0]) - z_before) < 5e-3
+    with pytest.raises(UpkieRuntimeError):
+        held.set_external_forces({"no_such_link": ExternalForce([0.0, 0.0, 1.0])})
+    with pytest.raises(UpkieRuntimeError):  # more links than force slots
+        held.set_external_forces({name: ExternalForce([0.0, 0.0, 1.0]) for name in ("imu", "left_thigh", "right_thigh", "left_calf")})

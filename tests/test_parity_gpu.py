@@ -504,3 +504,53 @@ def test_two_lanes_per_env_equals_one_lane_per_env(mode, monkeypatch):
         assert_mostly_close(outs[0][0][:, :, 0].cpu().numpy(), outs[1][0][:, :, 0].cpu().numpy(), atol=5e-3, fraction=0.9)
     else:
         assert_mostly_close(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-2, fraction=0.9)
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_external_forces_on_any_link_match_oracle(lanes, monkeypatch):
+    """Four simultaneous forces (pybullet_backend.py:603-658): world-frame on
+    the trunk, link-frame on a calf, world-frame on the other leg's thigh and
+    on a wheel, per env, through both lane mappings."""
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 200
+    cfg = randomized_config(B, seed=21)
+    cfg.init_pos[2] = 0.9  # hanging above the floor: no contact masks the effect of the forces
+    oracle, sim = make_pair(B, cfg=cfg)
+    rng = np.random.default_rng(4)
+    bodies, local = [0, 2, 4, 6], [False, True, False, False]
+    points = [[0.0, 0.0, 0.05], [0.01, -0.02, -0.1], [0.0, 0.03, -0.08], [0.0, 0.0, 0.0]]
+    forces = rng.uniform(-6.0, 6.0, (4, 3, B))
+    forces[0, 2] += 30.0  # most of the weight is carried
+    slots = abi.UpkieExternalForces()
+    slots.count = 4
+    for i in range(4):
+        slots.body[i], slots.local[i] = bodies[i], int(local[i])
+        for k in range(3):
+            slots.point[i][k] = points[i][k]
+    oracle.ext_force, oracle.ext_slots = forces, slots
+    sim.set_external_forces(torch.from_numpy(forces).float(), bodies=bodies, points=points, local=local)
+    oracle.reset()
+    sim.reset()
+    act = np.zeros((B, 6, 6))
+    act[:, :, 0] = np.nan  # no position feedback: the legs swing under the forces
+    act[:, :, 4] = 1.0
+    act[:, :, 5] = 16.0
+    for _ in range(8):
+        oracle.step_servos(act)
+        sim.step_servos(torch.from_numpy(act).float())
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 2e-5 and err["quat"] < 2e-5, err
+    assert err["q"] < 2e-4, err
+    # joint velocities per env: a few legs reach a joint stop during the swing (a discontinuity)
+    assert_mostly_close(sim.state_numpy()[abi.S_QD : abi.S_QD + 6].T, oracle.state[abi.S_QD : abi.S_QD + 6].T, atol=2e-2, fraction=0.95, hard_atol=0.2)
+    moved = np.abs(sim.state_numpy()[abi.S_Q : abi.S_Q + 6]).max(axis=1)
+    assert moved[1] > 1e-2 and moved[3] > 1e-2  # left knee (calf force) and right hip (thigh force) did swing
+    # removing the forces: free fall again
+    sim.set_external_forces(None)
+    oracle.ext_force, oracle.ext_slots = None, None
+    vz0 = sim.state_numpy()[abi.S_LINVEL + 2].copy()
+    sim.step_servos(torch.from_numpy(act).float())
+    oracle.step_servos(act)
+    dv = sim.state_numpy()[abi.S_LINVEL + 2] - vz0
+    assert np.allclose(dv, -9.81 * 0.005, atol=8e-3)  # the base is not the centre of mass: swinging legs shift it
+    assert state_errors(oracle.state, sim.state_numpy())["pos"] < 3e-5

@@ -168,6 +168,21 @@ class UpkieMpcConfig(C.Structure):
     ]
 
 
+MAX_EXTERNAL_FORCES = 4
+
+
+class UpkieExternalForces(C.Structure):
+    """Bodies, frames and application points of the external forces."""
+
+    _fields_ = [
+        ("count", C.c_int32),
+        ("body", C.c_int32 * MAX_EXTERNAL_FORCES),
+        ("local", C.c_int32 * MAX_EXTERNAL_FORCES),
+        ("reserved0", C.c_int32),
+        ("point", (C.c_double * 3) * MAX_EXTERNAL_FORCES),
+    ]
+
+
 class UpkieObserverConfig(C.Structure):
     _fields_ = [
         ("num_envs", C.c_int32),

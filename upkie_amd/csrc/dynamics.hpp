@@ -631,13 +631,53 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
   general_constraint_solve(M, S, R, rt, tb, tl, tr);
 }
 
+// External forces (pybullet_backend.py:603-658): up to 4 forces at a time, each
+// on one composite body (0 trunk, 1-3 left leg, 4-6 right leg) at a point given
+// in the body frame, expressed in the world frame or (local) in the body frame.
+struct ExtSlots {
+  int count;
+  int body[UPKIE_MAX_EXTERNAL_FORCES];
+  int local[UPKIE_MAX_EXTERNAL_FORCES];
+  float point[UPKIE_MAX_EXTERNAL_FORCES][3];
+};
+// Forces of ONE env: component d of slot i at force[(3 i + d) * stride];
+// force == nullptr: no external force. Read inside the substep (a rare path)
+// so that nothing of it stays live in the common path.
+struct ExtForces {
+  const float* force;
+  size_t stride;
+  const ExtSlots* slots;
+};
+
+// Force on link k (0 thigh, 1 calf, 2 wheel) of a leg. In: Fe = force in the
+// base frame (or in the body frame when `local`), `point` in the body frame.
+// Out: Fe in the base frame, application point p in the base frame, joint
+// torques S_j' [Fe; p x Fe] of the joints above the link.
+UPKIE_HD void ext_on_leg(const Leg& G, const float* q3, int k, bool local, V3 point, V3& Fe, V3& p, float (&text)[3]) {
+  float psi = 0.f;
+  V3 ok = G.o[0];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j <= k) psi = fmaf(G.sgn[j], q3[j], psi);
+    if (j == k) ok = G.o[j];
+  }
+  float sn, cs;
+  joint_sincos(psi, &sn, &cs);
+  p = ok + rot_y(cs, sn, point);
+  if (local) Fe = rot_y(cs, sn, Fe);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    V3 rr = p - G.o[j];
+    text[j] = j <= k ? G.sgn[j] * (rr.z * Fe.x - rr.x * Fe.z) : 0.f;
+  }
+}
+
 // One physics substep of duration h. tau: commanded joint torques.
-// scale: per-body inertia scales of this env or nullptr. ext_force (world
-// frame) acts on the trunk at base-frame point ext_point when has_ext.
+// scale: per-body inertia scales of this env or nullptr. ext: external forces.
 // Returns the floor-contact flag.
 template <class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
-                                                const float* scale, bool has_ext, V3 ext_force, V3 ext_point) {
+                                                const float* scale, const ExtForces& ext) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
   // unilateral rows with ERP 0.2): rare, handled by the general solver
   bool any_limit = false;
@@ -720,18 +760,36 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     V3 F = (-m0 * (kl + kl * vn)) * vc;
     V3 T = (-(ka + ka * wn)) * I0w;
     V3 Ntot = T + cross(c0, F);
-    if (has_ext) {
-      V3 Fe = v3(r00 * ext_force.x + r10 * ext_force.y + r20 * ext_force.z, r01 * ext_force.x + r11 * ext_force.y + r21 * ext_force.z,
-                 r02 * ext_force.x + r12 * ext_force.y + r22 * ext_force.z);
-      F = F + Fe;
-      Ntot = Ntot + cross(ext_point, Fe);
+    float tel[3] = {0.f, 0.f, 0.f}, ter[3] = {0.f, 0.f, 0.f};
+    if (ext.force) {
+      for (int i = 0; i < ext.slots->count; ++i) {
+        const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride],
+                        ext.force[(size_t)(3 * i + 2) * ext.stride]);
+        const int b = ext.slots->body[i];
+        const bool local = ext.slots->local[i] != 0;
+        const V3 pt = v3(ext.slots->point[i][0], ext.slots->point[i][1], ext.slots->point[i][2]);
+        V3 Fe = local ? f : v3(r00 * f.x + r10 * f.y + r20 * f.z, r01 * f.x + r11 * f.y + r21 * f.z, r02 * f.x + r12 * f.y + r22 * f.z);
+        V3 pe = pt;
+        float t3[3] = {0.f, 0.f, 0.f};
+        if (b >= 4) {
+          ext_on_leg(S.leg[1], &s.q[3], b - 4, local, pt, Fe, pe, t3);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) ter[j] += t3[j];
+        } else if (b >= 1) {
+          ext_on_leg(S.leg[0], &s.q[0], b - 1, local, pt, Fe, pe, t3);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) tel[j] += t3[j];
+        }
+        F = F + Fe;
+        Ntot = Ntot + cross(pe, Fe);
+      }
     }
     bb[0] = F.x - bias_f.x; bb[1] = F.y - bias_f.y; bb[2] = F.z - bias_f.z;
     bb[3] = Ntot.x - bias_n.x; bb[4] = Ntot.y - bias_n.y; bb[5] = Ntot.z - bias_n.z;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      bl[k] = tau[k] - M.joint_damping[k] * s.qd[k] - S.leg[0].bias[k];
-      br[k] = tau[3 + k] - M.joint_damping[3 + k] * s.qd[3 + k] - S.leg[1].bias[k];
+      bl[k] = tau[k] + tel[k] - M.joint_damping[k] * s.qd[k] - S.leg[0].bias[k];
+      br[k] = tau[3 + k] + ter[k] - M.joint_damping[3 + k] * s.qd[3 + k] - S.leg[1].bias[k];
     }
   }
   // Generalised impulse so far: t = h (applied - bias). The contact impulses

@@ -79,8 +79,7 @@ struct PhysPair {
 // owns. Returns the floor-contact flag (identical in both lanes).
 template <class ModelT>
 __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
-                                                     const float (&tau)[3], float h, float scale0, bool has_ext, V3 ext_force,
-                                                     V3 ext_point) {
+                                                     const float (&tau)[3], float h, float scale0, const ExtForces& ext) {
   bool own_limit = false;
   if (Lm.enforce) {
 #pragma unroll
@@ -159,16 +158,39 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     V3 F = (-m0 * (kl + kl * vn)) * vc;
     V3 T = (-(ka + ka * wn)) * I0w;
     V3 Ntot = T + cross(c0, F);
-    if (has_ext) {
-      V3 Fe = v3(r00 * ext_force.x + r10 * ext_force.y + r20 * ext_force.z, r01 * ext_force.x + r11 * ext_force.y + r21 * ext_force.z,
-                 r02 * ext_force.x + r12 * ext_force.y + r22 * ext_force.z);
-      F = F + Fe;
-      Ntot = Ntot + cross(ext_point, Fe);
+    float te[3] = {0.f, 0.f, 0.f};
+    if (ext.force) {
+      for (int i = 0; i < ext.slots->count; ++i) {
+        const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride],
+                        ext.force[(size_t)(3 * i + 2) * ext.stride]);
+        const int b = ext.slots->body[i];
+        const bool local = ext.slots->local[i] != 0;
+        const V3 pt = v3(ext.slots->point[i][0], ext.slots->point[i][1], ext.slots->point[i][2]);
+        V3 Fe = local ? f : v3(r00 * f.x + r10 * f.y + r20 * f.z, r01 * f.x + r11 * f.y + r21 * f.z, r02 * f.x + r12 * f.y + r22 * f.z);
+        if (b == 0) {  // trunk: identical in both lanes
+          F = F + Fe;
+          Ntot = Ntot + cross(pt, Fe);
+        } else {  // a leg link: the lane owning the leg computes, both add own + partner
+          const bool mine = (b >= 4) == (leg == 1);
+          V3 pe = pt;
+          float t3[3] = {0.f, 0.f, 0.f};
+          ext_on_leg(G, s.q, b >= 4 ? b - 4 : b - 1, local, pt, Fe, pe, t3);
+          V3 Ne = cross(pe, Fe);
+          if (!mine) {
+            Fe = v3(0.f, 0.f, 0.f);
+            Ne = v3(0.f, 0.f, 0.f);
+          }
+          F = F + pair_sum(Fe);
+          Ntot = Ntot + pair_sum(Ne);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) te[j] += mine ? t3[j] : 0.f;
+        }
+      }
     }
     tb[0] = h * (F.x - bias_f.x); tb[1] = h * (F.y - bias_f.y); tb[2] = h * (F.z - bias_f.z);
     tb[3] = h * (Ntot.x - bias_n.x); tb[4] = h * (Ntot.y - bias_n.y); tb[5] = h * (Ntot.z - bias_n.z);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tl[k] = h * (tau[k] - PL.damping[k] * s.qd[k] - G.bias[k]);
+    for (int k = 0; k < 3; ++k) tl[k] = h * (tau[k] + te[k] - PL.damping[k] * s.qd[k] - G.bias[k]);
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) rt[c] = tb[c] - pair_sum(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
@@ -485,20 +507,14 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     yawvel = SW(UPKIE_S_YAWVEL);
   }
   float scale0 = 1.f, scale3[3] = {1.f, 1.f, 1.f};
-  V3 fext = v3(0.f, 0.f, 0.f);
-  bool has_ext = false;
   if (RAND) {
     if (inertia_scale) {
       scale0 = inertia_scale[e];
 #pragma unroll
       for (int k = 0; k < 3; ++k) scale3[k] = inertia_scale[(size_t)(1 + 3 * leg + k) * B + e];
     }
-    if (ext_force) {
-      has_ext = true;
-      fext = v3(ext_force[e], ext_force[(size_t)B + e], ext_force[(size_t)2 * B + e]);
-    }
   }
-  const V3 ext_point = v3(C.ext_point[0], C.ext_point[1], C.ext_point[2]);
+  const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
   // the owned leg's constants: selected once, kept in registers for the launch
   const PairLeg PL = load_pair_leg(*(ConstModelPtr)Mp, Lm, C, leg, RAND ? scale3 : nullptr);
   const DevModel& M = *Mp;
@@ -624,7 +640,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     {
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, scale0, has_ext, fext, ext_point);
+      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, scale0, ext);
     }
   }
 

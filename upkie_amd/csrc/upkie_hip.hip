@@ -40,7 +40,7 @@ struct DevConfig {
   int autoreset_mode;
   float agent_gains[4];
   float agent_clip;
-  float ext_point[3];
+  ExtSlots ext;
 };
 
 enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4, MODE_BASE_VELOCITY = 5 };
@@ -232,8 +232,6 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     yawvel = SW(UPKIE_S_YAWVEL);
   }
   float scale[UPKIE_NB];
-  V3 fext = v3(0.f, 0.f, 0.f);
-  bool has_ext = false;
   if (RAND) {
     if (inertia_scale) {
 #pragma unroll
@@ -242,12 +240,8 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
 #pragma unroll
       for (int i = 0; i < UPKIE_NB; ++i) scale[i] = 1.f;
     }
-    if (ext_force) {
-      has_ext = true;
-      fext = v3(ext_force[e], ext_force[(size_t)B + e], ext_force[(size_t)2 * B + e]);
-    }
   }
-  const V3 ext_point = v3(C.ext_point[0], C.ext_point[1], C.ext_point[2]);
+  const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
 
   bool do_reset;
   if (MODE == MODE_RESET) {
@@ -362,7 +356,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, has_ext, fext, ext_point);
+      contact = physics_substep(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, ext);
     }
   }
 
@@ -833,7 +827,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
   DevConfig next;
   std::string why;
   if (!convert_config(config, &next, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);
-  for (int k = 0; k < 3; ++k) next.ext_point[k] = sim->config.ext_point[k];
+  next.ext = sim->config.ext;
   sim->config = next;
   return UPKIE_OK;
 }
@@ -857,7 +851,32 @@ extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_s
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   sim->inertia_scale = inertia_scale;
   sim->ext_force = ext_force;
-  for (int k = 0; k < 3; ++k) sim->config.ext_point[k] = ext_point ? (float)ext_point[k] : 0.f;
+  ExtSlots& x = sim->config.ext;  // one world-frame force on the trunk
+  x = ExtSlots{};
+  x.count = ext_force ? 1 : 0;
+  for (int k = 0; k < 3; ++k) x.point[0][k] = ext_point ? (float)ext_point[k] : 0.f;
+  return UPKIE_OK;
+}
+
+extern "C" int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces, const UpkieExternalForces* slots) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  ExtSlots x{};
+  if (forces && slots && slots->count > 0) {
+    if (slots->count > UPKIE_MAX_EXTERNAL_FORCES)
+      return fail(sim, UPKIE_ERR_INVALID_ARGUMENT,
+                  "at most " + std::to_string(UPKIE_MAX_EXTERNAL_FORCES) + " external forces at a time");
+    x.count = slots->count;
+    for (int i = 0; i < slots->count; ++i) {
+      if (slots->body[i] < 0 || slots->body[i] >= UPKIE_NB) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "external force on an unknown body");
+      x.body[i] = slots->body[i];
+      x.local[i] = slots->local[i] ? 1 : 0;
+      for (int k = 0; k < 3; ++k) x.point[i][k] = (float)slots->point[i][k];
+    }
+    sim->ext_force = forces;
+  } else {
+    sim->ext_force = nullptr;
+  }
+  sim->config.ext = x;
   return UPKIE_OK;
 }
 

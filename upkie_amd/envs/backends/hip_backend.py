@@ -13,6 +13,7 @@ from ...model.model import Model
 from ...utils.external_force import ExternalForce
 from ...utils.robot_state import RobotState
 from ...utils.robot_state_randomization import RobotStateRandomization
+from ..external_forces import ExternalForceSet
 from ..spine_observation import spine_observation_dict
 from .backend import Backend
 
@@ -59,6 +60,7 @@ class HipBackend(Backend):
 
             sim_factory = lambda c, m, d: BatchedSim(c, m, device=d)  # noqa: E731
         self.sim = sim_factory(cfg, self._model.struct, device)
+        self._external_forces = ExternalForceSet(self._model, 1)
         self.config = cfg
         self.inertia_variation = inertia_variation
         self.torque_control_kd = torque_control_kd
@@ -129,18 +131,7 @@ class HipBackend(Backend):
         self.sim.randomize_inertias(inertia_variation)
 
     def set_external_forces(self, external_forces: Dict[str, ExternalForce]) -> None:
-        """pybullet_backend.py:603-623. One world-frame force on a link that is
-        rigidly part of the trunk (base, torso, imu, hip stators)."""
-        if len(external_forces) > 1:
-            raise UpkieRuntimeError("the HIP backend applies one external force at a time")
-        for link_name, external_force in external_forces.items():
-            if link_name not in self._model.link_names:
-                raise UpkieRuntimeError(f"Robot does not have a link named '{link_name}'")
-            if self._model.body_of_link(link_name) != 0:
-                raise UpkieRuntimeError(f"external forces on '{link_name}': only trunk links are supported")
-            if external_force.local:
-                raise UpkieRuntimeError("link-frame external forces are not supported by the HIP backend")
-            force = torch.tensor(external_force.force, dtype=torch.float32).reshape(3, 1)
-            self.sim.set_external_force(force, point=tuple(self._model.link_position_in_base(link_name)))
-        if not external_forces:
-            self.sim.set_external_force(None)
+        """pybullet_backend.py:603-623: forces on any link, world or link
+        frame, persisting until the link is given another force."""
+        self._external_forces.update(external_forces)
+        self._external_forces.push(self.sim)

@@ -25,6 +25,7 @@ from ..model.joint_properties import JointProperties
 from ..model.model import Model
 from ..utils.robot_state import RobotState
 from .spaces import Box, Dict as DictSpace, batch_box
+from .external_forces import ExternalForceSet
 from .spine_observation import LazySpineObservation
 
 
@@ -117,7 +118,7 @@ class UpkieVecEnv:
         if abs(self.inertia_variation) > 1e-10:  # pybullet_backend.py:178-179
             self.sim.randomize_inertias(self.inertia_variation)
         self._spine = LazySpineObservation(self.sim)
-        self._external_forces: Dict[str, object] = {}
+        self._external_forces = ExternalForceSet(self.model, self.num_envs)
         self._elapsed = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         self._pending_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         # Optional spine observer pipeline (FloorContact, WheelOdometry,
@@ -196,24 +197,22 @@ class UpkieVecEnv:
         self.init_state.write_to_config(self.config)
         self.sim.push_config()
 
-    def set_external_forces(self, link_name: str, forces: Optional[torch.Tensor]) -> None:
-        """World-frame force ``[B, 3]`` (or ``[3]``) applied at the origin of
-        `link_name`'s frame every substep until overwritten
-        (pybullet_backend.py:603-658). Links rigidly part of the trunk only."""
-        if link_name not in self.model.link_names:
-            raise UpkieRuntimeError(f"Robot does not have a link named '{link_name}'")
-        if self.model.body_of_link(link_name) != 0:
-            raise UpkieRuntimeError(f"external forces on '{link_name}': only trunk links are supported")
-        if forces is None:
-            self.sim.set_external_force(None)
-            return
-        forces = torch.as_tensor(forces, dtype=torch.float32)
-        if forces.shape == (3,):
-            forces = forces.expand(self.num_envs, 3)
-        if tuple(forces.shape) != (self.num_envs, 3):
-            raise ValueError(f"Force must be a 3D vector per env, got shape {tuple(forces.shape)}")
-        point = self.model.link_position_in_base(link_name)
-        self.sim.set_external_force(forces.t().contiguous(), point=tuple(point))
+    def set_external_forces(self, external_forces, forces: Optional[torch.Tensor] = None) -> None:
+        """``set_external_forces({link: ExternalForce | (force, local) | force})``
+        as PyBulletBackend.set_external_forces (pybullet_backend.py:603-658):
+        forces on any link, world or link frame, applied at the link's centre
+        of mass at every substep until the link is given another force; a
+        force is a 3-vector (all envs) or ``[B, 3]`` (one per env). The
+        two-argument form ``set_external_forces(link_name, forces)`` sets one
+        world-frame force (``None``: remove every force)."""
+        if isinstance(external_forces, str):
+            if forces is None:
+                self._external_forces.clear()
+            else:
+                self._external_forces.update({external_forces: (forces, False)})
+        else:
+            self._external_forces.update(external_forces)
+        self._external_forces.push(self.sim)
 
     def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
         if mask is None:

@@ -64,6 +64,20 @@ class Model:
         """Origin of a link frame in the base frame at the zero configuration."""
         return self._tree.p[link_name].copy()
 
+    def link_attachment(self, link_name: str):
+        """Where an external force on `link_name` acts: (composite body index,
+        the link's centre of mass in that body's frame, rotation from the link
+        frame to the body frame). Bullet applies forces at the link's inertial
+        frame: `getLinkState(...)[0]` / `getBasePositionAndOrientation` are
+        centre-of-mass positions and a LINK_FRAME position of [0, 0, 0] is the
+        centre of mass (pybullet_backend.py:636-658)."""
+        tree = self._tree
+        body = self.body_of_link(link_name)
+        root = tree.body_root_of(link_name)
+        origin = np.zeros(3) if body == 0 else tree.p[root]
+        com = tree.p[link_name] + tree.R[link_name] @ tree.links[link_name].com
+        return body, com - origin, tree.R[link_name].copy()
+
     def body_of_link(self, link_name: str) -> int:
         """Index of the composite body a link is rigidly part of."""
         order = {"left_hip": 1, "left_knee": 2, "left_wheel": 3, "right_hip": 4, "right_knee": 5, "right_wheel": 6}

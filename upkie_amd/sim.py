@@ -108,25 +108,44 @@ class BatchedSim:
     def set_external_force(self, force: Optional[torch.Tensor], point=(0.0, 0.0, 0.0)):
         """World-frame force ``[3, B]`` on the trunk at base-frame ``point``,
         held until overwritten (pybullet_backend.py:603-658)."""
-        if force is not None:
+        if force is None:
+            self.set_external_forces(None)
+        else:
             if tuple(force.shape) != (3, self.num_envs):
                 raise ValueError(  # external_force.py:38-41
                     f"force must have shape (3, {self.num_envs})"
                 )
-            force = force.to(self.device, torch.float32).contiguous()
-        self.ext_force = force
-        self._ext_point = (C.c_double * 3)(*[float(x) for x in point])
+            self.set_external_forces(force[None], bodies=[0], points=[point], local=[False])
+
+    def set_external_forces(self, forces: Optional[torch.Tensor], bodies=(), points=(), local=()):
+        """Forces ``[count, 3, B]`` acting at the same time, force `i` on
+        composite body ``bodies[i]`` (0 trunk, 1-3 left thigh/calf/wheel, 4-6
+        right) at ``points[i]`` of that body's frame, in the world frame or,
+        with ``local[i]``, in the body frame; re-applied at every substep until
+        replaced (pybullet_backend.py:603-658). None removes them."""
+        slots = abi.UpkieExternalForces()
+        if forces is not None:
+            count = len(bodies)
+            if count > abi.MAX_EXTERNAL_FORCES:
+                raise ValueError(f"at most {abi.MAX_EXTERNAL_FORCES} external forces at a time")
+            if tuple(forces.shape) != (count, 3, self.num_envs) or len(points) != count or len(local) != count:
+                raise ValueError(f"forces must have shape ({count}, 3, {self.num_envs})")
+            forces = forces.to(self.device, torch.float32).contiguous()
+            slots.count = count
+            for i in range(count):
+                slots.body[i] = int(bodies[i])
+                slots.local[i] = 1 if local[i] else 0
+                for k in range(3):
+                    slots.point[i][k] = float(points[i][k])
+        self.ext_force = forces
+        self._ext_slots = slots
         self._push_randomization()
 
     def _push_randomization(self):
-        self._check(
-            self._lib.upkie_sim_set_randomization(
-                self._handle,
-                _ptr(self.inertia_scale),
-                _ptr(self.ext_force),
-                self._ext_point,
-            )
-        )
+        self._check(self._lib.upkie_sim_set_randomization(self._handle, _ptr(self.inertia_scale), None, None))
+        slots = getattr(self, "_ext_slots", None)
+        if self.ext_force is not None and slots is not None:
+            self._check(self._lib.upkie_sim_set_external_forces(self._handle, _ptr(self.ext_force), C.byref(slots)))
 
     # ---------------------------------------------------------------- API
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
