@@ -420,3 +420,23 @@ def test_external_forces_on_leg_links_and_link_frames():
         held.set_external_forces({"no_such_link": ExternalForce([0.0, 0.0, 1.0])})
     with pytest.raises(UpkieRuntimeError):  # more links than force slots
         held.set_external_forces({name: ExternalForce([0.0, 0.0, 1.0]) for name in ("imu", "left_thigh", "right_thigh", "left_calf")})
+
+
+def test_cookie_ids_build_a_right_wheeled_robot():
+    """Cookie-* ids (entry_points.py:295-336): same envs on the right-wheeled
+    model; commands and odometry keep their meaning (model.py:92-104,
+    upkie_gyropod.py:276-291)."""
+    cookie = envs.make("Cookie-HIP-Gyropod-Vec", num_envs=1, **KW)
+    upkie = envs.make("Upkie-HIP-Gyropod-Vec", num_envs=1, **KW)
+    assert cookie.model.left_wheeled is False and upkie.model.left_wheeled is True
+    results = {}
+    for name, env in (("cookie", cookie), ("upkie", upkie)):
+        obs, _ = env.reset(seed=0)
+        for _ in range(40):
+            obs, *_ = env.step(torch.tensor([[0.5, 0.0]]))
+        results[name] = (float(env.sim.state[abi.S_POS, 0]), float(obs[0, 0]), float(env.sim.state[abi.S_QD + 2, 0]))
+    assert results["cookie"][1] > 0.02 and results["upkie"][1] > 0.02  # both roll forward (wheel odometry) ...
+    assert results["cookie"][0] == pytest.approx(results["upkie"][0], abs=1e-4)  # ... the same way (the unbalanced body leans back)
+    assert results["cookie"][1] == pytest.approx(results["upkie"][1], abs=1e-4)
+    assert results["cookie"][2] * results["upkie"][2] < 0  # with the left wheel turning the other way
+    assert "Cookie-PyBullet-Pendulum" in envs.entry_points.COOKIE_IDS

@@ -5,8 +5,14 @@ upkie/envs/__init__.py:24-44. Ids follow ``<Robot>-<Backend>-<Action>``:
     Upkie-HIP-{...}-Vec                                     num_envs robots, torch API
 
 ``Upkie-PyBullet-*`` resolves to the HIP envs when pybullet is not installed,
-so agents written against the reference ids run unchanged.
+so agents written against the reference ids run unchanged. ``Cookie-*`` ids
+(the right-wheeled sibling robot, entry_points.py:295-336) build the same envs
+on the Cookie model.
 """
+
+import os
+
+from ..model.model import Model
 
 from .single import UpkieBaseVelocity, UpkieGyropod, UpkiePendulum, UpkieServos
 from .vec_env import (
@@ -56,6 +62,23 @@ def make_upkie_hip_base_velocity_vec(**kwargs):
     return UpkieBaseVelocityVecEnv(**kwargs)
 
 
+def _get_cookie_model() -> Model:
+    """entry_points.py:295-308: the Cookie URDF of `cookie_description` when
+    that package is installed, else the synthetic right-wheeled model."""
+    try:
+        import cookie_description  # type: ignore
+
+        return Model(urdf_path=cookie_description.URDF_PATH)
+    except ImportError:
+        here = os.path.dirname(os.path.abspath(__file__))
+        return Model(urdf_path=os.path.join(here, "..", "model", "cookie_synthetic.urdf"))
+
+
+def make_cookie(env_id: str, **kwargs):
+    kwargs.setdefault("model", _get_cookie_model())
+    return globals()[REGISTRY["Upkie" + env_id[len("Cookie"):]]](**kwargs)
+
+
 def _snake(name: str) -> str:
     return "base_velocity" if name == "BaseVelocity" else name.lower()
 
@@ -67,8 +90,13 @@ for _action in ACTIONS:
     REGISTRY[f"Upkie-PyBullet-{_action}"] = f"make_upkie_hip_{_snake(_action)}"
 
 
+COOKIE_IDS = tuple("Cookie" + env_id[len("Upkie"):] for env_id in REGISTRY)
+
+
 def make(env_id: str, **kwargs):
     """``gym.make`` equivalent that works without gymnasium installed."""
+    if env_id in COOKIE_IDS:
+        return make_cookie(env_id, **kwargs)
     if env_id not in REGISTRY:
         raise KeyError(f"unknown environment id {env_id!r}; known: {sorted(REGISTRY)}")
     return globals()[REGISTRY[env_id]](**kwargs)

@@ -34,16 +34,23 @@ def _rx(angle):
     return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
 
 
-def synthetic_urdf() -> str:
+def synthetic_urdf(right_wheeled: bool = False) -> str:
+    """URDF of the synthetic model. With `right_wheeled` the leg link frames
+    are built the other way round (z-axis of the LEFT wheel hub pointing to +y,
+    model.py:92-104), which is what distinguishes a Cookie from an Upkie
+    (model.py:22): every joint then turns about -y instead of +y in the base
+    frame and the wheel / odometry signs flip."""
     model = dm.default_model()
-    out = ['<?xml version="1.0"?>\n<robot name="upkie_synthetic">\n']
+    flip = -1.0 if right_wheeled else 1.0
+    name = "cookie_synthetic" if right_wheeled else "upkie_synthetic"
+    out = [f'<?xml version="1.0"?>\n<robot name="{name}">\n']
 
     # virtual links fixed to the base
     virtual = [
         ("torso", dm.TORSO_POS, (0.0, 0.0, 0.0)),
         ("imu", dm.IMU_POS, (np.pi, 0.0, np.pi)),  # tests/utils/test_rotations.py:48-55
-        ("left_hip_qdd100_stator", dm.HIP_POS, (np.pi / 2, 0.0, 0.0)),
-        ("right_hip_qdd100_stator", dm.mirror_y(dm.HIP_POS), (-np.pi / 2, 0.0, 0.0)),
+        ("left_hip_qdd100_stator", dm.HIP_POS, (flip * np.pi / 2, 0.0, 0.0)),
+        ("right_hip_qdd100_stator", dm.mirror_y(dm.HIP_POS), (-flip * np.pi / 2, 0.0, 0.0)),
     ]
     # base link inertial = trunk minus the virtual point masses
     M = model.mass[0]
@@ -71,8 +78,8 @@ def synthetic_urdf() -> str:
         )
 
     for side, (prefix, sign) in enumerate((("left", +1.0), ("right", -1.0))):
-        R = _rx(sign * np.pi / 2)  # leg link frames: z-axis lateral, pointing away from +-y
-        inertial_rpy = (-sign * np.pi / 2, 0.0, 0.0)  # brings the inertia axes back to base axes
+        R = _rx(flip * sign * np.pi / 2)  # leg link frames: z-axis lateral, pointing away from +-y
+        inertial_rpy = (-flip * sign * np.pi / 2, 0.0, 0.0)  # brings the inertia axes back to base axes
         chain = [
             (f"{prefix}_hip", f"{prefix}_hip_qdd100_stator", f"{prefix}_thigh", "revolute"),
             (f"{prefix}_knee", f"{prefix}_thigh", f"{prefix}_calf", "revolute"),
@@ -125,7 +132,9 @@ def synthetic_urdf() -> str:
 if __name__ == "__main__":
     import os
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "upkie_synthetic.urdf")
-    with open(path, "w") as f:
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "upkie_synthetic.urdf"), "w") as f:
         f.write(synthetic_urdf())
-    print("wrote", path)
+    with open(os.path.join(here, "cookie_synthetic.urdf"), "w") as f:
+        f.write(synthetic_urdf(right_wheeled=True))
+    print("wrote upkie_synthetic.urdf and cookie_synthetic.urdf")
