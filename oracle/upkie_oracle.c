@@ -1156,6 +1156,35 @@ double oracle_low_pass_filter(double prev_output, double cutoff_period, double n
 double oracle_pitch_from_quat(const double quat_wxyz[4]) { return pitch_from_quat(quat_wxyz); }
 
 
+/* ---- command / observation maps exposed for the golden tests
+ * (tests/test_reference_env_goldens.py compares them with the spine actions
+ * the reference's own wrappers produced, tests/golden/reference_envs.json) */
+void oracle_servo_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
+                           const double act[36], OracleServoCommand cmd[6]) {
+  for (int j = 0; j < NJ; ++j) {
+    cmd[j].position = act[6 * j + 0];
+    cmd[j].velocity = act[6 * j + 1];
+    cmd[j].feedforward_torque = act[6 * j + 2];
+    cmd[j].kp_scale = act[6 * j + 3];
+    cmd[j].kd_scale = act[6 * j + 4];
+    cmd[j].maximum_torque = act[6 * j + 5];
+  }
+  clamp_servo_commands(model, cfg, cmd);
+}
+
+/* state: one env as an array of UPKIE_STATE_WORDS doubles (leg filter words
+ * are advanced as a step would). */
+void oracle_gyropod_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
+                             double* state, double ground_velocity, double yaw_velocity,
+                             OracleServoCommand cmd[6]) {
+  gyropod_commands(model, cfg, state, ground_velocity, yaw_velocity, cmd);
+  clamp_servo_commands(model, cfg, cmd);
+}
+
+void oracle_gyropod_observation(const UpkieModel* model, const double* state, double obs6[6]) {
+  gyropod_observation(model, state, obs6);
+}
+
 /* One world-frame force at a trunk point (the original entry point). */
 int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
                    double h, const double* inertia_scale,

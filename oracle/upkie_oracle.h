@@ -161,6 +161,14 @@ void oracle_mpc_step(const UpkieMpcConfig* cfg, double* workspace,
                      double* first_input);
 
 
+/* ---- command / observation maps for the golden tests ---- */
+void oracle_servo_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
+                           const double act[36], OracleServoCommand cmd[6]);
+void oracle_gyropod_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
+                             double* state, double ground_velocity, double yaw_velocity,
+                             OracleServoCommand cmd[6]);
+void oracle_gyropod_observation(const UpkieModel* model, const double* state, double obs6[6]);
+
 /* ---- observer pipeline (upkie_oracle_observers.c) ---- */
 int oracle_observers_check(const UpkieObserverConfig* c);
 double oracle_pitch_frame_in_parent(const double R[9]);

@@ -170,8 +170,9 @@ class UpkieServos(_SingleEnv):
         act = np.zeros((6, 6), dtype=np.float32)
         for j, name in enumerate(JOINT_NAMES):
             for k, key in enumerate(ACTION_KEYS):
-                # missing keys fall back to the neutral action, upkie_servos.py:326-330
-                value = action[name][key] if key in action.get(name, {}) else self._neutral_action[name][key]
+                # missing keys fall back to the neutral action; a missing joint
+                # is a KeyError as in the reference (upkie_servos.py:326-330)
+                value = action[name][key] if key in action[name] else self._neutral_action[name][key]
                 act[j, k] = value.item() if isinstance(value, np.ndarray) else float(value)
         obs, reward, terminated, truncated, _ = self._vec.step(torch.from_numpy(act)[None])
         return self._obs(obs), float(reward[0].item()), bool(terminated[0].item()), bool(truncated[0].item()), self._info()
