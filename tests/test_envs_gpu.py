@@ -178,7 +178,7 @@ def test_hip_spine_serves_one_env_of_a_gpu_batch():
     spine = HipSpine(env, shm_name=name, env_index=5, batch_policy=batch_policy)
     thread = threading.Thread(target=spine.run, kwargs=dict(idle_sleep=1e-4), daemon=True)
     thread.start()
-    backend = SpineBackend(shm_name=name, retries=1)
+    backend = SpineBackend(shm_name=name, retries=1, timeout_ns=5_000_000_000)
     obs = backend.reset(RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58])))
     for _ in range(100):
         v = 10.0 * obs["base_orientation"]["pitch"] + obs["wheel_odometry"]["position"] + 0.1 * obs["wheel_odometry"]["velocity"]

@@ -153,7 +153,7 @@ def served_batch():
 
 def test_agent_drives_one_env_of_the_batch(served_batch):
     name, env, spine = served_batch
-    backend = SpineBackend(shm_name=name, retries=1)
+    backend = SpineBackend(shm_name=name, retries=1, timeout_ns=5_000_000_000)  # the spine is a thread of this (busy) process
     init = RobotState(position_base_in_world=np.array([0.1, 0.0, 0.58]), joint_configuration=np.array([0.1, -0.2, 0.0, 0.1, -0.2, 0.0]))
     with pytest.raises(SpineError):  # acting before start: Request.kError, StateMachine.cpp:83-85
         backend._spine.set_action({"servo": {}})

@@ -43,7 +43,14 @@ def nested_update(target: dict, new: dict) -> None:
 
 
 class SpineBackend(Backend):
-    def __init__(self, shm_name: str = "/upkie", model: Optional[Model] = None, spine_config: Optional[dict] = None, retries: int = 10):
+    def __init__(
+        self,
+        shm_name: str = "/upkie",
+        model: Optional[Model] = None,
+        spine_config: Optional[dict] = None,
+        retries: int = 10,
+        timeout_ns: int = 100_000_000,
+    ):
         model = model if model is not None else Model()
         sign = +1.0 if model.left_wheeled else -1.0  # spine_backend.py:137-139
         signed_radius = sign * model.wheel_radius
@@ -57,7 +64,7 @@ class SpineBackend(Backend):
         )
         if spine_config is not None:
             nested_update(config, spine_config)
-        self._spine = SpineInterface(shm_name, retries=retries)
+        self._spine = SpineInterface(shm_name, retries=retries, timeout_ns=timeout_ns)
         self._spine_config = config
         self._last_observation: dict = {}
 

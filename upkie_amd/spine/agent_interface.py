@@ -4,7 +4,6 @@ creates ``/dev/shm/<name>`` exclusively, lays it out as
 closed."""
 
 import sys
-from multiprocessing import resource_tracker
 from multiprocessing.shared_memory import SharedMemory
 
 from ..exceptions import UpkieRuntimeError
@@ -24,10 +23,6 @@ class AgentInterface:
                 f'Cannot open shared memory "{name}": file already exists. Is a spine already running? '
                 f"If a previous spine did not exit properly, remove /dev/shm{name if name.startswith('/') else '/' + name}"
             ) from exn
-        try:  # the interface unlinks the file itself; keep Python's tracker from doing it twice
-            resource_tracker.unregister(self._shm._name, "shared_memory")
-        except Exception:  # noqa: BLE001
-            pass
         self._buf = self._shm.buf
         self.set_request(Request.kNone)
 
