@@ -60,7 +60,7 @@ class StateMachine:
                 self._enter_state(State.kIdle)  # resets the request
             elif request == Request.kStop:
                 self._enter_state(State.kSendStops)
-            else:
+            elif request != Request.kError:
                 self._interface.set_request(Request.kError)
         elif self._state == State.kSendStops:
             if request == Request.kNone:
@@ -72,7 +72,10 @@ class StateMachine:
                     self._enter_state(State.kReset)
             elif request == Request.kStop:
                 self._enter_state(State.kSendStops)
-            else:
+            elif request != Request.kError:
+                # (the C++ default branch rewrites kError over kError; not
+                # rewriting it is the same protocol without the window in which
+                # the agent's acknowledgement kError -> kNone gets overwritten)
                 self._interface.set_request(Request.kError)
         # kReset / kStep: a cycle beginning should not happen; kShutdown / kOver: nothing
 
