@@ -60,6 +60,35 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+_REF_PATH = os.path.join(_HERE, "_ref", "libupkie_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+
+def build_ref(force: bool = False):
+    """Compile oracle/_ref from the reference's own sources when they are
+    present (build container); returns the path of the library or None."""
+    if os.path.isdir(REFERENCE_ROOT) and (force or not os.path.exists(_REF_PATH)):
+        subprocess.run(["make", "-C", _HERE, "ref", "-B"], check=True, capture_output=True)
+    return _REF_PATH if os.path.exists(_REF_PATH) else None
+
+
+_ref = None
+
+
+def ref_lib():
+    """The compiled reference pieces (oracle/_ref), or None when they were
+    never built."""
+    global _ref
+    if _ref is None:
+        path = build_ref()
+        if path is None:
+            return None
+        _ref = C.CDLL(path)
+        _ref.ref_low_pass_filter.restype = C.c_double
+        _ref.ref_low_pass_filter.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    return _ref
+
+
 _lib = None
 
 
