@@ -112,7 +112,27 @@ UPKIE_HD S3 rot_y(float c, float s, const S3& I) {
 }
 
 // Model constants, uniform across lanes (kernel argument => scalar loads).
+// Per-leg constants in the order the two-lanes-per-env kernel keeps them in
+// registers: a lane reads its own leg's row with a handful of 16-byte loads
+// instead of selecting every value out of the left / right pair.
+enum LegTableWord {
+  LT_MASS = 0,      // 3
+  LT_SIGN = 3,      // 3
+  LT_COM = 6,       // 3 x 3
+  LT_POS = 15,      // 3 x 3
+  LT_INERTIA = 24,  // 3 x 6
+  LT_DAMPING = 42,  // 3
+  LT_EFFORT = 45,
+  LT_VELOCITY = 48,
+  LT_WHEEL_CENTER = 51,
+  LT_LOWER = 54,
+  LT_UPPER = 57,
+  LT_BOUNDED = 60,  // 3, as 0.f / 1.f
+  LT_WORDS = 64
+};
+
 struct DevModel {
+  alignas(16) float leg_table[2][LT_WORDS];
   float mass[UPKIE_NB];
   float com[UPKIE_NB][3];
   float inertia[UPKIE_NB][6];

@@ -39,31 +39,44 @@ struct PairLeg {
 
 template <class ModelT>
 __device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int leg, const float* scale3) {
+  // the lane's row of DevModel::leg_table, 16 x 16 bytes (cached: two rows for the whole grid)
+  float t[LT_WORDS];
+  {
+    typedef float Vec4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) Vec4* GlobalVec;
+    GlobalVec row = (GlobalVec)(const void*)&M.leg_table[leg][0];
+#pragma unroll
+    for (int i = 0; i < LT_WORDS / 4; ++i) {
+      const Vec4 v = row[i];
+      t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+  }
   PairLeg P;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const int bl = 1 + k, br = 4 + k, jl = k, jr = 3 + k;
-    P.regs.m[k] = pick(leg, M.mass[bl], M.mass[br]);
+    const int jl = k, jr = 3 + k;
+    P.regs.m[k] = t[LT_MASS + k];
     P.regs.sc[k] = scale3 ? scale3[k] : 1.f;
-    P.regs.sg[k] = pick(leg, M.joint_sign[jl], M.joint_sign[jr]);
+    P.regs.sg[k] = t[LT_SIGN + k];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      P.regs.c[k][d] = pick(leg, M.com[bl][d], M.com[br][d]);
-      P.regs.p[k][d] = pick(leg, M.joint_pos[jl][d], M.joint_pos[jr][d]);
+      P.regs.c[k][d] = t[LT_COM + 3 * k + d];
+      P.regs.p[k][d] = t[LT_POS + 3 * k + d];
     }
 #pragma unroll
-    for (int d = 0; d < 6; ++d) P.regs.I[k][d] = pick(leg, M.inertia[bl][d], M.inertia[br][d]);
-    P.damping[k] = pick(leg, M.joint_damping[jl], M.joint_damping[jr]);
-    P.lower[k] = pick(leg, Lm.lower[jl], Lm.lower[jr]);
-    P.upper[k] = pick(leg, Lm.upper[jl], Lm.upper[jr]);
-    P.bounded[k] = pick(leg, Lm.bounded[jl], Lm.bounded[jr]);
-    P.effort[k] = pick(leg, M.joint_effort[jl], M.joint_effort[jr]);
-    P.velocity[k] = pick(leg, M.joint_velocity[jl], M.joint_velocity[jr]);
+    for (int d = 0; d < 6; ++d) P.regs.I[k][d] = t[LT_INERTIA + 6 * k + d];
+    P.damping[k] = t[LT_DAMPING + k];
+    P.lower[k] = t[LT_LOWER + k];
+    P.upper[k] = t[LT_UPPER + k];
+    P.bounded[k] = t[LT_BOUNDED + k] != 0.f;
+    P.effort[k] = t[LT_EFFORT + k];
+    P.velocity[k] = t[LT_VELOCITY + k];
     P.friction[k] = pick(leg, C.joint_friction[jl], C.joint_friction[jr]);
     P.control_noise[k] = pick(leg, C.control_noise[jl], C.control_noise[jr]);
     P.measurement_noise[k] = pick(leg, C.measurement_noise[jl], C.measurement_noise[jr]);
-    P.wheel_center[k] = pick(leg, M.wheel_center[0][k], M.wheel_center[1][k]);
+    P.wheel_center[k] = t[LT_WHEEL_CENTER + k];
   }
+  (void)Lm;
   return P;
 }
 

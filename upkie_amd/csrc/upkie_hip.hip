@@ -720,6 +720,26 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   d->pgs_iterations = m->pgs_iterations;
   d->pgs_tolerance = (float)m->pgs_tolerance;
   d->enforce_joint_limits = m->enforce_joint_limits ? 1 : 0;
+  for (int leg = 0; leg < 2; ++leg) {
+    float* t = d->leg_table[leg];
+    for (int k = 0; k < 3; ++k) {
+      const int b = 1 + 3 * leg + k, j = 3 * leg + k;
+      t[LT_MASS + k] = d->mass[b];
+      t[LT_SIGN + k] = d->joint_sign[j];
+      for (int a = 0; a < 3; ++a) {
+        t[LT_COM + 3 * k + a] = d->com[b][a];
+        t[LT_POS + 3 * k + a] = d->joint_pos[j][a];
+      }
+      for (int a = 0; a < 6; ++a) t[LT_INERTIA + 6 * k + a] = d->inertia[b][a];
+      t[LT_DAMPING + k] = d->joint_damping[j];
+      t[LT_EFFORT + k] = d->joint_effort[j];
+      t[LT_VELOCITY + k] = d->joint_velocity[j];
+      t[LT_WHEEL_CENTER + k] = d->wheel_center[leg][k];
+      t[LT_LOWER + k] = d->joint_lower[j];
+      t[LT_UPPER + k] = d->joint_upper[j];
+      t[LT_BOUNDED + k] = (d->joint_lower[j] > -1e30f && d->joint_upper[j] < 1e30f) ? 1.f : 0.f;
+    }
+  }
   return true;
 }
 
