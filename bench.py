@@ -5,8 +5,9 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): Upkie-Pendulum,
 README's PD-gain balancer evaluated on-device, init-state randomisation pitch
 +-0.1 rad, x +-0.05 m, omega_y +-0.1 rad/s, v_x +-0.05 m/s, fall_pitch 1.0,
 NEXT_STEP autoreset. One "step" = one env.step() of every env = ONE kernel
-launch per GPU; for N > 1 ranks each step also gathers the packed
-(obs, reward, terminated, truncated) records to rank 0 over RCCL.
+launch per GPU; for N > 1 ranks the packed (obs, reward, terminated,
+truncated) records of every step are gathered to rank 0 over RCCL, one
+asynchronous collective per 8-step chunk.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -145,7 +146,7 @@ def main() -> None:
             "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset",
             "envs_per_gpu": B,
             "total_envs": total_envs,
-            "gather": "RCCL gather of packed obs/reward/done records into rank 0's rollout ring buffer every step, overlapped with the next step" if world > 1 else "none (single GPU): records written straight into the rollout ring buffer",
+            "gather": f"RCCL gather of the packed obs/reward/done records of every step into rank 0's rollout ring buffer, one asynchronous collective per {env.gather.chunk}-step chunk, overlapped with the next chunk's kernels" if world > 1 else "none (single GPU): records written straight into the rollout ring buffer",
             "episode_resets_in_timed_region": resets,
         },
         "roofline": {

@@ -46,20 +46,38 @@ def produce(gather: RolloutGather, steps: int, lo: int, hi: int) -> bool:
     return ok
 
 
-def _worker(rank: int, world: int, port: int, envs: int, steps: int, horizon: int, out_path: str):
+def produce_more(gather: RolloutGather, first: int, last: int, lo: int, hi: int) -> bool:
+    ok = True
+    for step in range(first, last):
+        out = gather.begin_step()
+        ok = ok and torch.equal(gather.previous, record_pattern(step - 1, lo, hi))
+        out.copy_(record_pattern(step, lo, hi))
+        gather.end_step()
+    gather.flush()
+    return ok
+
+
+def _worker(rank: int, world: int, port: int, envs: int, steps: int, horizon: int, chunk: int, out_path: str):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r, w, _ = init_distributed(world, backend="gloo")
     assert (r, w) == (rank, world)
-    gather = RolloutGather(envs, rank, world, device="cpu", horizon=horizon)
+    gather = RolloutGather(envs, rank, world, device="cpu", horizon=horizon, chunk=chunk)
     lo, hi = shard_range(rank, world, envs * world)
     ok = produce(gather, steps, lo, hi)
     if rank == 0:
-        for step in range(max(0, steps - horizon), steps):  # the ring keeps the last `horizon` steps
-            flat = gather.rollout[step % horizon].reshape(world * envs, RECORD_WORDS)
+        kept = gather.horizon - gather.chunk  # whole chunks older than the one being filled
+        for step in range(max(0, steps - kept), steps):  # the ring keeps the last chunks
+            flat = gather.records(step).reshape(world * envs, RECORD_WORDS)
             ok = ok and torch.equal(flat, record_pattern(step, 0, world * envs))
-        ok = ok and torch.equal(gather.last(), gather.rollout[(steps - 1) % horizon])
+        ok = ok and torch.equal(gather.last(), gather.records(steps - 1))
+        ok = ok and torch.equal(gather.last(2), gather.records(steps - 3))
     else:
         ok = ok and gather.rollout is None and gather.last() is None
+    # a rollout continues after a flush in the middle of a chunk
+    ok = ok and produce_more(gather, steps, steps + 5, lo, hi)
+    if rank == 0:
+        for step in range(steps, steps + 5):
+            ok = ok and torch.equal(gather.records(step).reshape(world * envs, RECORD_WORDS), record_pattern(step, 0, world * envs))
     # max-over-ranks reduction used for the timing contract
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -73,19 +91,20 @@ def _worker(rank: int, world: int, port: int, envs: int, steps: int, horizon: in
         raise SystemExit(1)
 
 
-@pytest.mark.parametrize("steps,horizon", [(7, 16), (21, 8)])
-def test_pipelined_gather_world_size_2_gloo(tmp_path, steps, horizon):
+@pytest.mark.parametrize("steps,horizon,chunk", [(7, 16, 1), (21, 8, 1), (21, 16, 4), (37, 24, 8), (5, 32, 8)])
+def test_pipelined_gather_world_size_2_gloo(tmp_path, steps, horizon, chunk):
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(2, free_port(), 33, steps, horizon, str(out)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, free_port(), 33, steps, horizon, chunk, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
 
 
-def test_single_rank_writes_straight_into_the_ring():
-    gather = RolloutGather(5, 0, 1, device="cpu", horizon=4)
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_single_rank_writes_straight_into_the_ring(chunk):
+    gather = RolloutGather(5, 0, 1, device="cpu", horizon=4, chunk=chunk)
     assert produce(gather, 6, 0, 5)
     for step in (2, 3, 4, 5):
-        assert torch.equal(gather.rollout[step % 4, 0], record_pattern(step, 0, 5))
-    assert gather.current.data_ptr() == gather.rollout[6 % 4, 0].data_ptr()  # no staging copy
+        assert torch.equal(gather.records(step)[0], record_pattern(step, 0, 5))
+    assert gather.staging is None and gather.current.data_ptr() == gather.records(6)[0].data_ptr()  # no staging copy
 
 
 def test_world_size_mismatch_is_an_error(monkeypatch):

@@ -8,13 +8,14 @@ world (pybullet_backend.py:100-125), so envs are independent units and the
 random streams are keyed by the GLOBAL env index (results do not depend on the
 number of ranks).
 
-xGMI is point-to-point and the message is tiny (32 B/env: 128 KB per rank at
-4096 envs), so the gather is latency bound, not bandwidth bound. It is
-therefore taken off the critical path: records are double-buffered, the
-gather of step t is issued asynchronously and overlaps the kernel of step
-t + 1, and rank 0 receives straight into the slot of a rollout ring buffer
-``[T, world, B, 8]`` (the "PPO rollout consumer" of BASELINE.json configs[3]),
-so there is no extra copy on the consumer side either.
+xGMI is point-to-point and the message is tiny (32 B/env: 128 KB per rank and
+step at 4096 envs), so the gather is latency bound, not bandwidth bound. It is
+therefore taken off the critical path: records are staged in double-buffered
+chunks of `chunk` consecutive steps, a full chunk is gathered in one
+asynchronous collective that overlaps the kernels of the next chunk, and rank
+0 receives straight into a rollout ring buffer ``[chunks, world, chunk, B, 8]``
+(the "PPO rollout consumer" of BASELINE.json configs[3]), so there is no extra
+copy on the consumer side either.
 """
 
 import os
@@ -61,7 +62,7 @@ def init_distributed(expected_world: Optional[int] = None, backend: Optional[str
 
 
 class RolloutGather:
-    """Double-buffered per-env records on every rank + a rollout ring buffer on
+    """Per-env records of every step on each rank + a rollout ring buffer on
     rank 0 that the gathers write into directly.
 
     Usage per step ``t`` on every rank::
@@ -69,85 +70,112 @@ class RolloutGather:
         out = g.begin_step()          # buffer this step's kernel writes
         prev = g.previous             # buffer holding step t-1 (agent input)
         ... launch the step writing `out` ...
-        g.end_step()                  # async gather of `out` to rank 0
+        g.end_step()                  # every `chunk` steps: async gather to rank 0
 
-    `begin_step` first waits (stream-level) for the gather that last used the
-    buffer about to be overwritten, i.e. the one issued two steps earlier: the
-    gather of step t-1 is still free to run during step t's kernel.
+    Records are staged in chunks of `chunk` consecutive steps (two chunks,
+    double-buffered); a full chunk ``[chunk, B, words]`` travels in ONE
+    collective, issued asynchronously, that overlaps the kernels of the next
+    chunk. xGMI moves 128 KB in about a microsecond but a collective costs tens
+    of microseconds of launch latency, i.e. more than one env step: shipping
+    `chunk` steps per message takes the gather off the critical path whatever
+    the number of ranks ("gather per T-step rollout chunk
+    when the consumer allows"). `chunk=1` gathers every step.
     Works on any device / backend (RCCL for GPU tensors, gloo for CPU tests).
     """
 
-    def __init__(self, local_envs: int, rank: int, world_size: int, device, horizon: int = 128, words: int = RECORD_WORDS):
-        self.rank, self.world_size, self.horizon = rank, world_size, horizon
-        self.buffers = [torch.zeros((local_envs, words), dtype=torch.float32, device=device) for _ in range(2)]
+    def __init__(self, local_envs: int, rank: int, world_size: int, device, horizon: int = 128, words: int = RECORD_WORDS, chunk: int = 8):
+        self.rank, self.world_size = rank, world_size
+        self.chunk = max(1, int(chunk))
+        self.num_chunks = max(2, -(-int(horizon) // self.chunk))  # ring of chunks on rank 0
+        self.horizon = self.num_chunks * self.chunk
+        K = self.chunk
+        f32 = dict(dtype=torch.float32, device=device)
+        self.staging = torch.zeros((2, K, local_envs, words), **f32) if world_size > 1 else None
         self._work = [None, None]
         self._step = 0  # index of the step being produced
         self.rollout: Optional[torch.Tensor] = None
         if rank == 0:
-            # [T, world, B, words]: slot t % T holds step t of every env (rank-major = global env order)
-            self.rollout = torch.zeros((horizon, world_size, local_envs, words), dtype=torch.float32, device=device)
+            # [chunks, world, K, B, words]: step t of rank r at [t // K % chunks, r, t % K]
+            self.rollout = torch.zeros((self.num_chunks, world_size, K, local_envs, words), **f32)
+
+    def _slot(self, step: int) -> torch.Tensor:
+        K = self.chunk
+        if self.world_size == 1:  # single rank: produce straight into the ring
+            return self.rollout[(step // K) % self.num_chunks, 0, step % K]
+        return self.staging[(step // K) % 2, step % K]
 
     @property
     def current(self) -> torch.Tensor:
-        if self.world_size == 1:  # single rank: produce straight into the ring slot
-            return self.rollout[self._step % self.horizon, 0]
-        return self.buffers[self._step % 2]
+        return self._slot(self._step)
 
     @property
     def previous(self) -> torch.Tensor:
-        if self.world_size == 1:
-            return self.rollout[(self._step - 1) % self.horizon, 0]
-        return self.buffers[(self._step + 1) % 2]
+        return self._slot(self._step - 1)
 
     def begin_step(self) -> torch.Tensor:
-        work = self._work[self._step % 2]
-        if work is not None:
-            work.wait()  # the gather issued two steps ago has read this buffer
-            self._work[self._step % 2] = None
+        if self.world_size > 1 and self._step % self.chunk == 0:
+            c = (self._step // self.chunk) % 2
+            if self._work[c] is not None:
+                self._work[c].wait()  # the gather issued two chunks ago has read this buffer
+                self._work[c] = None
         return self.current
 
+    def _gather_chunk(self, chunk_index: int) -> None:
+        c = chunk_index % 2
+        gather_list: Optional[List[torch.Tensor]] = None
+        if self.rank == 0:
+            gather_list = list(self.rollout[chunk_index % self.num_chunks].unbind(0))
+        if self._work[c] is not None:
+            self._work[c].wait()
+        self._work[c] = dist.gather(self.staging[c], gather_list, dst=0, async_op=True)
+
     def end_step(self) -> None:
-        slot = self._step % self.horizon
-        out = self.current
-        if self.world_size > 1:
-            gather_list: Optional[List[torch.Tensor]] = None
-            if self.rank == 0:
-                gather_list = list(self.rollout[slot].unbind(0))
-            self._work[self._step % 2] = dist.gather(out, gather_list, dst=0, async_op=True)
+        step = self._step
         self._step += 1
+        if self.world_size > 1 and step % self.chunk == self.chunk - 1:
+            self._gather_chunk(step // self.chunk)
 
     def flush(self) -> None:
-        """Wait for every gather in flight (end of a rollout / of the bench)."""
+        """Ship a partially filled chunk and wait for every gather in flight
+        (end of a rollout / of the bench). Every rank must call it at the same
+        step."""
+        if self.world_size > 1 and self._step % self.chunk != 0:
+            self._gather_chunk(self._step // self.chunk)  # re-sent in full when the chunk completes
         for i, work in enumerate(self._work):
             if work is not None:
                 work.wait()
                 self._work[i] = None
 
-    def last(self, steps_back: int = 0) -> Optional[torch.Tensor]:
-        """Rank 0: records ``[world, B, words]`` of the step issued
-        `steps_back` steps before the latest one (after `flush`)."""
+    def records(self, step: int) -> Optional[torch.Tensor]:
+        """Rank 0: records ``[world, B, words]`` of absolute step `step` (one of
+        the last `horizon` steps, after `flush`)."""
         if self.rollout is None:
             return None
-        return self.rollout[(self._step - 1 - steps_back) % self.horizon]
+        return self.rollout[(step // self.chunk) % self.num_chunks, :, step % self.chunk]
+
+    def last(self, steps_back: int = 0) -> Optional[torch.Tensor]:
+        """Rank 0: records of the step issued `steps_back` steps before the
+        latest one (after `flush`)."""
+        return self.records(self._step - 1 - steps_back)
 
 
 class ShardedPendulum:
     """This rank's shard of a batch of Upkie-Pendulum envs plus the pipelined
     gather of per-step records into rank 0's rollout buffer."""
 
-    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128):
+    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8):
         from .sim import BatchedSim
 
         self.rank, self.world_size = rank, world_size
         self.sim = BatchedSim(config, model, device=device)
-        self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon)
+        self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon, chunk=chunk)
         self._device = self.sim.device
 
     def reset(self) -> None:
         obs6 = self.sim.reset()
         self.gather.flush()
-        for buf in self.gather.buffers:
-            buf.zero_()
+        if self.gather.staging is not None:
+            self.gather.staging.zero_()
         self.gather.previous.zero_()
         # the agent's first input: the reset observation, upkie_pendulum.py:17
         self.gather.previous[:, :4] = obs6[:, [1, 0, 4, 3]]
