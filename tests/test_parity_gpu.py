@@ -554,3 +554,61 @@ def test_external_forces_on_any_link_match_oracle(lanes, monkeypatch):
     dv = sim.state_numpy()[abi.S_LINVEL + 2] - vz0
     assert np.allclose(dv, -9.81 * 0.005, atol=8e-3)  # the base is not the centre of mass: swinging legs shift it
     assert state_errors(oracle.state, sim.state_numpy())["pos"] < 3e-5
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_joint_limit_on_one_leg_only(lanes, monkeypatch):
+    """Asymmetric joint stops: only the RIGHT knee is driven into its stop (the
+    left leg is held). In the two-lanes-per-env mapping the lane owning the left
+    leg learns about the limit from its partner: regression test for an
+    exchange that was skipped by a short-circuit `||` (the left lane then took
+    the contact-only branch while the right one took the limit branch)."""
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 96
+    cfg = randomized_config(B, seed=33)
+    cfg.init_pos[2] = 3.0  # falling freely for the whole test: the limit rows are the only constraints
+    oracle, sim = make_pair(B, cfg=cfg)
+    oracle.reset()
+    sim.reset()
+    act = np.zeros((B, 6, 6))
+    act[:, :, 3:5] = 1.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = np.nan
+    act[:, 4, 0] = np.nan  # right knee: no position feedback, pushed by a feedforward torque
+    act[:, 4, 2] = 10.0
+    for _ in range(120):  # 10 N m against kd = 1: about 10 rad/s, the stop at 2.51 rad is reached after ~0.3 s
+        oracle.step_servos(act)
+        sim.step_servos(torch.from_numpy(act).float())
+    s = sim.state_numpy()
+    assert np.isfinite(s[:25]).all()
+    limit = float(sim.model.joint_upper[4])
+    assert np.all(np.abs(s[abi.S_Q + 4]) > limit - 2e-3) and np.all(np.abs(s[abi.S_Q + 4]) < limit + 2e-2)  # resting on the stop
+    assert np.all(np.abs(s[abi.S_Q + 1]) < 0.2)  # the left knee stayed where it was held
+    err = state_errors(oracle.state, s)
+    legs = [abi.S_Q + j for j in (0, 1, 3, 4)]  # (free wheels drift apart in fp32: 2.8e-4 kg m^2 of inertia)
+    assert np.abs(oracle.state[legs] - s[legs]).max() < 2e-3 and err["pos"] < 1e-3 and err["q"] < 2e-2, err
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_collapse_with_limp_joints_stays_finite(lanes, monkeypatch):
+    """Every servo limp (no position feedback, zero damping gain): the robots
+    fall, fold into hip and knee stops on one side or both and roll on their
+    tires. 400 steps through the rare paths (limit rows + contacts, PGS
+    fallback) in either mapping: finite, joints within their stops."""
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 192
+    cfg = randomized_config(B, seed=5)
+    _, sim = make_pair(B, cfg=cfg)
+    sim.reset()
+    act = torch.zeros((B, 6, 6))
+    act[:, :, 0] = float("nan")
+    act[:, :, 3] = 1.0
+    act[:, :, 5] = 16.0
+    for _ in range(400):
+        sim.step_servos(act)
+    s = sim.state_numpy()
+    assert np.isfinite(s[:25]).all()
+    lower, upper = np.array(sim.model.joint_lower[:]), np.array(sim.model.joint_upper[:])
+    for j in (0, 1, 3, 4):
+        assert np.all(s[abi.S_Q + j] > lower[j] - 0.05) and np.all(s[abi.S_Q + j] < upper[j] + 0.05)
+    assert np.abs(s[abi.S_LINVEL : abi.S_LINVEL + 3]).max() < 20.0

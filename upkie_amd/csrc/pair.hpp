@@ -23,7 +23,12 @@ __device__ __forceinline__ float xchg(float x) {
 }
 __device__ __forceinline__ float pair_sum(float x) { return x + xchg(x); }
 __device__ __forceinline__ V3 pair_sum(V3 a) { return V3{pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)}; }
-__device__ __forceinline__ bool pair_any(bool b) { return b || xchg(b ? 1.f : 0.f) != 0.f; }
+// (the exchange comes first: under `b || xchg(...)` a lane whose b is true would skip the DPP
+// move and its partner would read a disabled lane)
+__device__ __forceinline__ bool pair_any(bool b) {
+  const float partner = xchg(b ? 1.f : 0.f);
+  return b || partner != 0.f;
+}
 template <class T>
 __device__ __forceinline__ T pick(int leg, T left, T right) {
   return leg ? right : left;
@@ -99,6 +104,12 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     for (int k = 0; k < 3; ++k) own_limit = own_limit || (PL.bounded[k] && (s.q[k] <= PL.lower[k] || s.q[k] >= PL.upper[k]));
   }
   const bool any_limit = Lm.enforce ? pair_any(own_limit) : false;
+#ifdef UPKIE_DEBUG_LIMIT
+  if (blockIdx.x == 0 && threadIdx.x < 2)
+    printf("pair lane %d leg %d enforce %d own_limit %d any_limit %d q %.9g %.9g %.9g lower %.9g %.9g upper %.9g %.9g bounded %d %d %d\n",
+           (int)threadIdx.x, leg, Lm.enforce, (int)own_limit, (int)any_limit, s.q[0], s.q[1], s.q[2], PL.lower[0], PL.lower[1], PL.upper[0],
+           PL.upper[1], PL.bounded[0], PL.bounded[1], PL.bounded[2]);
+#endif
 
   float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
   float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
