@@ -454,6 +454,204 @@ UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], floa
   }
 }
 
+// Rare path shared by both lane mappings: some hip/knee joint sits at its
+// position limit. Contacts and limits are solved together as ONE system of ten
+// rows with a fixed layout, so that every index below is a compile-time
+// constant and the whole solve lives in registers (no scratch arrays):
+//   rows 0-2 left tire (normal, rolling, lateral), rows 3-5 right tire,
+//   rows 6-9 limits of left hip, left knee, right hip, right knee.
+// A row that does not exist this substep (tire out of range, joint inside its
+// limits) is masked: unit diagonal, zero couplings, zero right-hand side, so it
+// leaves the other rows' arithmetic untouched and gets lam = 0. Same rows,
+// ordering and numerics as the 6-row path: direct LDL' solve, accepted when
+// feasible, otherwise projected and used as the warm start of projected
+// Gauss-Seidel sweeps (normals, then frictions, then limits). Row data come
+// reduced onto the base: Jt (6) and the leg part (3). On return
+// (tb, tl, tr) += J' lam.
+constexpr int kRows = 10;
+UPKIE_HD constexpr int row_leg(int r) { return r < 3 ? 0 : (r < 6 ? 1 : (r < 8 ? 0 : 1)); }
+UPKIE_HD constexpr int row_kind(int r) { return r >= 6 ? 2 : (r % 3 == 0 ? 0 : 1); }  // 0 normal, 1 friction, 2 limit
+UPKIE_HD constexpr int sym(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+template <class ModelT>
+UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
+                         const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
+                         const float (&Jt6)[6][6], const float (&Jb)[6][6], const float (&Jl6)[6][3], const float (&vnow)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
+                         float (&tb)[6], float (&tl)[3], float (&tr)[3]) {
+  float J[kRows][6], Ll[kRows][3], vn[kRows], bias[kRows], cf[kRows];
+  bool on[kRows];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int w = r / 3, k = r % 3;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) J[r][c] = Jt6[r][c];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Ll[r][j] = Jl6[r][j];
+    on[r] = active[w];
+    vn[r] = vnow[r];
+    cf[r] = k == 0 ? cfm : M.friction_cfm;
+    bias[r] = k == 0 ? (dists[w] <= 0.f ? erp * (-dists[w]) * ih : -dists[w] * ih) : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = i < 2 ? i : i + 1;  // joints 0, 1, 3, 4
+    const int w = j / 3, kk = j % 3, r = 6 + i;
+    float sign = 0.f, err = 0.f;
+    if (bounded[j] && q[j] <= lower[j]) {
+      sign = 1.f;
+      err = lower[j] - q[j];
+    } else if (bounded[j] && q[j] >= upper[j]) {
+      sign = -1.f;
+      err = q[j] - upper[j];
+    }
+    const Leg& G = S.leg[w];
+    // J = sign * e_j: no base part, reduced row = -D_w J_leg
+#pragma unroll
+    for (int c = 0; c < 6; ++c) J[r][c] = -sign * G.D[c][kk];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) Ll[r][jj] = jj == kk ? sign : 0.f;
+    on[r] = sign != 0.f;
+    vn[r] = sign * qd[j];
+    cf[r] = 0.f;
+    bias[r] = 0.2f * err * ih;  // Bullet's default ERP
+  }
+
+  // A = J M^-1 J' + CFM column by column (packed lower), rhs = -(v + J M^-1 t) + bias
+  float A[kRows * (kRows + 1) / 2], rhs[kRows], lam[kRows];
+#pragma unroll
+  for (int b = 0; b < kRows; ++b) {
+    float y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) y[c] = J[b][c];
+    ldl6_solve(S.A, y);
+    const float* hv = S.leg[row_leg(b)].Hinv;
+    const float k0 = hv[0] * Ll[b][0] + hv[3] * Ll[b][1] + hv[4] * Ll[b][2];
+    const float k1 = hv[3] * Ll[b][0] + hv[1] * Ll[b][1] + hv[5] * Ll[b][2];
+    const float k2 = hv[4] * Ll[b][0] + hv[5] * Ll[b][1] + hv[2] * Ll[b][2];
+    float vf = vn[b];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) vf = fmaf(y[c], rt[c], vf);
+    if (row_leg(b) == 0)
+      vf += k0 * tl[0] + k1 * tl[1] + k2 * tl[2];
+    else
+      vf += k0 * tr[0] + k1 * tr[1] + k2 * tr[2];
+    rhs[b] = on[b] ? -vf + bias[b] : 0.f;
+    lam[b] = 0.f;
+#pragma unroll
+    for (int a = b; a < kRows; ++a) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc = fmaf(J[a][c], y[c], acc);
+      if (row_leg(a) == row_leg(b)) acc += Ll[a][0] * k0 + Ll[a][1] * k1 + Ll[a][2] * k2;
+      if (a == b)
+        acc = on[a] ? acc + cf[a] : 1.f;
+      else
+        acc = (on[a] && on[b]) ? acc : 0.f;
+      A[sym(a, b)] = acc;
+    }
+  }
+
+  // LDL' of the 10 x 10 system (unit lower L stored in place of A's strict
+  // lower part, reciprocal pivots in idg), then two triangular solves
+  float Lf[kRows * (kRows + 1) / 2], idg[kRows];
+  bool spd = true;
+#pragma unroll
+  for (int j = 0; j < kRows; ++j) {
+    float d = A[sym(j, j)];
+#pragma unroll
+    for (int c = 0; c < j; ++c) d -= Lf[sym(j, c)] * Lf[sym(j, c)] * Lf[sym(c, c)];
+    spd = spd && d > 0.f;
+    Lf[sym(j, j)] = d;
+    idg[j] = fast_rcp(fmaxf(d, 1e-30f));
+#pragma unroll
+    for (int i = j + 1; i < kRows; ++i) {
+      float v = A[sym(i, j)];
+#pragma unroll
+      for (int c = 0; c < j; ++c) v -= Lf[sym(i, c)] * Lf[sym(j, c)] * Lf[sym(c, c)];
+      Lf[sym(i, j)] = v * idg[j];
+    }
+  }
+  const float mu = M.friction_mu;
+  bool need_pgs = !spd;
+  if (spd) {
+    float z[kRows];
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      float v = rhs[i];
+#pragma unroll
+      for (int c = 0; c < i; ++c) v -= Lf[sym(i, c)] * z[c];
+      z[i] = v;
+    }
+#pragma unroll
+    for (int i = kRows - 1; i >= 0; --i) {
+      float v = z[i] * idg[i];
+#pragma unroll
+      for (int c = i + 1; c < kRows; ++c) v -= Lf[sym(c, i)] * lam[c];
+      lam[i] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+      if (row_kind(r) != 1 && lam[r] < 0.f) {
+        lam[r] = 0.f;
+        need_pgs = true;
+      }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+      if (row_kind(r) == 1) {
+        const float lim = mu * lam[3 * (r / 3)];
+        if (lam[r] < -lim) { lam[r] = -lim; need_pgs = true; }
+        if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
+      }
+  }
+  if (need_pgs) {
+    float idiag[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) idiag[r] = fast_rcp(A[sym(r, r)]);
+    for (int it = 0; it < M.pgs_iterations; ++it) {
+      float change = 0.f, scale = 0.f;
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          if (row_kind(r) != pass) continue;
+          float al = 0.f;
+#pragma unroll
+          for (int b = 0; b < kRows; ++b) al = fmaf(A[sym(r, b)], lam[b], al);
+          float x = lam[r] + (rhs[r] - al) * idiag[r];
+          if (row_kind(r) == 1) {
+            const float lim = mu * lam[3 * (r / 3)];
+            x = fminf(fmaxf(x, -lim), lim);
+          } else {
+            x = fmaxf(x, 0.f);
+          }
+          x = on[r] ? x : 0.f;
+          change = fmaxf(change, fabsf(x - lam[r]));
+          scale = fmaxf(scale, fabsf(x));
+          lam[r] = x;
+        }
+      }
+      if (change <= M.pgs_tolerance * scale) break;
+    }
+  }
+  // t += J' lam (limit rows have no base part)
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tb[c] = fmaf(Jb[r][c], lam[r], tb[c]);
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (row_leg(r) == 0)
+        tl[j] = fmaf(Ll[r][j], lam[r], tl[j]);
+      else
+        tr[j] = fmaf(Ll[r][j], lam[r], tr[j]);
+    }
+  }
+}
+
 // General constraint solve (contacts + active hip/knee limits, up to 10 rows),
 // the rare path: taken only by envs with a joint at its limit. Same rows,
 // ordering and numerics as the 6-row path: rows = per touching wheel (normal,
@@ -595,12 +793,14 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
   }
 }
 
-// Rare path shared by both lane mappings: some hip/knee joint sits at its
-// position limit. Builds the row list (contact rows of the touching wheels in
+// Scratch-memory variant of limit_path() (same rows, same numerics) for the
+// register-capped build that runs two waves per SIMD on very large batches:
+// there the register-resident solve above would spill into the path every env
+// takes. Builds the row list (contact rows of the touching wheels in
 // wheel order, then one row per limited joint in joint order) from data of
 // BOTH legs and runs the general solver; (tb, tl, tr) += J' lam.
 template <class ModelT>
-UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
+UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt)[6][6], const float (&Jb)[6][6], const float (&Jl)[6][3], const float (&vnow)[6],
                          const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
@@ -706,7 +906,7 @@ UPKIE_HD void ext_on_leg(const Leg& G, const float* q3, int k, bool local, V3 po
 // One physics substep of duration h. tau: commanded joint torques.
 // scale: per-body inertia scales of this env or nullptr. ext: external forces.
 // Returns the floor-contact flag.
-template <class ModelT>
+template <bool SCRATCH_LIMITS = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
                                                 const float* scale, const ExtForces& ext) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
@@ -896,7 +1096,10 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   }
   float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (any_limit) {
-    limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
+    if (SCRATCH_LIMITS)
+      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
+    else
+      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
   } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors

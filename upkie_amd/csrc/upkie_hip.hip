@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, ext);
+      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, ext);
     }
   }
 
