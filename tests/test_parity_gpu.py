@@ -634,6 +634,16 @@ def test_flailing_robots_both_mappings_step_alike():
     os.environ.pop("UPKIE_LANES_PER_ENV")
     a, b = sims["1"], sims["2"]
     a.reset()
+    # third schedule: the 256-register build that very large batches run (its joint-limit solve
+    # works in scratch memory): the first B envs of a 131072-env batch mirror the trajectory
+    BIG = 131072
+    dense = BatchedSim(randomized_config(BIG, seed=77))
+    dense.reset()
+    act_big = torch.zeros((BIG, 6, 6), device=dense.device)
+    act_big[:, :, 0] = float("nan")
+    act_big[:, :, 4] = 0.2
+    act_big[:, :, 5] = 16.0
+    act_big[:, :, 2] = (torch.rand((BIG, 6), device=dense.device) * 2 - 1) * torch.tensor([16, 16, 1.7, 16, 16, 1.7], device=dense.device)
     from oracle import oracle as O
 
     oracle = O.Oracle(a.model, cfg)
@@ -651,10 +661,16 @@ def test_flailing_robots_both_mappings_step_alike():
         b.state.copy_(a.state)
         oracle.state[:] = a.state_numpy().astype(np.float64)
         t = torch.from_numpy(act)
+        dense.state[:, :B].copy_(a.state)
+        act_big[:B].copy_(t)
         a.step_servos(t)
         b.step_servos(t)
+        dense.step_servos(act_big)
         oracle.step_servos(act.astype(np.float64))
         sa, sb = a.state_numpy(), b.state_numpy()
+        sd = dense.state[:, :B].cpu().numpy()
+        assert np.isfinite(sd[:25]).all(), step
+        assert np.mean(np.abs(sa[:19] - sd[:19]).max(axis=0) > 2e-3) <= 0.05, step
         # ... and the fp64 oracle takes the same step from the same state
         eo = np.abs(sa[:19] - oracle.state[:19]).max(axis=0)
         oracle_far.append(float(np.mean(eo > 5e-3)))
