@@ -197,3 +197,40 @@ def test_hip_spine_serves_one_env_of_a_gpu_batch():
     assert spine.state_machine.state == State.kOver
     spine.close()
     env.close()
+
+
+def test_graph_captured_loop_equals_eager():
+    """hipGraph capture of policy ops + env.step (upkie_amd.graphs): same
+    trajectory as the eager loop, bit for bit."""
+    from upkie_amd.graphs import GraphedLoop
+    from upkie_amd.sim import BatchedSim
+
+    def make():
+        cfg = abi.default_sim_config(512, seed=3)
+        cfg.rand_pitch = 0.1
+        cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+        sim = BatchedSim(cfg)
+        sim.reset()
+        sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+        return sim
+
+    gain = torch.tensor([10.0, 1.0, 0.0, 0.1], device="cuda:0")
+    eager, graphed = make(), make()
+    act_e = torch.zeros(512, device="cuda:0")
+    act_g = torch.zeros(512, device="cuda:0")
+
+    def body(sim, act):
+        torch.matmul(sim.obs4, gain, out=act)
+        act.clamp_(-0.99, 0.99)
+        sim.step_pendulum(act)
+
+    loop = GraphedLoop(lambda: body(graphed, act_g), unroll=4, warmup=2)
+    # the warm-up and the capture itself advanced `graphed`: bring both to the same state
+    eager.state.copy_(graphed.state)
+    eager.obs4.copy_(graphed.obs4)
+    for _ in range(10):
+        loop.replay()
+    for _ in range(40):
+        body(eager, act_e)
+    torch.cuda.synchronize()
+    assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs4, graphed.obs4)
