@@ -413,7 +413,17 @@ int64_t upkie_observers_state_bytes(const UpkieObservers* observers);
 /* Observer::reset for masked envs (all when mask is NULL): filters, contacts
  * and odometry back to zero (FloorContact.cpp:26-35, WheelOdometry.cpp:10-14). */
 int upkie_observers_reset(UpkieObservers* observers, float* state, const uint8_t* mask, void* stream);
-/* One ObserverPipeline::run (read + write of the three observers). */
+/* Run FloorContact / WheelContact / WheelOdometry INSIDE every env step, one
+ * observer cycle per 1 ms physics substep: what the spine does under a slower
+ * agent (Spine::simulate, Spine.cpp:119-141: nb_substeps cycles per action).
+ * The spine period is the substep dt / nb_substeps (config->dt is ignored);
+ * observer_state is the caller's [UPKIE_OBSERVER_STATE_WORDS][B] buffer, read
+ * and written by the step kernels and cleared for envs that (auto)reset; its
+ * words are the observers' outputs. NULL config or state detaches. */
+int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConfig* config, float* observer_state);
+
+/* One ObserverPipeline::run (read + write of the three observers). in->servo
+ * == NULL: no "servo" block, only BaseOrientation runs (FloorContact.cpp:42-44). */
 int upkie_observers_step(UpkieObservers* observers, float* state, const UpkieObserverInput* in,
                          const UpkieObserverOutput* out, void* stream);
 

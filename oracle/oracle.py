@@ -36,6 +36,8 @@ class Randomization(C.Structure):
         ("ext_force", C.c_void_p),
         ("ext_point", C.c_double * 3),
         ("ext_slots", C.c_void_p),
+        ("observer_config", C.c_void_p),
+        ("observer_state", C.c_void_p),
     ]
 
 
@@ -153,19 +155,34 @@ class Oracle:
         self.ext_force = None  # [3, B] (legacy: trunk, world frame) or [count, 3, B] with ext_slots
         self.ext_point = np.zeros(3)
         self.ext_slots = None  # abi.UpkieExternalForces
+        self.observer_config = None  # abi.UpkieObserverConfig: spine observers inside the step ...
+        self.observer_state = None  # ... and their memory [OBSERVER_STATE_WORDS, B]
         self._lib = lib()
 
     # -- randomisation -----------------------------------------------------
     def _rnd(self):
-        if self.inertia_scale is None and self.ext_force is None:
+        if self.inertia_scale is None and self.ext_force is None and self.observer_config is None:
             return None
         r = Randomization()
         r.inertia_scale = _ptr(self.inertia_scale)
         r.ext_force = _ptr(self.ext_force)
         r.ext_point[:] = list(self.ext_point)
         r.ext_slots = C.cast(C.pointer(self.ext_slots), C.c_void_p) if (self.ext_slots is not None and self.ext_force is not None) else None
+        if self.observer_config is not None:
+            r.observer_config = C.cast(C.pointer(self.observer_config), C.c_void_p)
+            r.observer_state = _ptr(self.observer_state)
         self._rnd_keepalive = r
         return C.byref(r)
+
+    def attach_observers(self, config: abi.UpkieObserverConfig):
+        """Spine observers inside the step, one cycle per substep."""
+        h = self.config.dt / self.config.nb_substeps
+        check = abi.UpkieObserverConfig.from_buffer_copy(config)
+        check.dt = h
+        if self._lib.oracle_observers_check(C.byref(check)) != 0:
+            raise ValueError("observer filters need cutoff period > 2 dt (FilterError in the reference)")
+        self.observer_config = config
+        self.observer_state = np.zeros((abi.OBSERVER_STATE_WORDS, self.B))
 
     def sample_inertia_scales(self, variation: float):
         scale = np.zeros((abi.NB, self.B))

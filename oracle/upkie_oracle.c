@@ -665,6 +665,34 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
 }
 
 /* ------------------------------------------------------- SoA <-> env state */
+/* Spine observers attached to the simulation: the batched entry points point
+ * this at the observer memory of the env they are stepping (one OpenMP thread
+ * per env at a time). */
+typedef struct {
+  const UpkieObserverConfig* config;
+  double st[UPKIE_OBSERVER_STATE_WORDS];
+  int active;
+} SpineHook;
+static _Thread_local SpineHook g_spine;
+
+static void spine_begin(const OracleRandomization* rnd, int B, int e) {
+  g_spine.active = rnd && rnd->observer_config && rnd->observer_state;
+  if (!g_spine.active) return;
+  g_spine.config = rnd->observer_config;
+  for (int w = 0; w < UPKIE_OBSERVER_STATE_WORDS; ++w) g_spine.st[w] = rnd->observer_state[(int64_t)w * B + e];
+}
+static void spine_end(const OracleRandomization* rnd, int B, int e) {
+  if (!g_spine.active) return;
+  for (int w = 0; w < UPKIE_OBSERVER_STATE_WORDS; ++w) rnd->observer_state[(int64_t)w * B + e] = g_spine.st[w];
+  g_spine.active = 0;
+}
+static void spine_reset(void) {
+  if (g_spine.active) memset(g_spine.st, 0, sizeof(g_spine.st));
+}
+static void spine_cycle(const double* s, const double tau[6], double h) {
+  if (g_spine.active) oracle_observers_cycle_env(g_spine.config, h, g_spine.st, s + UPKIE_S_QD, tau);
+}
+
 static void load_env(const double* state, int B, int e, double s[NW]) {
   for (int w = 0; w < NW; ++w) s[w] = state[(int64_t)w * B + e];
 }
@@ -778,7 +806,9 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   }
   /* pybullet_backend.py:228: one stepSimulation() with no motor torque */
   const double zero_tau[6] = {0, 0, 0, 0, 0, 0};
+  spine_reset(); /* Observer::reset, then the spine cycles once */
   oracle_substep_ext(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, force, point);
+  spine_cycle(s, zero_tau, cfg->dt / cfg->nb_substeps);
   /* upkie_gyropod.py:236-240 */
   s[UPKIE_S_LEGREF + 0] = s[UPKIE_S_Q + 0];
   s[UPKIE_S_LEGREF + 1] = s[UPKIE_S_Q + 1];
@@ -821,7 +851,9 @@ void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
     load_env(state, B, e, s);
     if (!mask || mask[e]) {
       env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+      spine_begin(rnd, B, e);
       reset_env(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp);
+      spine_end(rnd, B, e);
       store_env(state, B, e, s);
     }
     if (obs6) gyropod_observation(model, s, obs6 + 6 * (int64_t)e);
@@ -878,6 +910,7 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
       s[UPKIE_S_TORQUE + j] = tau[j]; /* :293 */
     }
     oracle_substep_ext(model, s, tau, h, scale, force, point);
+    spine_cycle(s, tau, h);
   }
   s[UPKIE_S_STEP] = (double)(step + 1u);
 }
@@ -970,10 +1003,12 @@ void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
     const UpkieExternalForces* pp;
     load_env(state, B, e, s);
     env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+    spine_begin(rnd, B, e);
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[2 * e], act[2 * e + 1],
                      obs + 6 * (int64_t)e, &terminated[e], sp, fp, pp);
     reward[e] = 0.0; /* upkie_env.py:230 */
     truncated[e] = 0;
+    spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
 }
@@ -994,12 +1029,14 @@ void oracle_step_pendulum(const UpkieModel* model, const UpkieSimConfig* cfg,
     const UpkieExternalForces* pp;
     load_env(state, B, e, s);
     env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+    spine_begin(rnd, B, e);
     /* upkie_pendulum.py:139: action_2d = [action[0], 0.0] */
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[e], 0.0, obs6,
                      &terminated[e], sp, fp, pp);
     for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
     reward[e] = 0.0;
     truncated[e] = 0;
+    spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
 }
@@ -1018,6 +1055,7 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
     const UpkieExternalForces* pp;
     load_env(state, B, e, s);
     env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+    spine_begin(rnd, B, e);
     /* README.md:62-64 / examples/pybullet/pd_balancing.py:23-31 */
     double a = 0.0;
     for (int i = 0; i < 4; ++i) a += cfg->agent_gains[i] * obs[4 * (int64_t)e + i];
@@ -1027,6 +1065,7 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
     for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
     reward[e] = 0.0;
     truncated[e] = 0;
+    spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
 }
@@ -1062,6 +1101,7 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
     int did_reset;
     load_env(state, B, e, s);
     env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+    spine_begin(rnd, B, e);
     autoreset_or_null(model, cfg, s, cfg->env_id_offset + e, sp, fp, pp, &did_reset);
     if (!did_reset) {
       OracleServoCommand cmd[NJ];
@@ -1081,6 +1121,7 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
     reward[e] = 0.0;
     terminated[e] = 0; /* upkie_env.py:231-238: only the joystick ends it */
     truncated[e] = 0;
+    spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
 }

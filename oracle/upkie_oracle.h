@@ -45,6 +45,9 @@ typedef struct OracleRandomization {
   const double* ext_force;     /* [count][3][B] (count = 1 without ext_slots) */
   double ext_point[3];         /* without ext_slots: application point on the trunk, base frame */
   const UpkieExternalForces* ext_slots; /* bodies / points / frames of the forces, or NULL */
+  /* spine observers run inside the step, one cycle per substep (or NULL) */
+  const UpkieObserverConfig* observer_config;
+  double* observer_state; /* [UPKIE_OBSERVER_STATE_WORDS][B] */
 } OracleRandomization;
 
 /* Philox4x32-10 counter-based generator (Salmon et al., SC'11). */
@@ -170,6 +173,8 @@ void oracle_gyropod_commands(const UpkieModel* model, const UpkieSimConfig* cfg,
 void oracle_gyropod_observation(const UpkieModel* model, const double* state, double obs6[6]);
 
 /* ---- observer pipeline (upkie_oracle_observers.c) ---- */
+void oracle_observers_cycle_env(const UpkieObserverConfig* p, double dt, double* st,
+                                const double velocity[6], const double torque[6]);
 int oracle_observers_check(const UpkieObserverConfig* c);
 double oracle_pitch_frame_in_parent(const double R[9]);
 void oracle_base_orientation_from_imu(const double q[4], const double base_to_imu[9],

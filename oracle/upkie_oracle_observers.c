@@ -209,3 +209,46 @@ void oracle_observers_step(const UpkieObserverConfig* p, double* state, const do
 #undef OW
   }
 }
+
+/* One spine cycle of FloorContact + WheelOdometry for ONE env whose observer
+ * memory is st[UPKIE_OBSERVER_STATE_WORDS] (array of words, not SoA): used by
+ * the simulator when the observers run inside the step, once per physics
+ * substep of duration dt (Spine::simulate, Spine.cpp:119-141). velocity /
+ * torque: the six servo readings of this cycle. */
+void oracle_observers_cycle_env(const UpkieObserverConfig* p, double dt, double* st,
+                                const double velocity[6], const double torque[6]) {
+  int at_least_one_contact = 0;
+  WheelContactState wc[2];
+  for (int w = 0; w < 2; ++w) {
+    const int joint = 3 * w + 2;
+    wc[w].velocity = st[UPKIE_O_WHEEL + 5 * w + 0];
+    wc[w].abs_acceleration = st[UPKIE_O_WHEEL + 5 * w + 1];
+    wc[w].abs_torque = st[UPKIE_O_WHEEL + 5 * w + 2];
+    wc[w].inertia = st[UPKIE_O_WHEEL + 5 * w + 3];
+    wc[w].contact = st[UPKIE_O_WHEEL + 5 * w + 4];
+    wheel_contact_observe(p, &wc[w], torque[joint], velocity[joint], dt);
+    if (wc[w].contact != 0.0) at_least_one_contact = 1;
+    st[UPKIE_O_WHEEL + 5 * w + 0] = wc[w].velocity;
+    st[UPKIE_O_WHEEL + 5 * w + 1] = wc[w].abs_acceleration;
+    st[UPKIE_O_WHEEL + 5 * w + 2] = wc[w].abs_torque;
+    st[UPKIE_O_WHEEL + 5 * w + 3] = wc[w].inertia;
+    st[UPKIE_O_WHEEL + 5 * w + 4] = wc[w].contact;
+  }
+  const double squared = torque[0] * torque[0] + torque[1] * torque[1] + torque[3] * torque[3] + torque[4] * torque[4];
+  const double upper = low_pass_filter(st[UPKIE_O_UPPER_LEG_TORQUE], 0.01, sqrt(squared), dt);
+  st[UPKIE_O_UPPER_LEG_TORQUE] = upper;
+  const int contact = at_least_one_contact || (upper > p->upper_leg_torque_threshold);
+  st[UPKIE_O_CONTACT] = contact ? 1.0 : 0.0;
+  if (contact) {
+    double velocity_sum = 0.0;
+    unsigned nb = 0u;
+    for (int w = 0; w < 2; ++w) {
+      if (wc[w].contact == 0.0) continue;
+      velocity_sum += p->signed_radius[w] * velocity[3 * w + 2];
+      ++nb;
+    }
+    const double v = nb == 0u ? 0.0 : velocity_sum / nb;
+    st[UPKIE_O_ODOMETRY_VELOCITY] = v;
+    st[UPKIE_O_ODOMETRY_POSITION] += v * dt;
+  }
+}

@@ -41,6 +41,17 @@ class OracleSim:
     def flag_done(self, done):
         self._o.state[abi.S_DONE] = done.double().numpy()
 
+    def attach_observers(self, config):
+        if config is None:
+            self._o.observer_config = self._o.observer_state = None
+            return None
+        self._o.attach_observers(config)
+        return self.observer_state
+
+    @property
+    def observer_state(self):
+        return None if self._o.observer_state is None else torch.from_numpy(self._o.observer_state.astype(np.float32))
+
     def push_config(self):
         self._o.config = self.config
 
@@ -154,9 +165,16 @@ class OracleObservers:
         from upkie_amd.observers import observer_blocks
 
         n = lambda t: None if t is None else t.double().numpy()
+        only_base = servo is None
+        if only_base:
+            servo = torch.zeros((self.num_envs, 6, 5))
+            saved = self._o.state.copy()
         out = self._o.step(n(servo), n(imu_orientation), n(imu_angular_velocity), None if cross_button is None else cross_button.numpy())
+        if only_base:
+            self._o.state[:] = saved
         tensors = {k: torch.from_numpy(np.asarray(v, dtype=np.uint8 if v.dtype == np.uint8 else np.float32)) for k, v in out.items()}
-        return observer_blocks(tensors)
+        blocks = observer_blocks(tensors)
+        return {"base_orientation": blocks["base_orientation"]} if only_base else blocks
 
     def step_from_sim(self, sim, update_imu=False, cross_button=None):
         obs = sim.observe(update_imu=update_imu)

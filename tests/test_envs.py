@@ -221,18 +221,20 @@ def test_external_force_pushes_the_robot():
 
 
 def test_spine_observers_in_the_vector_env():
-    """`spine_observers=True` appends what the C++ spine's observer pipeline
-    writes (spines/common/observers.h:22-42) to info["spine_observation"] and
-    restarts the observers of envs that were reset."""
+    """`spine_observers=True`: the C++ spine's FloorContact / WheelContact /
+    WheelOdometry run inside the step, one observer cycle per 1 ms substep
+    (Spine::simulate cycles nb_substeps times per action), BaseOrientation
+    with the observation; their blocks are merged into
+    info["spine_observation"] and restart with the env."""
     from .fake_sim import OracleObservers
 
     kw = dict(KW, observers_factory=OracleObservers)
-    with pytest.raises(ValueError):  # 200 Hz: the 0.01 s torque filter is <= 2 dt (FilterError in the reference)
-        envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, frequency=200.0, spine_observers=True, **kw)
+    with pytest.raises(ValueError):  # one 5 ms cycle per step: the 0.01 s torque filter is <= 2 dt (FilterError in the reference)
+        envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, frequency=200.0, nb_substeps=1, spine_observers=True, **kw)
     env = envs.make(
         "Upkie-HIP-Pendulum-Vec",
         num_envs=4,
-        frequency=500.0,
+        frequency=200.0,  # the reference's agent rate: 5 spine cycles per step
         fall_pitch=0.25,
         init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58]), randomization=RobotStateRandomization(pitch=0.05)),
         spine_observers=True,
@@ -243,26 +245,31 @@ def test_spine_observers_in_the_vector_env():
     assert set(spine["floor_contact"]) >= {"contact", "upper_leg_torque", "left_wheel", "right_wheel"}
     assert spine["base_orientation"]["linear_velocity"].shape == (4, 3)  # the backend's block is kept, the observer's merged in
     odometry = []
-    restarted = torch.zeros(4, dtype=torch.bool)
+    restarted = False
     episodes = env.sim.state[abi.S_EPISODE].clone()
-    for k in range(700):
-        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.02 * k)
-        if k > 400:
+    for k in range(300):
+        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.05 * k)
+        if k > 160:
             act[0] = 3.0  # env 0 is driven into a fall and autoresets
         obs, _, terminated, _, info = env.step(act.reshape(4, 1))
         now = env.sim.state[abi.S_EPISODE]
-        if (now != episodes)[0] and not restarted[0]:
-            restarted[0] = True
-            # observers of a restarted env start from zero and have seen exactly one observation
+        if (now != episodes)[0] and not restarted:
+            restarted = True
+            # observers of a restarted env start from zero and have seen exactly one cycle
             assert abs(float(info["spine_observation"]["wheel_odometry"]["position"][0])) < 1e-3
+            assert float(info["spine_observation"]["floor_contact"]["upper_leg_torque"][0]) < 0.5
         episodes = now.clone()
         odometry.append(info["spine_observation"]["wheel_odometry"]["position"].clone())
     spine = info["spine_observation"]
-    assert restarted[0]
-    # the spine's pitch estimate agrees with the backend's (same frames by default)
+    assert restarted
     assert spine["floor_contact"]["contact"][1:].all()
     assert torch.stack(odometry)[:, 1:].abs().max() > 1e-3  # the integrator moved
     assert spine["floor_contact"]["left_wheel"]["inertia"].shape == (4,)
+    # the spine's pitch estimate agrees with the backend's (same frames by default)
+    assert torch.allclose(spine["base_orientation"]["pitch"], env.sim.observe(update_imu=False)["pitch"], atol=1e-5)
+    # velocity-integrating odometry tracks the position-based one while the wheels stay in contact
+    truth = env.sim.observe(update_imu=False)["wheel_odometry"][:, 0]
+    assert (spine["wheel_odometry"]["position"][1:] - truth[1:]).abs().max() < 0.05
 
 
 @pytest.mark.parametrize("env_id", ["Upkie-HIP-Pendulum-Vec", "Upkie-HIP-Gyropod-Vec"])

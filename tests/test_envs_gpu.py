@@ -124,16 +124,16 @@ def test_spine_observers_in_the_vector_env_on_device():
     env = envs.make(
         "Upkie-HIP-Pendulum-Vec",
         num_envs=B,
-        frequency=500.0,
+        frequency=200.0,  # 5 observer cycles (1 ms) inside every step
         fall_pitch=0.25,
         init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 0.58]), randomization=RobotStateRandomization(pitch=0.05)),
         spine_observers=True,
     )
     obs, info = env.reset(seed=1)
     first_episode = env.sim.state[abi.S_EPISODE].clone()
-    for k in range(700):
-        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.02 * k)
-        if k > 400:
+    for k in range(300):
+        act = (10.0 * obs[:, 0] + obs[:, 1] + 0.1 * obs[:, 3]).clamp(-0.99, 0.99) + 0.4 * math.sin(0.05 * k)
+        if k > 160:
             act[:16] = 3.0  # the first 16 envs are driven into a fall
         obs, _, terminated, _, info = env.step(act.reshape(B, 1))
     spine = info["spine_observation"]

@@ -158,3 +158,48 @@ def test_observers_on_simulated_robots():
     moved_true = (truth - truth0)[contact]
     moved_est = (out["wheel_odometry"]["position"] - est0)[contact]
     assert torch.allclose(moved_est, moved_true, atol=5e-3)
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_in_step_spine_observers_match_oracle(lanes, monkeypatch):
+    """FloorContact / WheelContact / WheelOdometry inside the step kernel (one
+    observer cycle per 1 ms substep, `upkie_sim_attach_observers`) against the
+    oracle doing the same, both lane mappings, with autoresets: observer memory
+    word by word."""
+    from tests.helpers import make_pair, randomized_config
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 300
+    cfg = randomized_config(B, seed=9, autoreset=True)
+    cfg.fall_pitch = 0.35
+    cfg.init_pos[2] = 0.58
+    oracle, sim = make_pair(B, cfg=cfg)
+    obs_cfg = abi.default_observer_config(B, 1e-3)
+    oracle.attach_observers(obs_cfg)
+    mem = sim.attach_observers(obs_cfg)
+    obs_o = oracle.reset()[:, [1, 0, 4, 3]]
+    sim.reset()
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    rng = np.random.default_rng(0)
+    flips = 0
+    for k in range(260):
+        drive = 0.5 * np.sin(0.03 * k) + (2.5 if k > 150 else 0.0) * (np.arange(B) < 40)  # the first 40 envs get driven into a fall
+        act = np.clip(10.0 * obs_o[:, 0] + obs_o[:, 1] + 0.1 * obs_o[:, 3], -0.99, 0.99) + drive
+        obs_o, _, _, _ = oracle.step_pendulum(act)
+        sim.step_pendulum(torch.from_numpy(act).float())
+        # follow the oracle's trajectory: the comparison is about the observers, not about chaos
+        sim.state.copy_(torch.from_numpy(oracle.state).float())
+        a, b = mem.cpu().numpy().astype(np.float64), oracle.observer_state
+        flags = [abi.O_WHEEL + 4, abi.O_WHEEL + 9, abi.O_CONTACT]
+        mism = (a[flags] != b[flags]).any(axis=0)
+        flips += int(mism.sum())
+        ok = ~mism
+        np.testing.assert_allclose(a[abi.O_UPPER_LEG_TORQUE, ok], b[abi.O_UPPER_LEG_TORQUE, ok], rtol=1e-3, atol=2e-3)
+        np.testing.assert_allclose(a[abi.O_ODOMETRY_POSITION, ok], b[abi.O_ODOMETRY_POSITION, ok], rtol=1e-3, atol=2e-4)
+        for w in (0, 1):
+            np.testing.assert_allclose(a[abi.O_WHEEL + 5 * w + 2, ok], b[abi.O_WHEEL + 5 * w + 2, ok], rtol=2e-3, atol=2e-4)  # abs_torque
+        if mism.any():  # a threshold decision flipped in fp32: resynchronise those envs
+            mem[:, torch.from_numpy(mism)] = torch.from_numpy(b[:, mism]).float().to(mem.device)
+    assert flips <= 0.01 * B * 260, flips
+    assert (oracle.state[abi.S_EPISODE] > 1).sum() >= 30  # resets happened, observers restarted with them
+    assert oracle.observer_state[abi.O_CONTACT].mean() > 0.5

@@ -30,6 +30,26 @@ struct ObserverDev {
 // upkie/cpp/utils/low_pass_filter.h:32-34 with alpha = dt / cutoff precomputed
 __device__ __forceinline__ float obs_low_pass(float prev, float alpha, float input) { return prev + alpha * (input - prev); }
 
+// WheelContact::observe, WheelContact.cpp:19-48 (one spine cycle of one wheel)
+__device__ __forceinline__ void wheel_contact_observe(const ObserverDev& P, float torque, float velocity, float& filt_vel, float& abs_acc,
+                                                      float& abs_tau, float& inertia, bool& contact) {
+  if (!P.wheels_configured) return;
+  const float prev = filt_vel;
+  filt_vel = obs_low_pass(filt_vel, P.wheel_alpha, velocity);
+  const float acc = (filt_vel - prev) * P.inv_dt;
+  abs_acc = obs_low_pass(abs_acc, P.wheel_alpha, fabsf(acc));
+  abs_tau = obs_low_pass(abs_tau, P.wheel_alpha, fabsf(torque));
+  const bool skip = !contact && (abs_acc < P.min_touchdown_acceleration || abs_tau < P.min_touchdown_torque);
+  if (!skip) {
+    inertia = abs_tau / (abs_acc + 1e-4f);
+    if (inertia < P.liftoff_inertia) {
+      contact = false;
+    } else if (inertia > P.touchdown_inertia) {
+      contact = true;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void observers_reset_kernel(int B, float* __restrict__ st, const uint8_t* __restrict__ mask) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
@@ -93,6 +113,7 @@ __global__ __launch_bounds__(64) void observers_step_kernel(ObserverDev P, float
   }
 
   // ---- FloorContact::read (FloorContact.cpp:37-50) -------------------------
+  if (!in.servo) return;  // no "servo" block: nothing to read, FloorContact.cpp:42-44
   const float* servo = in.servo + (size_t)30 * e;  // [6][5]: position, velocity, torque, ...
   const bool cross = in.cross_button && in.cross_button[e];
   bool any_wheel = false;
@@ -106,22 +127,7 @@ __global__ __launch_bounds__(64) void observers_step_kernel(ObserverDev P, float
     float filt_vel = OW(UPKIE_O_WHEEL + 5 * w + 0), abs_acc = OW(UPKIE_O_WHEEL + 5 * w + 1), abs_tau = OW(UPKIE_O_WHEEL + 5 * w + 2),
           inertia = OW(UPKIE_O_WHEEL + 5 * w + 3);
     bool contact = OW(UPKIE_O_WHEEL + 5 * w + 4) != 0.f;
-    if (P.wheels_configured) {  // WheelContact::observe, WheelContact.cpp:19-48
-      const float prev = filt_vel;
-      filt_vel = obs_low_pass(filt_vel, P.wheel_alpha, velocity);
-      const float acc = (filt_vel - prev) * P.inv_dt;
-      abs_acc = obs_low_pass(abs_acc, P.wheel_alpha, fabsf(acc));
-      abs_tau = obs_low_pass(abs_tau, P.wheel_alpha, fabsf(torque));
-      const bool skip = !contact && (abs_acc < P.min_touchdown_acceleration || abs_tau < P.min_touchdown_torque);
-      if (!skip) {
-        inertia = abs_tau / (abs_acc + 1e-4f);
-        if (inertia < P.liftoff_inertia) {
-          contact = false;
-        } else if (inertia > P.touchdown_inertia) {
-          contact = true;
-        }
-      }
-    }
+    wheel_contact_observe(P, torque, velocity, filt_vel, abs_acc, abs_tau, inertia, contact);
     if (cross) {  // FloorContact.cpp:62-64
       contact = false;
     } else if (contact) {

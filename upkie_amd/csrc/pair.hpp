@@ -496,13 +496,14 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
 }
 
 // One env.step() of B envs on 2 B lanes. Same contract as step_kernel.
-template <int MODE, bool RAND>
+template <int MODE, bool RAND, bool SPINE>
 __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
                                                         float* __restrict__ state, const float* __restrict__ act,
                                                         float* __restrict__ obs, float* __restrict__ reward,
                                                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                         const uint8_t* __restrict__ mask, const float* __restrict__ inertia_scale,
-                                                        const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv) {
+                                                        const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
+                                                        float* __restrict__ spine_state) {
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -665,6 +666,34 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
       contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, scale0, ext);
+    }
+    if (SPINE) {
+      // one cycle of the spine's observer pipeline: each lane runs the WheelContact estimator of its
+      // own wheel, the env-level quantities are own + partner (identical in both lanes)
+#define OM(w) spine_state[(size_t)(w) * B + e]
+      const int ow = UPKIE_O_WHEEL + 5 * leg;
+      float fv = OM(ow), aa = OM(ow + 1), at = OM(ow + 2), in = OM(ow + 3);
+      bool ct = OM(ow + 4) != 0.f;
+      if (do_reset) { fv = aa = at = in = 0.f; ct = false; }
+      wheel_contact_observe(C.spine, tau[2], s.qd[2], fv, aa, at, in, ct);
+      OM(ow) = fv; OM(ow + 1) = aa; OM(ow + 2) = at; OM(ow + 3) = in; OM(ow + 4) = ct ? 1.f : 0.f;
+      const float sq = pair_sum(tau[0] * tau[0] + tau[1] * tau[1]);
+      const float upper = obs_low_pass(do_reset ? 0.f : OM(UPKIE_O_UPPER_LEG_TORQUE), C.spine.leg_alpha, sqrtf(sq));
+      const bool fc = pair_any(ct) || upper > C.spine.upper_leg_torque_threshold;
+      float op = do_reset ? 0.f : OM(UPKIE_O_ODOMETRY_POSITION), ov = do_reset ? 0.f : OM(UPKIE_O_ODOMETRY_VELOCITY);
+      const float sum = pair_sum(ct ? pick(leg, C.spine.signed_radius[0], C.spine.signed_radius[1]) * s.qd[2] : 0.f);
+      const float n = pair_sum(ct ? 1.f : 0.f);
+      if (fc) {
+        ov = n > 0.f ? sum / n : 0.f;
+        op += ov * C.h;
+      }
+      if (lead) {
+        OM(UPKIE_O_UPPER_LEG_TORQUE) = upper;
+        OM(UPKIE_O_CONTACT) = fc ? 1.f : 0.f;
+        OM(UPKIE_O_ODOMETRY_POSITION) = op;
+        OM(UPKIE_O_ODOMETRY_VELOCITY) = ov;
+      }
+#undef OM
     }
   }
 

@@ -41,6 +41,7 @@ struct DevConfig {
   float agent_gains[4];
   float agent_clip;
   ExtSlots ext;
+  ObserverDev spine;  // in-step spine observers (one cycle per physics substep), used when attached
 };
 
 enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4, MODE_BASE_VELOCITY = 5 };
@@ -197,13 +198,14 @@ __device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phy
 // WPS = waves per SIMD the register allocation is capped for: 1 (up to 512
 // registers, no spills: lowest latency, small batches) or 2 (256 registers,
 // ~90 spilled: +25 % throughput once the batch oversubscribes the chip).
-template <int MODE, bool RAND, int WPS>
+template <int MODE, bool RAND, int WPS, bool SPINE>
 __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C, float* __restrict__ state,
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ inertia_scale,
-                                                   const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv) {
+                                                   const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
+                                                   float* __restrict__ spine_state) {
   const DevModel& M = *Mp;
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +359,44 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
       contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, ext);
+    }
+    if (SPINE) {
+      // one cycle of the spine's observer pipeline (spines/common/observers.h:22-42): it sees the
+      // torques commanded for this cycle and the joint velocities the simulator reports after it
+#define OM(w) spine_state[(size_t)(w) * B + e]
+      bool any_wheel = false, wc[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float fv = OM(UPKIE_O_WHEEL + 5 * w), aa = OM(UPKIE_O_WHEEL + 5 * w + 1), at = OM(UPKIE_O_WHEEL + 5 * w + 2),
+              in = OM(UPKIE_O_WHEEL + 5 * w + 3);
+        bool ct = OM(UPKIE_O_WHEEL + 5 * w + 4) != 0.f;
+        if (do_reset) { fv = aa = at = in = 0.f; ct = false; }
+        wheel_contact_observe(C.spine, tau[3 * w + 2], s.qd[3 * w + 2], fv, aa, at, in, ct);
+        OM(UPKIE_O_WHEEL + 5 * w) = fv; OM(UPKIE_O_WHEEL + 5 * w + 1) = aa; OM(UPKIE_O_WHEEL + 5 * w + 2) = at;
+        OM(UPKIE_O_WHEEL + 5 * w + 3) = in; OM(UPKIE_O_WHEEL + 5 * w + 4) = ct ? 1.f : 0.f;
+        wc[w] = ct;
+        any_wheel = any_wheel || ct;
+      }
+      const float sq = tau[0] * tau[0] + tau[1] * tau[1] + tau[3] * tau[3] + tau[4] * tau[4];
+      const float upper = obs_low_pass(do_reset ? 0.f : OM(UPKIE_O_UPPER_LEG_TORQUE), C.spine.leg_alpha, sqrtf(sq));
+      OM(UPKIE_O_UPPER_LEG_TORQUE) = upper;
+      const bool fc = any_wheel || upper > C.spine.upper_leg_torque_threshold;
+      OM(UPKIE_O_CONTACT) = fc ? 1.f : 0.f;
+      float op = do_reset ? 0.f : OM(UPKIE_O_ODOMETRY_POSITION), ov = do_reset ? 0.f : OM(UPKIE_O_ODOMETRY_VELOCITY);
+      if (fc) {
+        float sum = 0.f, n = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+          if (wc[w]) {
+            sum += C.spine.signed_radius[w] * s.qd[3 * w + 2];
+            n += 1.f;
+          }
+        ov = n > 0.f ? sum / n : 0.f;
+        op += ov * C.h;
+      }
+      OM(UPKIE_O_ODOMETRY_POSITION) = op;
+      OM(UPKIE_O_ODOMETRY_VELOCITY) = ov;
+#undef OM
     }
   }
 
@@ -637,6 +677,7 @@ struct UpkieSim {
   DevConfig config;
   const float* inertia_scale = nullptr;
   const float* ext_force = nullptr;
+  float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   std::string error;
 };
 
@@ -848,6 +889,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
   std::string why;
   if (!convert_config(config, &next, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);
   next.ext = sim->config.ext;
+  next.spine = sim->config.spine;
   sim->config = next;
   return UPKIE_OK;
 }
@@ -933,12 +975,19 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // fewer lanes than SIMD slots: split every env over two lanes (pair.hpp)
   const bool dense = sim->config.num_envs >= kDenseBatch;
   const bool paired = sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
-#define UPKIE_LAUNCH(R, W)                                                                                          \
-  hipLaunchKernelGGL((step_kernel<MODE, R, W>), grid, block, 0, st, sim->d_model, sim->limits, sim->config, state, act, obs, \
-                     reward, terminated, truncated, mask, scale, force, packed, bv)
-#define UPKIE_LAUNCH_PAIR(R)                                                                                               \
-  hipLaunchKernelGGL((step_kernel_pair<MODE, R>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
-                     sim->config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv)
+  // SPINE: the spine observers run inside the step (a separate instantiation:
+  // compiled in but switched off they would still cost the common path 2 %)
+#define UPKIE_LAUNCH_S(R, W, S)                                                                                            \
+  hipLaunchKernelGGL((step_kernel<MODE, R, W, S>), grid, block, 0, st, sim->d_model, sim->limits, sim->config, state, act, obs, \
+                     reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
+#define UPKIE_LAUNCH(R, W) \
+  do { if (spine) UPKIE_LAUNCH_S(R, W, true); else UPKIE_LAUNCH_S(R, W, false); } while (0)
+#define UPKIE_LAUNCH_PAIR_S(R, S)                                                                                                 \
+  hipLaunchKernelGGL((step_kernel_pair<MODE, R, S>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
+                     sim->config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
+#define UPKIE_LAUNCH_PAIR(R) \
+  do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
+  const bool spine = sim->spine_state != nullptr;
   if (paired) {
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
   } else if (rnd) {
@@ -946,6 +995,8 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   } else {
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
+#undef UPKIE_LAUNCH_PAIR_S
+#undef UPKIE_LAUNCH_S
 #undef UPKIE_LAUNCH_PAIR
 #undef UPKIE_LAUNCH
   return check_hip(sim, hipGetLastError(), "step_kernel");
@@ -1138,45 +1189,73 @@ static int observers_fail(UpkieObservers* h, int status, const std::string& msg)
   return status;
 }
 
-extern "C" int upkie_observers_create(const UpkieObserverConfig* c, UpkieObservers** out) {
-  if (!c || !out) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  *out = nullptr;
-  if (c->num_envs <= 0) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "num_envs must be positive");
-  if (!(c->dt > 0.0) || !std::isfinite(c->dt))
-    return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "observers are not configured: dt must be a positive number");
+// UpkieObserverConfig -> device parameters for a spine period `dt`; false (with
+// the reference's FilterError message) when a filter violates cutoff > 2 dt.
+static bool convert_observer_config(const UpkieObserverConfig* c, double dt, upkie::ObserverDev* d, std::string* why) {
+  if (!(dt > 0.0) || !std::isfinite(dt)) {
+    *why = "observers are not configured: dt must be a positive number";
+    return false;
+  }
   const bool wheels = c->wheel_cutoff_period >= 1e-6;  // WheelContact.cpp:21
   auto nyquist = [&](double cutoff, const char* what) {
-    if (cutoff <= 2.0 * c->dt) {  // low_pass_filter.h:22-30
-      observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT,
-                     std::string("[low_pass_filter] ") + what + " cutoff period " + std::to_string(cutoff) +
-                         " s is less than 2 * dt = " + std::to_string(2.0 * c->dt) + " s, causing information loss");
+    if (cutoff <= 2.0 * dt) {  // low_pass_filter.h:22-30
+      *why = std::string("[low_pass_filter] ") + what + " cutoff period " + std::to_string(cutoff) + " s is less than 2 * dt = " +
+             std::to_string(2.0 * dt) + " s, causing information loss";
       return false;
     }
     return true;
   };
-  if (wheels && !nyquist(c->wheel_cutoff_period, "wheel contact")) return UPKIE_ERR_INVALID_ARGUMENT;
-  if (!nyquist(0.01, "upper-leg torque")) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (wheels && !nyquist(c->wheel_cutoff_period, "wheel contact")) return false;
+  if (!nyquist(0.01, "upper-leg torque")) return false;
+  d->num_envs = c->num_envs;
+  d->wheels_configured = wheels ? 1 : 0;
+  d->dt = (float)dt;
+  d->inv_dt = (float)(1.0 / dt);
+  d->wheel_alpha = wheels ? (float)(dt / c->wheel_cutoff_period) : 0.f;
+  d->leg_alpha = (float)(dt / 0.01);
+  d->upper_leg_torque_threshold = (float)c->upper_leg_torque_threshold;
+  d->liftoff_inertia = (float)c->liftoff_inertia;
+  d->min_touchdown_acceleration = (float)c->min_touchdown_acceleration;
+  d->min_touchdown_torque = (float)c->min_touchdown_torque;
+  d->touchdown_inertia = (float)c->touchdown_inertia;
+  for (int i = 0; i < 2; ++i) d->signed_radius[i] = (float)c->signed_radius[i];
+  for (int i = 0; i < 9; ++i) {
+    d->base_to_imu[i] = (float)c->rotation_base_to_imu[i];
+    d->ars_to_world[i] = (float)c->rotation_ars_to_world[i];
+  }
+  return true;
+}
+
+extern "C" int upkie_observers_create(const UpkieObserverConfig* c, UpkieObservers** out) {
+  if (!c || !out) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (c->num_envs <= 0) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "num_envs must be positive");
+  upkie::ObserverDev dev;
+  std::string why;
+  if (!convert_observer_config(c, c->dt, &dev, &why)) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   if (upkie_hip_device_count() <= 0) return observers_fail(nullptr, UPKIE_ERR_NO_DEVICE, "no HIP device visible");
   UpkieObservers* h = new (std::nothrow) UpkieObservers();
   if (!h) return observers_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "out of host memory");
-  upkie::ObserverDev& d = h->dev;
-  d.num_envs = c->num_envs;
-  d.wheels_configured = wheels ? 1 : 0;
-  d.dt = (float)c->dt;
-  d.inv_dt = (float)(1.0 / c->dt);
-  d.wheel_alpha = wheels ? (float)(c->dt / c->wheel_cutoff_period) : 0.f;
-  d.leg_alpha = (float)(c->dt / 0.01);
-  d.upper_leg_torque_threshold = (float)c->upper_leg_torque_threshold;
-  d.liftoff_inertia = (float)c->liftoff_inertia;
-  d.min_touchdown_acceleration = (float)c->min_touchdown_acceleration;
-  d.min_touchdown_torque = (float)c->min_touchdown_torque;
-  d.touchdown_inertia = (float)c->touchdown_inertia;
-  for (int i = 0; i < 2; ++i) d.signed_radius[i] = (float)c->signed_radius[i];
-  for (int i = 0; i < 9; ++i) {
-    d.base_to_imu[i] = (float)c->rotation_base_to_imu[i];
-    d.ars_to_world[i] = (float)c->rotation_ars_to_world[i];
-  }
+  h->dev = dev;
   *out = h;
+  return UPKIE_OK;
+}
+
+// Spine observers inside the step: one observer cycle per physics substep (the
+// spine's own rate under a slower agent, spines/bullet_spine.cpp runs
+// nb_substeps cycles per action), observer memory [16][B] owned by the caller.
+extern "C" int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConfig* config, float* observer_state) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (!config || !observer_state) {
+    sim->spine_state = nullptr;
+    return UPKIE_OK;
+  }
+  upkie::ObserverDev dev;
+  std::string why;
+  if (!convert_observer_config(config, (double)sim->config.h, &dev, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);
+  dev.num_envs = sim->config.num_envs;
+  sim->config.spine = dev;
+  sim->spine_state = observer_state;
   return UPKIE_OK;
 }
 
@@ -1202,7 +1281,7 @@ extern "C" int upkie_observers_reset(UpkieObservers* h, float* state, const uint
 extern "C" int upkie_observers_step(UpkieObservers* h, float* state, const UpkieObserverInput* in, const UpkieObserverOutput* out,
                                     void* stream) {
   if (!h || !state || !in || !out) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  if (!in->servo) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "observation has no \"servo\" block");
+  if (!in->servo && !in->imu_orientation) return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "observation has neither a \"servo\" nor an \"imu\" block");
   if (in->imu_orientation && !in->imu_angular_velocity)  // KeyError in BaseOrientation::read, BaseOrientationTest.cpp:93-98
     return observers_fail(h, UPKIE_ERR_INVALID_ARGUMENT, "imu observation has an orientation but no angular_velocity");
   hipLaunchKernelGGL(upkie::observers_step_kernel, grid_for(h->dev.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, h->dev, state,

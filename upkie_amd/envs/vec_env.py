@@ -35,6 +35,24 @@ def _default_sim_factory(config, model_struct, device):
     return BatchedSim(config, model_struct, device=device)
 
 
+class _SpineObserverBlocks(dict):
+    """Blocks the spine observers write, materialised together with the lazy
+    spine observation: filters come out of the observer memory the step kernel
+    maintains, BaseOrientation is computed from the IMU block."""
+
+    def __init__(self, sim, observers):
+        super().__init__()
+        self._sim, self._observers = sim, observers
+
+    def items(self):
+        from ..observers import observer_blocks_from_state
+
+        blocks = observer_blocks_from_state(self._sim.observer_state)
+        raw = self._sim.observe(update_imu=False)
+        blocks.update(self._observers.step(None, raw["imu_orientation"], raw["imu_angular_velocity"]))
+        return blocks.items()
+
+
 class UpkieVecEnv:
     """Common part of the batched envs: owns the simulation handle, the model
     and the configuration (the role of UpkieEnv + PyBulletBackend,
@@ -121,21 +139,25 @@ class UpkieVecEnv:
         self._external_forces = ExternalForceSet(self.model, self.num_envs)
         self._elapsed = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         self._pending_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
-        # Optional spine observer pipeline (FloorContact, WheelOdometry,
-        # BaseOrientation of upkie/cpp/observers), run once per env step with
-        # the env period as spine period; `spine_observers` is True or a spine
-        # configuration dictionary (spine_backend.py:77-105). The reference's
-        # filters refuse cutoff periods <= 2 dt: frequencies above 200 Hz only.
+        # Optional spine observer pipeline (upkie/cpp/observers, order of
+        # spines/common/observers.h:22-42); `spine_observers` is True or a spine
+        # configuration dictionary (spine_backend.py:77-105). FloorContact, its
+        # WheelContact estimators and WheelOdometry carry filters: they run
+        # INSIDE the step kernel, one observer cycle per physics substep, which
+        # is the spine's rate (1 kHz) under this env's agent rate, exactly as
+        # Spine::simulate cycles nb_substeps times per action. BaseOrientation
+        # is stateless and evaluated with the observation, on request.
         self._observers = None
+        self._observer_config = None
         if spine_observers:
             from ..observers import BatchedObservers, observer_config_from_spine_config
 
             spine_config = spine_observers if isinstance(spine_observers, dict) else None
-            obs_cfg = observer_config_from_spine_config(self.num_envs, self.dt, spine_config)
+            substep = self.dt / int(cfg.nb_substeps)
+            self._observer_config = observer_config_from_spine_config(self.num_envs, substep, spine_config)
+            self.sim.attach_observers(self._observer_config)
             make = observers_factory if observers_factory is not None else BatchedObservers
-            self._observers = make(obs_cfg, device)
-            self._observers.reset()
-            self._episodes = self.sim.state[abi.S_EPISODE].clone()
+            self._observers = make(self._observer_config, device)  # used for its stateless BaseOrientation stage
 
     # hooks ------------------------------------------------------------
     def _configure(self, cfg) -> None:
@@ -159,12 +181,7 @@ class UpkieVecEnv:
     def _info(self) -> dict:
         self._spine.invalidate()
         if self._observers is not None:
-            # envs that (auto)reset during this call start from fresh observers
-            episodes = self.sim.state[abi.S_EPISODE]
-            restarted = episodes != self._episodes
-            self._episodes = episodes.clone()
-            self._observers.reset(restarted)
-            self._spine.set_overrides(self._observers.step_from_sim(self.sim))
+            self._spine.set_overrides(_SpineObserverBlocks(self.sim, self._observers))
         if self.eager_spine_observation:
             self._spine.materialize()
         return {"spine_observation": self._spine}

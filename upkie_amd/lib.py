@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = (
     "upkie_mpc_reset",
     "upkie_mpc_step",
     "upkie_mpc_step_env",
+    "upkie_sim_attach_observers",
     "upkie_observers_create",
     "upkie_observers_destroy",
     "upkie_observers_last_error",
@@ -187,6 +188,8 @@ def load() -> C.CDLL:
     lib.upkie_mpc_step.argtypes = [vp, vp, vp, vp, vp, C.c_double, vp, vp, vp]
     lib.upkie_mpc_step_env.restype = C.c_int
     lib.upkie_mpc_step_env.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, vp, vp]
+    lib.upkie_sim_attach_observers.restype = C.c_int
+    lib.upkie_sim_attach_observers.argtypes = [vp, C.POINTER(abi.UpkieObserverConfig), vp]
     lib.upkie_observers_create.restype = C.c_int
     lib.upkie_observers_create.argtypes = [C.POINTER(abi.UpkieObserverConfig), C.POINTER(vp)]
     lib.upkie_observers_destroy.restype = C.c_int

@@ -81,6 +81,27 @@ def observer_blocks(tensors: Dict[str, Optional[torch.Tensor]]) -> Dict[str, dic
     return result
 
 
+def observer_blocks_from_state(state: torch.Tensor) -> Dict[str, dict]:
+    """The "floor_contact" and "wheel_odometry" blocks out of observer memory
+    ``[16, B]`` (what `BatchedSim.attach_observers` maintains inside the step)."""
+    W = abi.O_WHEEL
+    wheel = lambda w: {  # noqa: E731
+        "abs_acceleration": state[W + 5 * w + 1],
+        "abs_torque": state[W + 5 * w + 2],
+        "contact": state[W + 5 * w + 4] != 0,
+        "inertia": state[W + 5 * w + 3],
+    }
+    return {
+        "floor_contact": {
+            "contact": state[abi.O_CONTACT] != 0,
+            "upper_leg_torque": state[abi.O_UPPER_LEG_TORQUE],
+            "left_wheel": wheel(0),
+            "right_wheel": wheel(1),
+        },
+        "wheel_odometry": {"position": state[abi.O_ODOMETRY_POSITION], "velocity": state[abi.O_ODOMETRY_VELOCITY]},
+    }
+
+
 class BatchedObservers:
     """Observer memory `[16, B]` on the device + one launch per spine cycle."""
 
@@ -144,7 +165,7 @@ class BatchedObservers:
                 raise ValueError(f"expected shape {shape}, got {tuple(t.shape)}")
             return t
 
-        servo = f(servo, (B, 6, 5))
+        servo = f(servo, (B, 6, 5))  # None: no "servo" block, only BaseOrientation runs (FloorContact.cpp:42-44)
         imu_orientation = f(imu_orientation, (B, 4))
         imu_angular_velocity = f(imu_angular_velocity, (B, 3))
         if cross_button is not None:
@@ -168,6 +189,8 @@ class BatchedObservers:
                 self._handle, C.c_void_p(self.state.data_ptr()), C.byref(inp), C.byref(out), self._stream()
             )
         lib.check(status, self._handle, what="observers")
+        if servo is None:
+            return {k: v for k, v in observer_blocks(tensors).items() if k == "base_orientation"}
         return observer_blocks(tensors)
 
     def step_from_sim(self, sim, update_imu: bool = False, cross_button: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

@@ -309,6 +309,20 @@ class BatchedSim:
             )
         return out
 
+    def attach_observers(self, config: Optional[abi.UpkieObserverConfig]) -> Optional[torch.Tensor]:
+        """Run the spine's FloorContact / WheelContact / WheelOdometry observers
+        inside every step, one observer cycle per physics substep (the spine's
+        rate under a slower agent). Returns the observer memory ``[16, B]``
+        (words `abi.O_*`), which holds their outputs; None detaches."""
+        if config is None:
+            self._check(self._lib.upkie_sim_attach_observers(self._handle, None, None))
+            self.observer_state = None
+            return None
+        self.observer_state = torch.zeros((abi.OBSERVER_STATE_WORDS, self.num_envs), dtype=torch.float32, device=self.device)
+        self._observer_config = config
+        self._check(self._lib.upkie_sim_attach_observers(self._handle, C.byref(config), _ptr(self.observer_state)))
+        return self.observer_state
+
     def flag_done(self, done: torch.Tensor) -> None:
         """Overwrite the per-env `done` word the NEXT_STEP autoreset reads: envs
         flagged here are re-initialised by their next step (used by the
