@@ -163,7 +163,8 @@ def main() -> None:
         },
     }
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(B)
+        # (the budget can be shortened for tests; the default sample is ~15 s of CPU work)
+        line["cpu_baseline"] = cpu_baseline(B, float(os.environ.get("UPKIE_CPU_BASELINE_BUDGET_S", "15")))
     else:
         line["cpu_baseline"] = None
     env.shutdown()

@@ -106,6 +106,17 @@ class OracleSim:
     def step_pendulum_agent(self):
         return self._out(*self._o.step_pendulum_agent(self.obs4.double().numpy()), "obs4")
 
+    def step_pendulum_records(self, prev_records, records):
+        """The on-device linear agent acting on the observation held in the
+        previous step's records; this step's packed records written in place."""
+        obs, rew, term, trunc = self._o.step_pendulum_agent(prev_records[:, :4].double().numpy())
+        records[:, :4] = torch.from_numpy(np.asarray(obs, dtype=np.float32))
+        records[:, 4] = torch.from_numpy(np.asarray(rew, dtype=np.float32))
+        records[:, 5] = torch.from_numpy(np.asarray(term, dtype=np.float32))
+        records[:, 6] = torch.from_numpy(np.asarray(trunc, dtype=np.float32))
+        records[:, 7] = 0.0
+        return records
+
     def observe(self, update_imu=True):
         out = self._o.observe(update_imu)
         return {k: torch.from_numpy(v if v.dtype == np.uint8 else v.astype(np.float32)) for k, v in out.items()}

@@ -111,3 +111,62 @@ def test_world_size_mismatch_is_an_error(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     with pytest.raises(RuntimeError):
         init_distributed(expected_world=2)
+
+
+def _sharded_worker(rank: int, world: int, port: int, out_path: str):
+    """bench.py's driver object on two ranks (gloo), each rank's shard backed
+    by the oracle double: sharding by global env id, chunked gather into rank
+    0's rollout, reset counting and max-over-ranks timing."""
+    import numpy as np
+
+    from tests.fake_sim import OracleSim
+    from tests.helpers import randomized_config
+    from upkie_amd import abi
+    from upkie_amd.distributed import ShardedPendulum
+    from upkie_amd.model.default_model import default_model
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = init_distributed(world, backend="gloo")
+    B = 6
+    factory = lambda cfg, model, device: OracleSim(cfg, model if model is not None else default_model(), device)  # noqa: E731
+
+    def config(num_envs, offset):
+        cfg = randomized_config(num_envs, seed=4, autoreset=True)
+        cfg.fall_pitch = 0.12
+        cfg.env_id_offset = offset
+        return cfg
+
+    env = ShardedPendulum(config(B, rank * B), device="cpu", rank=rank, world_size=world, horizon=32, chunk=4, sim_factory=factory)
+    env.reset()
+    steps = 22
+    for _ in range(steps):
+        env.step_agent()
+    env.flush()
+    env.barrier()
+    assert env.max_over_ranks(float(rank + 1)) == float(world)
+    resets = env.total_resets()
+    ok = True
+    if rank == 0:
+        # one process stepping all 2 B envs gives the same records: results do not depend on the sharding
+        whole = ShardedPendulum(config(world * B, 0), device="cpu", rank=0, world_size=1, horizon=32, chunk=4, sim_factory=factory)
+        whole.reset()
+        for _ in range(steps):
+            whole.step_agent()
+        for back in range(8):
+            sharded = env.gather.last(back).reshape(world * B, -1)
+            single = whole.gather.last(back).reshape(world * B, -1)
+            ok = ok and np.allclose(sharded.numpy(), single.numpy(), atol=1e-6)
+        ok = ok and resets == whole.total_resets() and resets >= world * B
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "bad")
+    dist.barrier()
+    env.gather.flush()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+def test_sharded_pendulum_two_ranks_equal_one_rank(tmp_path):
+    out = tmp_path / "sharded.txt"
+    mp.spawn(_sharded_worker, args=(2, free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"

@@ -163,11 +163,12 @@ class ShardedPendulum:
     """This rank's shard of a batch of Upkie-Pendulum envs plus the pipelined
     gather of per-step records into rank 0's rollout buffer."""
 
-    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8):
+    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8, sim_factory=None):
         from .sim import BatchedSim
 
         self.rank, self.world_size = rank, world_size
-        self.sim = BatchedSim(config, model, device=device)
+        # (sim_factory: test doubles only; the product always builds a BatchedSim)
+        self.sim = sim_factory(config, model, device) if sim_factory is not None else BatchedSim(config, model, device=device)
         self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon, chunk=chunk)
         self._device = self.sim.device
 
