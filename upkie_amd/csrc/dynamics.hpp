@@ -769,17 +769,6 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
       }
     if (change <= M.pgs_tolerance * scale) break;
   }
-#ifdef UPKIE_DEBUG_LIMIT
-#ifdef __HIP_DEVICE_COMPILE__
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    printf("lane %d n=%d spd=%d pgs=%d rt=%g %g %g %g %g %g tl=%g %g %g tr=%g %g %g\n", (int)threadIdx.x, n, (int)spd, (int)need_pgs, rt[0], rt[1],
-           rt[2], rt[3], rt[4], rt[5], tl[0], tl[1], tl[2], tr[0], tr[1], tr[2]);
-    for (int r = 0; r < n; ++r)
-      printf("lane %d row %d kind %d leg %d rhs %g diag %g lam %g Jt %g %g %g %g %g %g Jl %g %g %g\n", (int)threadIdx.x, r, R.kind[r], R.leg[r],
-             rhs[r], A[r][r], lam[r], R.Jt[r][0], R.Jt[r][1], R.Jt[r][2], R.Jt[r][3], R.Jt[r][4], R.Jt[r][5], R.Jl[r][0], R.Jl[r][1], R.Jl[r][2]);
-  }
-#endif
-#endif
   for (int r = 0; r < n; ++r) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) tb[c] = fmaf(R.Jb[r][c], lam[r], tb[c]);

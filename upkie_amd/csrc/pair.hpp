@@ -104,12 +104,6 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     for (int k = 0; k < 3; ++k) own_limit = own_limit || (PL.bounded[k] && (s.q[k] <= PL.lower[k] || s.q[k] >= PL.upper[k]));
   }
   const bool any_limit = Lm.enforce ? pair_any(own_limit) : false;
-#ifdef UPKIE_DEBUG_LIMIT
-  if (blockIdx.x == 0 && threadIdx.x < 2)
-    printf("pair lane %d leg %d enforce %d own_limit %d any_limit %d q %.9g %.9g %.9g lower %.9g %.9g upper %.9g %.9g bounded %d %d %d\n",
-           (int)threadIdx.x, leg, Lm.enforce, (int)own_limit, (int)any_limit, s.q[0], s.q[1], s.q[2], PL.lower[0], PL.lower[1], PL.upper[0],
-           PL.upper[1], PL.bounded[0], PL.bounded[1], PL.bounded[2]);
-#endif
 
   float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
   float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
