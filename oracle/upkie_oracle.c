@@ -21,6 +21,7 @@
 #define MAXROWS 10
 
 long oracle_debug_sweeps = 0, oracle_debug_fallbacks = 0, oracle_debug_substeps = 0;
+long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they needed */
 
 /* ------------------------------------------------------------------ vec3 */
 static void v3_cross(const double a[3], const double b[3], double c[3]) {
@@ -413,6 +414,57 @@ double oracle_energy(const UpkieModel* model, const double pos[3],
   return T + V;
 }
 
+
+/* The two LATERAL friction rows (third row of each tire) nearly coincide in a
+ * symmetric stance: coupling a25 = diagonals up to friction_cfm. Swept one at a
+ * time they converge like (a / (a + cfm))^2 per sweep (hundreds of sweeps). In
+ * sum / difference coordinates s = l2 + l5, d = l2 - l5 the block is almost
+ * diagonal: the SUM (lateral force on the robot) is well posed and solved
+ * exactly each sweep; the DIFFERENCE (how the two tires share it) is statically
+ * indeterminate, only friction_cfm decides it: it relaxes slowly (as it did
+ * under plain sweeps) and does not count in the convergence test. */
+static int lateral_pair_exists(int nrows, const int* kind, const int* normal_row) {
+  int n = 0;
+  for (int r = 0; r < nrows; ++r)
+    if (kind[r] == 1 && r == normal_row[r] + 2) ++n;
+  return n == 2;
+}
+static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row, const double* W, int ldw,
+                               const double* cfm, const double* rhs, double mu, double* lam, double* change, double* scale) {
+  int lat[2], n = 0;
+  for (int r = 0; r < nrows; ++r)
+    if (kind[r] == 1 && r == normal_row[r] + 2 && n < 2) lat[n++] = r;
+  if (n != 2) return; /* a single lateral row is swept like any friction row */
+  const int i2 = lat[0], i5 = lat[1];
+  double r2 = rhs[i2], r5 = rhs[i5];
+  for (int b = 0; b < nrows; ++b) {
+    if (b == i2 || b == i5) continue;
+    r2 -= W[i2 * ldw + b] * lam[b];
+    r5 -= W[i5 * ldw + b] * lam[b];
+  }
+  const double a22 = W[i2 * ldw + i2] + cfm[i2], a55 = W[i5 * ldw + i5] + cfm[i5], a25 = W[i5 * ldw + i2];
+  const double S11 = 0.5 * (a22 + 2.0 * a25 + a55), S12 = 0.5 * (a22 - a55), S22 = 0.5 * (a22 - 2.0 * a25 + a55);
+  double d = lam[i2] - lam[i5];
+  const double s_old = lam[i2] + lam[i5];
+  const double s_new = (r2 + r5 - S12 * d) / S11;
+  const double d_exact = (r2 - r5 - S12 * s_new) / S22;
+  double omega = 2.0 * S22 / S11; /* the pace of the plain sweeps */
+  if (omega > 1.0) omega = 1.0;
+  d += omega * (d_exact - d);
+  double x2 = 0.5 * (s_new + d), x5 = 0.5 * (s_new - d);
+  const double lim2 = mu * lam[normal_row[i2]], lim5 = mu * lam[normal_row[i5]];
+  if (x2 < -lim2) x2 = -lim2;
+  if (x2 > lim2) x2 = lim2;
+  if (x5 < -lim5) x5 = -lim5;
+  if (x5 > lim5) x5 = lim5;
+  const double ds = fabs((x2 + x5) - s_old);
+  if (ds > *change) *change = ds;
+  if (fabs(x2) > *scale) *scale = fabs(x2);
+  if (fabs(x5) > *scale) *scale = fabs(x5);
+  lam[i2] = x2;
+  lam[i5] = x5;
+}
+
 /* --------------------------------------------------------------- substep */
 /* One Bullet-like stepSimulation() (call site pybullet_backend.py:306):
  * free acceleration -> contact/limit rows -> PGS -> velocity update ->
@@ -603,11 +655,14 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
           }
       }
     }
+    int sweeps_here = 0;
     for (int it = 0; need_pgs && it < model->pgs_iterations; ++it) {
       double change = 0.0, scale = 0.0;
       for (int pass = 0; pass < 3; ++pass) { /* normals, friction, limits */
+        if (pass == 2) lateral_pair_sweep(nrows, kind, normal_row, &W[0][0], MAXROWS, cfm, rhs_c, mu, lam, &change, &scale);
         for (int r_ = 0; r_ < nrows; ++r_) {
           if (kind[r_] != pass) continue;
+          if (kind[r_] == 1 && r_ == normal_row[r_] + 2 && lateral_pair_exists(nrows, kind, normal_row)) continue;
           double wl = 0.0;
           for (int b = 0; b < nrows; ++b) wl += W[r_][b] * lam[b];
           double delta = (rhs_c[r_] - wl - cfm[r_] * lam[r_]) / (W[r_][r_] + cfm[r_]);
@@ -625,11 +680,15 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
         }
       }
       oracle_debug_sweeps += 1;
+      sweeps_here += 1;
       /* converged: the sweep moved no impulse by more than pgs_tolerance of
        * the largest one (each env stops on its own criterion) */
       if (change <= model->pgs_tolerance * scale) break;
     }
-    if (need_pgs) oracle_debug_fallbacks += 1;
+    if (need_pgs) {
+      oracle_debug_fallbacks += 1;
+      oracle_debug_sweep_hist[sweeps_here < 63 ? sweeps_here : 63] += 1;
+    }
     for (int r_ = 0; r_ < nrows; ++r_)
       for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
   }

@@ -454,6 +454,29 @@ UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], floa
   }
 }
 
+// Projected Gauss-Seidel sweep of the two LATERAL friction rows (row 2 of each
+// tire) together. In a symmetric stance the two rows nearly coincide (coupling
+// a25 = diagonals up to friction_cfm): swept one at a time they converge like
+// (a / (a + cfm))^2 per sweep, hundreds of sweeps. In sum / difference
+// coordinates s = l2 + l5, d = l2 - l5 the block is almost diagonal: the SUM
+// (the lateral force on the robot) is well posed and solved exactly; the
+// DIFFERENCE (how the tires share it) is statically indeterminate, only
+// friction_cfm decides it: it relaxes at the pace plain sweeps gave it and does
+// not count in the convergence test. r2, r5: right-hand sides minus the
+// contributions of every other row. Returns |change of the sum|.
+UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, float r5, float lim2, float lim5, float& l2, float& l5) {
+  const float S11 = 0.5f * (a22 + 2.f * a25 + a55), S12 = 0.5f * (a22 - a55), S22 = 0.5f * (a22 - 2.f * a25 + a55);
+  float d = l2 - l5;
+  const float s_old = l2 + l5;
+  const float s_new = (r2 + r5 - S12 * d) * fast_rcp(S11);
+  const float d_exact = (r2 - r5 - S12 * s_new) * fast_rcp(S22);
+  const float omega = fminf(2.f * S22 * fast_rcp(S11), 1.f);
+  d = fmaf(omega, d_exact - d, d);
+  l2 = fminf(fmaxf(0.5f * (s_new + d), -lim2), lim2);
+  l5 = fminf(fmaxf(0.5f * (s_new - d), -lim5), lim5);
+  return fabsf((l2 + l5) - s_old);
+}
+
 // Rare path shared by both lane mappings: some hip/knee joint sits at its
 // position limit. Contacts and limits are solved together as ONE system of ten
 // rows with a fixed layout, so that every index below is a compile-time
@@ -612,9 +635,21 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
       float change = 0.f, scale = 0.f;
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
+        const bool pair = on[2] && on[5];  // both tires touch: their lateral rows are swept together
+        if (pass == 2 && pair) {
+          float r2 = rhs[2], r5 = rhs[5];
+#pragma unroll
+          for (int b = 0; b < kRows; ++b) {
+            if (b == 2 || b == 5) continue;
+            r2 -= A[sym(2, b)] * lam[b];
+            r5 -= A[sym(5, b)] * lam[b];
+          }
+          change = fmaxf(change, lateral_pair_sweep(A[sym(2, 2)], A[sym(5, 2)], A[sym(5, 5)], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
+          scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
+        }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-          if (row_kind(r) != pass) continue;
+          if (row_kind(r) != pass || ((r == 2 || r == 5) && pair)) continue;
           float al = 0.f;
 #pragma unroll
           for (int b = 0; b < kRows; ++b) al = fmaf(A[sym(r, b)], lam[b], al);
@@ -749,11 +784,26 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
         if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
       }
   }
+  // rows 2 and 5 are the two lateral rows when both tires touch (contact rows come first, in wheel order)
+  const bool pair = n >= 6 && R.kind[2] == 1 && R.kind[5] == 1 && R.normal_row[2] == 0 && R.normal_row[5] == 3;
   for (int it = 0; need_pgs && it < M.pgs_iterations; ++it) {
     float change = 0.f, scale = 0.f;
-    for (int pass = 0; pass < 3; ++pass)
+    for (int pass = 0; pass < 3; ++pass) {
+      if (pass == 2 && pair) {  // lateral_pair_sweep, as in the register-resident solve
+        float r2 = rhs[2], r5 = rhs[5];
+        for (int b = 0; b < n; ++b) {
+          if (b == 2 || b == 5) continue;
+          r2 -= A[2][b] * lam[b];
+          r5 -= A[5][b] * lam[b];
+        }
+        float l2 = lam[2], l5 = lam[5];
+        change = fmaxf(change, lateral_pair_sweep(A[2][2], A[5][2], A[5][5], r2, r5, mu * lam[0], mu * lam[3], l2, l5));
+        scale = fmaxf(scale, fmaxf(fabsf(l2), fabsf(l5)));
+        lam[2] = l2;
+        lam[5] = l5;
+      }
       for (int r = 0; r < n; ++r) {
-        if (R.kind[r] != pass) continue;
+        if (R.kind[r] != pass || ((r == 2 || r == 5) && pair)) continue;
         float al = 0.f;
         for (int b = 0; b < n; ++b) al = fmaf(A[r][b], lam[b], al);
         float x = lam[r] + (rhs[r] - al) * fast_rcp(A[r][r]);
@@ -767,6 +817,7 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
         scale = fmaxf(scale, fabsf(x));
         lam[r] = x;
       }
+    }
     if (change <= M.pgs_tolerance * scale) break;
   }
   for (int r = 0; r < n; ++r) {
@@ -1160,6 +1211,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
       float idiag[6];
       idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
       idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+      const bool pair = active[0] && active[1];  // both tires touch: their lateral rows are swept together
       for (int it = 0; it < M.pgs_iterations; ++it) {
         float change = 0.f, scale = 0.f;
         // normals of both wheels first, then friction rows
@@ -1168,7 +1220,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
             const bool is_normal = (r % 3) == 0;
-            if (is_normal != (pass == 0)) continue;
+            if (is_normal != (pass == 0) || ((r % 3) == 2 && pair)) continue;
             float al = 0.f;  // (W + CFM) lam, row r
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
@@ -1186,6 +1238,17 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
             scale = fmaxf(scale, fabsf(x));
             lam[r] = x;
           }
+        }
+        if (pair) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
+          float r2 = rhs[2], r5 = rhs[5];
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            if (b == 2 || b == 5) continue;
+            r2 -= A[sym(2, b)] * lam[b];
+            r5 -= A[sym(5, b)] * lam[b];
+          }
+          change = fmaxf(change, lateral_pair_sweep(A[sym(2, 2)], A[sym(5, 2)], A[sym(5, 5)], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
+          scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
         }
         // each env stops on its own criterion: lanes leave the loop one by one
         if (change <= M.pgs_tolerance * scale) break;

@@ -398,6 +398,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       float idiag[6];
       idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
       idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+      const bool both = active_l && active_r;  // both tires touch: their lateral rows are swept together
       for (int it = 0; it < M.pgs_iterations; ++it) {
         float change = 0.f, scale = 0.f;
 #pragma unroll
@@ -405,7 +406,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
             const bool is_normal = (r % 3) == 0;
-            if (is_normal != (pass == 0)) continue;
+            if (is_normal != (pass == 0) || ((r % 3) == 2 && both)) continue;
             float al = 0.f;
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
@@ -423,6 +424,17 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
             scale = fmaxf(scale, fabsf(x));
             lam[r] = x;
           }
+        }
+        if (both) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep, dynamics.hpp)
+          float r2 = rhs[2], r5 = rhs[5];
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            if (b == 2 || b == 5) continue;
+            r2 -= A[sym(2, b)] * lam[b];
+            r5 -= A[sym(5, b)] * lam[b];
+          }
+          change = fmaxf(change, lateral_pair_sweep(A[sym(2, 2)], A[sym(5, 2)], A[sym(5, 5)], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
+          scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
         }
         if (change <= M.pgs_tolerance * scale) break;
       }
