@@ -295,6 +295,19 @@ int upkie_sim_observe(UpkieSim* sim, float* state,
                       const UpkieSpineObservation* out, int update_imu,
                       void* stream);
 
+/* Replaces PyBulletBackend.get_contact_points (upkie/envs/backends/
+ * pybullet_backend.py:660-716) for the whole batch. The only links that can
+ * touch the floor are the two tires, with at most one contact point each:
+ *   out [B][2][UPKIE_CONTACT_POINT_WORDS] = per tire (0 "left_wheel_tire",
+ *   1 "right_wheel_tire") {exists (0/1), position_contact_in_world (3),
+ *   force_in_world (3) = normal + both friction forces in N, 0}.
+ * The forces are those of the contact solve of one simulator substep from the
+ * current state under the last commanded torques (Bullet reports the last
+ * solved substep; the two differ by one 1 ms substep of motion). `state` is
+ * only read. */
+#define UPKIE_CONTACT_POINT_WORDS 8
+int upkie_sim_contact_points(UpkieSim* sim, const float* state, float* out, void* stream);
+
 /* ---- MPC balancer (upkie/controllers/mpc_balancer.py:168-312) ---------- */
 typedef struct UpkieMpcConfig {
   int32_t num_envs;

@@ -278,6 +278,13 @@ class Oracle:
         )
         return out
 
+    def contact_points(self) -> np.ndarray:
+        """[B, 2, 8]: per tire [exists, position in world, force in world, 0]
+        (PyBulletBackend.get_contact_points, pybullet_backend.py:660-716)."""
+        out = np.zeros((self.B, 2, 8))
+        self._lib.oracle_contact_points(C.byref(self.model), C.byref(self.config), _ptr(self.state), self._rnd(), _ptr(out))
+        return out
+
     # -- low level ---------------------------------------------------------
     def substep(self, env: int, tau, h: float) -> int:
         s = np.ascontiguousarray(self.state[:, env])

@@ -465,6 +465,11 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
   lam[i5] = x5;
 }
 
+/* Where oracle_substep_ext() leaves the contact points of the substep it
+ * solved when asked (oracle_contact_points): [2][8] = per tire {exists,
+ * position in world (3), force in world (3), 0}. */
+static _Thread_local double* g_contact_sink = NULL;
+
 /* --------------------------------------------------------------- substep */
 /* One Bullet-like stepSimulation() (call site pybullet_backend.py:306):
  * free acceleration -> contact/limit rows -> PGS -> velocity update ->
@@ -542,6 +547,9 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   double rhs_c[MAXROWS], cfm[MAXROWS];
   int kind[MAXROWS], normal_row[MAXROWS];
   int nrows = 0, any_contact = 0;
+  int contact_row[2] = {-1, -1};
+  double contact_dirs[2][3][3];
+  if (g_contact_sink) memset(g_contact_sink, 0, sizeof(double) * 16);
   double kpc = model->contact_stiffness, kdc = model->contact_damping;
   double denom = h * kpc + kdc;
   double erp = denom > 0 ? h * kpc / denom : 0.2;
@@ -571,6 +579,13 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
     double Jv[3][NV], Jw[3][NV];
     point_jacobian(&k, body, P, Jv, Jw);
     const double* dirs[3] = {n, t1, t2};
+    contact_row[wheel] = nrows;
+    for (int r_ = 0; r_ < 3; ++r_)
+      for (int d = 0; d < 3; ++d) contact_dirs[wheel][r_][d] = dirs[r_][d];
+    if (g_contact_sink) {
+      g_contact_sink[8 * wheel] = 1.0;
+      for (int d = 0; d < 3; ++d) g_contact_sink[8 * wheel + 1 + d] = P[d];
+    }
     for (int r_ = 0; r_ < 3; ++r_) {
       for (int c = 0; c < NV; ++c)
         J[nrows][c] = dirs[r_][0] * Jv[0][c] + dirs[r_][1] * Jv[1][c] +
@@ -691,6 +706,19 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
     }
     for (int r_ = 0; r_ < nrows; ++r_)
       for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
+  }
+
+  if (g_contact_sink) {
+    /* getContactPoints: normalForce and lateralFriction1/2 are the applied
+     * impulses over the time step (pybullet_backend.py:697-708 sums them) */
+    for (int wheel = 0; wheel < 2; ++wheel) {
+      if (contact_row[wheel] < 0) continue;
+      for (int d = 0; d < 3; ++d) {
+        double f = 0.0;
+        for (int r_ = 0; r_ < 3; ++r_) f += lam[contact_row[wheel] + r_] * contact_dirs[wheel][r_][d];
+        g_contact_sink[8 * wheel + 4 + d] = f / h;
+      }
+    }
   }
 
   /* Bullet clamps generalised joint speeds to maxCoordinateVelocity */
@@ -1240,6 +1268,26 @@ void oracle_observe(const UpkieModel* model, const UpkieSimConfig* cfg,
 }
 
 /* ------------------------------------------------ helpers exposed to tests */
+/* PyBulletBackend.get_contact_points, pybullet_backend.py:660-716, for the
+ * batch: the contact solve of one substep from the current state under the
+ * last commanded torques; the state is not modified. out [B][2][8]. */
+void oracle_contact_points(const UpkieModel* model, const UpkieSimConfig* cfg,
+                           const double* state, const OracleRandomization* rnd, double* out) {
+  const int B = cfg->num_envs;
+  const double h = cfg->dt / cfg->nb_substeps;
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    UpkieExternalForces slots;
+    const double *scale_p, *force_p;
+    const UpkieExternalForces* slots_p;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &slots, &scale_p, &force_p, &slots_p);
+    g_contact_sink = out + (int64_t)16 * e;
+    oracle_substep_ext(model, s, s + UPKIE_S_TORQUE, h, scale_p, force_p, slots_p);
+    g_contact_sink = NULL;
+  }
+}
+
 void oracle_quat_to_matrix(const double quat_wxyz[4], double R[9]) { quat_to_matrix(quat_wxyz, R); }
 void oracle_matrix_to_quat(const double R[9], double quat_wxyz[4]) { matrix_to_quat_scipy(R, quat_wxyz); }
 void oracle_euler_zyx_compose(const double base_wxyz[4], const double ypr[3], double out_wxyz[4]) {

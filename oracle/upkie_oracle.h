@@ -122,6 +122,12 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
                                 uint8_t* terminated, uint8_t* truncated,
                                 const OracleRandomization* rnd);
 
+/* PyBulletBackend.get_contact_points (pybullet_backend.py:660-716) of every
+ * env: out [B][2][8] = per tire {exists, position in world (3), force in
+ * world (3), 0}. Same contract as upkie_sim_contact_points. */
+void oracle_contact_points(const UpkieModel* model, const UpkieSimConfig* cfg,
+                           const double* state, const OracleRandomization* rnd, double* out);
+
 typedef struct OracleSpineObservation {
   double* pitch;
   double* angular_velocity;

@@ -117,6 +117,14 @@ class OracleSim:
         records[:, 7] = 0.0
         return records
 
+    def contact_points(self):
+        return torch.from_numpy(self._o.contact_points().astype(np.float32))
+
+    def get_contact_points(self, link_name=None, env=0):
+        from upkie_amd.utils.point_contact import point_contacts
+
+        return point_contacts(self.contact_points()[env].numpy(), link_name)
+
     def observe(self, update_imu=True):
         out = self._o.observe(update_imu)
         return {k: torch.from_numpy(v if v.dtype == np.uint8 else v.astype(np.float32)) for k, v in out.items()}

@@ -447,3 +447,38 @@ def test_cookie_ids_build_a_right_wheeled_robot():
     assert results["cookie"][1] == pytest.approx(results["upkie"][1], abs=1e-4)
     assert results["cookie"][2] * results["upkie"][2] < 0  # with the left wheel turning the other way
     assert "Cookie-PyBullet-Pendulum" in envs.entry_points.COOKIE_IDS
+
+
+def test_contact_points_like_count_wheel_contacts_example():
+    """examples/pybullet/count_wheel_contacts.py + PyBulletBackend.
+    get_contact_points (pybullet_backend.py:660-716): a balancing robot has one
+    contact point per tire, under the wheel, and the floor carries its weight;
+    in the air there is none; unknown links give an empty list."""
+    env = envs.make("Upkie-HIP-Pendulum", frequency=200.0, **KW)
+    obs, _ = env.reset()
+    simulator = env.unwrapped.backend
+    for _ in range(100):
+        v = 10.0 * obs[0] + 1.0 * obs[1] + 0.1 * obs[3]
+        obs, _, terminated, truncated, _ = env.step(np.clip([v], -0.9, 0.9).astype(np.float32))
+        assert not (terminated or truncated)
+    left = simulator.get_contact_points("left_wheel_tire")
+    right = simulator.get_contact_points("right_wheel_tire")
+    assert len(left) == 1 and len(right) == 1
+    assert simulator.get_contact_points("no_such_link") == [] and simulator.get_contact_points("torso") == []
+    both = simulator.get_contact_points()
+    assert [c.link_name for c in both] == ["left_wheel_tire", "right_wheel_tire"]
+    weight = 9.81 * sum(env.model.struct.mass[:])
+    total = sum(c.force_in_world for c in both)
+    assert abs(total[2] - weight) < 0.05 * weight and np.all(np.abs(total[:2]) < 0.3 * weight)
+    st = env._vec.sim.state
+    for c, side in zip(both, (1.0, -1.0)):
+        assert abs(c.position_contact_in_world[2]) < 2e-3  # on the floor
+        assert side * (c.position_contact_in_world[1] - float(st[abi.S_POS + 1, 0])) > 0.05  # left tire at +y of the base
+        assert "PointContact(link_name='" in repr(c)
+    # batch form + a robot in the air
+    vec = envs.make("Upkie-HIP-Servos-Vec", num_envs=3, autoreset=False,
+                    init_state=RobotState(position_base_in_world=np.array([0.0, 0.0, 1.5])), **KW)
+    vec.reset()
+    pts = vec.contact_points()
+    assert tuple(pts.shape) == (3, 2, 8) and float(pts.abs().max()) == 0.0
+    assert vec.sim.get_contact_points(env=2) == []

@@ -228,6 +228,7 @@ O_CONTACT = 11
 O_ODOMETRY_POSITION = 12
 O_ODOMETRY_VELOCITY = 13
 OBSERVER_STATE_WORDS = 16
+CONTACT_POINT_WORDS = 8  # UPKIE_CONTACT_POINT_WORDS
 
 
 def default_sim_config(

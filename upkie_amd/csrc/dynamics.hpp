@@ -501,7 +501,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt6)[6][6], const float (&Jb)[6][6], const float (&Jl6)[6][3], const float (&vnow)[6],
                          const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
-                         float (&tb)[6], float (&tl)[3], float (&tr)[3]) {
+                         float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   float J[kRows][6], Ll[kRows][3], vn[kRows], bias[kRows], cf[kRows];
   bool on[kRows];
 #pragma unroll
@@ -672,6 +672,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
   // t += J' lam (limit rows have no base part)
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
+    contact_lam[r] = lam[r];
 #pragma unroll
     for (int c = 0; c < 6; ++c) tb[c] = fmaf(Jb[r][c], lam[r], tb[c]);
   }
@@ -709,7 +710,7 @@ struct GeneralRows {
 
 template <class ModelT>
 UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const GeneralRows& R, const float (&rt)[6], float (&tb)[6],
-                                       float (&tl)[3], float (&tr)[3]) {
+                                       float (&tl)[3], float (&tr)[3], float (&lam_out)[10]) {
   const int n = R.n;
   float A[10][10], Y[10][6], K[10][3], rhs[10], lam[10];
   for (int b = 0; b < n; ++b) {
@@ -821,6 +822,7 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
     if (change <= M.pgs_tolerance * scale) break;
   }
   for (int r = 0; r < n; ++r) {
+    lam_out[r] = lam[r];
 #pragma unroll
     for (int c = 0; c < 6; ++c) tb[c] = fmaf(R.Jb[r][c], lam[r], tb[c]);
 #pragma unroll
@@ -844,7 +846,7 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt)[6][6], const float (&Jb)[6][6], const float (&Jl)[6][3], const float (&vnow)[6],
                          const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
-                         float (&tb)[6], float (&tl)[3], float (&tr)[3]) {
+                         float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   GeneralRows R;
   R.n = 0;
 #pragma unroll
@@ -899,7 +901,15 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
       R.n = i + 1;
     }
   }
-  general_constraint_solve(M, S, R, rt, tb, tl, tr);
+  float lam_rows[10];
+  general_constraint_solve(M, S, R, rt, tb, tl, tr, lam_rows);
+  {  // contact impulses back in the fixed (wheel, row) layout
+    int i = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) contact_lam[3 * w + k] = active[w] ? lam_rows[i++] : 0.f;
+  }
 }
 
 // External forces (pybullet_backend.py:603-658): up to 4 forces at a time, each
@@ -943,12 +953,24 @@ UPKIE_HD void ext_on_leg(const Leg& G, const float* q3, int k, bool local, V3 po
   }
 }
 
+// What PyBulletBackend.get_contact_points reads back from Bullet
+// (pybullet_backend.py:660-716): per tire, whether a contact point exists, where
+// (base frame) and the force the floor exerts on the tire (base frame, N),
+// i.e. the impulses of one substep divided by its duration. Filled by
+// physics_substep() when asked (never on the step path).
+struct ContactReport {
+  bool active[2];
+  V3 point[2];
+  V3 dir[2][3];  // normal, rolling, lateral directions of the rows
+  V3 force[2];
+};
+
 // One physics substep of duration h. tau: commanded joint torques.
 // scale: per-body inertia scales of this env or nullptr. ext: external forces.
 // Returns the floor-contact flag.
 template <bool SCRATCH_LIMITS = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
-                                                const float* scale, const ExtForces& ext) {
+                                                const float* scale, const ExtForces& ext, ContactReport* report = nullptr) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
   // unilateral rows with ERP 0.2): rare, handled by the general solver
   bool any_limit = false;
@@ -1112,6 +1134,11 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);  // a x n / |a x n|
     V3 t2 = cross(nB, t1);
     V3 dirs[3] = {nB, t1, t2};
+    if (report) {
+      report->active[w] = active[w];
+      report->point[w] = P;
+      report->dir[w][0] = nB; report->dir[w][1] = t1; report->dir[w][2] = t2;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       int r = 3 * w + k;
@@ -1137,9 +1164,9 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (any_limit) {
     if (SCRATCH_LIMITS)
-      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
+      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr, lam);
     else
-      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr);
+      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr, lam);
   } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors
@@ -1313,6 +1340,11 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     float nz = dw * qz + dx * qy - dy * qx + dz * qw;
     float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
     s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
+  }
+  if (report) {
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      report->force[w] = ih * (lam[3 * w] * report->dir[w][0] + lam[3 * w + 1] * report->dir[w][1] + lam[3 * w + 2] * report->dir[w][2]);
   }
   return any_contact;
 }

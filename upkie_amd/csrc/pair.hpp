@@ -298,7 +298,8 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
         Jl6[k][j] = pick(leg, Jl[k][j], pjl); Jl6[3 + k][j] = pick(leg, pjl, Jl[k][j]);
       }
     }
-    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl2, tr2);
+    float contact_lam[6];
+    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl2, tr2, contact_lam);
 #pragma unroll
     for (int k = 0; k < 3; ++k) tl[k] = pick(leg, tl2[k], tr2[k]);
   } else if (any_contact) {

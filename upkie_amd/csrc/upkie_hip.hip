@@ -649,6 +649,58 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
 #undef SW
 }
 
+// PyBulletBackend.get_contact_points (pybullet_backend.py:660-716) for every env:
+// the contact solve of one substep from the current state under the last
+// commanded torques, run on a register copy (the state is not written).
+// out [B][2][8] = per tire {exists, position in world (3), force in world (3), 0}.
+// Query path, not the step path: one env per lane, any batch size.
+__global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
+                                                           const float* __restrict__ state, const float* __restrict__ inertia_scale,
+                                                           const float* __restrict__ ext_force, float* __restrict__ out) {
+  const int B = C.num_envs;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  const float* st = state + e;
+#define SW(w) st[(size_t)(w) * B]
+  Phys s;
+  s.pos = v3(SW(UPKIE_S_POS), SW(UPKIE_S_POS + 1), SW(UPKIE_S_POS + 2));
+  s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
+  s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
+  s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
+  float tau[UPKIE_NJ];
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    s.q[j] = SW(UPKIE_S_Q + j);
+    s.qd[j] = SW(UPKIE_S_QD + j);
+    tau[j] = SW(UPKIE_S_TORQUE + j);
+  }
+#undef SW
+  float scale[UPKIE_NB];
+#pragma unroll
+  for (int i = 0; i < UPKIE_NB; ++i) scale[i] = inertia_scale ? inertia_scale[(size_t)i * B + e] : 1.f;
+  const ExtForces ext{ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
+  const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+  const V3 origin = s.pos;
+  ContactReport rep;
+  rep.active[0] = rep.active[1] = false;
+  physics_substep<true>(*Mp, Lm, s, tau, C.h, scale, ext, &rep);
+  const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qz * qw), 2.f * (qw * qy + qx * qz),
+                      2.f * (qx * qy + qz * qw), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qx * qw),
+                      2.f * (qx * qz - qy * qw), 2.f * (qy * qz + qx * qw), 1.f - 2.f * (qx * qx + qy * qy)};
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (rep.active[w]) {
+      const V3 P = rep.point[w], F = rep.force[w];
+      a = make_float4(1.f, origin.x + R[0] * P.x + R[1] * P.y + R[2] * P.z, origin.y + R[3] * P.x + R[4] * P.y + R[5] * P.z,
+                      origin.z + R[6] * P.x + R[7] * P.y + R[8] * P.z);
+      b = make_float4(R[0] * F.x + R[1] * F.y + R[2] * F.z, R[3] * F.x + R[4] * F.y + R[5] * F.z, R[6] * F.x + R[7] * F.y + R[8] * F.z, 0.f);
+    }
+    reinterpret_cast<float4*>(out)[(size_t)4 * e + 2 * w] = a;
+    reinterpret_cast<float4*>(out)[(size_t)4 * e + 2 * w + 1] = b;
+  }
+}
+
 // inertia_scale[body][env] = 1 + U(-v, v), pybullet_backend.py:588-594.
 __global__ __launch_bounds__(64) void inertia_scale_kernel(DevConfig C, float* __restrict__ scale, float variation) {
   const int B = C.num_envs;
@@ -1065,6 +1117,13 @@ extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineOb
   hipLaunchKernelGGL(observe_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->model, sim->config,
                      state, p, update_imu);
   return check_hip(sim, hipGetLastError(), "observe_kernel");
+}
+
+extern "C" int upkie_sim_contact_points(UpkieSim* sim, const float* state, float* out, void* stream) {
+  if (!sim || !state || !out) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(contact_points_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model,
+                     sim->limits, sim->config, state, sim->inertia_scale, sim->ext_force, out);
+  return check_hip(sim, hipGetLastError(), "contact_points_kernel");
 }
 
 // ------------------------------------------------------------------- MPC

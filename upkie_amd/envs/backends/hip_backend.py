@@ -1,7 +1,7 @@
 """Single-robot backend on the HIP library with the reference's Backend
 interface and spine dictionaries (upkie/envs/backends/pybullet_backend.py)."""
 
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -11,6 +11,7 @@ from ...exceptions import UpkieException, UpkieRuntimeError
 from ...model.joint_properties import JointProperties
 from ...model.model import Model
 from ...utils.external_force import ExternalForce
+from ...utils.point_contact import PointContact, point_contacts
 from ...utils.robot_state import RobotState
 from ...utils.robot_state_randomization import RobotStateRandomization
 from ..external_forces import ExternalForceSet
@@ -135,3 +136,9 @@ class HipBackend(Backend):
         frame, persisting until the link is given another force."""
         self._external_forces.update(external_forces)
         self._external_forces.push(self.sim)
+
+    def get_contact_points(self, link_name: Optional[str] = None) -> List[PointContact]:
+        """pybullet_backend.py:660-716: contact points between the robot and
+        the floor, optionally only those of one link. Only the tires collide
+        with the floor here, one point each at most."""
+        return point_contacts(self.sim.contact_points()[0].cpu().numpy(), link_name)

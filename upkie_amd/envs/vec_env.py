@@ -231,6 +231,14 @@ class UpkieVecEnv:
             self._external_forces.update(external_forces)
         self._external_forces.push(self.sim)
 
+    def contact_points(self) -> torch.Tensor:
+        """Tire/floor contact points of every env, ``[B, 2, 8]`` (left, right
+        tire): ``[exists, position in world (3), force in world (3), 0]`` --
+        PyBulletBackend.get_contact_points (pybullet_backend.py:660-716) for
+        the batch; `sim.get_contact_points(link_name, env)` gives the
+        reference's list of `PointContact` for one env."""
+        return self.sim.contact_points()
+
     def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
         if mask is None:
             self._elapsed.zero_()

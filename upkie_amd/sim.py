@@ -309,6 +309,24 @@ class BatchedSim:
             )
         return out
 
+    def contact_points(self) -> torch.Tensor:
+        """Tire/floor contact points of every env, ``[B, 2, 8]``: per tire (left,
+        right) ``[exists, position in world (3), force in world (3), 0]``
+        (PyBulletBackend.get_contact_points, pybullet_backend.py:660-716). A
+        query, not part of the step: one extra small launch."""
+        out = torch.empty((self.num_envs, 2, abi.CONTACT_POINT_WORDS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.upkie_sim_contact_points(self._handle, _ptr(self.state), _ptr(out), self._stream()))
+        return out
+
+    def get_contact_points(self, link_name: Optional[str] = None, env: int = 0) -> list:
+        """`PyBulletBackend.get_contact_points(link_name)` for one env of the
+        batch (what ``env.unwrapped.backend.get_contact_points(...)`` of
+        examples/pybullet/count_wheel_contacts.py:34-48 calls)."""
+        from .utils.point_contact import point_contacts
+
+        return point_contacts(self.contact_points()[env].cpu().numpy(), link_name)
+
     def attach_observers(self, config: Optional[abi.UpkieObserverConfig]) -> Optional[torch.Tensor]:
         """Run the spine's FloorContact / WheelContact / WheelOdometry observers
         inside every step, one observer cycle per physics substep (the spine's
