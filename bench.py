@@ -94,7 +94,9 @@ def main() -> None:
     B = args.envs_per_gpu
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
-    env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world)
+    # UPKIE_FORCE_PROCESS_GROUP=1: run the RCCL gather path on a one-rank group (test of the N > 1 code on one GPU)
+    forced = True if os.environ.get("UPKIE_FORCE_PROCESS_GROUP") == "1" else None
+    env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world, collectives=forced)
     env.reset()
 
     for _ in range(args.warmup):
@@ -146,7 +148,7 @@ def main() -> None:
             "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset",
             "envs_per_gpu": B,
             "total_envs": total_envs,
-            "gather": f"RCCL gather of the packed obs/reward/done records of every step into rank 0's rollout ring buffer, one asynchronous collective per {env.gather.chunk}-step chunk, overlapped with the next chunk's kernels" if world > 1 else "none (single GPU): records written straight into the rollout ring buffer",
+            "gather": f"RCCL gather of the packed obs/reward/done records of every step into rank 0's rollout ring buffer, one asynchronous collective per {env.gather.chunk}-step chunk, overlapped with the next chunk's kernels" if env.gather.collectives else "none (single GPU): records written straight into the rollout ring buffer",
             "episode_resets_in_timed_region": resets,
         },
         "roofline": {

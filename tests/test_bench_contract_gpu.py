@@ -33,3 +33,52 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == "env-steps/s"
     assert out["value"] > 100 * cpu["value"] / cpu["cores"]  # sanity: a GPU is not slower than a CPU core
+
+
+def test_bench_under_torchrun_through_rccl_on_one_rank():
+    """The driver's N > 1 launch line (`python -m torch.distributed.run
+    --nproc-per-node N ... bench.py --gpus N`) with N = 1 and the collective
+    path forced on: RCCL init with `device_id`, the asynchronous chunked
+    `dist.gather` into the rollout ring, barrier, MAX / SUM all-reduces and the
+    shutdown all run on the GPU (a one-GPU box cannot host two ranks)."""
+    env = dict(os.environ, UPKIE_CPU_BASELINE_BUDGET_S="1", UPKIE_FORCE_PROCESS_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100", "--warmup", "20"]
+    result = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 1e6
+    assert out["config"]["gather"].startswith("RCCL gather")
+
+
+def test_rccl_gather_delivers_every_step_to_the_ring():
+    """RolloutGather over a one-rank RCCL group: what reaches the rollout ring
+    through the collectives equals what a rank without collectives writes."""
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from upkie_amd.distributed import ShardedPendulum
+from upkie_amd import abi
+def run(collectives):
+    cfg = abi.default_sim_config(512, frequency=200.0, seed=3)
+    cfg.rand_pitch = 0.1; cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+    env = ShardedPendulum(cfg, device="cuda:0", horizon=32, chunk=8, collectives=collectives)
+    env.reset()
+    for _ in range(29):  # not a multiple of the chunk: flush ships the partial one
+        env.step_agent()
+    env.flush(); env.barrier()
+    return torch.stack([env.gather.last(k).clone() for k in range(24)]), env.total_resets(), env.max_over_ranks(1.5)
+a, ra, ma = run(True)
+b, rb, mb = run(False)
+assert torch.equal(a, b) and ra == rb and ma == mb == 1.5, (float((a - b).abs().max()), ra, rb)
+assert float(a.abs().sum()) > 0
+dist.destroy_process_group()
+print("RCCL_GATHER_OK")
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    result = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert result.returncode == 0 and "RCCL_GATHER_OK" in result.stdout, (result.stdout[-1000:], result.stderr[-3000:])

@@ -38,7 +38,9 @@ def shard_range(rank: int, world_size: int, total_envs: int) -> Tuple[int, int]:
 def init_distributed(expected_world: Optional[int] = None, backend: Optional[str] = None):
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them). Backend
-    "nccl" is RCCL on ROCm; "gloo" is used for CPU tests. Returns
+    "nccl" is RCCL on ROCm; "gloo" is used for CPU tests. A single process
+    joins no group unless UPKIE_FORCE_PROCESS_GROUP=1 (a one-rank RCCL group:
+    how the collective path is exercised on a one-GPU box). Returns
     (rank, world_size, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -48,7 +50,7 @@ def init_distributed(expected_world: Optional[int] = None, backend: Optional[str
             f"--gpus {expected_world} but WORLD_SIZE={world}: launch with "
             "python -m torch.distributed.run --nproc-per-node N"
         )
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("UPKIE_FORCE_PROCESS_GROUP") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -83,14 +85,18 @@ class RolloutGather:
     Works on any device / backend (RCCL for GPU tensors, gloo for CPU tests).
     """
 
-    def __init__(self, local_envs: int, rank: int, world_size: int, device, horizon: int = 128, words: int = RECORD_WORDS, chunk: int = 8):
+    def __init__(self, local_envs: int, rank: int, world_size: int, device, horizon: int = 128, words: int = RECORD_WORDS, chunk: int = 8,
+                 collectives: Optional[bool] = None):
         self.rank, self.world_size = rank, world_size
+        # staged + gathered (several ranks) or produced straight into the ring (one rank);
+        # `collectives=True` forces the gather path on a one-rank group (RCCL smoke test on one GPU)
+        self.collectives = world_size > 1 if collectives is None else bool(collectives)
         self.chunk = max(1, int(chunk))
         self.num_chunks = max(2, -(-int(horizon) // self.chunk))  # ring of chunks on rank 0
         self.horizon = self.num_chunks * self.chunk
         K = self.chunk
         f32 = dict(dtype=torch.float32, device=device)
-        self.staging = torch.zeros((2, K, local_envs, words), **f32) if world_size > 1 else None
+        self.staging = torch.zeros((2, K, local_envs, words), **f32) if self.collectives else None
         self._work = [None, None]
         self._step = 0  # index of the step being produced
         self.rollout: Optional[torch.Tensor] = None
@@ -100,7 +106,7 @@ class RolloutGather:
 
     def _slot(self, step: int) -> torch.Tensor:
         K = self.chunk
-        if self.world_size == 1:  # single rank: produce straight into the ring
+        if not self.collectives:  # single rank: produce straight into the ring
             return self.rollout[(step // K) % self.num_chunks, 0, step % K]
         return self.staging[(step // K) % 2, step % K]
 
@@ -113,7 +119,7 @@ class RolloutGather:
         return self._slot(self._step - 1)
 
     def begin_step(self) -> torch.Tensor:
-        if self.world_size > 1 and self._step % self.chunk == 0:
+        if self.collectives and self._step % self.chunk == 0:
             c = (self._step // self.chunk) % 2
             if self._work[c] is not None:
                 self._work[c].wait()  # the gather issued two chunks ago has read this buffer
@@ -132,14 +138,14 @@ class RolloutGather:
     def end_step(self) -> None:
         step = self._step
         self._step += 1
-        if self.world_size > 1 and step % self.chunk == self.chunk - 1:
+        if self.collectives and step % self.chunk == self.chunk - 1:
             self._gather_chunk(step // self.chunk)
 
     def flush(self) -> None:
         """Ship a partially filled chunk and wait for every gather in flight
         (end of a rollout / of the bench). Every rank must call it at the same
         step."""
-        if self.world_size > 1 and self._step % self.chunk != 0:
+        if self.collectives and self._step % self.chunk != 0:
             self._gather_chunk(self._step // self.chunk)  # re-sent in full when the chunk completes
         for i, work in enumerate(self._work):
             if work is not None:
@@ -163,13 +169,15 @@ class ShardedPendulum:
     """This rank's shard of a batch of Upkie-Pendulum envs plus the pipelined
     gather of per-step records into rank 0's rollout buffer."""
 
-    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8, sim_factory=None):
+    def __init__(self, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8, sim_factory=None,
+                 collectives: Optional[bool] = None):
         from .sim import BatchedSim
 
         self.rank, self.world_size = rank, world_size
         # (sim_factory: test doubles only; the product always builds a BatchedSim)
         self.sim = sim_factory(config, model, device) if sim_factory is not None else BatchedSim(config, model, device=device)
-        self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon, chunk=chunk)
+        self.gather = RolloutGather(self.sim.num_envs, rank, world_size, self.sim.device, horizon=horizon, chunk=chunk, collectives=collectives)
+        self._collectives = self.gather.collectives
         self._device = self.sim.device
 
     def reset(self) -> None:
@@ -197,11 +205,11 @@ class ShardedPendulum:
         self.gather.flush()
 
     def barrier(self) -> None:
-        if self.world_size > 1:
+        if self._collectives:
             dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world_size == 1:
+        if not self._collectives:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self._device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -212,12 +220,12 @@ class ShardedPendulum:
         from . import abi
 
         n = self.sim.state[abi.S_EPISODE].sum().to(torch.float64).reshape(1)
-        if self.world_size > 1:
+        if self._collectives:
             dist.all_reduce(n, op=dist.ReduceOp.SUM)
         return int(n.item())
 
     def shutdown(self) -> None:
         self.gather.flush()
         self.sim.close()
-        if self.world_size > 1 and dist.is_initialized():
+        if self._collectives and dist.is_initialized():
             dist.destroy_process_group()
