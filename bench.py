@@ -77,6 +77,36 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     }
 
 
+def issue_floor(launch_us: float):
+    """What actually bounds the step at this batch size: 4096 envs are 128
+    waves on 1024 SIMDs, one wave per SIMD, and a lone gfx950 wave issues one
+    instruction per >= 4.5 cycles whatever its kind (tools/microbench/
+    issue_rate.hip, profiles/r01_issue_rate_microbench.txt). Instructions per
+    wave come from the committed PMC passes of this same kernel and batch;
+    the launch duration is the live one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_b4096_final.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = {k: v["mean_per_launch"] for k, v in json.load(f).items()}
+    try:
+        instructions = sum(pmc[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"))
+        per_wave = instructions / pmc["SQ_WAVES"]
+    except KeyError:
+        return None
+    cycles, ghz = 4.5, 2.4
+    floor_us = per_wave * cycles / (ghz * 1e3)
+    return {
+        "instructions_per_wave": per_wave,
+        "cycles_per_instruction_lone_wave": cycles,
+        "clock_ghz": ghz,
+        "floor_us": floor_us,
+        "achieved_us": launch_us,
+        "frac": floor_us / launch_us,
+        "source": "profiles/r01_pmc_summary_b4096_final.json (rocprofv3 --pmc), profiles/r01_issue_rate_microbench.txt",
+    }
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -164,6 +194,9 @@ def main() -> None:
             "note": "the step is fp32-VALU/latency bound (~2e4 VALU instructions vs 258 B per env-step), not HBM bound: see DESIGN.md section 6",
         },
     }
+    issue = issue_floor(launch_us) if B == ENVS_PER_GPU else None
+    if issue is not None:
+        line["roofline"]["issue_floor"] = issue
     if world == 1 and not args.no_cpu_baseline:
         # (the budget can be shortened for tests; the default sample is ~15 s of CPU work)
         line["cpu_baseline"] = cpu_baseline(B, float(os.environ.get("UPKIE_CPU_BASELINE_BUDGET_S", "15")))
