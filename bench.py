@@ -7,7 +7,7 @@ README's PD-gain balancer evaluated on-device, init-state randomisation pitch
 NEXT_STEP autoreset. One "step" = one env.step() of every env = ONE kernel
 launch per GPU; for N > 1 ranks the packed (obs, reward, terminated,
 truncated) records of every step are gathered to rank 0 over RCCL, one
-asynchronous collective per 8-step chunk.
+asynchronous collective per 32-step chunk.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
+GATHER_CHUNK = 32  # steps per collective: a gather costs ~27 us of queue time whatever its size (profiles/r01_gather_chunk_sweep.txt)
 # 29 fp32 state words read + written (232 B), action 4,
 # obs 16, reward 4, terminated 1, truncated 1.
 ALGORITHMIC_BYTES_PER_ENV_STEP = 258
@@ -114,6 +115,7 @@ def main() -> None:
     parser.add_argument("--warmup", type=int, default=200)
     parser.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--gather-chunk", type=int, default=GATHER_CHUNK, help="steps per RCCL gather (N > 1)")
     args = parser.parse_args()
 
     import torch
@@ -126,7 +128,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     # UPKIE_FORCE_PROCESS_GROUP=1: run the RCCL gather path on a one-rank group (test of the N > 1 code on one GPU)
     forced = True if os.environ.get("UPKIE_FORCE_PROCESS_GROUP") == "1" else None
-    env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world, collectives=forced)
+    env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world, collectives=forced, chunk=args.gather_chunk)
     env.reset()
 
     for _ in range(args.warmup):
