@@ -69,12 +69,23 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
         elapsed = time.perf_counter() - t0
         if elapsed >= budget_s or steps >= 5000:
             break
+    # the reference's own execution model: one env, one thread
+    single = O.Oracle(default_model(), make_config(1))
+    o1 = single.reset()[:, [1, 0, 4, 3]]
+    n1, t1 = 0, time.perf_counter()
+    while True:
+        o1, *_ = single.step_pendulum_agent(o1)
+        n1 += 1
+        e1 = time.perf_counter() - t1
+        if e1 >= min(2.0, budget_s) or n1 >= 100000:
+            break
     return {
         "value": envs * steps / elapsed,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{steps} env.step() of {envs} envs, fp64 C oracle, OpenMP over envs ({elapsed:.1f} s)",
+        "single_env_single_thread": {"value": n1 / e1, "unit": "env-steps/s", "sample": f"{n1} env.step() of 1 env ({e1:.1f} s)"},
     }
 
 
