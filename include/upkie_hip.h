@@ -58,6 +58,12 @@ enum UpkieStateWord {
  * the done flag); everything else is untouched by that kernel. */
 #define UPKIE_PENDULUM_STATE_WORDS 29
 
+/* URDF links the model remembers (upkie_description's Upkie has 15 with mass). */
+#define UPKIE_MAX_LINKS 24
+/* Per-env inertial record of one composite body: mass, com (3, body frame),
+ * inertia about the com (xx yy zz xy xz yz, body axes). */
+#define UPKIE_INERTIAL_WORDS 10
+
 enum UpkieStatus {
   UPKIE_OK = 0,
   UPKIE_ERR_INVALID_ARGUMENT = -1,
@@ -111,6 +117,19 @@ typedef struct UpkieModel {
                                       than this fraction of the largest one  */
   int32_t pgs_iterations;          /* Bullet numSolverIterations, 50        */
   int32_t enforce_joint_limits;    /* hip/knee limit rows in the solver     */
+  /* The URDF links each composite body was fused from: what Bullet keeps as
+   * separate links (no URDF_MERGE_FIXED_LINKS, pybullet_backend.py:121-125) and
+   * randomize_inertias() scales one by one (pybullet_backend.py:555-601).
+   * num_links = 0: one link per body. */
+  int32_t num_links;
+  int32_t link_body[UPKIE_MAX_LINKS];       /* composite body of the link   */
+  int32_t link_randomized[UPKIE_MAX_LINKS]; /* 0 for the URDF root link: Bullet's
+                                               base (index -1) is not in
+                                               range(getNumJoints), :563     */
+  double link_mass[UPKIE_MAX_LINKS];
+  double link_com[UPKIE_MAX_LINKS][3];      /* link com in its body's frame  */
+  double link_inertia[UPKIE_MAX_LINKS][6];  /* about the link com, body axes:
+                                               xx yy zz xy xz yz             */
 } UpkieModel;
 
 /* Everything gym.make(...) kwargs decide for one batch of environments
@@ -174,11 +193,12 @@ int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config);
 int64_t upkie_sim_state_bytes(const UpkieSim* sim);
 
 /* Optional per-env domain randomisation buffers (device pointers, may be
- * NULL): inertia_scale[UPKIE_NB][B] multiplies mass and inertia of each body
- * (pybullet_backend.py:571-601); ext_force[3][B] is a world-frame force
- * applied at point `ext_point` of the trunk, re-applied every substep until
- * overwritten (pybullet_backend.py:603-658). */
-int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_scale,
+ * NULL): body_inertials[UPKIE_NB * UPKIE_INERTIAL_WORDS][B] replaces mass,
+ * centre of mass and inertia of every composite body of every env (filled by
+ * upkie_sim_sample_body_inertials; pybullet_backend.py:571-601); ext_force[3][B]
+ * is a world-frame force applied at point `ext_point` of the trunk, re-applied
+ * every substep until overwritten (pybullet_backend.py:603-658). */
+int upkie_sim_set_randomization(UpkieSim* sim, const float* body_inertials,
                                 const float* ext_force,
                                 const double ext_point[3]);
 
@@ -203,9 +223,14 @@ typedef struct UpkieExternalForces {
 int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
                                   const UpkieExternalForces* slots);
 
-/* Fill inertia_scale[UPKIE_NB][B] with 1 + U(-v, v), one draw per body and
- * env (pybullet_backend.py:571-601). */
-int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale,
+/* PyBulletBackend.randomize_inertias (pybullet_backend.py:571-601) for every
+ * env: one epsilon ~ U(-v, v) per URDF link and env scales that link's mass
+ * and inertia by (1 + epsilon); the links of each composite body are then
+ * fused again (mass, centre of mass, inertia about it) into
+ * body_inertials[UPKIE_NB * UPKIE_INERTIAL_WORDS][B], row 10 * body + word.
+ * link_scale (may be NULL) receives the factors, [UPKIE_MAX_LINKS][B]. */
+int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inertials,
+                                    float* link_scale,
                                     double inertia_variation, void* stream);
 
 /* Reset the envs whose mask byte is non-zero (all when mask is NULL):

@@ -32,7 +32,7 @@ class ServoCommand(C.Structure):
 
 class Randomization(C.Structure):
     _fields_ = [
-        ("inertia_scale", C.c_void_p),
+        ("body_inertials", C.c_void_p),
         ("ext_force", C.c_void_p),
         ("ext_point", C.c_double * 3),
         ("ext_slots", C.c_void_p),
@@ -151,7 +151,8 @@ class Oracle:
         self.config = config
         self.B = config.num_envs
         self.state = np.zeros((abi.STATE_WORDS, self.B), dtype=np.float64)
-        self.inertia_scale = None
+        self.body_inertials = None  # [70, B] per-env inertial records of the bodies (randomize_inertias)
+        self.link_scale = None
         self.ext_force = None  # [3, B] (legacy: trunk, world frame) or [count, 3, B] with ext_slots
         self.ext_point = np.zeros(3)
         self.ext_slots = None  # abi.UpkieExternalForces
@@ -161,10 +162,10 @@ class Oracle:
 
     # -- randomisation -----------------------------------------------------
     def _rnd(self):
-        if self.inertia_scale is None and self.ext_force is None and self.observer_config is None:
+        if self.body_inertials is None and self.ext_force is None and self.observer_config is None:
             return None
         r = Randomization()
-        r.inertia_scale = _ptr(self.inertia_scale)
+        r.body_inertials = _ptr(self.body_inertials)
         r.ext_force = _ptr(self.ext_force)
         r.ext_point[:] = list(self.ext_point)
         r.ext_slots = C.cast(C.pointer(self.ext_slots), C.c_void_p) if (self.ext_slots is not None and self.ext_force is not None) else None
@@ -184,12 +185,16 @@ class Oracle:
         self.observer_config = config
         self.observer_state = np.zeros((abi.OBSERVER_STATE_WORDS, self.B))
 
-    def sample_inertia_scales(self, variation: float):
-        scale = np.zeros((abi.NB, self.B))
-        self._lib.oracle_sample_inertia_scales(
-            C.byref(self.config), C.c_double(variation), _ptr(scale)
+    def sample_body_inertials(self, variation: float):
+        """randomize_inertias (pybullet_backend.py:571-601): per-link factors
+        ``[MAX_LINKS, B]`` and the fused per-env body records ``[70, B]``."""
+        records = np.zeros((abi.NB * abi.INERTIAL_WORDS, self.B))
+        link_scale = np.zeros((abi.MAX_LINKS, self.B))
+        self._lib.oracle_sample_body_inertials(
+            C.byref(self.model), C.byref(self.config), C.c_double(variation), _ptr(records), _ptr(link_scale)
         )
-        return scale
+        self.link_scale = link_scale
+        return records
 
     # -- env API -----------------------------------------------------------
     def reset(self, mask=None):
@@ -290,8 +295,8 @@ class Oracle:
         s = np.ascontiguousarray(self.state[:, env])
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         scale = (
-            np.ascontiguousarray(self.inertia_scale[:, env])
-            if self.inertia_scale is not None
+            np.ascontiguousarray(self.body_inertials[:, env])
+            if self.body_inertials is not None
             else None
         )
         if self.ext_force is not None and self.ext_slots is not None:

@@ -216,7 +216,9 @@ static int on_path(int j, int i) {
   return leg_i == leg_j && (j % 3) <= ((i - 1) % 3);
 }
 
-static void kinematics(const UpkieModel* model, const double* scale,
+/* inertials: per-env records of the bodies (mass, com, inertia about it:
+ * [10 * body + word], what randomize_inertias leaves behind) or NULL */
+static void kinematics(const UpkieModel* model, const double* inertials,
                        const double pos[3], const double quat[4],
                        const double q[NJ], Kin* k) {
   quat_to_matrix(quat, k->R[0]);
@@ -231,19 +233,18 @@ static void kinematics(const UpkieModel* model, const double* scale,
     m3_mulv(k->R[i], model->joint_axis[j], k->a[j]);
   }
   for (int i = 0; i < NB; ++i) {
-    double s = scale ? scale[i] : 1.0;
+    const double* rec = inertials ? inertials + UPKIE_INERTIAL_WORDS * i : NULL;
     double r[3];
-    m3_mulv(k->R[i], model->com[i], r);
+    m3_mulv(k->R[i], rec ? rec + 1 : model->com[i], r);
     for (int d = 0; d < 3; ++d) k->c[i][d] = k->o[i][d] + r[d];
-    const double* I6 = model->inertia[i];
+    const double* I6 = rec ? rec + 4 : model->inertia[i];
     double Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5],
                     I6[4], I6[5], I6[2]};
     double Rt[9], T[9];
     m3_transpose(k->R[i], Rt);
     m3_mul(k->R[i], Ib, T);
     m3_mul(T, Rt, k->Iw[i]);
-    for (int e = 0; e < 9; ++e) k->Iw[i][e] *= s;
-    k->m[i] = model->mass[i] * s;
+    k->m[i] = rec ? rec[0] : model->mass[i];
   }
 }
 
@@ -476,7 +477,7 @@ static _Thread_local double* g_contact_sink = NULL;
  * position integration (semi-implicit Euler, pinned by
  * upkie/cpp/interfaces/tests/BulletInterfaceTest.cpp:263-285). */
 int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
-                       double h, const double* inertia_scale,
+                       double h, const double* body_inertials,
                        const double* ext_forces, const UpkieExternalForces* ext_slots) {
   double* pos = s + UPKIE_S_POS;
   double* quat = s + UPKIE_S_QUAT;
@@ -487,7 +488,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
 
   oracle_debug_substeps += 1;
   Kin k;
-  kinematics(model, inertia_scale, pos, quat, q, &k);
+  kinematics(model, body_inertials, pos, quat, q, &k);
   double M[NV * NV], bias[NV], L[NV * NV];
   mass_matrix_and_bias(&k, model->gravity, linvel, angvel, qd, M, bias);
 
@@ -787,7 +788,7 @@ static void store_env(double* state, int B, int e, const double s[NW]) {
   for (int w = 0; w < NW; ++w) state[(int64_t)w * B + e] = s[w];
 }
 static void env_randomization(const OracleRandomization* rnd, int B, int e,
-                              double scale[NB], double force[3 * UPKIE_MAX_EXTERNAL_FORCES],
+                              double scale[NB * UPKIE_INERTIAL_WORDS], double force[3 * UPKIE_MAX_EXTERNAL_FORCES],
                               UpkieExternalForces* slots,
                               const double** scale_p, const double** force_p,
                               const UpkieExternalForces** slots_p) {
@@ -795,8 +796,8 @@ static void env_randomization(const OracleRandomization* rnd, int B, int e,
   *force_p = NULL;
   *slots_p = NULL;
   if (!rnd) return;
-  if (rnd->inertia_scale) {
-    for (int i = 0; i < NB; ++i) scale[i] = rnd->inertia_scale[(int64_t)i * B + e];
+  if (rnd->body_inertials) { /* this env's inertial records, [10 * body + word] */
+    for (int i = 0; i < NB * UPKIE_INERTIAL_WORDS; ++i) scale[i] = rnd->body_inertials[(int64_t)i * B + e];
     *scale_p = scale;
   }
   if (rnd->ext_force) {
@@ -910,17 +911,57 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   s[UPKIE_S_DONE] = 0.0;
 }
 
-void oracle_sample_inertia_scales(const UpkieSimConfig* cfg,
-                                  double inertia_variation, double* scale) {
+/* PyBulletBackend.randomize_inertias, pybullet_backend.py:571-601, for every
+ * env: epsilon ~ U(-v, v) per URDF link scales its mass and inertia (:588-594;
+ * the root link is not in range(getNumJoints), :563); the links of a composite
+ * body are then fused again: records[(10 * body + word)][B]. */
+void oracle_sample_body_inertials(const UpkieModel* model, const UpkieSimConfig* cfg,
+                                  double inertia_variation, double* records, double* link_scale) {
   int B = cfg->num_envs;
+  int n = model->num_links > 0 ? model->num_links : NB;
   for (int e = 0; e < B; ++e) {
-    double u0[4], u1[4];
-    philox_uniform4(cfg->seed, cfg->env_id_offset + e, 0, STREAM_INERTIA, 0, u0);
-    philox_uniform4(cfg->seed, cfg->env_id_offset + e, 0, STREAM_INERTIA, 1, u1);
-    for (int i = 0; i < NB; ++i) {
-      double u = i < 4 ? u0[i] : u1[i - 4];
-      /* pybullet_backend.py:588-594 */
-      scale[(int64_t)i * B + e] = 1.0 + uniform(-inertia_variation, inertia_variation, u);
+    double f[UPKIE_MAX_LINKS];
+    for (int blk = 0; blk < UPKIE_MAX_LINKS / 4; ++blk) {
+      double u[4];
+      philox_uniform4(cfg->seed, cfg->env_id_offset + e, 0, STREAM_INERTIA, blk, u);
+      for (int i = 0; i < 4; ++i) {
+        int l = 4 * blk + i;
+        int randomized = l < n && (model->num_links > 0 ? model->link_randomized[l] != 0 : 1);
+        f[l] = randomized ? 1.0 + uniform(-inertia_variation, inertia_variation, u[i]) : 1.0;
+        if (link_scale) link_scale[(int64_t)l * B + e] = f[l];
+      }
+    }
+    for (int b = 0; b < NB; ++b) {
+      double m = 0.0, mc[3] = {0, 0, 0};
+      for (int l = 0; l < n; ++l) {
+        int lb = model->num_links > 0 ? model->link_body[l] : l;
+        if (lb != b) continue;
+        double ml = f[l] * (model->num_links > 0 ? model->link_mass[l] : model->mass[l]);
+        const double* c = model->num_links > 0 ? model->link_com[l] : model->com[l];
+        m += ml;
+        for (int d = 0; d < 3; ++d) mc[d] += ml * c[d];
+      }
+      double com[3] = {mc[0] / m, mc[1] / m, mc[2] / m};
+      double I[6] = {0, 0, 0, 0, 0, 0};
+      for (int l = 0; l < n; ++l) {
+        int lb = model->num_links > 0 ? model->link_body[l] : l;
+        if (lb != b) continue;
+        double ml = f[l] * (model->num_links > 0 ? model->link_mass[l] : model->mass[l]);
+        const double* c = model->num_links > 0 ? model->link_com[l] : model->com[l];
+        const double* Il = model->num_links > 0 ? model->link_inertia[l] : model->inertia[l];
+        double d[3] = {c[0] - com[0], c[1] - com[1], c[2] - com[2]};
+        /* parallel axis: I + m (|d|^2 1 - d d') */
+        I[0] += f[l] * Il[0] + ml * (d[1] * d[1] + d[2] * d[2]);
+        I[1] += f[l] * Il[1] + ml * (d[0] * d[0] + d[2] * d[2]);
+        I[2] += f[l] * Il[2] + ml * (d[0] * d[0] + d[1] * d[1]);
+        I[3] += f[l] * Il[3] - ml * d[0] * d[1];
+        I[4] += f[l] * Il[4] - ml * d[0] * d[2];
+        I[5] += f[l] * Il[5] - ml * d[1] * d[2];
+      }
+      double* r = records + (int64_t)(UPKIE_INERTIAL_WORDS * b) * B + e;
+      r[0] = m;
+      for (int d = 0; d < 3; ++d) r[(int64_t)(1 + d) * B] = com[d];
+      for (int d = 0; d < 6; ++d) r[(int64_t)(4 + d) * B] = I[d];
     }
   }
 }
@@ -931,7 +972,7 @@ void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
     UpkieExternalForces slots;
     const double *sp, *fp;
     const UpkieExternalForces* pp;
@@ -1084,7 +1125,7 @@ void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
     UpkieExternalForces slots;
     const double *sp, *fp;
     const UpkieExternalForces* pp;
@@ -1110,7 +1151,7 @@ void oracle_step_pendulum(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
     UpkieExternalForces slots;
     const double *sp, *fp;
     const UpkieExternalForces* pp;
@@ -1136,7 +1177,7 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6];
     UpkieExternalForces slots;
     const double *sp, *fp;
     const UpkieExternalForces* pp;
@@ -1181,7 +1222,7 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
   int B = cfg->num_envs;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
     UpkieExternalForces slots;
     const double *sp, *fp;
     const UpkieExternalForces* pp;
@@ -1276,7 +1317,7 @@ void oracle_contact_points(const UpkieModel* model, const UpkieSimConfig* cfg,
   const int B = cfg->num_envs;
   const double h = cfg->dt / cfg->nb_substeps;
   for (int e = 0; e < B; ++e) {
-    double s[NW], scale[NB], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES];
     UpkieExternalForces slots;
     const double *scale_p, *force_p;
     const UpkieExternalForces* slots_p;
@@ -1335,12 +1376,12 @@ void oracle_gyropod_observation(const UpkieModel* model, const double* state, do
 
 /* One world-frame force at a trunk point (the original entry point). */
 int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
-                   double h, const double* inertia_scale,
+                   double h, const double* body_inertials,
                    const double* ext_force, const double* ext_point) {
   UpkieExternalForces slots;
   memset(&slots, 0, sizeof(slots));
   slots.count = 1;
   if (ext_point)
     for (int d = 0; d < 3; ++d) slots.point[0][d] = ext_point[d];
-  return oracle_substep_ext(model, s, tau, h, inertia_scale, ext_force, ext_force ? &slots : NULL);
+  return oracle_substep_ext(model, s, tau, h, body_inertials, ext_force, ext_force ? &slots : NULL);
 }

@@ -41,7 +41,7 @@ typedef struct OracleServoCommand {
 
 /* Optional per-env randomisation inputs (any pointer may be NULL). */
 typedef struct OracleRandomization {
-  const double* inertia_scale; /* [UPKIE_NB][B] */
+  const double* body_inertials; /* [UPKIE_NB * UPKIE_INERTIAL_WORDS][B], oracle_sample_body_inertials */
   const double* ext_force;     /* [count][3][B] (count = 1 without ext_slots) */
   double ext_point[3];         /* without ext_slots: application point on the trunk, base frame */
   const UpkieExternalForces* ext_slots; /* bodies / points / frames of the forces, or NULL */
@@ -91,16 +91,17 @@ double oracle_energy(const UpkieModel* model, const double pos[3],
  * state[UPKIE_STATE_WORDS]; tau = commanded joint torques. Returns the floor
  * contact flag. */
 int oracle_substep(const UpkieModel* model, double* state, const double tau[6],
-                   double h, const double* inertia_scale,
+                   double h, const double* body_inertials /* [70] of this env or NULL */,
                    const double* ext_force, const double* ext_point);
 /* Same with forces on any link: ext_forces[count][3], pybullet_backend.py:603-658. */
 int oracle_substep_ext(const UpkieModel* model, double* state, const double tau[6],
-                       double h, const double* inertia_scale,
+                       double h, const double* body_inertials /* [70] of this env or NULL */,
                        const double* ext_forces, const UpkieExternalForces* ext_slots);
 
 /* Batched entry points mirroring the HIP C-ABI (state is [WORDS][B]). */
-void oracle_sample_inertia_scales(const UpkieSimConfig* cfg,
-                                  double inertia_variation, double* scale);
+void oracle_sample_body_inertials(const UpkieModel* model, const UpkieSimConfig* cfg,
+                                  double inertia_variation, double* records /* [70][B] */,
+                                  double* link_scale /* [UPKIE_MAX_LINKS][B] or NULL */);
 void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
                   double* state, const uint8_t* mask,
                   const OracleRandomization* rnd, double* obs6);

@@ -28,7 +28,7 @@ class OracleSim:
         self.reward = torch.zeros(B)
         self.terminated = torch.zeros(B, dtype=torch.uint8)
         self.truncated = torch.zeros(B, dtype=torch.uint8)
-        self.inertia_scale = None
+        self.body_inertials = None
         self.ext_force = None
 
     @property
@@ -56,9 +56,10 @@ class OracleSim:
         self._o.config = self.config
 
     def randomize_inertias(self, variation):
-        self._o.inertia_scale = self._o.sample_inertia_scales(variation)
-        self.inertia_scale = torch.from_numpy(self._o.inertia_scale.astype(np.float32))
-        return self.inertia_scale
+        self._o.body_inertials = self._o.sample_body_inertials(variation)
+        self.body_inertials = torch.from_numpy(self._o.body_inertials.astype(np.float32))
+        self.link_scale = torch.from_numpy(self._o.link_scale.astype(np.float32))
+        return self.body_inertials
 
     def set_external_force(self, force, point=(0.0, 0.0, 0.0)):
         self.ext_force = force

@@ -99,18 +99,72 @@ def test_substep_matches_oracle(harness, on_floor):
     assert worst[19:25].max() < 2e-2  # joint velocities (wheel inertia 2.8e-4)
 
 
-def test_substep_with_inertia_scales_and_external_force(harness):
+def records_of_model(model, scale=None):
+    """Per-env inertial records [70] of the model's bodies, each scaled as a whole."""
+    rec = np.zeros(abi.NB * abi.INERTIAL_WORDS)
+    for b in range(abi.NB):
+        f = 1.0 if scale is None else scale[b]
+        rec[10 * b] = f * model.mass[b]
+        rec[10 * b + 1 : 10 * b + 4] = list(model.com[b])
+        rec[10 * b + 4 : 10 * b + 10] = [f * x for x in model.inertia[b]]
+    return rec
+
+
+def test_substep_with_body_inertials_and_external_force(harness):
     rng = np.random.default_rng(6)
     model = default_model()
-    for _ in range(50):
+    for trial in range(50):
         s = random_state(rng, True)
-        scale = rng.uniform(0.8, 1.2, 7)
+        rec = records_of_model(model, rng.uniform(0.8, 1.2, 7))
+        if trial % 2:  # shifted centres of mass and full inertia tensors, as fused links give
+            for b in range(abi.NB):
+                if b in (3, 6):  # wheels stay axisymmetric (the model says so: their rotation is skipped)
+                    rec[10 * b + 2] += rng.uniform(-0.01, 0.01)
+                    continue
+                rec[10 * b + 1 : 10 * b + 4] += rng.uniform(-0.01, 0.01, 3)
+                rec[10 * b + 7 : 10 * b + 10] += rng.uniform(-0.1, 0.1, 3) * rec[10 * b + 4 : 10 * b + 7].min()
         force = rng.uniform(-20, 20, 3)
         point = np.array([0.0, 0.0, -0.1])
-        so, sh = run_both(harness, model, s, rng.uniform(-1, 1, 6), scale=scale, force=force, point=point)
+        so, sh = run_both(harness, model, s, rng.uniform(-1, 1, 6), scale=rec, force=force, point=point)
         assert np.abs(so[7:10] - sh[7:10]).max() < 2e-4
         assert np.abs(so[10:13] - sh[10:13]).max() < 1e-3
         assert np.abs(so[0:7] - sh[0:7]).max() < 5e-7
+
+
+def test_fuse_links_matches_oracle_and_link_semantics(harness):
+    """randomize_inertias (pybullet_backend.py:571-601) per URDF link: the
+    device's fuse_links() against the oracle's, on the URDF-derived model whose
+    trunk and wheels are fused from several links; and against first
+    principles (total mass, first moment, unit factors give the model back)."""
+    from upkie_amd.model.model import Model
+
+    model = Model().struct
+    assert model.num_links > abi.NB and model.link_randomized[0] == 0  # root link: not in range(getNumJoints), :563
+    cfg = abi.default_sim_config(16, seed=9)
+    o = O.Oracle(model, cfg)
+    rec = o.sample_body_inertials(0.3)  # [70, B]
+    f = o.link_scale  # [MAX_LINKS, B]
+    n = model.num_links
+    assert np.all(f[0] == 1.0) and np.all(f[n:] == 1.0)
+    assert np.all(np.abs(f[1:n] - 1.0) <= 0.3) and np.std(f[1:n]) > 0.1
+    harness.harness_fuse_links.restype = C.c_int
+    for e in range(16):
+        got = np.zeros(70, dtype=np.float32)
+        fe = np.ascontiguousarray(f[:, e], dtype=np.float32)
+        assert harness.harness_fuse_links(C.byref(model), fe.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p)) == n
+        np.testing.assert_allclose(got, rec[:, e], rtol=2e-5, atol=1e-9)
+        for b in range(abi.NB):
+            links = [l for l in range(n) if model.link_body[l] == b]
+            m = sum(f[l, e] * model.link_mass[l] for l in links)
+            first = sum(f[l, e] * model.link_mass[l] * np.array(model.link_com[l][:]) for l in links)
+            assert rec[10 * b, e] == pytest.approx(m, rel=1e-12)
+            np.testing.assert_allclose(rec[10 * b + 1 : 10 * b + 4, e], first / m, atol=1e-12)
+    ones = np.ones(abi.MAX_LINKS, dtype=np.float32)
+    got = np.zeros(70, dtype=np.float32)
+    harness.harness_fuse_links(C.byref(model), ones.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p))
+    np.testing.assert_allclose(got, records_of_model(model), rtol=2e-5, atol=2e-9)
+    # variation 0 -> the oracle gives the model back, too
+    np.testing.assert_allclose(o.sample_body_inertials(0.0)[:, 3], records_of_model(model), rtol=1e-12, atol=1e-15)
 
 
 def test_free_fall_semi_implicit_euler_in_fp32(harness):

@@ -482,3 +482,32 @@ def test_contact_points_like_count_wheel_contacts_example():
     pts = vec.contact_points()
     assert tuple(pts.shape) == (3, 2, 8) and float(pts.abs().max()) == 0.0
     assert vec.sim.get_contact_points(env=2) == []
+
+
+def test_inertia_variation_scales_every_urdf_link():
+    """`inertia_variation` (entry_points.py:41-48 -> PyBulletBackend.
+    randomize_inertias, pybullet_backend.py:571-601): one factor per URDF link
+    and env, same factor for a link's mass and inertia, the root link left
+    alone (:563); the 13 links are fused back into the 7 bodies' records."""
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=32, inertia_variation=0.2, **KW)
+    m = env.model.struct
+    f = env.sim.link_scale.numpy().astype(np.float64)
+    rec = env.sim.body_inertials.numpy().astype(np.float64)
+    n = m.num_links
+    assert n == 13 and np.all(f[0] == 1.0) and np.all(np.abs(f[1:n] - 1.0) <= 0.2 + 1e-6) and np.std(f[1:n]) > 0.05
+    for b in range(abi.NB):
+        links = [l for l in range(n) if m.link_body[l] == b]
+        mass = sum(f[l] * m.link_mass[l] for l in links)
+        np.testing.assert_allclose(rec[10 * b], mass, rtol=1e-5)
+        if len(links) == 1:  # a body made of one link is scaled as a whole
+            np.testing.assert_allclose(rec[10 * b + 4 : 10 * b + 10], np.outer(m.inertia[b][:], f[links[0]]), rtol=1e-5, atol=1e-12)
+            np.testing.assert_allclose(rec[10 * b + 1 : 10 * b + 4], np.outer(m.com[b][:], np.ones(32)), atol=1e-7)
+    # wheel = hub + tire, each with its own factor: the body follows neither
+    hub, tire = [l for l in range(n) if m.link_body[l] == 3]
+    wheel_mass = rec[30] / m.mass[3]
+    assert np.max(np.abs(wheel_mass - f[hub])) > 1e-2 and np.max(np.abs(wheel_mass - f[tire])) > 1e-2
+    env.reset(seed=0)
+    obs, *_ = env.step(env.get_neutral_action())
+    assert torch.isfinite(obs).all()
+    env0 = envs.make("Upkie-HIP-Servos-Vec", num_envs=4, inertia_variation=0.0, **KW)
+    assert env0.sim.body_inertials is None  # pybullet_backend.py:178-179: no call below 1e-10

@@ -4,6 +4,8 @@ the constants the reference pins (tests/model/*.py)."""
 import os
 
 import numpy as np
+
+from upkie_amd import abi
 import pytest
 
 from oracle import oracle as O
@@ -24,10 +26,28 @@ def test_urdf_reduces_to_the_default_model():
     m = Model()
     d = default_model()
     for name, _ in d._fields_:
+        if name.startswith("link_") or name == "num_links":
+            continue  # the URDF remembers its 13 links, the hand-written model has one per body (checked below)
         a, b = getattr(m.struct, name), getattr(d, name)
         a = np.array(a, dtype=float).ravel() if hasattr(b, "__len__") else np.array([float(a)])
         b = np.array(b, dtype=float).ravel() if hasattr(b, "__len__") else np.array([float(b)])
         np.testing.assert_allclose(np.nan_to_num(a, posinf=1e30, neginf=-1e30), np.nan_to_num(b, posinf=1e30, neginf=-1e30), atol=1e-12, err_msg=name)
+
+
+def test_link_tables_fuse_back_into_the_bodies():
+    """The links behind each composite body (what Bullet keeps apart and
+    randomize_inertias scales one by one, pybullet_backend.py:555-601) sum up
+    to the body's mass and first moment; the root link is not randomised (:563)."""
+    for s in (Model().struct, default_model()):
+        n = s.num_links
+        assert abi.NB <= n <= abi.MAX_LINKS and s.link_randomized[0] == 0 and all(s.link_randomized[l] == 1 for l in range(1, n))
+        for b in range(abi.NB):
+            links = [l for l in range(n) if s.link_body[l] == b]
+            assert sum(s.link_mass[l] for l in links) == pytest.approx(s.mass[b], rel=1e-12)
+            first = sum(s.link_mass[l] * np.array(s.link_com[l][:]) for l in links)
+            np.testing.assert_allclose(first / s.mass[b], s.com[b][:], atol=1e-12)
+    m = Model().struct
+    assert m.num_links == 13 and [m.link_body[l] for l in range(13)].count(0) == 5  # base, torso, imu, two stators
 
 
 def test_reference_model_constants():

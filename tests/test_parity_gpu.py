@@ -237,11 +237,13 @@ def test_autoreset_next_step():
 
 def test_randomization_buffers():
     oracle, sim = make_pair(128, seed=4)
-    scale_h = sim.randomize_inertias(0.2).cpu().numpy()
-    scale_o = oracle.sample_inertia_scales(0.2)
-    np.testing.assert_allclose(scale_h, scale_o, atol=1e-6)
-    assert scale_h.min() >= 0.8 - 1e-6 and scale_h.max() <= 1.2 + 1e-6
-    oracle.inertia_scale = scale_o
+    rec_h = sim.randomize_inertias(0.2).cpu().numpy()
+    rec_o = oracle.sample_body_inertials(0.2)
+    np.testing.assert_allclose(rec_h, rec_o, rtol=2e-5, atol=1e-9)
+    link_scale = sim.link_scale.cpu().numpy()
+    np.testing.assert_allclose(link_scale, oracle.link_scale, atol=1e-6)
+    assert link_scale.min() >= 0.8 - 1e-6 and link_scale.max() <= 1.2 + 1e-6
+    oracle.body_inertials = rec_o
     force = np.zeros((3, 128))
     force[0] = np.linspace(-10, 10, 128)
     force[1] = 3.0
@@ -696,8 +698,8 @@ def test_contact_points_match_oracle():
     randomised inertias; and the query leaves the state untouched."""
     B = 256
     oracle, sim = make_pair(B, seed=21)
-    scale = sim.randomize_inertias(0.2)
-    oracle.inertia_scale = scale.cpu().numpy().astype(np.float64)
+    records = sim.randomize_inertias(0.2)
+    oracle.body_inertials = records.cpu().numpy().astype(np.float64)
     rng = np.random.default_rng(5)
     force = rng.uniform(-3.0, 3.0, size=(3, B))
     sim.set_external_force(torch.from_numpy(force.astype(np.float32)), point=(0.0, 0.0, 0.1))

@@ -9,6 +9,8 @@ import ctypes as C
 
 NB = 7  # merged bodies
 NJ = 6  # actuated joints
+MAX_LINKS = 24  # UPKIE_MAX_LINKS
+INERTIAL_WORDS = 10  # UPKIE_INERTIAL_WORDS: mass, com (3), inertia about the com (6)
 
 ## Joint order of the reference (static_config.h:64-69).
 JOINT_NAMES = (
@@ -95,6 +97,12 @@ class UpkieModel(C.Structure):
         ("pgs_tolerance", C.c_double),
         ("pgs_iterations", C.c_int32),
         ("enforce_joint_limits", C.c_int32),
+        ("num_links", C.c_int32),
+        ("link_body", C.c_int32 * MAX_LINKS),
+        ("link_randomized", C.c_int32 * MAX_LINKS),
+        ("link_mass", C.c_double * MAX_LINKS),
+        ("link_com", (C.c_double * 3) * MAX_LINKS),
+        ("link_inertia", (C.c_double * 6) * MAX_LINKS),
     ]
 
 

@@ -261,26 +261,64 @@ struct Composite {
 // model (scalar loads, leg chosen at compile time); LegRegs is a per-lane copy
 // of one leg's constants for the two-lanes-per-env mapping, where the leg a
 // lane owns varies across lanes.
+// Inertial records of the 7 composite bodies of ONE env (mass, centre of mass
+// in the body frame, inertia about it): what randomize_inertias leaves behind
+// (pybullet_backend.py:571-601), loaded once per step from the
+// body_inertials[UPKIE_NB * UPKIE_INERTIAL_WORDS][B] buffer and held in
+// registers. Only the randomised kernel variants carry it.
+struct BodyInertials {
+  float m[UPKIE_NB];
+  float c[UPKIE_NB][3];
+  float I[UPKIE_NB][6];
+};
+
+template <class ModelT>
+UPKIE_HD void body_inertials_of_model(const ModelT& M, BodyInertials& bi) {
+#pragma unroll
+  for (int b = 0; b < UPKIE_NB; ++b) {
+    bi.m[b] = M.mass[b];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) bi.c[b][d] = M.com[b][d];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) bi.I[b][d] = M.inertia[b][d];
+  }
+}
+
+// records: this env's column of the buffer (stride = number of envs)
+UPKIE_HD void load_body_inertials(const float* records, size_t stride, BodyInertials& bi) {
+#pragma unroll
+  for (int b = 0; b < UPKIE_NB; ++b) {
+    const float* r = records + (size_t)(UPKIE_INERTIAL_WORDS * b) * stride;
+    bi.m[b] = r[0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) bi.c[b][d] = r[(size_t)(1 + d) * stride];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) bi.I[b][d] = r[(size_t)(4 + d) * stride];
+  }
+}
+
 template <class ModelT>
 struct LegOfModel {
   const ModelT& M;
-  const float* scale;  // per-body inertia scales of this env or nullptr
+  const BodyInertials* bi;  // inertials of this env or nullptr (the model's)
   int body0, joint0;
-  UPKIE_HD float mass(int k) const { return M.mass[body0 + k] * (scale ? scale[body0 + k] : 1.f); }
-  UPKIE_HD float inertia_scale(int k) const { return scale ? scale[body0 + k] : 1.f; }
-  UPKIE_HD V3 com(int k) const { return v3(M.com[body0 + k][0], M.com[body0 + k][1], M.com[body0 + k][2]); }
+  UPKIE_HD float mass(int k) const { return bi ? bi->m[body0 + k] : M.mass[body0 + k]; }
+  UPKIE_HD V3 com(int k) const {
+    const int b = body0 + k;
+    return bi ? v3(bi->c[b][0], bi->c[b][1], bi->c[b][2]) : v3(M.com[b][0], M.com[b][1], M.com[b][2]);
+  }
   UPKIE_HD S3 inertia(int k) const {
     const int b = body0 + k;
-    return S3{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
+    return bi ? S3{bi->I[b][0], bi->I[b][1], bi->I[b][2], bi->I[b][3], bi->I[b][4], bi->I[b][5]}
+              : S3{M.inertia[b][0], M.inertia[b][1], M.inertia[b][2], M.inertia[b][3], M.inertia[b][4], M.inertia[b][5]};
   }
   UPKIE_HD V3 joint_pos(int k) const { return v3(M.joint_pos[joint0 + k][0], M.joint_pos[joint0 + k][1], M.joint_pos[joint0 + k][2]); }
   UPKIE_HD float sign(int k) const { return M.joint_sign[joint0 + k]; }
 };
 
 struct LegRegs {
-  float m[3], sc[3], c[3][3], I[3][6], p[3][3], sg[3];
-  UPKIE_HD float mass(int k) const { return m[k] * sc[k]; }
-  UPKIE_HD float inertia_scale(int k) const { return sc[k]; }
+  float m[3], c[3][3], I[3][6], p[3][3], sg[3];
+  UPKIE_HD float mass(int k) const { return m[k]; }
   UPKIE_HD V3 com(int k) const { return v3(c[k][0], c[k][1], c[k][2]); }
   UPKIE_HD S3 inertia(int k) const { return S3{I[k][0], I[k][1], I[k][2], I[k][3], I[k][4], I[k][5]}; }
   UPKIE_HD V3 joint_pos(int k) const { return v3(p[k][0], p[k][1], p[k][2]); }
@@ -316,7 +354,6 @@ UPKIE_HD void leg_pass(const LegParams& P, bool wheel_axisymmetric, const float 
   S3 Ib[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float sc = P.inertia_scale(k);
     float m = P.mass(k);
     V3 r = L.o[k] - oprev;
     // origin acceleration uses the PARENT's omega/alpha
@@ -328,7 +365,6 @@ UPKIE_HD void leg_pass(const LegParams& P, bool wheel_axisymmetric, const float 
     V3 rc = rot_y(cs[k], sn[k], P.com(k));
     V3 c = L.o[k] + rc;
     S3 Ic = rot_y(cs[k], sn[k], P.inertia(k));
-    Ic = S3{sc * Ic.xx, sc * Ic.yy, sc * Ic.zz, sc * Ic.xy, sc * Ic.xz, sc * Ic.yz};
     V3 ac = ao + cross(al, rc) + cross(w, cross(w, rc));
     V3 f = m * (ac + gn);
     V3 n = mul(Ic, al) + cross(w, mul(Ic, w));
@@ -966,11 +1002,11 @@ struct ContactReport {
 };
 
 // One physics substep of duration h. tau: commanded joint torques.
-// scale: per-body inertia scales of this env or nullptr. ext: external forces.
+// bi: inertial records of this env's bodies or nullptr (the model's). ext: external forces.
 // Returns the floor-contact flag.
 template <bool SCRATCH_LIMITS = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
-                                                const float* scale, const ExtForces& ext, ContactReport* report = nullptr) {
+                                                const BodyInertials* bi, const ExtForces& ext, ContactReport* report = nullptr) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
   // unilateral rows with ERP 0.2): rare, handled by the general solver
   bool any_limit = false;
@@ -993,10 +1029,10 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   V3 gn = M.gravity * nB;
 
   // trunk
-  float sc0 = scale ? scale[0] : 1.f;
-  float m0 = M.mass[0] * sc0;
-  V3 c0 = v3(M.com[0][0], M.com[0][1], M.com[0][2]);
-  S3 I0 = S3{sc0 * M.inertia[0][0], sc0 * M.inertia[0][1], sc0 * M.inertia[0][2], sc0 * M.inertia[0][3], sc0 * M.inertia[0][4], sc0 * M.inertia[0][5]};
+  const LegOfModel<ModelT> trunk{M, bi, 0, 0};
+  float m0 = trunk.mass(0);
+  V3 c0 = trunk.com(0);
+  S3 I0 = trunk.inertia(0);
   V3 I0w = mul(I0, wB);
   V3 bias_f, bias_n;
   {
@@ -1012,8 +1048,8 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   {
     const float ql[3] = {s.q[0], s.q[1], s.q[2]}, qdl[3] = {s.qd[0], s.qd[1], s.qd[2]};
     const float qr[3] = {s.q[3], s.q[4], s.q[5]}, qdr[3] = {s.qd[3], s.qd[4], s.qd[5]};
-    leg_pass(LegOfModel<ModelT>{M, scale, 1, 0}, M.wheel_axisymmetric != 0, ql, qdl, wB, gn, S.leg[0], total, bias_f, bias_n);
-    leg_pass(LegOfModel<ModelT>{M, scale, 4, 3}, M.wheel_axisymmetric != 0, qr, qdr, wB, gn, S.leg[1], total, bias_f, bias_n);
+    leg_pass(LegOfModel<ModelT>{M, bi, 1, 0}, M.wheel_axisymmetric != 0, ql, qdl, wB, gn, S.leg[0], total, bias_f, bias_n);
+    leg_pass(LegOfModel<ModelT>{M, bi, 4, 3}, M.wheel_axisymmetric != 0, qr, qdr, wB, gn, S.leg[1], total, bias_f, bias_n);
   }
 
   // base block (generalised velocity [v, omega]) minus the legs' Schur terms

@@ -43,7 +43,8 @@ struct PairLeg {
 };
 
 template <class ModelT>
-__device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int leg, const float* scale3) {
+__device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int leg, const float* records,
+                                                 size_t stride) {
   // the lane's row of DevModel::leg_table, 16 x 16 bytes (cached: two rows for the whole grid)
   float t[LT_WORDS];
   {
@@ -61,7 +62,6 @@ __device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimit
   for (int k = 0; k < 3; ++k) {
     const int jl = k, jr = 3 + k;
     P.regs.m[k] = t[LT_MASS + k];
-    P.regs.sc[k] = scale3 ? scale3[k] : 1.f;
     P.regs.sg[k] = t[LT_SIGN + k];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -81,9 +81,27 @@ __device__ __forceinline__ PairLeg load_pair_leg(const ModelT& M, const DevLimit
     P.measurement_noise[k] = pick(leg, C.measurement_noise[jl], C.measurement_noise[jr]);
     P.wheel_center[k] = t[LT_WHEEL_CENTER + k];
   }
+  if (records) {  // this env's inertial records of the owned leg's bodies (randomize_inertias)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float* r = records + (size_t)(UPKIE_INERTIAL_WORDS * (1 + 3 * leg + k)) * stride;
+      P.regs.m[k] = r[0];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) P.regs.c[k][d] = r[(size_t)(1 + d) * stride];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) P.regs.I[k][d] = r[(size_t)(4 + d) * stride];
+    }
+  }
   (void)Lm;
   return P;
 }
+
+// The trunk's inertial record of one env (both lanes hold it).
+struct TrunkInertial {
+  float m;
+  V3 c;
+  S3 I;
+};
 
 struct PhysPair {
   V3 pos;
@@ -97,7 +115,7 @@ struct PhysPair {
 // owns. Returns the floor-contact flag (identical in both lanes).
 template <class ModelT>
 __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
-                                                     const float (&tau)[3], float h, float scale0, const ExtForces& ext) {
+                                                     const float (&tau)[3], float h, const TrunkInertial* trunk, const ExtForces& ext) {
   bool own_limit = false;
   if (Lm.enforce) {
 #pragma unroll
@@ -117,10 +135,9 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   V3 gn = M.gravity * nB;
 
   // trunk (both lanes, identical)
-  float m0 = M.mass[0] * scale0;
-  V3 c0 = v3(M.com[0][0], M.com[0][1], M.com[0][2]);
-  S3 I0 = S3{scale0 * M.inertia[0][0], scale0 * M.inertia[0][1], scale0 * M.inertia[0][2],
-             scale0 * M.inertia[0][3], scale0 * M.inertia[0][4], scale0 * M.inertia[0][5]};
+  float m0 = trunk ? trunk->m : M.mass[0];
+  V3 c0 = trunk ? trunk->c : v3(M.com[0][0], M.com[0][1], M.com[0][2]);
+  S3 I0 = trunk ? trunk->I : S3{M.inertia[0][0], M.inertia[0][1], M.inertia[0][2], M.inertia[0][3], M.inertia[0][4], M.inertia[0][5]};
   V3 I0w = mul(I0, wB);
   V3 bias_f, bias_n;
   {
@@ -508,7 +525,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
                                                         float* __restrict__ state, const float* __restrict__ act,
                                                         float* __restrict__ obs, float* __restrict__ reward,
                                                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                                                        const uint8_t* __restrict__ mask, const float* __restrict__ inertia_scale,
+                                                        const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                         const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                         float* __restrict__ spine_state) {
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
@@ -538,18 +555,24 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     yaw = SW(UPKIE_S_YAW);
     yawvel = SW(UPKIE_S_YAWVEL);
   }
-  float scale0 = 1.f, scale3[3] = {1.f, 1.f, 1.f};
-  if (RAND) {
-    if (inertia_scale) {
-      scale0 = inertia_scale[e];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) scale3[k] = inertia_scale[(size_t)(1 + 3 * leg + k) * B + e];
-    }
-  }
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
   // the owned leg's constants: selected once, kept in registers for the launch
-  const PairLeg PL = load_pair_leg(*(ConstModelPtr)Mp, Lm, C, leg, RAND ? scale3 : nullptr);
+  const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
+  const PairLeg PL = load_pair_leg(*(ConstModelPtr)Mp, Lm, C, leg, records, (size_t)B);
   const DevModel& M = *Mp;
+  TrunkInertial trunk;
+  if (RAND) {
+    if (records) {
+      trunk.m = records[0];
+      trunk.c = v3(records[(size_t)1 * B], records[(size_t)2 * B], records[(size_t)3 * B]);
+      trunk.I = S3{records[(size_t)4 * B], records[(size_t)5 * B], records[(size_t)6 * B],
+                   records[(size_t)7 * B], records[(size_t)8 * B], records[(size_t)9 * B]};
+    } else {
+      trunk.m = M.mass[0];
+      trunk.c = v3(M.com[0][0], M.com[0][1], M.com[0][2]);
+      trunk.I = S3{M.inertia[0][0], M.inertia[0][1], M.inertia[0][2], M.inertia[0][3], M.inertia[0][4], M.inertia[0][5]};
+    }
+  }
 
   bool do_reset;
   if (MODE == MODE_RESET) {
@@ -672,7 +695,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     {
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, scale0, ext);
+      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext);
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline: each lane runs the WheelContact estimator of its

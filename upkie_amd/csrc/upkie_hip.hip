@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
-                                                   const float* __restrict__ inertia_scale,
+                                                   const float* __restrict__ body_inertials,
                                                    const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                    float* __restrict__ spine_state) {
   const DevModel& M = *Mp;
@@ -233,14 +233,12 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     yaw = SW(UPKIE_S_YAW);
     yawvel = SW(UPKIE_S_YAWVEL);
   }
-  float scale[UPKIE_NB];
+  BodyInertials inertials;
   if (RAND) {
-    if (inertia_scale) {
-#pragma unroll
-      for (int i = 0; i < UPKIE_NB; ++i) scale[i] = inertia_scale[(size_t)i * B + e];
+    if (body_inertials) {
+      load_body_inertials(body_inertials + e, (size_t)B, inertials);
     } else {
-#pragma unroll
-      for (int i = 0; i < UPKIE_NB; ++i) scale[i] = 1.f;
+      body_inertials_of_model(M, inertials);
     }
   }
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
@@ -358,7 +356,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? scale : nullptr, ext);
+      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext);
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline (spines/common/observers.h:22-42): it sees the
@@ -655,7 +653,7 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
 // out [B][2][8] = per tire {exists, position in world (3), force in world (3), 0}.
 // Query path, not the step path: one env per lane, any batch size.
 __global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
-                                                           const float* __restrict__ state, const float* __restrict__ inertia_scale,
+                                                           const float* __restrict__ state, const float* __restrict__ body_inertials,
                                                            const float* __restrict__ ext_force, float* __restrict__ out) {
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,15 +673,14 @@ __global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __re
     tau[j] = SW(UPKIE_S_TORQUE + j);
   }
 #undef SW
-  float scale[UPKIE_NB];
-#pragma unroll
-  for (int i = 0; i < UPKIE_NB; ++i) scale[i] = inertia_scale ? inertia_scale[(size_t)i * B + e] : 1.f;
+  BodyInertials inertials;
+  if (body_inertials) load_body_inertials(body_inertials + e, (size_t)B, inertials);
   const ExtForces ext{ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
   const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
   const V3 origin = s.pos;
   ContactReport rep;
   rep.active[0] = rep.active[1] = false;
-  physics_substep<true>(*Mp, Lm, s, tau, C.h, scale, ext, &rep);
+  physics_substep<true>(*Mp, Lm, s, tau, C.h, body_inertials ? &inertials : nullptr, ext, &rep);
   const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qz * qw), 2.f * (qw * qy + qx * qz),
                       2.f * (qx * qy + qz * qw), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qx * qw),
                       2.f * (qx * qz - qy * qw), 2.f * (qy * qz + qx * qw), 1.f - 2.f * (qx * qx + qy * qy)};
@@ -701,19 +698,69 @@ __global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __re
   }
 }
 
-// inertia_scale[body][env] = 1 + U(-v, v), pybullet_backend.py:588-594.
-__global__ __launch_bounds__(64) void inertia_scale_kernel(DevConfig C, float* __restrict__ scale, float variation) {
+// The URDF links behind the composite bodies, as randomize_inertias sees them.
+struct DevLinks {
+  int count;
+  int body[UPKIE_MAX_LINKS];
+  int randomized[UPKIE_MAX_LINKS];
+  float mass[UPKIE_MAX_LINKS];
+  float com[UPKIE_MAX_LINKS][3];
+  float inertia[UPKIE_MAX_LINKS][6];
+};
+
+// Fuse the (scaled) links of every composite body: mass, centre of mass and
+// inertia about it, written to records[(10 * body + word) * stride].
+UPKIE_HD void fuse_links(const DevLinks& L, const float (&f)[UPKIE_MAX_LINKS], float* records, size_t stride) {
+  for (int b = 0; b < UPKIE_NB; ++b) {
+    float m = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
+    for (int l = 0; l < L.count; ++l) {
+      if (L.body[l] != b) continue;
+      const float ml = f[l] * L.mass[l];
+      m += ml;
+      mx = fmaf(ml, L.com[l][0], mx); my = fmaf(ml, L.com[l][1], my); mz = fmaf(ml, L.com[l][2], mz);
+    }
+    const float cx = mx / m, cy = my / m, cz = mz / m;
+    float I[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L.count; ++l) {
+      if (L.body[l] != b) continue;
+      const float ml = f[l] * L.mass[l];
+      const float dx = L.com[l][0] - cx, dy = L.com[l][1] - cy, dz = L.com[l][2] - cz;
+      I[0] += f[l] * L.inertia[l][0] + ml * (dy * dy + dz * dz);
+      I[1] += f[l] * L.inertia[l][1] + ml * (dx * dx + dz * dz);
+      I[2] += f[l] * L.inertia[l][2] + ml * (dx * dx + dy * dy);
+      I[3] += f[l] * L.inertia[l][3] - ml * dx * dy;
+      I[4] += f[l] * L.inertia[l][4] - ml * dx * dz;
+      I[5] += f[l] * L.inertia[l][5] - ml * dy * dz;
+    }
+    float* r = records + (size_t)(UPKIE_INERTIAL_WORDS * b) * stride;
+    r[0] = m;
+    r[(size_t)1 * stride] = cx; r[(size_t)2 * stride] = cy; r[(size_t)3 * stride] = cz;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) r[(size_t)(4 + d) * stride] = I[d];
+  }
+}
+
+// PyBulletBackend.randomize_inertias (pybullet_backend.py:571-601) for env e:
+// epsilon ~ U(-v, v) per link scales that link's mass and inertia; the links
+// of each composite body are fused again into records[10 * body + word][env].
+__global__ __launch_bounds__(64) void body_inertials_kernel(DevConfig C, DevLinks L, float* __restrict__ records,
+                                                            float* __restrict__ link_scale, float variation) {
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
-  float u0[4], u1[4];
-  philox_uniform4(C, (unsigned)e, 0u, STREAM_INERTIA, 0, u0);
-  philox_uniform4(C, (unsigned)e, 0u, STREAM_INERTIA, 1, u1);
+  float f[UPKIE_MAX_LINKS];
 #pragma unroll
-  for (int i = 0; i < UPKIE_NB; ++i) {
-    float u = i < 4 ? u0[i] : u1[i - 4];
-    scale[(size_t)i * B + e] = 1.f + uniform(-variation, variation, u);
+  for (int blk = 0; blk < UPKIE_MAX_LINKS / 4; ++blk) {
+    float u[4];
+    philox_uniform4(C, (unsigned)e, 0u, STREAM_INERTIA, blk, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int l = 4 * blk + i;
+      f[l] = (l < L.count && L.randomized[l]) ? 1.f + uniform(-variation, variation, u[i]) : 1.f;
+      if (link_scale) link_scale[(size_t)l * B + e] = f[l];
+    }
   }
+  fuse_links(L, f, records + e, (size_t)B);
 }
 
 }  // namespace upkie
@@ -727,7 +774,8 @@ struct UpkieSim {
   DevLimits limits;
   DevModel* d_model = nullptr;  // device copy read through scalar loads
   DevConfig config;
-  const float* inertia_scale = nullptr;
+  const float* body_inertials = nullptr;  // [UPKIE_NB * UPKIE_INERTIAL_WORDS][B], caller-owned
+  DevLinks links;
   const float* ext_force = nullptr;
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   std::string error;
@@ -792,6 +840,15 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
     int b = 3 * w + 3;
     const double* I = m->inertia[b];
     const double* c = m->com[b];
+    if (std::fabs(c[0]) > 1e-9 || std::fabs(c[2]) > 1e-9 || std::fabs(I[0] - I[2]) > 1e-12 || std::fabs(I[3]) > 1e-12 ||
+        std::fabs(I[4]) > 1e-12 || std::fabs(I[5]) > 1e-12)
+      axisym = false;
+  }
+  // ... and stays so under randomize_inertias only if every link fused into a wheel is
+  for (int l = 0; l < m->num_links && l < UPKIE_MAX_LINKS; ++l) {
+    if (m->link_body[l] != 3 && m->link_body[l] != 6) continue;
+    const double* I = m->link_inertia[l];
+    const double* c = m->link_com[l];
     if (std::fabs(c[0]) > 1e-9 || std::fabs(c[2]) > 1e-9 || std::fabs(I[0] - I[2]) > 1e-12 || std::fabs(I[3]) > 1e-12 ||
         std::fabs(I[4]) > 1e-12 || std::fabs(I[5]) > 1e-12)
       axisym = false;
@@ -905,6 +962,31 @@ static bool convert_config(const UpkieSimConfig* c, DevConfig* d, std::string* w
   return true;
 }
 
+// the links randomize_inertias scales (one per body when the model names none)
+static bool convert_links(const UpkieModel* model, DevLinks* out, std::string* why) {
+  DevLinks& L = *out;
+  L = DevLinks{};
+  const int n = model->num_links;
+  if (n < 0 || n > UPKIE_MAX_LINKS) {
+    *why = "num_links out of range";
+    return false;
+  }
+  L.count = n > 0 ? n : UPKIE_NB;
+  for (int l = 0; l < L.count; ++l) {
+    const int b = n > 0 ? model->link_body[l] : l;
+    if (b < 0 || b >= UPKIE_NB) {
+      *why = "link_body out of range";
+      return false;
+    }
+    L.body[l] = b;
+    L.randomized[l] = n > 0 ? (model->link_randomized[l] != 0) : 1;
+    L.mass[l] = (float)(n > 0 ? model->link_mass[l] : model->mass[b]);
+    for (int k = 0; k < 3; ++k) L.com[l][k] = (float)(n > 0 ? model->link_com[l][k] : model->com[b][k]);
+    for (int k = 0; k < 6; ++k) L.inertia[l][k] = (float)(n > 0 ? model->link_inertia[l][k] : model->inertia[b][k]);
+  }
+  return true;
+}
+
 extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* model, UpkieSim** out) {
   if (!config || !model || !out) return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
@@ -921,6 +1003,10 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
     return fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
   model_limits(sim->model, &sim->limits);
+  if (!convert_links(model, &sim->links, &why)) {
+    delete sim;
+    return fail(nullptr, UPKIE_ERR_UNSUPPORTED_MODEL, why);
+  }
   if (const char* forced = std::getenv("UPKIE_LANES_PER_ENV")) sim->lanes_per_env = std::atoi(forced);
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
@@ -960,10 +1046,10 @@ extern "C" int64_t upkie_sim_state_bytes(const UpkieSim* sim) {
   return sim ? (int64_t)UPKIE_STATE_WORDS * sim->config.num_envs * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* inertia_scale, const float* ext_force,
+extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* body_inertials, const float* ext_force,
                                            const double ext_point[3]) {
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
-  sim->inertia_scale = inertia_scale;
+  sim->body_inertials = body_inertials;
   sim->ext_force = ext_force;
   ExtSlots& x = sim->config.ext;  // one world-frame force on the trunk
   x = ExtSlots{};
@@ -997,11 +1083,12 @@ extern "C" int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
 static int block_lanes() { return 64; }  // one wavefront per block
 static dim3 grid_for(int B) { return dim3((unsigned)((B + block_lanes() - 1) / block_lanes())); }
 
-extern "C" int upkie_sim_sample_inertia_scales(UpkieSim* sim, float* inertia_scale, double inertia_variation, void* stream) {
-  if (!sim || !inertia_scale) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  hipLaunchKernelGGL(inertia_scale_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config,
-                     inertia_scale, (float)inertia_variation);
-  return check_hip(sim, hipGetLastError(), "inertia_scale_kernel");
+extern "C" int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inertials, float* link_scale, double inertia_variation,
+                                               void* stream) {
+  if (!sim || !body_inertials) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(body_inertials_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config,
+                     sim->links, body_inertials, link_scale, (float)inertia_variation);
+  return check_hip(sim, hipGetLastError(), "body_inertials_kernel");
 }
 
 // 256 CUs x 4 SIMDs x 64 lanes x 2 waves
@@ -1018,9 +1105,9 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
   if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS || MODE == MODE_BASE_VELOCITY) && !act)
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
-  const bool rnd = sim->inertia_scale || sim->ext_force;
+  const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
-  const float* scale = rnd ? sim->inertia_scale : nullptr;
+  const float* scale = rnd ? sim->body_inertials : nullptr;
   const float* force = rnd ? sim->ext_force : nullptr;
   hipStream_t st = (hipStream_t)stream;
   // more than two waves per SIMD in flight: favour occupancy over registers;
@@ -1122,7 +1209,7 @@ extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineOb
 extern "C" int upkie_sim_contact_points(UpkieSim* sim, const float* state, float* out, void* stream) {
   if (!sim || !state || !out) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   hipLaunchKernelGGL(contact_points_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model,
-                     sim->limits, sim->config, state, sim->inertia_scale, sim->ext_force, out);
+                     sim->limits, sim->config, state, sim->body_inertials, sim->ext_force, out);
   return check_hip(sim, hipGetLastError(), "contact_points_kernel");
 }
 

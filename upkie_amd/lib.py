@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_state_bytes",
     "upkie_sim_set_randomization",
     "upkie_sim_set_external_forces",
-    "upkie_sim_sample_inertia_scales",
+    "upkie_sim_sample_body_inertials",
     "upkie_sim_reset",
     "upkie_sim_step_pendulum",
     "upkie_sim_step_pendulum_agent",
@@ -145,8 +145,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_randomization.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
     lib.upkie_sim_set_external_forces.restype = C.c_int
     lib.upkie_sim_set_external_forces.argtypes = [vp, vp, C.POINTER(abi.UpkieExternalForces)]
-    lib.upkie_sim_sample_inertia_scales.restype = C.c_int
-    lib.upkie_sim_sample_inertia_scales.argtypes = [vp, vp, C.c_double, vp]
+    lib.upkie_sim_sample_body_inertials.restype = C.c_int
+    lib.upkie_sim_sample_body_inertials.argtypes = [vp, vp, vp, C.c_double, vp]
     lib.upkie_sim_reset.restype = C.c_int
     lib.upkie_sim_reset.argtypes = [vp, vp, vp, vp, vp]
     for name in (

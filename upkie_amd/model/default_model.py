@@ -124,6 +124,14 @@ def default_model() -> UpkieModel:
     m.pgs_iterations = 50
     m.pgs_tolerance = 1e-6
     m.enforce_joint_limits = 1  # Bullet enforces URDF revolute limits
+    # one URDF link per body (the URDF loader records the real fused links)
+    m.num_links = 7
+    for b in range(7):
+        m.link_body[b] = b
+        m.link_randomized[b] = 0 if b == 0 else 1  # the trunk is the URDF root: Bullet's base is not in range(getNumJoints)
+        m.link_mass[b] = m.mass[b]
+        m.link_com[b][:] = list(m.com[b])
+        m.link_inertia[b][:] = list(m.inertia[b])
     return m
 
 

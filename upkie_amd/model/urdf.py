@@ -15,7 +15,7 @@ from xml.etree import ElementTree
 
 import numpy as np
 
-from ..abi import JOINT_NAMES, NJ, UpkieModel
+from ..abi import JOINT_NAMES, MAX_LINKS, NJ, UpkieModel
 from ..exceptions import ModelError
 from ..utils.rotations import rotation_matrix_from_rpy
 
@@ -210,6 +210,26 @@ def load_urdf_model(urdf_path: str, template: Optional[UpkieModel] = None) -> Up
         model.mass[b] = mass[b]
         model.com[b][:] = list(com - origins[b])
         model.inertia[b][:] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+
+    # the links behind each composite body: Bullet keeps them apart and
+    # randomize_inertias scales them one by one (pybullet_backend.py:555-601)
+    n = 0
+    for b in range(7):
+        for name in members[b]:
+            link = tree.links[name]
+            if link.mass <= 0.0:
+                continue
+            if n >= MAX_LINKS:
+                raise ModelError(f"more than {MAX_LINKS} links with mass")
+            R = tree.R[name]
+            Il = R @ link.inertia @ R.T
+            model.link_body[n] = b
+            model.link_randomized[n] = 0 if name == tree.root else 1  # Bullet's base is not in range(getNumJoints)
+            model.link_mass[n] = link.mass
+            model.link_com[n][:] = list(tree.p[name] + R @ link.com - origins[b])
+            model.link_inertia[n][:] = [Il[0, 0], Il[1, 1], Il[2, 2], Il[0, 1], Il[0, 2], Il[1, 2]]
+            n += 1
+    model.num_links = n
 
     for idx, j in enumerate(joints):
         parent_body = body_of_root[tree.body_root_of(j.parent)]

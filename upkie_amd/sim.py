@@ -59,7 +59,8 @@ class BatchedSim:
         self.obs4 = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
         self.obs6 = torch.zeros((B, 6), dtype=torch.float32, device=self.device)
         self.obs_servos = None
-        self.inertia_scale = None
+        self.body_inertials = None  # [70, B] per-env inertial records (randomize_inertias)
+        self.link_scale = None  # [MAX_LINKS, B] the factors drawn per URDF link
         self.ext_force = None
         self._ext_point = (C.c_double * 3)(0.0, 0.0, 0.0)
 
@@ -87,23 +88,37 @@ class BatchedSim:
 
     # ---------------------------------------------------------- randomise
     def randomize_inertias(self, inertia_variation: float) -> torch.Tensor:
-        """Per-env, per-body mass/inertia scales 1 + U(-v, v)
-        (pybullet_backend.py:571-601)."""
-        if self.inertia_scale is None:
-            self.inertia_scale = torch.ones(
-                (abi.NB, self.num_envs), dtype=torch.float32, device=self.device
-            )
+        """`PyBulletBackend.randomize_inertias` (pybullet_backend.py:571-601)
+        for every env: one factor 1 + U(-v, v) per URDF link (kept in
+        ``self.link_scale``) scales that link's mass and inertia; returns the
+        per-env inertial records of the 7 composite bodies the links are fused
+        into, ``[NB * INERTIAL_WORDS, B]`` (row ``10 * body + word``: mass,
+        centre of mass, inertia about it)."""
+        if self.body_inertials is None:
+            self.body_inertials = torch.zeros((abi.NB * abi.INERTIAL_WORDS, self.num_envs), dtype=torch.float32, device=self.device)
+            self.link_scale = torch.ones((abi.MAX_LINKS, self.num_envs), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             self._check(
-                self._lib.upkie_sim_sample_inertia_scales(
+                self._lib.upkie_sim_sample_body_inertials(
                     self._handle,
-                    _ptr(self.inertia_scale),
+                    _ptr(self.body_inertials),
+                    _ptr(self.link_scale),
                     float(inertia_variation),
                     self._stream(),
                 )
             )
         self._push_randomization()
-        return self.inertia_scale
+        return self.body_inertials
+
+    def set_body_inertials(self, body_inertials: Optional[torch.Tensor]) -> None:
+        """Install caller-made inertial records ``[NB * INERTIAL_WORDS, B]``
+        (None: back to the model's)."""
+        if body_inertials is not None:
+            body_inertials = body_inertials.to(self.device, torch.float32).contiguous()
+            if tuple(body_inertials.shape) != (abi.NB * abi.INERTIAL_WORDS, self.num_envs):
+                raise ValueError(f"body_inertials must be [{abi.NB * abi.INERTIAL_WORDS}, {self.num_envs}]")
+        self.body_inertials = body_inertials
+        self._push_randomization()
 
     def set_external_force(self, force: Optional[torch.Tensor], point=(0.0, 0.0, 0.0)):
         """World-frame force ``[3, B]`` on the trunk at base-frame ``point``,
@@ -142,7 +157,7 @@ class BatchedSim:
         self._push_randomization()
 
     def _push_randomization(self):
-        self._check(self._lib.upkie_sim_set_randomization(self._handle, _ptr(self.inertia_scale), None, None))
+        self._check(self._lib.upkie_sim_set_randomization(self._handle, _ptr(self.body_inertials), None, None))
         slots = getattr(self, "_ext_slots", None)
         if self.ext_force is not None and slots is not None:
             self._check(self._lib.upkie_sim_set_external_forces(self._handle, _ptr(self.ext_force), C.byref(slots)))
