@@ -759,3 +759,39 @@ def test_contact_points_in_the_air_and_on_one_wheel():
     lists = sim.get_contact_points(env=B - 1)
     assert len(lists) == 1 and lists[0].link_name in ("left_wheel_tire", "right_wheel_tire")
     assert sim.get_contact_points("torso", env=B - 1) == []
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_per_link_inertia_randomisation_on_the_urdf_model(lanes, monkeypatch):
+    """randomize_inertias on the URDF-derived model (13 links behind 7 bodies,
+    pybullet_backend.py:555-601): link factors and fused body records equal the
+    oracle's, and both step alike with them (shifted centres of mass, wheels
+    whose hub and tire got different factors)."""
+    from upkie_amd.model.model import Model
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 192
+    oracle, sim = make_pair(B, seed=31, model=Model().struct)
+    rec_h = sim.randomize_inertias(0.3).cpu().numpy().astype(np.float64)
+    rec_o = oracle.sample_body_inertials(0.3)
+    np.testing.assert_allclose(sim.link_scale.cpu().numpy(), oracle.link_scale, atol=1e-6)
+    np.testing.assert_allclose(rec_h, rec_o, rtol=3e-5, atol=1e-9)
+    assert np.all(oracle.link_scale[0] == 1.0) and np.std(oracle.link_scale[1:13]) > 0.1
+    assert np.std(rec_o[0]) > 0 and np.std(rec_o[30]) > 0.01  # trunk barely (light links only), wheels a lot
+    oracle.body_inertials = rec_h  # same records on both sides: compare the dynamics, not the fp32 fusion
+    oracle.reset()
+    sim.reset()
+    rng = np.random.default_rng(2)
+    act = rng.uniform(-0.3, 0.3, size=B).astype(np.float32)
+    for _ in range(4):
+        obs_o, *_ = oracle.step_pendulum(act.astype(np.float64))
+        obs_h, *_ = sim.step_pendulum(torch.from_numpy(act))
+    assert_mostly_close(obs_h.cpu().numpy(), obs_o, atol=2e-3, hard_atol=2e-2)
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 2e-4 and err["quat"] < 2e-4, err
+    # and the randomisation matters: the same actions without it end elsewhere
+    plain_o, plain = make_pair(B, seed=31, model=Model().struct)
+    plain.reset()
+    for _ in range(4):
+        obs_p, *_ = plain.step_pendulum(torch.from_numpy(act))
+    assert float((obs_p - obs_h).abs().max()) > 1e-3
