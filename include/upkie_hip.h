@@ -314,7 +314,9 @@ typedef struct UpkieSpineObservation {
   float* wheel_odometry;         /* [B][2] position, velocity               */
 } UpkieSpineObservation;
 
-/* update_imu != 0 advances the finite-difference accelerometer memory the
+/* Output buffers must be 16-byte aligned (the rows of 64 consecutive envs are
+ * streamed out with 16-byte stores).
+ * update_imu != 0 advances the finite-difference accelerometer memory the
  * way one get_spine_observation() call does (pybullet_backend.py:405-408). */
 int upkie_sim_observe(UpkieSim* sim, float* state,
                       const UpkieSpineObservation* out, int update_imu,

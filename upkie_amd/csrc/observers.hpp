@@ -4,12 +4,14 @@
 // lane. Pure load/filter/store work: ~45 words read, ~16 + outputs written per
 // env, HBM bound. State is SoA [UPKIE_OBSERVER_STATE_WORDS][B] so every state
 // access of a wave is one coalesced 256-byte transaction; inputs and outputs
-// keep the row-major layouts of UpkieSpineObservation.
+// keep the row-major layouts of UpkieSpineObservation and move through LDS as
+// contiguous runs (wave_io.hpp).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include "../../include/upkie_hip.h"
+#include "wave_io.hpp"
 
 namespace upkie {
 
@@ -60,9 +62,13 @@ __global__ __launch_bounds__(64) void observers_reset_kernel(int B, float* __res
 
 __global__ __launch_bounds__(64) void observers_step_kernel(ObserverDev P, float* __restrict__ st, UpkieObserverInput in,
                                                             UpkieObserverOutput out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float lds[64 * 30];
   const int B = P.num_envs;
-  if (e >= B) return;
+  const int e0 = blockIdx.x * blockDim.x;
+  const int n_valid = min(64, B - e0);
+  // lanes past the batch shadow the last env: they take part in the LDS staging, nothing of theirs is stored
+  const bool live = (int)threadIdx.x < n_valid;
+  const int e = live ? e0 + (int)threadIdx.x : B - 1;
 #define OW(w) st[(size_t)(w) * B + e]
 
   // ---- BaseOrientation::read (BaseOrientation.cpp:16-34) -------------------
@@ -98,23 +104,22 @@ __global__ __launch_bounds__(64) void observers_step_kernel(ObserverDev P, float
     if (R[8] < 0.f) hxy = -hxy;
     const float sign = sz < 0.f ? 1.f : -1.f;
     const float pitch = sign * atan2f(fabsf(sz), hxy);
-    if (out.base_pitch) out.base_pitch[e] = pitch;
-    if (out.rotation_base_to_world) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) out.rotation_base_to_world[(size_t)9 * e + i] = R[i];
-    }
+    if (out.base_pitch && live) out.base_pitch[e] = pitch;
+    if (out.rotation_base_to_world) wave_store_rows(out.rotation_base_to_world, e0, n_valid, R, lds);
     if (out.base_angular_velocity) {  // base_to_imu^T * omega_imu, BaseOrientation.h:144-148
-      const float wx = in.imu_angular_velocity[(size_t)3 * e], wy = in.imu_angular_velocity[(size_t)3 * e + 1],
-                  wz = in.imu_angular_velocity[(size_t)3 * e + 2];
+      float w[3], wb[3];
+      wave_load_rows(in.imu_angular_velocity, e0, n_valid, w, lds);
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        out.base_angular_velocity[(size_t)3 * e + j] = P.base_to_imu[j] * wx + P.base_to_imu[3 + j] * wy + P.base_to_imu[6 + j] * wz;
+      for (int j = 0; j < 3; ++j) wb[j] = P.base_to_imu[j] * w[0] + P.base_to_imu[3 + j] * w[1] + P.base_to_imu[6 + j] * w[2];
+      wave_store_rows(out.base_angular_velocity, e0, n_valid, wb, lds);
     }
   }
 
   // ---- FloorContact::read (FloorContact.cpp:37-50) -------------------------
   if (!in.servo) return;  // no "servo" block: nothing to read, FloorContact.cpp:42-44
-  const float* servo = in.servo + (size_t)30 * e;  // [6][5]: position, velocity, torque, ...
+  float servo[30];        // [6][5]: position, velocity, torque, ...
+  wave_load_rows(in.servo, e0, n_valid, servo, lds);
+  if (!live) return;  // (no staging below)
   const bool cross = in.cross_button && in.cross_button[e];
   bool any_wheel = false;
   bool wheel_contact[2];

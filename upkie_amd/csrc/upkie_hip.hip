@@ -18,6 +18,7 @@
 #include "dynamics.hpp"
 #include "mpc.hpp"
 #include "observers.hpp"
+#include "wave_io.hpp"
 #include "rollout.hpp"
 
 namespace upkie {
@@ -539,9 +540,13 @@ __device__ __forceinline__ void mat3_mul(const float (&A)[9], const float (&Bm)[
 
 __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, float* __restrict__ state, ObsPtrs out,
                                                       int update_imu) {
+  __shared__ __attribute__((aligned(16))) float lds[64 * 30];
   const int B = C.num_envs;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B) return;
+  const int e0 = blockIdx.x * blockDim.x;
+  const int n_valid = min(64, B - e0);
+  // lanes past the batch compute on the last env (they take part in the LDS staging, their rows are not stored)
+  const bool live = (int)threadIdx.x < n_valid;
+  const int e = live ? e0 + (int)threadIdx.x : B - 1;
   float* st = state + e;
 #define SW(w) st[(size_t)(w) * B]
   float qw = SW(UPKIE_S_QUAT), qx = SW(UPKIE_S_QUAT + 1), qy = SW(UPKIE_S_QUAT + 2), qz = SW(UPKIE_S_QUAT + 3);
@@ -553,20 +558,14 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
   float wb[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) wb[i] = R[i] * w[0] + R[3 + i] * w[1] + R[6 + i] * w[2];
-  if (out.pitch) {
+  if (out.pitch && live) {
     float x = fminf(fmaxf(2.f * (qw * qy - qz * qx), -1.f), 1.f);
     out.pitch[e] = asinf(x);
   }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    if (out.angular_velocity) out.angular_velocity[3 * (size_t)e + d] = wb[d];
-    if (out.linear_velocity) out.linear_velocity[3 * (size_t)e + d] = v[d];
-  }
-  if (out.rotation_base_to_world) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) out.rotation_base_to_world[9 * (size_t)e + i] = R[i];
-  }
-  if (out.floor_contact) out.floor_contact[e] = SW(UPKIE_S_CONTACT) != 0.f ? 1 : 0;
+  if (out.angular_velocity) wave_store_rows(out.angular_velocity, e0, n_valid, wb, lds);
+  if (out.linear_velocity) wave_store_rows(out.linear_velocity, e0, n_valid, v, lds);
+  if (out.rotation_base_to_world) wave_store_rows(out.rotation_base_to_world, e0, n_valid, R, lds);
+  if (out.floor_contact && live) out.floor_contact[e] = SW(UPKIE_S_CONTACT) != 0.f ? 1 : 0;
   {
     // IMU block, pybullet_backend.py:370-430
     float Rbi_t[9], Riw[9];
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
     float a_w[3], a_i[3], p_i[3], w_i[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) a_w[d] = (v_imu[d] - SW(UPKIE_S_IMUVEL + d)) / C.dt;
-    if (update_imu) {
+    if (update_imu && live) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) SW(UPKIE_S_IMUVEL + d) = v_imu[d];
     }
@@ -612,37 +611,30 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
       a_i[i] = Riw[i] * a_w[0] + Riw[3 + i] * a_w[1] + Riw[6 + i] * a_w[2];
       p_i[i] = Riw[i] * pw[0] + Riw[3 + i] * pw[1] + Riw[6 + i] * pw[2];
     }
-    if (out.imu_orientation) {
-      out.imu_orientation[4 * (size_t)e + 0] = q[3] * qn;
-      out.imu_orientation[4 * (size_t)e + 1] = q[0] * qn;
-      out.imu_orientation[4 * (size_t)e + 2] = q[1] * qn;
-      out.imu_orientation[4 * (size_t)e + 3] = q[2] * qn;
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (out.imu_angular_velocity) out.imu_angular_velocity[3 * (size_t)e + d] = w_i[d];
-      if (out.imu_linear_acceleration) out.imu_linear_acceleration[3 * (size_t)e + d] = a_i[d];
-      if (out.imu_raw_linear_acceleration) out.imu_raw_linear_acceleration[3 * (size_t)e + d] = p_i[d];
-    }
+    if (out.imu_orientation && live)  // 16 bytes per lane: already one contiguous run per wave
+      reinterpret_cast<float4*>(out.imu_orientation)[e] = make_float4(q[3] * qn, q[0] * qn, q[1] * qn, q[2] * qn);
+    if (out.imu_angular_velocity) wave_store_rows(out.imu_angular_velocity, e0, n_valid, w_i, lds);
+    if (out.imu_linear_acceleration) wave_store_rows(out.imu_linear_acceleration, e0, n_valid, a_i, lds);
+    if (out.imu_raw_linear_acceleration) wave_store_rows(out.imu_raw_linear_acceleration, e0, n_valid, p_i, lds);
   }
   float ql = SW(UPKIE_S_Q + 2), qr = SW(UPKIE_S_Q + 5), qdl = SW(UPKIE_S_QD + 2), qdr = SW(UPKIE_S_QD + 5);
   if (out.servo) {
     float zm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (C.any_measurement_noise) philox_normal6(C, (unsigned)e, (unsigned)SW(UPKIE_S_STEP), NOISE_SLOT_MEASUREMENT, zm);
+    float o[30];
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) {
-      float* o = out.servo + 30 * (size_t)e + 5 * j;
-      o[0] = SW(UPKIE_S_Q + j);
-      o[1] = SW(UPKIE_S_QD + j);
-      o[2] = SW(UPKIE_S_TORQUE + j) + C.measurement_noise[j] * zm[j];
-      o[3] = 42.0f;
-      o[4] = 18.0f;
+      o[5 * j + 0] = SW(UPKIE_S_Q + j);
+      o[5 * j + 1] = SW(UPKIE_S_QD + j);
+      o[5 * j + 2] = SW(UPKIE_S_TORQUE + j) + C.measurement_noise[j] * zm[j];
+      o[5 * j + 3] = 42.0f;
+      o[5 * j + 4] = 18.0f;
     }
+    wave_store_rows(out.servo, e0, n_valid, o, lds);
   }
-  if (out.wheel_odometry) {
+  if (out.wheel_odometry && live) {
     float sr = M.left_sign * M.wheel_radius;
-    out.wheel_odometry[2 * (size_t)e] = 0.5f * (ql - qr) * sr;
-    out.wheel_odometry[2 * (size_t)e + 1] = 0.5f * (qdl - qdr) * sr;
+    reinterpret_cast<float2*>(out.wheel_odometry)[e] = make_float2(0.5f * (ql - qr) * sr, 0.5f * (qdl - qdr) * sr);
   }
 #undef SW
 }

@@ -21,6 +21,7 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "pair.hpp"),
     os.path.join(_HERE, "csrc", "observers.hpp"),
     os.path.join(_HERE, "csrc", "rollout.hpp"),
+    os.path.join(_HERE, "csrc", "wave_io.hpp"),
     os.path.join(_HERE, "..", "include", "upkie_hip.h"),
 ]
 
