@@ -314,6 +314,26 @@ typedef struct UpkieSpineObservation {
   float* wheel_odometry;         /* [B][2] position, velocity               */
 } UpkieSpineObservation;
 
+/* gymnasium.vector AutoresetMode.SAME_STEP: the step that ends an episode
+ * also returns the first observation of the next one, the terminal observation
+ * going to info["final_obs"]. Call after a step made with
+ * UPKIE_AUTORESET_DISABLED: every env whose DONE word is set (by the step when
+ * the robot fell, or by the caller for a time limit: row UPKIE_S_DONE of the
+ * state) is re-initialised exactly as upkie_sim_reset does it and its row of
+ * `obs` (the buffer the step wrote, in that step's layout) replaced by the
+ * reset observation; `final_obs` (same layout, may be NULL; records: [B][4])
+ * receives the step's observation of EVERY env first. Reward and flags of the
+ * terminal step stay; envs that are not done are otherwise untouched. One
+ * launch. */
+enum UpkieObservationLayout {
+  UPKIE_OBSERVATION_PENDULUM = 1,         /* [B][4], upkie_sim_step_pendulum            */
+  UPKIE_OBSERVATION_PENDULUM_RECORDS = 2, /* [B][8] records, ..._step_pendulum_packed   */
+  UPKIE_OBSERVATION_GYROPOD = 3,          /* [B][6], upkie_sim_step_gyropod             */
+  UPKIE_OBSERVATION_SERVOS = 4            /* [B][6][5], upkie_sim_step_servos           */
+};
+int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state,
+                             float* obs, float* final_obs, void* stream);
+
 /* Output buffers must be 16-byte aligned (the rows of 64 consecutive envs are
  * streamed out with 16-byte stores).
  * update_imu != 0 advances the finite-difference accelerometer memory the

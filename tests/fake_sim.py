@@ -118,6 +118,25 @@ class OracleSim:
         records[:, 7] = 0.0
         return records
 
+    def autoreset_done(self, layout, obs, final_obs):
+        """SAME_STEP autoreset of the envs whose DONE word is set (what
+        upkie_sim_autoreset_done does in one launch)."""
+        done = self._o.state[abi.S_DONE] != 0
+        if final_obs is not None:
+            final_obs.copy_(obs[:, :4] if layout == abi.OBSERVATION_PENDULUM_RECORDS else obs)
+        if not done.any():
+            return obs
+        obs6 = torch.from_numpy(self._o.reset(done.astype(np.uint8)).astype(np.float32))
+        sel = torch.from_numpy(done)
+        if layout in (abi.OBSERVATION_PENDULUM, abi.OBSERVATION_PENDULUM_RECORDS):
+            obs[sel, :4] = obs6[sel][:, [1, 0, 4, 3]]
+        elif layout == abi.OBSERVATION_GYROPOD:
+            obs[sel] = obs6[sel]
+        else:
+            servo = torch.from_numpy(self._o.observe(False)["servo"].astype(np.float32))
+            obs[sel] = servo[sel]
+        return obs
+
     def contact_points(self):
         return torch.from_numpy(self._o.contact_points().astype(np.float32))
 

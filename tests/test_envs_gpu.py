@@ -234,3 +234,45 @@ def test_graph_captured_loop_equals_eager():
         body(eager, act_e)
     torch.cuda.synchronize()
     assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs4, graphed.obs4)
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("env_id,limit", [("Upkie-HIP-Pendulum-Vec", None), ("Upkie-HIP-Gyropod-Vec", 25), ("Upkie-HIP-Servos-Vec", 12)])
+def test_same_step_autoreset_is_one_launch_and_matches_the_double(env_id, limit, lanes, monkeypatch):
+    """SAME_STEP autoreset through upkie_sim_autoreset_done (the reset branch
+    of the step kernel run on the envs whose DONE word is set) against the
+    oracle-backed double: same terminal observations, same restart
+    observations, same flags, falls and time limits alike."""
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 96
+    kw = dict(num_envs=B, frequency=200.0, init_state=RobotState(randomization=RobotStateRandomization(pitch=0.12)),
+              autoreset_mode="same_step", max_episode_steps=limit, seed=4)
+    if "Servos" not in env_id:
+        kw["fall_pitch"] = 0.15
+    gpu = envs.make(env_id, **kw)
+    cpu = envs.make(env_id, sim_factory=oracle_sim_factory, **kw)
+    assert hasattr(gpu.sim, "autoreset_done") and gpu._same_step_layout is not None
+    og, _ = gpu.reset(seed=4)
+    oc, _ = cpu.reset(seed=4)
+    act = gpu.get_neutral_action() if "Servos" in env_id else torch.zeros((B,) + tuple(gpu.single_action_space.shape))
+    if "Servos" in env_id:
+        act[:, :, 3:5] = 0.0  # limp joints: the robots collapse, states move a lot between resets
+    ended = 0
+    for step in range(60):
+        og, rg, tg, ug, ig = gpu.step(act)
+        oc, rc, tc, uc, ic = cpu.step(act.cpu())
+        assert torch.equal(tg.cpu(), tc) and torch.equal(ug.cpu(), uc), step
+        m = ic["_final_obs"]
+        assert torch.equal(ig["_final_obs"].cpu(), m)
+        ended += int(m.sum())
+        # fp32 vs fp64 closed loops drift: compare what the autoreset itself produces tightly, the rest loosely
+        np.testing.assert_allclose(og.cpu()[m].numpy(), oc[m].numpy(), atol=3e-3)
+        np.testing.assert_allclose(ig["final_obs"].cpu().numpy(), ic["final_obs"].numpy(), atol=0.05 if "Servos" not in env_id else 0.5)
+        np.testing.assert_allclose(og.cpu().numpy(), oc.numpy(), atol=0.05 if "Servos" not in env_id else 0.5)
+        # resynchronise the double with the device so that flags keep agreeing
+        cpu.sim._o.state[:] = gpu.sim.state.cpu().numpy().astype(np.float64)
+    assert ended >= B // 4
+    np.testing.assert_array_equal(gpu.sim.state[abi.S_EPISODE].cpu().numpy(), cpu.sim._o.state[abi.S_EPISODE])

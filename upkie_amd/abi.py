@@ -237,6 +237,8 @@ O_ODOMETRY_POSITION = 12
 O_ODOMETRY_VELOCITY = 13
 OBSERVER_STATE_WORDS = 16
 CONTACT_POINT_WORDS = 8  # UPKIE_CONTACT_POINT_WORDS
+# enum UpkieObservationLayout
+OBSERVATION_PENDULUM, OBSERVATION_PENDULUM_RECORDS, OBSERVATION_GYROPOD, OBSERVATION_SERVOS = 1, 2, 3, 4
 
 
 def default_sim_config(

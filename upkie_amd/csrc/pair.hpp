@@ -578,7 +578,23 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && SW(UPKIE_S_DONE) != 0.f;
+    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && SW(UPKIE_S_DONE) != 0.f;
+    if (C.autoreset_mode == AUTORESET_DONE_PASS) {
+      // SAME_STEP autoreset, second launch (see step_kernel): both lanes of a pair agree on DONE
+      float* final_obs = const_cast<float*>(act);
+      if (final_obs) {  // every env, see step_kernel
+        constexpr int W = ObsWords<MODE>::value;
+        if (MODE == MODE_SERVOS) {  // each lane keeps its three servos
+#pragma unroll
+          for (int i = 0; i < 15; ++i) final_obs[(size_t)30 * e + 15 * leg + i] = obs[(size_t)30 * e + 15 * leg + i];
+        } else if (lead) {
+          const float* last = obs + (size_t)(packed ? 8 : W) * e;
+#pragma unroll
+          for (int i = 0; i < W; ++i) final_obs[(size_t)W * e + i] = last[i];
+        }
+      }
+      if (!do_reset) return;
+    }
   }
   const float signed_radius = M.left_sign * M.wheel_radius;
 
@@ -812,7 +828,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     if (packed) {
       float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
       rec[0] = o4;
-      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
       return;
     }
     reinterpret_cast<float4*>(obs)[e] = o4;
@@ -838,6 +854,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     o2[1] = make_float2(obs6[2], obs6[3]);
     o2[2] = make_float2(obs6[4], obs6[5]);
   }
+  if (C.autoreset_mode == AUTORESET_DONE_PASS) return;  // reward and flags are those of the terminal step
   reward[e] = 0.f;
   terminated[e] = fallen ? 1 : 0;
   truncated[e] = 0;

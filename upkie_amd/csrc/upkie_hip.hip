@@ -45,6 +45,14 @@ struct DevConfig {
   ObserverDev spine;  // in-step spine observers (one cycle per physics substep), used when attached
 };
 
+// DevConfig::autoreset_mode value of the second launch of a SAME_STEP autoreset
+// (upkie_sim_autoreset_done): only the envs whose DONE word is set run, down
+// the reset branch of the step that wrote their terminal observation.
+enum { AUTORESET_DONE_PASS = 100 };
+// words per env of a step mode's observation buffer (0: none)
+template <int MODE>
+struct ObsWords { static constexpr int value = MODE == 1 || MODE == 2 ? 4 : MODE == 3 ? 6 : MODE == 4 ? 30 : MODE == 5 ? 3 : 0; };
+
 enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4, MODE_BASE_VELOCITY = 5 };
 
 // Extra buffers of the fused UpkieBaseVelocity step (upkie_base_velocity.py:164-202).
@@ -248,7 +256,19 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP && SW(UPKIE_S_DONE) != 0.f;
+    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && SW(UPKIE_S_DONE) != 0.f;
+    if (C.autoreset_mode == AUTORESET_DONE_PASS) {
+      // SAME_STEP autoreset, second launch: the step has just written this env's
+      // terminal observation; keep it aside, then run the reset branch
+      float* final_obs = const_cast<float*>(act);  // (the action slot carries the buffer: actions are not read when resetting)
+      if (final_obs) {  // every env: final_obs is the step's observation, obs differs from it where an episode ended
+        constexpr int W = ObsWords<MODE>::value;
+        const float* last = obs + (size_t)(packed ? 8 : W) * e;
+#pragma unroll
+        for (int i = 0; i < W; ++i) final_obs[(size_t)W * e + i] = last[i];
+      }
+      if (!do_reset) return;
+    }
   }
 
   if (MODE == MODE_RESET && !do_reset) {
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       // [obs(4) | reward, terminated, truncated, 0]
       float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
       rec[0] = o4;
-      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
       return;
     }
     reinterpret_cast<float4*>(obs)[e] = o4;
@@ -508,6 +528,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       o[5 * j + 4] = 18.0f;
     }
   }
+  if (C.autoreset_mode == AUTORESET_DONE_PASS) return;  // reward and flags are those of the terminal step
   reward[e] = 0.f;  // upkie_env.py:230
   terminated[e] = fallen ? 1 : 0;
   truncated[e] = 0;
@@ -1091,12 +1112,14 @@ static const int kPairBatch = 32768;
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
-                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}) {
+                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}, bool done_pass = false) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  if (MODE != MODE_RESET && (!obs || (!packed && (!reward || !terminated || !truncated))))
+  if (MODE != MODE_RESET && (!obs || (!packed && !done_pass && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
-  if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS || MODE == MODE_BASE_VELOCITY) && !act)
+  if ((MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS || MODE == MODE_BASE_VELOCITY) && !act && !done_pass)
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
+  DevConfig config = sim->config;
+  if (done_pass) config.autoreset_mode = AUTORESET_DONE_PASS;
   const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   const float* scale = rnd ? sim->body_inertials : nullptr;
@@ -1109,13 +1132,13 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // SPINE: the spine observers run inside the step (a separate instantiation:
   // compiled in but switched off they would still cost the common path 2 %)
 #define UPKIE_LAUNCH_S(R, W, S)                                                                                            \
-  hipLaunchKernelGGL((step_kernel<MODE, R, W, S>), grid, block, 0, st, sim->d_model, sim->limits, sim->config, state, act, obs, \
+  hipLaunchKernelGGL((step_kernel<MODE, R, W, S>), grid, block, 0, st, sim->d_model, sim->limits, config, state, act, obs, \
                      reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
 #define UPKIE_LAUNCH(R, W) \
   do { if (spine) UPKIE_LAUNCH_S(R, W, true); else UPKIE_LAUNCH_S(R, W, false); } while (0)
 #define UPKIE_LAUNCH_PAIR_S(R, S)                                                                                                 \
   hipLaunchKernelGGL((step_kernel_pair<MODE, R, S>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
-                     sim->config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
+                     config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
   const bool spine = sim->spine_state != nullptr;
@@ -1177,6 +1200,22 @@ extern "C" int upkie_sim_step_base_velocity(UpkieSim* sim, float* state, const f
 extern "C" int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,
                                      uint8_t* terminated, uint8_t* truncated, void* stream) {
   return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+}
+
+extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state, float* obs, float* final_obs, void* stream) {
+  const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
+  switch (observation) {
+    case UPKIE_OBSERVATION_PENDULUM:
+      return launch_step<MODE_PENDULUM>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+    case UPKIE_OBSERVATION_PENDULUM_RECORDS:
+      return launch_step<MODE_PENDULUM>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 1, none, true);
+    case UPKIE_OBSERVATION_GYROPOD:
+      return launch_step<MODE_GYROPOD>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+    case UPKIE_OBSERVATION_SERVOS:
+      return launch_step<MODE_SERVOS>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+    default:
+      return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "unknown observation layout");
+  }
 }
 
 extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineObservation* out, int update_imu, void* stream) {

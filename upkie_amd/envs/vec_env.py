@@ -178,6 +178,11 @@ class UpkieVecEnv:
             self._observers.close()
         self.sim.close()
 
+    #: `abi.OBSERVATION_*` layout of the step's observation buffer when a SAME_STEP
+    #: autoreset can run as one launch on it (None: through `reset(mask=done)`)
+    _same_step_layout = None
+    _final_obs = None
+
     def _info(self) -> dict:
         self._spine.invalidate()
         if self._observers is not None:
@@ -201,6 +206,18 @@ class UpkieVecEnv:
         if self.autoreset_mode != "same_step":
             return obs, reward, terminated, truncated, self._info()
         done = terminated | truncated
+        if self._same_step_layout is not None and hasattr(self.sim, "autoreset_done"):
+            # one launch: envs whose DONE word is set restart, their terminal observation kept aside
+            if self.max_episode_steps is not None:
+                self.sim.flag_done(done)  # the kernel flags falls only, not time limits
+                self._elapsed.masked_fill_(done, 0)
+            if self._final_obs is None:
+                self._final_obs = torch.empty_like(obs)
+            self.sim.autoreset_done(self._same_step_layout, obs, self._final_obs)
+            info = dict(self._info())
+            info["final_obs"] = self._final_obs
+            info["_final_obs"] = done
+            return obs, reward, terminated, truncated, info
         final_obs = obs.clone()
         obs, info = self.reset(mask=done)  # untouched envs report their current observation
         info = dict(info)
@@ -258,6 +275,8 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
     [pitch, ground position, pitch rate, ground velocity]
     (upkie_pendulum.py:20-60)."""
 
+    _same_step_layout = abi.OBSERVATION_PENDULUM
+
     def __init__(self, num_envs: int = 1, fall_pitch: float = 1.0, max_ground_velocity: float = 3.0, **kwargs):
         self.fall_pitch = fall_pitch
         self.max_ground_velocity = max_ground_velocity
@@ -291,6 +310,8 @@ class UpkieGyropodVecEnv(UpkieVecEnv):
     """Batched ``UpkieGyropod``: action [ground velocity, yaw velocity],
     observation [ground position, pitch, yaw, ground velocity, pitch rate,
     yaw velocity] (upkie_gyropod.py:20-98)."""
+
+    _same_step_layout = abi.OBSERVATION_GYROPOD
 
     def __init__(
         self,
@@ -350,6 +371,8 @@ class UpkieServosVecEnv(UpkieVecEnv):
     torque, temperature, voltage) (upkie_servos.py:20-306). Never terminates
     on its own (upkie_env.py:231-238)."""
 
+    _same_step_layout = abi.OBSERVATION_SERVOS
+
     def __init__(self, num_envs: int = 1, **kwargs):
         super().__init__(num_envs=num_envs, **kwargs)
         m = self.model.struct
@@ -399,6 +422,8 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
     """Batched ``UpkieBaseVelocity``: action [linear velocity, yaw velocity]
     goes through the MPC balancer, observation is the dead-reckoned SE(2) pose
     [x, y, yaw] (upkie_base_velocity.py:21-202)."""
+
+    _same_step_layout = None  # the MPC workspace and the dead-reckoned pose restart with the env: through reset(mask)
 
     def __init__(
         self,

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_base_velocity",
     "upkie_sim_observe",
     "upkie_sim_contact_points",
+    "upkie_sim_autoreset_done",
     "upkie_mpc_create",
     "upkie_mpc_destroy",
     "upkie_mpc_last_error",
@@ -176,6 +177,8 @@ def load() -> C.CDLL:
         C.c_int,
         vp,
     ]
+    lib.upkie_sim_autoreset_done.restype = C.c_int
+    lib.upkie_sim_autoreset_done.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.upkie_sim_contact_points.restype = C.c_int
     lib.upkie_sim_contact_points.argtypes = [vp, vp, vp, vp]
     lib.upkie_mpc_create.restype = C.c_int

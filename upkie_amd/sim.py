@@ -324,6 +324,15 @@ class BatchedSim:
             )
         return out
 
+    def autoreset_done(self, layout: int, obs: torch.Tensor, final_obs: Optional[torch.Tensor]) -> torch.Tensor:
+        """gymnasium SAME_STEP autoreset in one launch: envs whose DONE word is
+        set are re-initialised; their rows of ``obs`` (what the step of layout
+        `abi.OBSERVATION_*` just wrote) go to ``final_obs`` and are replaced
+        by the reset observation. Returns ``obs``."""
+        with torch.cuda.device(self.device):
+            self._check(self._lib.upkie_sim_autoreset_done(self._handle, int(layout), _ptr(self.state), _ptr(obs), _ptr(final_obs), self._stream()))
+        return obs
+
     def contact_points(self) -> torch.Tensor:
         """Tire/floor contact points of every env, ``[B, 2, 8]``: per tire (left,
         right) ``[exists, position in world (3), force in world (3), 0]``
