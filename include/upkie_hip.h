@@ -51,6 +51,7 @@ enum UpkieStateWord {
   UPKIE_S_SE2_Y = 44,   /* 1: dead-reckoned y                               */
   UPKIE_S_CONTACT = 45, /* 1: floor contact flag after the last substep     */
   UPKIE_S_STEP = 46,    /* 1: env.step() calls so far (torque-noise stream)  */
+  UPKIE_S_ELAPSED = 47, /* 1: steps of the current episode (time limit)      */
   UPKIE_STATE_WORDS = 48
 };
 
@@ -162,7 +163,10 @@ typedef struct UpkieSimConfig {
   uint64_t seed;          /* Philox key                                     */
   int64_t env_id_offset;  /* global index of local env 0 (multi-GPU shards) */
   int32_t autoreset_mode; /* UpkieAutoreset                                 */
-  int32_t reserved0;
+  int32_t max_episode_steps; /* gymnasium TimeLimit for the batch: the step that
+                                brings an episode to this many steps reports
+                                `truncated` (unless the robot fell in it) and
+                                flags the env done; 0 = no limit            */
   /* Fused linear-feedback agent (README.md:62-64): a = clip(g . obs, +-c)  */
   double agent_gains[4];
   double agent_clip;

@@ -909,6 +909,7 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   s[UPKIE_S_SE2_Y] = 0.0;
   s[UPKIE_S_EPISODE] = (double)(episode + 1);
   s[UPKIE_S_DONE] = 0.0;
+  s[UPKIE_S_ELAPSED] = 0.0;
 }
 
 /* PyBulletBackend.randomize_inertias, pybullet_backend.py:571-601, for every
@@ -1095,15 +1096,30 @@ static void autoreset_or_null(const UpkieModel* model, const UpkieSimConfig* cfg
   }
 }
 
+/* gymnasium's TimeLimit for the batch (UpkieSimConfig.max_episode_steps): the
+ * step that brings an episode to the limit reports `truncated` unless the
+ * robot fell in it, and flags the env done like a fall does. An autoreset step
+ * is not a step of the new episode. */
+static uint8_t time_limit(const UpkieSimConfig* cfg, double s[NW], int did_reset, int terminated) {
+  if (cfg->max_episode_steps <= 0 || did_reset) return 0;
+  s[UPKIE_S_ELAPSED] += 1.0;
+  if (s[UPKIE_S_ELAPSED] >= (double)cfg->max_episode_steps && !terminated) {
+    s[UPKIE_S_DONE] = 1.0;
+    return 1;
+  }
+  return 0;
+}
+
 static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
                              double s[NW], int64_t env_global, double a0,
-                             double a1, double obs6[6], uint8_t* terminated,
+                             double a1, double obs6[6], uint8_t* terminated, uint8_t* truncated,
                              const double* sp, const double* fp, const UpkieExternalForces* pp) {
   int did_reset;
   autoreset_or_null(model, cfg, s, env_global, sp, fp, pp, &did_reset);
   if (did_reset) {
     gyropod_observation(model, s, obs6);
     *terminated = 0;
+    *truncated = 0;
     return;
   }
   OracleServoCommand cmd[NJ];
@@ -1116,6 +1132,7 @@ static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   /* __detect_fall, upkie_gyropod.py:344-345 */
   *terminated = fabs(obs6[1]) > cfg->fall_pitch ? 1 : 0;
   if (*terminated) s[UPKIE_S_DONE] = 1.0;
+  *truncated = time_limit(cfg, s, 0, *terminated);
 }
 
 void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
@@ -1133,9 +1150,8 @@ void oracle_step_gyropod(const UpkieModel* model, const UpkieSimConfig* cfg,
     env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
     spine_begin(rnd, B, e);
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[2 * e], act[2 * e + 1],
-                     obs + 6 * (int64_t)e, &terminated[e], sp, fp, pp);
+                     obs + 6 * (int64_t)e, &terminated[e], &truncated[e], sp, fp, pp);
     reward[e] = 0.0; /* upkie_env.py:230 */
-    truncated[e] = 0;
     spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
@@ -1160,10 +1176,9 @@ void oracle_step_pendulum(const UpkieModel* model, const UpkieSimConfig* cfg,
     spine_begin(rnd, B, e);
     /* upkie_pendulum.py:139: action_2d = [action[0], 0.0] */
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, act[e], 0.0, obs6,
-                     &terminated[e], sp, fp, pp);
+                     &terminated[e], &truncated[e], sp, fp, pp);
     for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
     reward[e] = 0.0;
-    truncated[e] = 0;
     spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
@@ -1189,10 +1204,9 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
     for (int i = 0; i < 4; ++i) a += cfg->agent_gains[i] * obs[4 * (int64_t)e + i];
     a = clamp_like_reference(a, -cfg->agent_clip, cfg->agent_clip);
     step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, a, 0.0, obs6,
-                     &terminated[e], sp, fp, pp);
+                     &terminated[e], &truncated[e], sp, fp, pp);
     for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = obs6[kPendulumObsIndices[i]];
     reward[e] = 0.0;
-    truncated[e] = 0;
     spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }
@@ -1248,7 +1262,7 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
     servo_observation(cfg, cfg->env_id_offset + e, s, obs + 30 * (int64_t)e);
     reward[e] = 0.0;
     terminated[e] = 0; /* upkie_env.py:231-238: only the joystick ends it */
-    truncated[e] = 0;
+    truncated[e] = time_limit(cfg, s, did_reset, 0);
     spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }

@@ -795,3 +795,39 @@ def test_per_link_inertia_randomisation_on_the_urdf_model(lanes, monkeypatch):
     for _ in range(4):
         obs_p, *_ = plain.step_pendulum(torch.from_numpy(act))
     assert float((obs_p - obs_h).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_time_limit_in_the_kernel_matches_oracle(lanes, monkeypatch):
+    """UpkieSimConfig.max_episode_steps (gymnasium's TimeLimit for the batch):
+    `truncated` on the step that reaches the limit unless the robot fell in it,
+    the DONE word set, NEXT_STEP autoreset restarting the count; the packed
+    record carries the flag in word 6."""
+    from upkie_amd.sim import BatchedSim
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 130
+    cfg = randomized_config(B, seed=8, autoreset=True)
+    cfg.max_episode_steps = 7
+    cfg.fall_pitch = 0.09  # some envs (initial pitch up to 0.1) fall before the limit
+    oracle, sim = make_pair(B, cfg=cfg)
+    oracle.reset()
+    sim.reset()
+    packed = BatchedSim(cfg)
+    packed.reset()
+    act = np.linspace(-0.6, 0.6, B).astype(np.float32)
+    records = torch.zeros((B, 8), device=sim.device)
+    seen_trunc = seen_term = 0
+    for step in range(30):
+        _, _, term_o, trunc_o = oracle.step_pendulum(act.astype(np.float64))
+        _, _, term_h, trunc_h = sim.step_pendulum(torch.from_numpy(act))
+        packed.step_pendulum_packed(records, torch.from_numpy(act))
+        oracle.state[:] = sim.state_numpy().astype(np.float64)  # keep the closed loops together
+        assert np.array_equal(term_h.cpu().numpy(), term_o) and np.array_equal(trunc_h.cpu().numpy(), trunc_o), step
+        assert np.array_equal(records[:, 5].cpu().numpy(), term_o.astype(np.float32))
+        assert np.array_equal(records[:, 6].cpu().numpy(), trunc_o.astype(np.float32))
+        assert not np.any(term_o & trunc_o)
+        seen_trunc += int(trunc_o.sum())
+        seen_term += int(term_o.sum())
+    assert seen_trunc > B and seen_term > 0
+    assert sim.state_numpy()[abi.S_ELAPSED].max() <= 7

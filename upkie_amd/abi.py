@@ -54,6 +54,7 @@ S_SE2_X = 43
 S_SE2_Y = 44
 S_CONTACT = 45
 S_STEP = 46
+S_ELAPSED = 47  # steps of the current episode (time limit)
 STATE_WORDS = 48
 PENDULUM_STATE_WORDS = 29
 
@@ -136,7 +137,7 @@ class UpkieSimConfig(C.Structure):
         ("seed", C.c_uint64),
         ("env_id_offset", C.c_int64),
         ("autoreset_mode", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("max_episode_steps", C.c_int32),
         ("agent_gains", C.c_double * 4),
         ("agent_clip", C.c_double),
     ]

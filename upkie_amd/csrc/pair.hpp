@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   }
 
   // ---- wrapper post-processing ---------------------------------------------
-  bool fallen = false;
+  bool fallen = false, timeout = false;
   float obs6[6];
   if (do_reset) {
     legref[0] = s.q[0];
@@ -759,6 +759,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       SW(UPKIE_S_SE2_Y) = 0.f;
       SW(UPKIE_S_EPISODE) = (float)(episode + 1);
       SW(UPKIE_S_DONE) = 0.f;
+      SW(UPKIE_S_ELAPSED) = 0.f;
     }
     observe6(yaw, yawvel, obs6);
   } else {
@@ -774,6 +775,14 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     if (MODE != MODE_SERVOS) {
       fallen = fabsf(obs6[1]) > C.fall_pitch;
       if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
+    }
+    if (C.max_episode_steps > 0) {  // time limit, see step_kernel
+      const float elapsed = SW(UPKIE_S_ELAPSED) + 1.f;
+      timeout = elapsed >= (float)C.max_episode_steps && !fallen;
+      if (lead) {
+        SW(UPKIE_S_ELAPSED) = elapsed;
+        if (timeout) SW(UPKIE_S_DONE) = 1.f;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) SW(UPKIE_S_TORQUE + 3 * leg + k) = tau[k];
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     if (packed) {
       float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
       rec[0] = o4;
-      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
       return;
     }
     reinterpret_cast<float4*>(obs)[e] = o4;
@@ -857,6 +866,6 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   if (C.autoreset_mode == AUTORESET_DONE_PASS) return;  // reward and flags are those of the terminal step
   reward[e] = 0.f;
   terminated[e] = fallen ? 1 : 0;
-  truncated[e] = 0;
+  truncated[e] = timeout ? 1 : 0;
 #undef SW
 }

@@ -39,6 +39,7 @@ struct DevConfig {
   unsigned seed_lo, seed_hi;
   unsigned env_lo, env_hi;  // env_id_offset
   int autoreset_mode;
+  int max_episode_steps;  // 0: no time limit
   float agent_gains[4];
   float agent_clip;
   ExtSlots ext;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   }
 
   // ---- wrapper post-processing -----------------------------------------
-  bool fallen = false;
+  bool fallen = false, timeout = false;
   float obs6[6];
   if (do_reset) {
     // upkie_gyropod.py:236-240
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     SW(UPKIE_S_SE2_Y) = 0.f;
     SW(UPKIE_S_EPISODE) = (float)(episode + 1);
     SW(UPKIE_S_DONE) = 0.f;
+    SW(UPKIE_S_ELAPSED) = 0.f;
     gyropod_observation(M, s, yaw, yawvel, obs6);
   } else {
     if (YAWING) {
@@ -446,6 +448,13 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     if (MODE != MODE_SERVOS) {
       fallen = fabsf(obs6[1]) > C.fall_pitch;  // upkie_gyropod.py:344-345
       if (fallen) SW(UPKIE_S_DONE) = 1.f;
+    }
+    if (C.max_episode_steps > 0) {
+      // gymnasium's TimeLimit: the step that brings the episode to the limit is truncated unless it fell
+      const float elapsed = SW(UPKIE_S_ELAPSED) + 1.f;
+      SW(UPKIE_S_ELAPSED) = elapsed;
+      timeout = elapsed >= (float)C.max_episode_steps && !fallen;
+      if (timeout) SW(UPKIE_S_DONE) = 1.f;
     }
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) SW(UPKIE_S_TORQUE + j) = tau[j];  // pybullet_backend.py:293
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       // [obs(4) | reward, terminated, truncated, 0]
       float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
       rec[0] = o4;
-      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, 0.f, 0.f);
+      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
       return;
     }
     reinterpret_cast<float4*>(obs)[e] = o4;
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   if (C.autoreset_mode == AUTORESET_DONE_PASS) return;  // reward and flags are those of the terminal step
   reward[e] = 0.f;  // upkie_env.py:230
   terminated[e] = fallen ? 1 : 0;
-  truncated[e] = 0;
+  truncated[e] = timeout ? 1 : 0;
 #undef SW
 }
 
@@ -970,6 +979,7 @@ static bool convert_config(const UpkieSimConfig* c, DevConfig* d, std::string* w
   d->env_lo = (unsigned)((uint64_t)c->env_id_offset & 0xffffffffu);
   d->env_hi = (unsigned)((uint64_t)c->env_id_offset >> 32);
   d->autoreset_mode = c->autoreset_mode;
+  d->max_episode_steps = c->max_episode_steps > 0 ? c->max_episode_steps : 0;
   for (int k = 0; k < 4; ++k) d->agent_gains[k] = (float)c->agent_gains[k];
   d->agent_clip = (float)c->agent_clip;
   return true;

@@ -121,6 +121,7 @@ class UpkieVecEnv:
         # of an episode (the reference registers no limit, envs/__init__.py:38-44)
         self.max_episode_steps = None if max_episode_steps is None else int(max_episode_steps)
         cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP if autoreset_mode == "next_step" else abi.AUTORESET_DISABLED
+        cfg.max_episode_steps = 0 if self.max_episode_steps is None else self.max_episode_steps
         cfg.env_id_offset = env_id_offset
         for idx, name in enumerate(abi.JOINT_NAMES):
             props = (joint_properties or {}).get(name, JointProperties())
@@ -137,8 +138,6 @@ class UpkieVecEnv:
             self.sim.randomize_inertias(self.inertia_variation)
         self._spine = LazySpineObservation(self.sim)
         self._external_forces = ExternalForceSet(self.model, self.num_envs)
-        self._elapsed = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
-        self._pending_reset = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         # Optional spine observer pipeline (upkie/cpp/observers, order of
         # spines/common/observers.h:22-42); `spine_observers` is True or a spine
         # configuration dictionary (spine_backend.py:77-105). FloorContact, its
@@ -195,22 +194,12 @@ class UpkieVecEnv:
         # the kernels write 0/1 bytes: reinterpreting them as bool launches nothing
         terminated = terminated.view(torch.bool) if terminated.dtype == torch.uint8 else terminated.bool()
         truncated = truncated.view(torch.bool) if truncated.dtype == torch.uint8 else truncated.bool()
-        if self.max_episode_steps is not None:
-            # a NEXT_STEP autoreset step is not a step of the new episode
-            self._elapsed = torch.where(self._pending_reset, torch.zeros_like(self._elapsed), self._elapsed + 1)
-            timeout = (self._elapsed >= self.max_episode_steps) & ~terminated
-            truncated = truncated | timeout
-            if self.autoreset_mode == "next_step":
-                self._pending_reset = terminated | truncated
-                self.sim.flag_done(self._pending_reset)  # the kernel's autoreset flag
+        # (the time limit lives in the kernel: `truncated` and the DONE word come from the step itself)
         if self.autoreset_mode != "same_step":
             return obs, reward, terminated, truncated, self._info()
         done = terminated | truncated
         if self._same_step_layout is not None and hasattr(self.sim, "autoreset_done"):
             # one launch: envs whose DONE word is set restart, their terminal observation kept aside
-            if self.max_episode_steps is not None:
-                self.sim.flag_done(done)  # the kernel flags falls only, not time limits
-                self._elapsed.masked_fill_(done, 0)
             if self._final_obs is None:
                 self._final_obs = torch.empty_like(obs)
             self.sim.autoreset_done(self._same_step_layout, obs, self._final_obs)
@@ -257,13 +246,6 @@ class UpkieVecEnv:
         return self.sim.contact_points()
 
     def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
-        if mask is None:
-            self._elapsed.zero_()
-            self._pending_reset.zero_()
-        else:
-            m = torch.as_tensor(mask).to(self.device).bool()
-            self._elapsed.masked_fill_(m, 0)  # (boolean indexing would synchronise with the device)
-            self._pending_reset.masked_fill_(m, False)
         if seed is not None:
             self.config.seed = int(seed)
             self.sim.push_config()
