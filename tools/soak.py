@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from upkie_amd import abi  # noqa: E402
+from upkie_amd.model.model import Model  # noqa: E402
 from upkie_amd.sim import BatchedSim  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -36,6 +37,7 @@ def config(seed):
     cfg.rand_pitch, cfg.rand_roll, cfg.rand_x, cfg.rand_omega_y = 0.2, 0.05, 0.05, 0.3
     cfg.rand_linvel[0] = 0.1
     cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+    cfg.max_episode_steps = 1500  # time limit kept by the kernel
     for j in range(6):
         cfg.torque_control_noise[j] = 0.05
         cfg.joint_friction[j] = 0.05
@@ -46,7 +48,7 @@ for lanes in ("2", "1"):
     os.environ["UPKIE_LANES_PER_ENV"] = lanes
     t0 = time.time()
     # Pendulum with the README agent, randomised inertias, random pushes renewed every 500 steps
-    sim = BatchedSim(config(1))
+    sim = BatchedSim(config(1), Model().struct)  # URDF model: 13 links behind the 7 bodies, randomised one by one
     sim.randomize_inertias(0.3)
     sim.reset()
     sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
