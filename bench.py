@@ -70,6 +70,12 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
         if elapsed >= budget_s or steps >= 5000:
             break
     # the reference's own execution model: one env, one thread
+    try:
+        import ctypes
+
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)  # the oracle's OpenMP runtime: no team to wake for one env
+    except OSError:
+        pass
     single = O.Oracle(default_model(), make_config(1))
     o1 = single.reset()[:, [1, 0, 4, 3]]
     n1, t1 = 0, time.perf_counter()
