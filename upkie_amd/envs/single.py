@@ -63,6 +63,14 @@ class _SingleEnv:
     def close(self) -> None:
         self._vec.close()
 
+    # `with gym.make(...) as env:` as every reference example does (gymnasium.Env.__enter__/__exit__)
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args) -> bool:
+        self.close()
+        return False
+
     def update_init_rand(self, **kwargs) -> None:
         self._vec.update_init_rand(**kwargs)
 

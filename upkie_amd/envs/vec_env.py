@@ -177,6 +177,13 @@ class UpkieVecEnv:
             self._observers.close()
         self.sim.close()
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args) -> bool:
+        self.close()
+        return False
+
     #: `abi.OBSERVATION_*` layout of the step's observation buffer when a SAME_STEP
     #: autoreset can run as one launch on it (None: through `reset(mask=done)`)
     _same_step_layout = None
