@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
                                                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                         const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                         const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
-                                                        float* __restrict__ spine_state) {
+                                                        float* __restrict__ spine_state, float* __restrict__ final_obs) {
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,7 +581,6 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && SW(UPKIE_S_DONE) != 0.f;
     if (C.autoreset_mode == AUTORESET_DONE_PASS) {
       // SAME_STEP autoreset, second launch (see step_kernel): both lanes of a pair agree on DONE
-      float* final_obs = const_cast<float*>(act);
       if (final_obs) {  // every env, see step_kernel
         constexpr int W = ObsWords<MODE>::value;
         if (MODE == MODE_SERVOS) {  // each lane keeps its three servos

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ body_inertials,
                                                    const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
-                                                   float* __restrict__ spine_state) {
+                                                   float* __restrict__ spine_state, float* __restrict__ final_obs) {
   const DevModel& M = *Mp;
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,7 +261,6 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     if (C.autoreset_mode == AUTORESET_DONE_PASS) {
       // SAME_STEP autoreset, second launch: the step has just written this env's
       // terminal observation; keep it aside, then run the reset branch
-      float* final_obs = const_cast<float*>(act);  // (the action slot carries the buffer: actions are not read when resetting)
       if (final_obs) {  // every env: final_obs is the step's observation, obs differs from it where an episode ended
         constexpr int W = ObsWords<MODE>::value;
         const float* last = obs + (size_t)(packed ? 8 : W) * e;
@@ -1122,7 +1121,8 @@ static const int kPairBatch = 32768;
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
-                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}, bool done_pass = false) {
+                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}, bool done_pass = false,
+                       float* final_obs = nullptr) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (MODE != MODE_RESET && (!obs || (!packed && !done_pass && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
@@ -1143,12 +1143,12 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // compiled in but switched off they would still cost the common path 2 %)
 #define UPKIE_LAUNCH_S(R, W, S)                                                                                            \
   hipLaunchKernelGGL((step_kernel<MODE, R, W, S>), grid, block, 0, st, sim->d_model, sim->limits, config, state, act, obs, \
-                     reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
+                     reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs)
 #define UPKIE_LAUNCH(R, W) \
   do { if (spine) UPKIE_LAUNCH_S(R, W, true); else UPKIE_LAUNCH_S(R, W, false); } while (0)
 #define UPKIE_LAUNCH_PAIR_S(R, S)                                                                                                 \
   hipLaunchKernelGGL((step_kernel_pair<MODE, R, S>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
-                     config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state)
+                     config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs)
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
   const bool spine = sim->spine_state != nullptr;
@@ -1216,13 +1216,13 @@ extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* s
   const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
   switch (observation) {
     case UPKIE_OBSERVATION_PENDULUM:
-      return launch_step<MODE_PENDULUM>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+      return launch_step<MODE_PENDULUM>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true, final_obs);
     case UPKIE_OBSERVATION_PENDULUM_RECORDS:
-      return launch_step<MODE_PENDULUM>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 1, none, true);
+      return launch_step<MODE_PENDULUM>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 1, none, true, final_obs);
     case UPKIE_OBSERVATION_GYROPOD:
-      return launch_step<MODE_GYROPOD>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+      return launch_step<MODE_GYROPOD>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true, final_obs);
     case UPKIE_OBSERVATION_SERVOS:
-      return launch_step<MODE_SERVOS>(sim, state, final_obs, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true);
+      return launch_step<MODE_SERVOS>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true, final_obs);
     default:
       return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "unknown observation layout");
   }
