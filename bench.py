@@ -7,7 +7,7 @@ README's PD-gain balancer evaluated on-device, init-state randomisation pitch
 NEXT_STEP autoreset. One "step" = one env.step() of every env = ONE kernel
 launch per GPU; for N > 1 ranks the packed (obs, reward, terminated,
 truncated) records of every step are gathered to rank 0 over RCCL, one
-asynchronous collective per 32-step chunk.
+asynchronous collective per 64-step chunk (two per 128-step rollout).
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-GATHER_CHUNK = 32  # steps per collective: a gather costs ~27 us of queue time whatever its size (profiles/r01_gather_chunk_sweep.txt)
+GATHER_CHUNK = 64  # steps per collective: a gather costs ~27 us of queue time whatever its size (profiles/r01_gather_chunk_sweep.txt); two per 128-step rollout
 # 29 fp32 state words read + written (232 B), action 4,
 # obs 16, reward 4, terminated 1, truncated 1.
 ALGORITHMIC_BYTES_PER_ENV_STEP = 258
