@@ -559,7 +559,9 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   // the owned leg's constants: selected once, kept in registers for the launch
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const PairLeg PL = load_pair_leg(*(ConstModelPtr)Mp, Lm, C, leg, records, (size_t)B);
-  const DevModel& M = *Mp;
+  // uniform model constants through the constant address space: scalar loads issued with the
+  // kernel arguments, not vector loads that wait behind the state
+  const auto& M = *(ConstModelPtr)Mp;
   TrunkInertial trunk;
   if (RAND) {
     if (records) {
@@ -574,11 +576,33 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     }
   }
 
+  // With the state, in ONE memory round trip (see step_kernel): the DONE word
+  // and this step's action (or the fused agent's previous observation).
+  float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
+  asm volatile("" : "+v"(done_word));  // pins the load here: the compiler would sink it into the branch that tests it
+  float act0 = 0.f, act1 = 0.f;
+  float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == MODE_PENDULUM) {
+    if (act) act0 = act[e];
+  } else if (MODE == MODE_PENDULUM_AGENT) {
+    const float* prev = act ? act : obs;
+    prev_obs = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+  } else if (MODE == MODE_GYROPOD) {
+    if (act) {
+      const float2 a = reinterpret_cast<const float2*>(act)[e];
+      act0 = a.x;
+      act1 = a.y;
+    }
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    act0 = bv.commanded[e];
+    act1 = act[2 * (size_t)e + 1];
+  }
+
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && SW(UPKIE_S_DONE) != 0.f;
+    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f;
     if (C.autoreset_mode == AUTORESET_DONE_PASS) {
       // SAME_STEP autoreset, second launch (see step_kernel): both lanes of a pair agree on DONE
       if (final_obs) {  // every env, see step_kernel
@@ -653,19 +677,13 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       cmd[k].maximum_torque = clamp_ref(a[6 * k + 5], 0.f, eff);
     }
   } else if (MODE != MODE_RESET) {
-    if (MODE == MODE_PENDULUM) {
-      a0 = act[e];
-    } else if (MODE == MODE_PENDULUM_AGENT) {
-      const float* prev = act ? act : obs;
-      const float4 o = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+    if (MODE == MODE_PENDULUM_AGENT) {
+      const float4 o = prev_obs;
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
-    } else if (MODE == MODE_BASE_VELOCITY) {
-      a0 = bv.commanded[e];
-      a1 = act[2 * (size_t)e + 1];
     } else {
-      a0 = act[2 * (size_t)e];
-      a1 = act[2 * (size_t)e + 1];
+      a0 = act0;
+      a1 = act1;
     }
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);

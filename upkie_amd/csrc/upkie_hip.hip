@@ -252,12 +252,36 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     }
   }
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
+  // With the state, in ONE memory round trip: the DONE word and this step's
+  // action (or, for the fused agent, the previous observation). Loaded inside
+  // the branches that use them they would each cost a dependent round trip
+  // (0.5-1 us at one wave per SIMD).
+  float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
+  asm volatile("" : "+v"(done_word));  // pins the load here: the compiler would sink it into the branch that tests it
+  float act0 = 0.f, act1 = 0.f;
+  float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == MODE_PENDULUM) {
+    if (act) act0 = act[e];  // (no action buffer in the SAME_STEP reset pass)
+  } else if (MODE == MODE_PENDULUM_AGENT) {
+    // previous observation: from `act` when the caller double-buffers its records
+    const float* prev = act ? act : obs;
+    prev_obs = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+  } else if (MODE == MODE_GYROPOD) {
+    if (act) {
+      const float2 a = reinterpret_cast<const float2*>(act)[e];
+      act0 = a.x;
+      act1 = a.y;
+    }
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    act0 = bv.commanded[e];  // MPCBalancer output, upkie_base_velocity.py:185-192
+    act1 = act[2 * (size_t)e + 1];
+  }
 
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && SW(UPKIE_S_DONE) != 0.f;
+    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f;
     if (C.autoreset_mode == AUTORESET_DONE_PASS) {
       // SAME_STEP autoreset, second launch: the step has just written this env's
       // terminal observation; keep it aside, then run the reset branch
@@ -305,21 +329,14 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       cmd[j].maximum_torque = clamp_ref(a[6 * j + 5], 0.f, eff);
     }
   } else if (MODE != MODE_RESET) {
-    if (MODE == MODE_PENDULUM) {
-      a0 = act[e];  // upkie_pendulum.py:139: [action[0], 0.0]
-    } else if (MODE == MODE_PENDULUM_AGENT) {
+    if (MODE == MODE_PENDULUM_AGENT) {
       // README.md:62-64: action = gains . observation, clipped
-      // previous observation: from `act` when the caller double-buffers its records
-      const float* prev = act ? act : obs;
-      const float4 o = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+      const float4 o = prev_obs;
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
-    } else if (MODE == MODE_BASE_VELOCITY) {
-      a0 = bv.commanded[e];  // MPCBalancer output, upkie_base_velocity.py:185-192
-      a1 = act[2 * (size_t)e + 1];
     } else {
-      a0 = act[2 * (size_t)e];
-      a1 = act[2 * (size_t)e + 1];
+      a0 = act0;  // Pendulum: [action[0], 0.0], upkie_pendulum.py:139
+      a1 = act1;
     }
     // UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
