@@ -4,8 +4,11 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): Upkie-Pendulum,
 4096 envs per GPU, 200 Hz control (5 x 1 ms physics substeps), fp32, the
 README's PD-gain balancer evaluated on-device, init-state randomisation pitch
 +-0.1 rad, x +-0.05 m, omega_y +-0.1 rad/s, v_x +-0.05 m/s, fall_pitch 1.0,
-NEXT_STEP autoreset. One "step" = one env.step() of every env = ONE kernel
-launch per GPU; for N > 1 ranks the packed (obs, reward, terminated,
+NEXT_STEP autoreset. One "step" = one env.step() of every env; the agent runs
+on the device, so up to --steps-per-launch (32) consecutive steps share ONE
+kernel launch per GPU in which the state stays in registers (every step's
+records are still written; results are bit-identical to one launch per step,
+whose rate is reported beside it as "single_step_launch"); for N > 1 ranks the packed (obs, reward, terminated,
 truncated) records of every step are gathered to rank 0 over RCCL, one
 asynchronous collective per 64-step chunk (two per 128-step rollout).
 
@@ -29,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
+STEPS_PER_LAUNCH = 32  # the state stays in registers between the steps of a launch; 1 = one launch per env.step()
 GATHER_CHUNK = 64  # steps per collective: a gather costs ~27 us of queue time whatever its size (profiles/r01_gather_chunk_sweep.txt); two per 128-step rollout
 # 29 fp32 state words read + written (232 B), action 4,
 # obs 16, reward 4, terminated 1, truncated 1.
@@ -95,32 +99,37 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     }
 
 
-def issue_floor(launch_us: float):
+def issue_floor(step_us: float, steps_per_launch: float):
     """What actually bounds the step at this batch size: 4096 envs are 128
     waves on 1024 SIMDs, one wave per SIMD, and a lone gfx950 wave issues one
     instruction per >= 4.5 cycles whatever its kind (tools/microbench/
     issue_rate.hip, profiles/r01_issue_rate_microbench.txt). Instructions per
-    wave come from the committed PMC passes of this same kernel and batch;
-    the launch duration is the live one."""
+    wave come from the committed PMC passes of this same kernel, batch and
+    steps per launch; the step duration is the live one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary_b4096_final.json")
-    if not os.path.exists(path):
+    meta = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path) or not os.path.exists(meta):
         return None
+    with open(meta) as f:
+        profiled_steps = json.load(f).get("steps_per_launch", 1)
+    if profiled_steps != steps_per_launch:
+        return None  # the committed counters describe another launch shape
     with open(path) as f:
         pmc = {k: v["mean_per_launch"] for k, v in json.load(f).items()}
     try:
         instructions = sum(pmc[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"))
-        per_wave = instructions / pmc["SQ_WAVES"]
+        per_wave = instructions / pmc["SQ_WAVES"] / profiled_steps
     except KeyError:
         return None
     cycles, ghz = 4.5, 2.4
     floor_us = per_wave * cycles / (ghz * 1e3)
     return {
-        "instructions_per_wave": per_wave,
+        "instructions_per_wave_per_step": per_wave,
         "cycles_per_instruction_lone_wave": cycles,
         "clock_ghz": ghz,
-        "floor_us": floor_us,
-        "achieved_us": launch_us,
-        "frac": floor_us / launch_us,
+        "floor_us_per_step": floor_us,
+        "achieved_us_per_step": step_us,
+        "frac": floor_us / step_us,
         "source": "profiles/r01_pmc_summary_b4096_final.json (rocprofv3 --pmc), profiles/r01_issue_rate_microbench.txt",
     }
 
@@ -132,7 +141,10 @@ def main() -> None:
     parser.add_argument("--warmup", type=int, default=200)
     parser.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-single-step", action="store_true", help="skip the extra one-launch-per-step measurement (profiling runs)")
     parser.add_argument("--gather-chunk", type=int, default=GATHER_CHUNK, help="steps per RCCL gather (N > 1)")
+    parser.add_argument("--steps-per-launch", type=int, default=STEPS_PER_LAUNCH,
+                        help="env.step() per kernel launch (the agent runs on the device: nothing returns to the host between steps)")
     args = parser.parse_args()
 
     import torch
@@ -148,24 +160,43 @@ def main() -> None:
     env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world, collectives=forced, chunk=args.gather_chunk)
     env.reset()
 
-    for _ in range(args.warmup):
-        env.step_agent()
-    env.barrier()
-    torch.cuda.synchronize()
-    start_evt = torch.cuda.Event(enable_timing=True)
-    stop_evt = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    start_evt.record()  # same stream the kernels are launched on
-    for _ in range(args.steps):
-        env.step_agent()
-    env.flush()  # records of the last steps must have reached rank 0
-    stop_evt.record()
-    env.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = env.max_over_ranks(elapsed)
-    device_ms = start_evt.elapsed_time(stop_evt)
+    def advance(total: int, per_launch: int) -> int:
+        """`total` env.step() of every local env, up to `per_launch` of them per
+        kernel launch (never across a gather chunk); returns the launches made."""
+        done = launches = 0
+        while done < total:
+            room = env.gather.chunk - env.gather._step % env.gather.chunk
+            n = min(per_launch, total - done, room)
+            if n == 1:
+                env.step_agent()
+            else:
+                env.rollout_agent(n)
+            launches += 1 if B <= 32768 else n  # beyond 32768 envs the library launches step by step
+            done += n
+        return launches
+
+    def timed(total: int, per_launch: int):
+        env.barrier()
+        torch.cuda.synchronize()
+        start_evt = torch.cuda.Event(enable_timing=True)
+        stop_evt = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        start_evt.record()  # same stream the kernels are launched on
+        launches = advance(total, per_launch)
+        env.flush()  # records of the last steps must have reached rank 0
+        stop_evt.record()
+        env.barrier()
+        torch.cuda.synchronize()
+        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+        return elapsed, start_evt.elapsed_time(stop_evt), launches
+
+    advance(args.warmup, args.steps_per_launch)
+    elapsed, device_ms, launches = timed(args.steps, args.steps_per_launch)
     resets = env.total_resets()
+    # for the record: the same steps launched one by one (what a host-side policy would see)
+    single_elapsed = None
+    if not args.no_single_step:
+        single_elapsed = timed(args.steps, 1)[0] if args.steps_per_launch > 1 else elapsed
 
     if rank != 0:
         env.shutdown()
@@ -173,13 +204,17 @@ def main() -> None:
 
     total_envs = B * world
     value = total_envs * args.steps / elapsed
-    launch_us = device_ms * 1e3 / args.steps  # avg per-launch device time, this rank
-    achieved = ALGORITHMIC_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+    step_us = device_ms * 1e3 / args.steps  # device time per env.step() of the batch, this rank
+    launch_us = device_ms * 1e3 / launches  # avg per-launch device time
+    steps_per_launch = args.steps / launches
+    achieved = ALGORITHMIC_BYTES_PER_ENV_STEP * B * steps_per_launch / (launch_us * 1e-6) / 1e9
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         with open(traffic_file) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            measured = json.load(f)
+        if measured.get("steps_per_launch", 1) == args.steps_per_launch and measured.get("launch_envs") == B:
+            traffic = measured.get("hbm_bytes_per_launch")  # PMC bytes of a launch of this shape
     line = {
         "metric": "env-steps/sec (batched Upkie-Pendulum, 200 Hz)",
         "value": value,
@@ -199,7 +234,10 @@ def main() -> None:
             "total_envs": total_envs,
             "gather": f"RCCL gather of the packed obs/reward/done records of every step into rank 0's rollout ring buffer, one asynchronous collective per {env.gather.chunk}-step chunk, overlapped with the next chunk's kernels" if env.gather.collectives else "none (single GPU): records written straight into the rollout ring buffer",
             "episode_resets_in_timed_region": resets,
+            "steps_per_launch": steps_per_launch,
         },
+        # the same steps launched one by one (a policy on the host side of the boundary sees this rate)
+        "single_step_launch": None if single_elapsed is None else {"value": total_envs * args.steps / single_elapsed, "ms_per_step": single_elapsed / args.steps * 1e3},
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -209,11 +247,13 @@ def main() -> None:
             "traffic": traffic,
             "kernel": "step_kernel_pair<MODE_PENDULUM_AGENT> (two lanes per env; step_kernel<...> above 32768 envs per GPU)" if B <= 32768 else "step_kernel<MODE_PENDULUM_AGENT>",
             "avg_launch_us": launch_us,
+            "env_steps_per_launch": B * steps_per_launch,
+            "avg_step_us": step_us,
             "algorithmic_bytes_per_env_step": ALGORITHMIC_BYTES_PER_ENV_STEP,
             "note": "the step is fp32-VALU/latency bound (~2e4 VALU instructions vs 258 B per env-step), not HBM bound: see DESIGN.md section 6",
         },
     }
-    issue = issue_floor(launch_us) if B == ENVS_PER_GPU else None
+    issue = issue_floor(step_us, args.steps_per_launch) if B == ENVS_PER_GPU else None
     if issue is not None:
         line["roofline"]["issue_floor"] = issue
     if world == 1 and not args.no_cpu_baseline:

@@ -276,6 +276,17 @@ int upkie_sim_step_pendulum_agent_records(UpkieSim* sim, float* state,
                                           const float* prev_records,
                                           float* records, void* stream);
 
+/* num_steps consecutive env.step() of the same fused-agent Pendulum env, i.e.
+ * num_steps calls of upkie_sim_step_pendulum_agent_records with
+ * records[k - 1] as the previous records of step k (prev_records for k = 0):
+ * records [num_steps][B][8]. Up to 32768 envs this is ONE launch in which the
+ * state stays in registers from step to step (the agent needs nothing from the
+ * host in between); results are bit-identical to the step-by-step calls. */
+int upkie_sim_step_pendulum_agent_rollout(UpkieSim* sim, float* state,
+                                          const float* prev_records,
+                                          float* records, int32_t num_steps,
+                                          void* stream);
+
 /* One env.step() of UpkieGyropod (upkie_gyropod.py:354-392):
  * act[B][2] -> obs[B][6]. */
 int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act,

@@ -145,6 +145,13 @@ class OracleSim:
 
         return point_contacts(self.contact_points()[env].numpy(), link_name)
 
+    def rollout_pendulum_records(self, prev_records, records):
+        prev = prev_records
+        for k in range(records.shape[0]):
+            self.step_pendulum_records(prev, records[k])
+            prev = records[k]
+        return records
+
     def observe(self, update_imu=True):
         out = self._o.observe(update_imu)
         return {k: torch.from_numpy(v if v.dtype == np.uint8 else v.astype(np.float32)) for k, v in out.items()}

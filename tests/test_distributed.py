@@ -139,8 +139,10 @@ def _sharded_worker(rank: int, world: int, port: int, out_path: str):
     env = ShardedPendulum(config(B, rank * B), device="cpu", rank=rank, world_size=world, horizon=32, chunk=4, sim_factory=factory)
     env.reset()
     steps = 22
-    for _ in range(steps):
-        env.step_agent()
+    for _ in range(steps // 2):
+        env.rollout_agent(2)  # two steps per call, inside the 4-step chunks; the single-rank run below steps one by one
+    with pytest.raises(ValueError):
+        env.gather.begin_steps(3)  # 22 % 4 = 2: three more steps would cross the chunk boundary
     env.flush()
     env.barrier()
     assert env.max_over_ranks(float(rank + 1)) == float(world)

@@ -831,3 +831,39 @@ def test_time_limit_in_the_kernel_matches_oracle(lanes, monkeypatch):
         seen_term += int(term_o.sum())
     assert seen_trunc > B and seen_term > 0
     assert sim.state_numpy()[abi.S_ELAPSED].max() <= 7
+
+
+@pytest.mark.parametrize("lanes", ["2", "1"])
+def test_rollout_in_one_launch_equals_step_by_step(lanes, monkeypatch):
+    """upkie_sim_step_pendulum_agent_rollout: K fused-agent steps in one launch
+    (two lanes per env: state carried in registers; one lane per env: K
+    launches) are bit-identical to K chained upkie_sim_step_pendulum_agent_records
+    calls -- with falls, NEXT_STEP autoresets, a time limit and torque noise in
+    the window."""
+    from upkie_amd.sim import BatchedSim
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B, K = 333, 24
+    cfg = randomized_config(B, seed=12, autoreset=True)
+    cfg.fall_pitch = 0.11
+    cfg.max_episode_steps = 9
+    for j in range(6):
+        cfg.torque_control_noise[j] = 0.05
+    a, b = BatchedSim(cfg), BatchedSim(cfg)
+    o6 = a.reset()
+    b.reset()
+    prev = torch.zeros((B, 8), device=a.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    for window in range(3):  # carried counters must survive the launch boundary too
+        fused = torch.zeros((K, B, 8), device=a.device)
+        a.rollout_pendulum_records(prev, fused)
+        chained = torch.zeros((K, B, 8), device=a.device)
+        p = prev
+        for k in range(K):
+            b.step_pendulum_records(p, chained[k])
+            p = chained[k]
+        assert torch.equal(fused, chained), window
+        assert torch.equal(a.state[:48], b.state[:48]), window
+        prev = fused[K - 1].clone()
+    assert float(fused[:, :, 5].sum()) + float(chained[:, :, 6].sum()) > 0  # falls / time limits happened
+    assert float(a.state[abi.S_EPISODE].max()) > 3

@@ -14,6 +14,6 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- \
-    python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/pass$i.log 2>&1
+    python $R/bench.py --steps 128 --warmup 64 --no-cpu-baseline --no-single-step > $OUT/pass$i.log 2>&1
 done
 ls -R $OUT | head -40

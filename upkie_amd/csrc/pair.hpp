@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
                                                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                         const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                         const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
-                                                        float* __restrict__ spine_state, float* __restrict__ final_obs) {
+                                                        float* __restrict__ spine_state, float* __restrict__ final_obs, int n_steps) {
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,6 +598,20 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     act1 = act[2 * (size_t)e + 1];
   }
 
+  // Several env.step() per launch (MODE_PENDULUM_AGENT writing packed records: the
+  // agent needs nothing from the host between steps): the state stays in
+  // registers from one step to the next, `records` advances by [B][8] per step.
+  // What the steps read back from the state words they write is carried in
+  // registers too: DONE, the episode / step / elapsed counters.
+  constexpr bool ROLLOUT = MODE == MODE_PENDULUM_AGENT;
+  int steps_left = ROLLOUT && packed && n_steps > 1 ? n_steps : 1;
+  float* records_out = obs;
+  float episode_word = ROLLOUT ? SW(UPKIE_S_EPISODE) : 0.f;
+  float elapsed_word = ROLLOUT && C.max_episode_steps > 0 ? SW(UPKIE_S_ELAPSED) : 0.f;
+  const bool any_noise = C.any_control_noise || C.any_measurement_noise;
+  unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
+
+next_step:
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
@@ -653,7 +667,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   float a0 = 0.f, a1 = 0.f;
   unsigned episode = 0;
   if (do_reset) {
-    episode = (unsigned)SW(UPKIE_S_EPISODE);
+    episode = ROLLOUT ? (unsigned)episode_word : (unsigned)SW(UPKIE_S_EPISODE);
     Phys full;
     sample_init_state(C, (unsigned)e, episode, full);  // same draws in both lanes
     s.pos = full.pos; s.qw = full.qw; s.qx = full.qx; s.qy = full.qy; s.qz = full.qz;
@@ -715,8 +729,6 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   // ---- substeps ------------------------------------------------------------
   float tau[3] = {0.f, 0.f, 0.f};
   bool contact = false;
-  const bool any_noise = C.any_control_noise || C.any_measurement_noise;
-  unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
   const int nsub = do_reset ? 1 : C.nb_substeps;
   for (int sub = 0; sub < C.nb_substeps; ++sub) {
     if (sub >= nsub) break;
@@ -778,6 +790,9 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       SW(UPKIE_S_DONE) = 0.f;
       SW(UPKIE_S_ELAPSED) = 0.f;
     }
+    episode_word = (float)(episode + 1);
+    done_word = 0.f;
+    elapsed_word = 0.f;
     observe6(yaw, yawvel, obs6);
   } else {
     if (YAWING) {
@@ -794,13 +809,15 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
     }
     if (C.max_episode_steps > 0) {  // time limit, see step_kernel
-      const float elapsed = SW(UPKIE_S_ELAPSED) + 1.f;
+      const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
       timeout = elapsed >= (float)C.max_episode_steps && !fallen;
+      elapsed_word = elapsed;
       if (lead) {
         SW(UPKIE_S_ELAPSED) = elapsed;
         if (timeout) SW(UPKIE_S_DONE) = 1.f;
       }
     }
+    if (fallen || timeout) done_word = 1.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) SW(UPKIE_S_TORQUE + 3 * leg + k) = tau[k];
     if (any_noise) {
@@ -809,7 +826,21 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     }
   }
 
-  // ---- store -----------------------------------------------------------------
+  // ---- store (last step of the launch) --------------------------------------
+  const bool more_steps = steps_left > 1;
+  if (more_steps) {
+    // next step of this launch: its agent reads this step's observation
+    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    if (lead) {
+      float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
+      rec[0] = o4;
+      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+    }
+    prev_obs = o4;
+    records_out += (size_t)8 * B;
+    steps_left -= 1;
+    goto next_step;
+  }
   if (lead) {
     SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
     SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
@@ -852,7 +883,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
     const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
     if (packed) {
-      float4* rec = reinterpret_cast<float4*>(obs) + 2 * (size_t)e;
+      float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
       rec[0] = o4;
       if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
       return;

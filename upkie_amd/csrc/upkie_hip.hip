@@ -1135,11 +1135,16 @@ static const int kDenseBatch = 131072;
 // up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
 static const int kPairBatch = 32768;
 
+// up to this many envs a launch maps two lanes to every env (step_kernel_pair)
+static bool uses_lane_pairs(const UpkieSim* sim) {
+  return sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
+}
+
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
                        BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}, bool done_pass = false,
-                       float* final_obs = nullptr) {
+                       float* final_obs = nullptr, int n_steps = 1) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (MODE != MODE_RESET && (!obs || (!packed && !done_pass && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
@@ -1155,7 +1160,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // more than two waves per SIMD in flight: favour occupancy over registers;
   // fewer lanes than SIMD slots: split every env over two lanes (pair.hpp)
   const bool dense = sim->config.num_envs >= kDenseBatch;
-  const bool paired = sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
+  const bool paired = uses_lane_pairs(sim);
   // SPINE: the spine observers run inside the step (a separate instantiation:
   // compiled in but switched off they would still cost the common path 2 %)
 #define UPKIE_LAUNCH_S(R, W, S)                                                                                            \
@@ -1165,7 +1170,8 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   do { if (spine) UPKIE_LAUNCH_S(R, W, true); else UPKIE_LAUNCH_S(R, W, false); } while (0)
 #define UPKIE_LAUNCH_PAIR_S(R, S)                                                                                                 \
   hipLaunchKernelGGL((step_kernel_pair<MODE, R, S>), grid_for(2 * sim->config.num_envs), block, 0, st, sim->d_model, sim->limits, \
-                     config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs)
+                     config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs, \
+                     n_steps)
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
   const bool spine = sim->spine_state != nullptr;
@@ -1209,6 +1215,23 @@ extern "C" int upkie_sim_step_pendulum_agent_records(UpkieSim* sim, float* state
                                                     void* stream) {
   if (!prev_records) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   return launch_step<MODE_PENDULUM_AGENT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1);
+}
+
+extern "C" int upkie_sim_step_pendulum_agent_rollout(UpkieSim* sim, float* state, const float* prev_records, float* records,
+                                                    int32_t num_steps, void* stream) {
+  if (!prev_records || !records || num_steps < 1) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument or num_steps < 1");
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
+  if (uses_lane_pairs(sim))  // one launch: the state stays in registers from step to step
+    return launch_step<MODE_PENDULUM_AGENT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1, none, false,
+                                            nullptr, num_steps);
+  const size_t stride = (size_t)8 * sim->config.num_envs;  // large batches: launch overhead is already amortised
+  for (int32_t k = 0; k < num_steps; ++k) {
+    const int status = launch_step<MODE_PENDULUM_AGENT>(sim, state, k ? records + (k - 1) * stride : prev_records, records + k * stride,
+                                                        nullptr, nullptr, nullptr, nullptr, stream, 1);
+    if (status != UPKIE_OK) return status;
+  }
+  return UPKIE_OK;
 }
 
 extern "C" int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act, float* obs, float* reward,

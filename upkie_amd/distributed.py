@@ -126,6 +126,24 @@ class RolloutGather:
                 self._work[c] = None
         return self.current
 
+    def begin_steps(self, n: int) -> torch.Tensor:
+        """Buffer ``[n, B, words]`` the next `n` steps write into (they must
+        fit into the current chunk: ``step % chunk + n <= chunk``)."""
+        k = self._step % self.chunk
+        if k + n > self.chunk:
+            raise ValueError(f"{n} steps from position {k} cross the boundary of a {self.chunk}-step chunk")
+        first = self.begin_step()
+        if self.collectives:
+            block = self.staging[(self._step // self.chunk) % 2]
+        else:
+            block = self.rollout[(self._step // self.chunk) % self.num_chunks, 0]
+        assert block[k].data_ptr() == first.data_ptr()
+        return block[k : k + n]
+
+    def end_steps(self, n: int) -> None:
+        self._step += n - 1
+        self.end_step()
+
     def _gather_chunk(self, chunk_index: int) -> None:
         c = chunk_index % 2
         gather_list: Optional[List[torch.Tensor]] = None
@@ -195,6 +213,15 @@ class ShardedPendulum:
         out = self.gather.begin_step()
         self.sim.step_pendulum_records(self.gather.previous, out)
         self.gather.end_step()
+
+    def rollout_agent(self, n: int) -> None:
+        """`n` env.step() with the on-device agent in one launch (two lanes per
+        env; `n` launches beyond 32768 envs): same records as `n` calls of
+        `step_agent`. The steps must stay inside one gather chunk."""
+        prev = self.gather.previous
+        out = self.gather.begin_steps(n)
+        self.sim.rollout_pendulum_records(prev, out)
+        self.gather.end_steps(n)
 
     def step(self, act: torch.Tensor) -> None:
         out = self.gather.begin_step()

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_pendulum_packed",
     "upkie_sim_step_pendulum_agent_packed",
     "upkie_sim_step_pendulum_agent_records",
+    "upkie_sim_step_pendulum_agent_rollout",
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
     "upkie_sim_step_base_velocity",
@@ -167,6 +168,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_step_pendulum_agent_packed.argtypes = [vp, vp, vp, vp]
     lib.upkie_sim_step_pendulum_agent_records.restype = C.c_int
     lib.upkie_sim_step_pendulum_agent_records.argtypes = [vp, vp, vp, vp, vp]
+    lib.upkie_sim_step_pendulum_agent_rollout.restype = C.c_int
+    lib.upkie_sim_step_pendulum_agent_rollout.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
     lib.upkie_sim_step_base_velocity.restype = C.c_int
     lib.upkie_sim_step_base_velocity.argtypes = [vp] * 11
     lib.upkie_sim_observe.restype = C.c_int

@@ -273,6 +273,21 @@ class BatchedSim:
             )
         return records
 
+    def rollout_pendulum_records(self, prev_records: torch.Tensor, records: torch.Tensor) -> torch.Tensor:
+        """``records.shape[0]`` consecutive on-device-agent steps, records
+        ``[K, B, 8]``: the same results as K `step_pendulum_records` calls
+        chained through their records, in one launch up to 32768 envs (the
+        state stays in registers between the steps)."""
+        assert records.dim() == 3 and records.shape[1:] == (self.num_envs, 8) and prev_records.shape == (self.num_envs, 8)
+        assert records.is_contiguous() and prev_records.is_contiguous()
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_step_pendulum_agent_rollout(
+                    self._handle, _ptr(self.state), _ptr(prev_records), _ptr(records), int(records.shape[0]), self._stream()
+                )
+            )
+        return records
+
     def step_pendulum_packed(self, records: torch.Tensor, act=None) -> torch.Tensor:
         """Pendulum step writing one ``[obs(4) | reward, terminated,
         truncated, 0]`` record per env into ``records[B, 8]``; with
