@@ -215,7 +215,7 @@ int upkie_sim_set_randomization(UpkieSim* sim, const float* body_inertials,
  * body frame (pybullet.LINK_FRAME). forces[count][3][B] is a device buffer
  * read at every substep until replaced; NULL or count = 0 removes all forces.
  * Replaces whatever upkie_sim_set_randomization installed as ext_force. */
-#define UPKIE_MAX_EXTERNAL_FORCES 4
+#define UPKIE_MAX_EXTERNAL_FORCES 16 /* one slot per link: upkie_description's Upkie has 15 */
 typedef struct UpkieExternalForces {
   int32_t count;
   int32_t body[UPKIE_MAX_EXTERNAL_FORCES];

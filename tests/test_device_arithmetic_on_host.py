@@ -24,7 +24,8 @@ LIB = os.path.join(ROOT, "tests", "_host_harness.so")
 def harness():
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    deps = [SRC] + [os.path.join(ROOT, "upkie_amd", "csrc", n) for n in ("upkie_hip.hip", "dynamics.hpp", "mpc.hpp")]
+    csrc = os.path.join(ROOT, "upkie_amd", "csrc")
+    deps = [SRC, os.path.join(ROOT, "include", "upkie_hip.h")] + [os.path.join(csrc, n) for n in sorted(os.listdir(csrc))]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run(
             ["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB],

@@ -425,8 +425,14 @@ def test_external_forces_on_leg_links_and_link_frames():
     assert abs(float(held.sim.state[abi.S_POS + 2, 0]) - z_before) < 5e-3
     with pytest.raises(UpkieRuntimeError):
         held.set_external_forces({"no_such_link": ExternalForce([0.0, 0.0, 1.0])})
-    with pytest.raises(UpkieRuntimeError):  # more links than force slots
-        held.set_external_forces({name: ExternalForce([0.0, 0.0, 1.0]) for name in ("imu", "left_thigh", "right_thigh", "left_calf")})
+    # every link can carry a force at the same time (one slot per link): each link held up by its own weight
+    m = free.model.struct
+    links = ["base", "torso", "imu", "left_hip_qdd100_stator", "right_hip_qdd100_stator", "left_thigh", "left_calf", "left_wheel_hub",
+             "left_wheel_tire", "right_thigh", "right_calf", "right_wheel_hub", "right_wheel_tire"]
+    assert m.num_links == len(links) <= abi.MAX_EXTERNAL_FORCES
+    floating = run({name: ExternalForce([0.0, 0.0, 9.81 * m.link_mass[i]]) for i, name in enumerate(links)}, steps=20)
+    assert abs(float(floating.sim.state[abi.S_POS + 2, 0]) - 1.5) < 1e-3
+    assert float(floating.sim.state[abi.S_QD : abi.S_QD + 6, 0].abs().max()) < 2e-2  # no link falls relative to the others
 
 
 def test_cookie_ids_build_a_right_wheeled_robot():

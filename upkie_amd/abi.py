@@ -177,7 +177,7 @@ class UpkieMpcConfig(C.Structure):
     ]
 
 
-MAX_EXTERNAL_FORCES = 4
+MAX_EXTERNAL_FORCES = 16
 
 
 class UpkieExternalForces(C.Structure):
