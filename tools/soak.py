@@ -61,6 +61,20 @@ for lanes in ("2", "1"):
             check(sim, f"pendulum lanes={lanes}", k)
     resets = int(sim.state[abi.S_EPISODE].sum()) - B
     print(f"lanes={lanes} pendulum agent + inertia 0.3 + pushes + noise: {steps} steps ok, {resets} episode resets, {time.time() - t0:.1f} s")
+    # the same agent in fused 32-step launches (state carried in registers from step to step)
+    sim = BatchedSim(config(3), Model().struct)
+    sim.randomize_inertias(0.3)
+    o6 = sim.reset()
+    prev = torch.zeros((B, 8), device=sim.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    window = torch.zeros((32, B, 8), device=sim.device)
+    for k in range(0, steps, 32):
+        sim.rollout_pendulum_records(prev, window)
+        prev.copy_(window[31])
+        assert torch.isfinite(window).all(), f"rollout lanes={lanes}: non-finite records at step {k}"
+        if k % 1024 == 992:
+            check(sim, f"rollout lanes={lanes}", k)
+    print(f"lanes={lanes} fused rollouts (32 steps per launch): {steps} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} episode resets")
     # Gyropod with random commands
     sim = BatchedSim(config(2))
     sim.reset()
