@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == MODE_PENDULUM) {
     if (act) act0 = act[e];
-  } else if (MODE == MODE_PENDULUM_AGENT) {
+  } else if (fused_agent(MODE)) {
     const float* prev = act ? act : obs;
     prev_obs = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
   } else if (MODE == MODE_GYROPOD) {
@@ -598,12 +598,12 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
     act1 = act[2 * (size_t)e + 1];
   }
 
-  // Several env.step() per launch (MODE_PENDULUM_AGENT writing packed records: the
+  // Several env.step() per launch (MODE_PENDULUM_ROLLOUT = the fused agent writing packed records: the
   // agent needs nothing from the host between steps): the state stays in
   // registers from one step to the next, `records` advances by [B][8] per step.
   // What the steps read back from the state words they write is carried in
   // registers too: DONE, the episode / step / elapsed counters.
-  constexpr bool ROLLOUT = MODE == MODE_PENDULUM_AGENT;
+  constexpr bool ROLLOUT = MODE == MODE_PENDULUM_ROLLOUT;
   int steps_left = ROLLOUT && packed && n_steps > 1 ? n_steps : 1;
   float* records_out = obs;
   float episode_word = ROLLOUT ? SW(UPKIE_S_EPISODE) : 0.f;
@@ -691,7 +691,7 @@ next_step:
       cmd[k].maximum_torque = clamp_ref(a[6 * k + 5], 0.f, eff);
     }
   } else if (MODE != MODE_RESET) {
-    if (MODE == MODE_PENDULUM_AGENT) {
+    if (fused_agent(MODE)) {
       const float4 o = prev_obs;
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
       a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
@@ -880,7 +880,7 @@ next_step:
     }
   }
   if (!lead) return;
-  if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
+  if (MODE == MODE_PENDULUM || fused_agent(MODE)) {
     const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
     if (packed) {
       float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;

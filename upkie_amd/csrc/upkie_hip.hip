@@ -52,9 +52,20 @@ struct DevConfig {
 enum { AUTORESET_DONE_PASS = 100 };
 // words per env of a step mode's observation buffer (0: none)
 template <int MODE>
-struct ObsWords { static constexpr int value = MODE == 1 || MODE == 2 ? 4 : MODE == 3 ? 6 : MODE == 4 ? 30 : MODE == 5 ? 3 : 0; };
+struct ObsWords { static constexpr int value = MODE == 1 || MODE == 2 || MODE == 6 ? 4 : MODE == 3 ? 6 : MODE == 4 ? 30 : MODE == 5 ? 3 : 0; };
 
-enum Mode { MODE_RESET = 0, MODE_PENDULUM = 1, MODE_PENDULUM_AGENT = 2, MODE_GYROPOD = 3, MODE_SERVOS = 4, MODE_BASE_VELOCITY = 5 };
+enum Mode {
+  MODE_RESET = 0,
+  MODE_PENDULUM = 1,
+  MODE_PENDULUM_AGENT = 2,
+  MODE_GYROPOD = 3,
+  MODE_SERVOS = 4,
+  MODE_BASE_VELOCITY = 5,
+  // MODE_PENDULUM_AGENT with several steps per launch (two-lane kernel only): its own
+  // instantiation, because the step loop around the body costs the one-step kernel 2.7 %
+  MODE_PENDULUM_ROLLOUT = 6
+};
+constexpr bool fused_agent(int mode) { return mode == MODE_PENDULUM_AGENT || mode == MODE_PENDULUM_ROLLOUT; }
 
 // Extra buffers of the fused UpkieBaseVelocity step (upkie_base_velocity.py:164-202).
 struct BaseVelocityPtrs {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == MODE_PENDULUM) {
     if (act) act0 = act[e];  // (no action buffer in the SAME_STEP reset pass)
-  } else if (MODE == MODE_PENDULUM_AGENT) {
+  } else if (fused_agent(MODE)) {
     // previous observation: from `act` when the caller double-buffers its records
     const float* prev = act ? act : obs;
     prev_obs = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       cmd[j].maximum_torque = clamp_ref(a[6 * j + 5], 0.f, eff);
     }
   } else if (MODE != MODE_RESET) {
-    if (MODE == MODE_PENDULUM_AGENT) {
+    if (fused_agent(MODE)) {
       // README.md:62-64: action = gains . observation, clipped
       const float4 o = prev_obs;
       a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     }
     return;
   }
-  if (MODE == MODE_PENDULUM || MODE == MODE_PENDULUM_AGENT) {
+  if (MODE == MODE_PENDULUM || fused_agent(MODE)) {
     // _PENDULUM_OBS_INDICES = [1, 0, 4, 3], upkie_pendulum.py:17
     const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
     if (packed) {
@@ -1177,6 +1188,8 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const bool spine = sim->spine_state != nullptr;
   if (paired) {
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
+  } else if constexpr (MODE == MODE_PENDULUM_ROLLOUT) {
+    return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "several steps per launch need the two-lane mapping");
   } else if (rnd) {
     if (dense) UPKIE_LAUNCH(true, 2); else UPKIE_LAUNCH(true, 1);
   } else {
@@ -1223,8 +1236,8 @@ extern "C" int upkie_sim_step_pendulum_agent_rollout(UpkieSim* sim, float* state
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
   if (uses_lane_pairs(sim))  // one launch: the state stays in registers from step to step
-    return launch_step<MODE_PENDULUM_AGENT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1, none, false,
-                                            nullptr, num_steps);
+    return launch_step<MODE_PENDULUM_ROLLOUT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1, none, false,
+                                              nullptr, num_steps);
   const size_t stride = (size_t)8 * sim->config.num_envs;  // large batches: launch overhead is already amortised
   for (int32_t k = 0; k < num_steps; ++k) {
     const int status = launch_step<MODE_PENDULUM_AGENT>(sim, state, k ? records + (k - 1) * stride : prev_records, records + k * stride,
