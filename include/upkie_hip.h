@@ -288,7 +288,9 @@ int upkie_sim_step_pendulum_agent_rollout(UpkieSim* sim, float* state,
                                           void* stream);
 
 /* One env.step() of UpkieGyropod (upkie_gyropod.py:354-392):
- * act[B][2] -> obs[B][6]. */
+ * act[B][2] -> obs[B][6]. Buffers of row-major observations, actions and
+ * records are read and written with 8- and 16-byte accesses: keep them
+ * 16-byte aligned (any allocator's default). */
 int upkie_sim_step_gyropod(UpkieSim* sim, float* state, const float* act,
                            float* obs, float* reward, uint8_t* terminated,
                            uint8_t* truncated, void* stream);
