@@ -140,6 +140,8 @@ def main() -> None:
     parser.add_argument("--steps", type=int, default=2000)
     parser.add_argument("--warmup", type=int, default=200)
     parser.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    parser.add_argument("--total-envs", type=int, default=0,
+                        help="strong scaling (SURVEY 8d): this many envs in total, split evenly over the ranks; default: --envs-per-gpu each (weak)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-single-step", action="store_true", help="skip the extra one-launch-per-step measurement (profiling runs)")
     parser.add_argument("--gather-chunk", type=int, default=GATHER_CHUNK, help="steps per RCCL gather (N > 1)")
@@ -152,7 +154,7 @@ def main() -> None:
     from upkie_amd.distributed import ShardedPendulum, init_distributed
 
     rank, world, local_rank = init_distributed(args.gpus)
-    B = args.envs_per_gpu
+    B = args.total_envs // world if args.total_envs > 0 else args.envs_per_gpu
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     # UPKIE_FORCE_PROCESS_GROUP=1: run the RCCL gather path on a one-rank group (test of the N > 1 code on one GPU)
@@ -224,7 +226,7 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.total_envs > 0 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
