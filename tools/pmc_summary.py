@@ -9,7 +9,8 @@ for path in sorted(glob.glob(os.path.join(root, "pass*", "pmc_counter_collection
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
-            if "step_kernel_pair<2, false" not in name and "step_kernel<2, false" not in name:
+            # the bench kernel: fused agent, several steps per launch (<6>) or one (<2>)
+            if not any(k in name for k in ("step_kernel_pair<6, false", "step_kernel_pair<2, false", "step_kernel<2, false")):
                 continue
             sums[row["Counter_Name"]] += float(row["Counter_Value"])
             counts[row["Counter_Name"]] += 1
