@@ -132,3 +132,38 @@ def test_free_fall_is_exact_for_every_env():
     assert float((z - (5.0 - 9.81 * 1e-6 * k * (k + 1) / 2)).abs().max()) < 2e-5
     assert float((sim.state[abi.S_LINVEL + 2] + 9.81e-3 * k).abs().max()) < 1e-5
     assert float(z.max() - z.min()) == 0.0  # identical envs stay identical
+
+
+@pytest.mark.parametrize("B", [4096, 32768, 65536])
+def test_bench_workload_fused_launches_equal_single_launches(B):
+    """bench.py's workload at full size: 2 x 32 fused steps (one launch each up
+    to 32768 envs; step by step inside the library beyond) give the records and
+    the state of 64 single-step launches, bit for bit, across the window in
+    which the README agent's robots start falling and restarting."""
+    import bench
+
+    a, b = BatchedSim(bench.make_config(B)), BatchedSim(bench.make_config(B))
+    o6 = a.reset()
+    b.reset()
+    prev = torch.zeros((B, 8), device=a.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    # run both well into the regime with falls first (same path on both: not what is compared)
+    warm = torch.zeros((32, B, 8), device=a.device)
+    for _ in range(56):  # ~9 s of simulated time: the README agent's slow unstable mode has started toppling robots
+        a.rollout_pendulum_records(prev, warm)
+        b.rollout_pendulum_records(prev, warm.clone())
+        prev = warm[31].clone()
+    assert torch.equal(a.state, b.state)
+    fused = torch.zeros((2, 32, B, 8), device=a.device)
+    chained = torch.zeros((64, B, 8), device=a.device)
+    p = prev
+    for w in range(2):
+        a.rollout_pendulum_records(p, fused[w])
+        p = fused[w, 31]
+    p = prev
+    for k in range(64):
+        b.step_pendulum_records(p, chained[k])
+        p = chained[k]
+    assert torch.equal(fused.reshape(64, B, 8), chained)
+    assert torch.equal(a.state, b.state)
+    assert float(a.state[abi.S_EPISODE].max()) >= 2  # episodes ended and restarted along the way
