@@ -44,16 +44,22 @@ enum UpkieStateWord {
                               observation, pybullet_backend.py:456-458)     */
   UPKIE_S_IMUVEL = 37,  /* 3: previous IMU linear velocity (world), for the
                               finite-difference accelerometer :405-408      */
-  UPKIE_S_EPISODE = 40, /* 1: number of resets done so far (RNG stream id)  */
+  UPKIE_S_EPISODE = 40, /* 1: number of resets done so far (RNG stream id),
+                              modulo 2^24 (UPKIE_COUNTER_MASK)              */
   UPKIE_S_DONE = 41,    /* 1: 1.0 when the env terminated and awaits reset  */
   UPKIE_S_MPC_V = 42,   /* 1: MPCBalancer.commanded_velocity                */
   UPKIE_S_SE2_X = 43,   /* 1: dead-reckoned x, upkie_base_velocity.py:197   */
   UPKIE_S_SE2_Y = 44,   /* 1: dead-reckoned y                               */
   UPKIE_S_CONTACT = 45, /* 1: floor contact flag after the last substep     */
-  UPKIE_S_STEP = 46,    /* 1: env.step() calls so far (torque-noise stream)  */
+  UPKIE_S_STEP = 46,    /* 1: env.step() calls so far (torque-noise stream),
+                              modulo 2^24                                    */
   UPKIE_S_ELAPSED = 47, /* 1: steps of the current episode (time limit)      */
   UPKIE_STATE_WORDS = 48
 };
+
+/* The counters are held as fp32 VALUES (so that they read naturally from a
+ * float tensor): exact up to 2^24, then they wrap to 0 instead of sticking. */
+#define UPKIE_COUNTER_MASK 0xFFFFFFu
 
 /* Words the fused Pendulum step reads and writes (29 physics/filter words +
  * the done flag); everything else is untouched by that kernel. */

@@ -895,7 +895,10 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   /* pybullet_backend.py:228: one stepSimulation() with no motor torque */
   const double zero_tau[6] = {0, 0, 0, 0, 0, 0};
   spine_reset(); /* Observer::reset, then the spine cycles once */
-  oracle_substep_ext(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, force, point);
+  /* ... and no external force: __apply_external_forces only runs in step() (:303), not in reset (:220-232) */
+  (void)force;
+  (void)point;
+  oracle_substep_ext(model, s, zero_tau, cfg->dt / cfg->nb_substeps, scale, NULL, NULL);
   spine_cycle(s, zero_tau, cfg->dt / cfg->nb_substeps);
   /* upkie_gyropod.py:236-240 */
   s[UPKIE_S_LEGREF + 0] = s[UPKIE_S_Q + 0];
@@ -907,7 +910,7 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   s[UPKIE_S_MPC_V] = 0.0;
   s[UPKIE_S_SE2_X] = 0.0;
   s[UPKIE_S_SE2_Y] = 0.0;
-  s[UPKIE_S_EPISODE] = (double)(episode + 1);
+  s[UPKIE_S_EPISODE] = (double)((episode + 1u) & UPKIE_COUNTER_MASK); /* counters live in fp32 words on the device: exact up to 2^24, then wrap */
   s[UPKIE_S_DONE] = 0.0;
   s[UPKIE_S_ELAPSED] = 0.0;
 }
@@ -1041,7 +1044,7 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
     oracle_substep_ext(model, s, tau, h, scale, force, point);
     spine_cycle(s, tau, h);
   }
-  s[UPKIE_S_STEP] = (double)(step + 1u);
+  s[UPKIE_S_STEP] = (double)((step + 1u) & UPKIE_COUNTER_MASK);
 }
 
 /* UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331 */

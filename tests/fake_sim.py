@@ -38,6 +38,10 @@ class OracleSim:
     def close(self):
         pass
 
+    def restart_random_streams(self):
+        self._o.state[abi.S_EPISODE] = 0.0
+        self._o.state[abi.S_STEP] = 0.0
+
     def flag_done(self, done):
         self._o.state[abi.S_DONE] = done.double().numpy()
 
@@ -53,6 +57,11 @@ class OracleSim:
         return None if self._o.observer_state is None else torch.from_numpy(self._o.observer_state.astype(np.float32))
 
     def push_config(self):
+        # the library refuses what the reference's rotation helpers refuse (rotations.py:50-51)
+        if abs(sum(q * q for q in self.config.init_quat) - 1.0) > 1e-5:
+            from upkie_amd.lib import UpkieHipError
+
+            raise UpkieHipError(abi.ERR_INVALID_ARGUMENT, "init_quat is not normalized")
         self._o.config = self.config
 
     def randomize_inertias(self, variation):

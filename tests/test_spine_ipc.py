@@ -21,6 +21,7 @@ from upkie_amd.exceptions import SpineError, UpkieRuntimeError, UpkieTimeoutErro
 from upkie_amd.spine import AgentInterface, Event, HipSpine, Request, SpineInterface, State, StateMachine
 from upkie_amd.spine.state_machine import kNbStopCycles
 from upkie_amd.utils.robot_state import RobotState
+from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 
 from .fake_sim import oracle_sim_factory
 
@@ -218,3 +219,23 @@ def abi_pos(axis):
     from upkie_amd import abi
 
     return abi.S_POS + axis
+
+
+def test_a_start_payload_the_simulator_refuses_does_not_kill_the_spine():
+    """A kStart whose reset state the simulator rejects (a quaternion that is
+    not normalized) is handled like a deserialization error (Spine.cpp:163-166):
+    the spine shuts down in order instead of dying with the request pending, and the
+    batch keeps its own initial-state distribution."""
+    name = shm_name()
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=2, frequency=200.0, autoreset_mode="disabled", sim_factory=oracle_sim_factory,
+                    init_state=RobotState(randomization=RobotStateRandomization(pitch=0.07)))
+    env.reset(seed=0)
+    spine = HipSpine(env, shm_name=name, shm_size=1 << 16, env_index=0)
+    bad = {"bullet": {"reset": {"orientation_base_in_world": [2.0, 0.0, 0.0, 0.0], "position_base_in_world": [0.0, 0.0, 0.9]}}}
+    spine.interface.write(msgpack.packb(bad))
+    spine.interface.set_request(Request.kStart)
+    for _ in range(kNbStopCycles + 2):
+        spine.cycle()  # must not raise
+    assert spine.state_machine.state in (State.kShutdown, State.kOver)
+    assert env.config.rand_pitch == 0.07 and list(env.config.init_pos) == [0.0, 0.0, 0.6] and list(env.config.init_quat) == [1.0, 0.0, 0.0, 0.0]
+    spine.close()

@@ -740,7 +740,8 @@ next_step:
     {
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext);
+      const ExtForces ext_now{do_reset ? nullptr : ext.force, ext.stride, ext.slots};  // reset steps once without external forces
+      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext_now);
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline: each lane runs the WheelContact estimator of its
@@ -786,11 +787,11 @@ next_step:
       SW(UPKIE_S_MPC_V) = 0.f;
       SW(UPKIE_S_SE2_X) = 0.f;
       SW(UPKIE_S_SE2_Y) = 0.f;
-      SW(UPKIE_S_EPISODE) = (float)(episode + 1);
+      SW(UPKIE_S_EPISODE) = (float)((episode + 1u) & UPKIE_COUNTER_MASK);
       SW(UPKIE_S_DONE) = 0.f;
       SW(UPKIE_S_ELAPSED) = 0.f;
     }
-    episode_word = (float)(episode + 1);
+    episode_word = (float)((episode + 1u) & UPKIE_COUNTER_MASK);
     done_word = 0.f;
     elapsed_word = 0.f;
     observe6(yaw, yawvel, obs6);
@@ -821,7 +822,7 @@ next_step:
 #pragma unroll
     for (int k = 0; k < 3; ++k) SW(UPKIE_S_TORQUE + 3 * leg + k) = tau[k];
     if (any_noise) {
-      step_count += 1u;
+      step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
       if (lead) SW(UPKIE_S_STEP) = (float)step_count;
     }
   }

@@ -405,7 +405,9 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
-      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext);
+      // PyBulletBackend.reset steps once WITHOUT __apply_external_forces (pybullet_backend.py:220-232 vs :303)
+      const ExtForces ext_now{do_reset ? nullptr : ext.force, ext.stride, ext.slots};
+      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now);
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline (spines/common/observers.h:22-42): it sees the
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     SW(UPKIE_S_MPC_V) = 0.f;
     SW(UPKIE_S_SE2_X) = 0.f;
     SW(UPKIE_S_SE2_Y) = 0.f;
-    SW(UPKIE_S_EPISODE) = (float)(episode + 1);
+    SW(UPKIE_S_EPISODE) = (float)((episode + 1u) & UPKIE_COUNTER_MASK);
     SW(UPKIE_S_DONE) = 0.f;
     SW(UPKIE_S_ELAPSED) = 0.f;
     gyropod_observation(M, s, yaw, yawvel, obs6);
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j) SW(UPKIE_S_TORQUE + j) = tau[j];  // pybullet_backend.py:293
     if (any_noise) {
-      step_count += 1u;
+      step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
       SW(UPKIE_S_STEP) = (float)step_count;
     }
   }

@@ -38,6 +38,7 @@ class _SingleEnv:
             )
         kwargs.pop("frequency_checks", None)
         self._vec = self._vec_class(num_envs=1, autoreset=False, **kwargs)
+        self._vec.host_sampling = True  # reset(seed=s) reproduces the reference's np_random states (upkie_env.py:180-190)
         self.observation_space = self._vec.single_observation_space
         self.action_space = self._vec.single_action_space
         self.model = self._vec.model

@@ -252,10 +252,33 @@ class UpkieVecEnv:
         reference's list of `PointContact` for one env."""
         return self.sim.contact_points()
 
+    #: True for the single-robot envs: the initial state is drawn on the host
+    #: from gymnasium's seeded generator exactly as the reference draws it
+    #: (upkie_env.py:180-190), so `reset(seed=s)` starts from the reference's
+    #: state; batched envs draw on the device (Philox keyed by seed, env, episode)
+    host_sampling = False
+    _np_random = None
+
     def _reset_sim(self, seed: Optional[int], mask: Optional[torch.Tensor]) -> torch.Tensor:
         if seed is not None:
             self.config.seed = int(seed)
             self.sim.push_config()
+            if mask is None:
+                # gymnasium's reset(seed) contract: the same seed replays the same
+                # episodes, so the counters that key the random streams restart too
+                self.sim.restart_random_streams()
+        if self.host_sampling and mask is None:
+            if seed is not None or self._np_random is None:
+                # gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))
+                self._np_random = np.random.default_rng(seed)
+            self.sampled_init_state = self.init_state.sample_state(self._np_random)
+            self.sampled_init_state.write_exact_to_config(self.config)
+            self.sim.push_config()
+            try:
+                return self.sim.reset(mask)
+            finally:
+                self.init_state.write_to_config(self.config)
+                self.sim.push_config()
         return self.sim.reset(mask)
 
 
@@ -461,7 +484,11 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         obs6, info = super().reset(seed=seed, options=options, mask=mask)
         self._remember(obs6)
         self.mpc_balancer.reset(mask)  # upkie_base_velocity.py:158
-        if mask is None:
+        if hasattr(self.sim, "step_base_velocity"):
+            # fused path: the dead-reckoned pose lives in the state words (the
+            # reset branch of the kernel has just zeroed them for the reset envs)
+            self._xy.copy_(self.sim.state[abi.S_SE2_X : abi.S_SE2_Y + 1].t())
+        elif mask is None:
             self._xy.zero_()
         else:
             self._xy.masked_fill_(mask.to(self.device).bool()[:, None], 0.0)

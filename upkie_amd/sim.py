@@ -386,5 +386,12 @@ class BatchedSim:
         envs' time limit, which the kernel knows nothing about)."""
         self.state[abi.S_DONE] = done.to(self.device, torch.float32)
 
+    def restart_random_streams(self) -> None:
+        """Zero the per-env episode and noise-step counters that key the Philox
+        streams: (seed, env, episode = 0) is replayed by the next reset, as
+        gymnasium's `reset(seed=s)` contract asks."""
+        self.state[abi.S_EPISODE].zero_()
+        self.state[abi.S_STEP].zero_()
+
     def state_numpy(self) -> np.ndarray:
         return self.state.detach().cpu().numpy()

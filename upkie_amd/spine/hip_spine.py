@@ -91,7 +91,7 @@ class HipSpine:
             elif state == State.kStep:
                 action = msgpack.unpackb(self.interface.data(), raw=False)
                 self._step(action if isinstance(action, dict) else {})
-        except (msgpack.exceptions.UnpackException, ValueError) as exn:  # "Deserialization error", :163-166
+        except (msgpack.exceptions.UnpackException, ValueError, UpkieRuntimeError) as exn:  # "Deserialization error", :163-166 (a payload the simulator refuses is treated alike)
             self.state_machine.process_event(Event.kInterrupt)
             self._last_error = exn
 
@@ -138,15 +138,17 @@ class HipSpine:
             cfg.torque_control_kp = float(torque_control["kp"])
         if "kd" in torque_control:
             cfg.torque_control_kd = float(torque_control["kd"])
-        state.write_to_config(cfg)  # no randomisation: the agent asked for this state
-        env.sim.push_config()
-        mask = torch.zeros(env.num_envs, dtype=torch.uint8)
-        mask[i] = 1
-        obs, info = env.reset(mask=mask)
-        # the rest of the batch keeps the env's own initial-state distribution
-        (cfg.init_pos[:], cfg.init_quat[:], cfg.init_linvel[:], cfg.init_angvel[:], cfg.init_joint[:],
-         cfg.rand_roll, cfg.rand_pitch, cfg.rand_x, cfg.rand_z, cfg.rand_omega_x, cfg.rand_omega_y, cfg.rand_linvel[:]) = saved
-        env.sim.push_config()
+        try:
+            state.write_to_config(cfg)  # no randomisation: the agent asked for this state
+            env.sim.push_config()  # (raises on a state the library refuses, e.g. a quaternion that is not normalized)
+            mask = torch.zeros(env.num_envs, dtype=torch.uint8)
+            mask[i] = 1
+            obs, info = env.reset(mask=mask)
+        finally:
+            # whatever happened, the rest of the batch keeps the env's own initial-state distribution
+            (cfg.init_pos[:], cfg.init_quat[:], cfg.init_linvel[:], cfg.init_angvel[:], cfg.init_joint[:],
+             cfg.rand_roll, cfg.rand_pitch, cfg.rand_x, cfg.rand_z, cfg.rand_omega_x, cfg.rand_omega_y, cfg.rand_linvel[:]) = saved
+            env.sim.push_config()
         self._obs = obs
         self._time = 0.0
         self._observation = self._spine_observation(info)

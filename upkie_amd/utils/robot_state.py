@@ -42,6 +42,8 @@ class RobotState:
         self.joint_velocity = vec(joint_velocity, np.zeros(6))  # never used, :261-267
         self.linear_velocity_base_to_world_in_world = vec(linear_velocity_base_to_world_in_world, np.zeros(3))
         self.orientation_base_in_world = _as_quat_wxyz(orientation_base_in_world)
+        # a scipy Rotation is kept as given so that sample_state composes exactly what the reference composes
+        self._rotation = orientation_base_in_world if hasattr(orientation_base_in_world, "as_quat") else None
         # Upkie above the horizontal plane, robot_state.py:112
         self.position_base_in_world = vec(position_base_in_world, np.array([0.0, 0.0, 0.6]))
         self.randomization = randomization if randomization is not None else RobotStateRandomization()
@@ -58,3 +60,40 @@ class RobotState:
         cfg.rand_x, cfg.rand_z = r.x, r.z
         cfg.rand_omega_x, cfg.rand_omega_y = r.omega_x, r.omega_y
         cfg.rand_linvel[:] = list(r.linear_velocity)
+
+    def sample_state(self, np_random: np.random.Generator) -> "RobotState":
+        """A state drawn around this one as `RobotState.sample_state` draws it
+        (robot_state.py:175-196): angular velocity, linear velocity,
+        orientation (offset composed on the right of the base orientation,
+        :158-160), position, in that order, from the env's seeded generator.
+        Used by the single-robot envs; batched envs draw on the device."""
+        from scipy.spatial.transform import Rotation
+
+        r = self.randomization
+        angular_velocity = self.angular_velocity_base_in_base + r.sample_angular_velocity(np_random)
+        linear_velocity = self.linear_velocity_base_to_world_in_world + r.sample_linear_velocity(np_random)
+        base = self._rotation
+        if base is None:
+            w, x, y, z = self.orientation_base_in_world
+            base = Rotation.from_quat([x, y, z, w])
+        orientation = base * r.sample_orientation(np_random)
+        position = self.position_base_in_world + r.sample_position(np_random)
+        return RobotState(
+            angular_velocity_base_in_base=angular_velocity,
+            joint_configuration=self.joint_configuration,
+            joint_velocity=self.joint_velocity,
+            linear_velocity_base_to_world_in_world=linear_velocity,
+            orientation_base_in_world=orientation,
+            position_base_in_world=position,
+            randomization=self.randomization,
+        )
+
+    def write_exact_to_config(self, cfg) -> None:
+        """This very state as the config's initial state, randomisation off."""
+        cfg.init_pos[:] = list(self.position_base_in_world)
+        cfg.init_quat[:] = list(self.orientation_base_in_world)
+        cfg.init_linvel[:] = list(self.linear_velocity_base_to_world_in_world)
+        cfg.init_angvel[:] = list(self.angular_velocity_base_in_base)
+        cfg.init_joint[:] = list(self.joint_configuration)
+        cfg.rand_roll = cfg.rand_pitch = cfg.rand_x = cfg.rand_z = cfg.rand_omega_x = cfg.rand_omega_y = 0.0
+        cfg.rand_linvel[:] = [0.0, 0.0, 0.0]
