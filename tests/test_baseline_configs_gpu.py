@@ -1,0 +1,362 @@
+"""BASELINE.json's configurations at THEIR OWN batch sizes against the fp64
+oracle (the oracle steps 4096 envs x 20 steps in a fraction of a second with
+OpenMP, 16384 x 10 in about a second), and the device pinned DIRECTLY to the
+reference-generated fixtures without the oracle in between.
+
+* C2  Upkie-Pendulum, 4096 envs, PD-gain agent on the device, through the
+      benchmarked instantiation (`upkie_sim_step_pendulum_agent_rollout`, K
+      steps in one launch) and through one launch per step.
+* C3  UpkieBaseVelocity + MPC balancer (N = 16, ADMM), 16384 envs.
+* C5  one GPU's share of the Servos config: 4096 envs, per-link inertia
+      randomisation 0.2, a push on the torso, wheel friction, the
+      torque-balancing action of examples/pybullet/torque_balancing.py:15-37.
+* `tests/golden/reference_backend.json` / `reference_envs.json`: states the
+  reference's own code observed / commands it sent, loaded into the device
+  state and compared with what the kernels report at fp32 tolerance.
+"""
+
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import upkie_amd.envs as envs
+from upkie_amd import abi
+from upkie_amd.model.default_model import default_model
+from upkie_amd.model.model import Model
+from upkie_amd.sim import BatchedSim
+
+from .fake_sim import OracleMpc, oracle_sim_factory
+from .helpers import make_pair, randomized_config, state_errors
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+JOINTS = list(abi.JOINT_NAMES)
+
+
+def num(v):
+    return {"nan": math.nan, "inf": math.inf, "-inf": -math.inf}.get(v, v) if isinstance(v, str) else v
+
+
+# ------------------------------------------------------------------ C2
+@pytest.mark.parametrize("lanes", ["0", "1"])
+def test_c2_rollout_kernel_4096_envs_matches_oracle(lanes, monkeypatch):
+    """bench.py's workload and entry point: 20 closed-loop env.step() of 4096
+    envs in ONE launch of the rollout kernel, every step's records against
+    `oracle.step_pendulum_agent` (tolerances of SURVEY A.9: closed loop
+    |dtheta|, |dp| <= 1e-3; here 20 steps stay 50x inside)."""
+    import bench
+    from oracle import oracle as O
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B, K = 4096, 20
+    cfg = bench.make_config(B)
+    sim = BatchedSim(cfg)
+    ref = O.Oracle(default_model(), cfg)
+    o6 = sim.reset()
+    obs_ref = ref.reset()[:, [1, 0, 4, 3]]
+    np.testing.assert_allclose(o6.cpu().numpy()[:, [1, 0]], obs_ref[:, :2], atol=2e-6)
+    prev = torch.zeros((B, 8), device=sim.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    records = torch.zeros((K, B, 8), device=sim.device)
+    sim.rollout_pendulum_records(prev, records)
+    rec = records.cpu().numpy()
+    worst = np.zeros(4)
+    for k in range(K):
+        obs_ref, rew_ref, term_ref, trunc_ref = ref.step_pendulum_agent(obs_ref)
+        worst = np.maximum(worst, np.abs(rec[k, :, :4] - obs_ref).max(axis=0))
+        assert np.array_equal(rec[k, :, 5] != 0, term_ref != 0) and not rec[k, :, 6].any() and not rec[k, :, 4].any()
+    assert worst[0] < 2e-5 and worst[1] < 2e-5, worst  # pitch (rad), ground position (m)
+    assert worst[2] < 2e-3 and worst[3] < 1e-3, worst  # pitch rate, ground velocity
+    err = state_errors(ref.state, sim.state_numpy())
+    assert err["pos"] < 2e-5 and err["quat"] < 2e-5 and err["q"] < 5e-4 and err["legref"] < 1e-6, err
+    assert err["episode"] == 0 and err["done"] == 0 and err["contact"] == 0, err
+
+
+def test_c2_one_launch_per_step_4096_envs_matches_oracle():
+    """The same workload as `VecEnv.step` sees it: one launch per step, action
+    computed by the caller."""
+    import bench
+    from oracle import oracle as O
+
+    B = 4096
+    cfg = bench.make_config(B)
+    sim = BatchedSim(cfg)
+    ref = O.Oracle(default_model(), cfg)
+    obs = sim.reset()[:, [1, 0, 4, 3]].contiguous()
+    obs_ref = ref.reset()[:, [1, 0, 4, 3]]
+    gains = torch.tensor([10.0, 1.0, 0.0, 0.1], device=sim.device)
+    for _ in range(20):
+        act = (obs @ gains).clamp(-0.99, 0.99)
+        obs, _, term, _ = sim.step_pendulum(act)
+        obs_ref, _, term_ref, _ = ref.step_pendulum_agent(obs_ref)
+    d = np.abs(obs.cpu().numpy() - obs_ref).max(axis=0)
+    assert d[0] < 2e-5 and d[1] < 2e-5 and d[2] < 2e-3 and d[3] < 1e-3, d
+    assert np.array_equal(term.cpu().numpy(), term_ref)
+
+
+# ------------------------------------------------------------------ C3
+def test_c3_base_velocity_mpc_16384_envs_matches_oracle():
+    """UpkieBaseVelocity with the MPC balancer in the loop (N = 16, 30 ADMM
+    iterations) on 16384 envs against the same env on the oracle doubles
+    (fp64 dynamics + fp64 ADMM): 10 steps, target velocities in +-0.5 m/s."""
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    B = 16384
+    kw = dict(num_envs=B, frequency=200.0, nb_timesteps=16, autoreset=False, seed=0,
+              init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0.0, 0.0]))))
+    gpu = envs.make("Upkie-HIP-BaseVelocity-Vec", **kw)
+    cpu = envs.make("Upkie-HIP-BaseVelocity-Vec", sim_factory=oracle_sim_factory, mpc_factory=OracleMpc, **kw)
+    gpu.reset(seed=0)
+    cpu.reset(seed=0)
+    rng = np.random.default_rng(0)
+    act = torch.zeros(B, 2)
+    act[:, 0] = torch.from_numpy(rng.uniform(-0.5, 0.5, B)).float()
+    for _ in range(10):
+        og, _, tg, _, _ = gpu.step(act)
+        oc, _, tc, _, _ = cpu.step(act)
+    assert torch.equal(tg.cpu(), tc) and not bool(tc.any())
+    np.testing.assert_allclose(og.cpu().numpy(), oc.numpy(), atol=1e-5)  # dead-reckoned pose
+    vg, vc = gpu.mpc_balancer.commanded_velocity.cpu().numpy(), cpu.mpc_balancer.commanded_velocity.numpy()
+    assert np.max(np.abs(vg - vc)) < 2e-3  # 2e-3 a_max dt / 2 per step would be 5e-5 x 10; warm starts add their share
+    err = state_errors(cpu.sim._o.state, gpu.sim.state_numpy())
+    assert err["pos"] < 5e-5 and err["quat"] < 5e-5, err
+    assert err["linvel"] < 5e-3 and err["q"] < 2e-3, err
+
+
+# ------------------------------------------------------------------ C5
+def test_c5_servos_share_4096_envs_matches_oracle():
+    """Servos env, per-link inertia randomisation 0.2, a world-frame push on
+    the torso (per env, up to 20 N, horizontal), wheel friction 0.1, the
+    torque-balancing action (hips/knees position 0, wheels feedforward torque
+    from the pitch, kd_scale 0), 4096 envs x 10 steps."""
+    B = 4096
+    cfg = randomized_config(B, seed=2)
+    cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
+    model = Model().struct  # the URDF model: 13 links behind the 7 bodies
+    oracle, sim = make_pair(B, cfg=cfg, model=model)
+    rec_h = sim.randomize_inertias(0.2).cpu().numpy()
+    rec_o = oracle.sample_body_inertials(0.2)
+    np.testing.assert_allclose(rec_h, rec_o, rtol=3e-5, atol=1e-9)
+    oracle.body_inertials = rec_o
+    rng = np.random.default_rng(5)
+    angle, norm = rng.uniform(0, 2 * np.pi, B), rng.uniform(0.0, 20.0, B)
+    force = np.stack([norm * np.cos(angle), norm * np.sin(angle), np.zeros(B)])
+    oracle.ext_force = force
+    oracle.ext_point = np.array([0.0, 0.0, -0.1])  # "torso" frame origin in the base frame
+    sim.set_external_force(torch.from_numpy(force).float(), point=(0.0, 0.0, -0.1))
+    obs_o = oracle.reset()
+    sim.reset()
+    act = np.zeros((B, 6, 6))
+    act[:, :, 3] = 1.0
+    act[:, :, 4] = 1.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = np.nan
+    act[:, [2, 5], 4] = 0.0  # kd_scale 0 on the wheels: pure torque control
+    pitch = obs_o[:, 1]
+    for _ in range(10):
+        act[:, 2, 2] = 10.0 * pitch  # examples/pybullet/torque_balancing.py:15-37 (left-wheeled signs)
+        act[:, 5, 2] = -10.0 * pitch
+        so, _, _, _ = oracle.step_servos(act)
+        sh, _, term, _ = sim.step_servos(torch.from_numpy(act).float())
+        st = oracle.state
+        pitch = np.arcsin(np.clip(2.0 * (st[abi.S_QUAT] * st[abi.S_QUAT + 2] - st[abi.S_QUAT + 3] * st[abi.S_QUAT + 1]), -1, 1))
+    sh = sh.cpu().numpy()
+    err = state_errors(oracle.state, sim.state_numpy())
+    assert err["pos"] < 5e-5 and err["quat"] < 5e-5, err
+    assert err["linvel"] < 5e-3 and err["angvel"] < 2e-2, err
+    np.testing.assert_allclose(sh[:, :, 0], so[:, :, 0], atol=2e-4)  # joint positions
+    np.testing.assert_allclose(sh[:, [0, 1, 3, 4], 1], so[:, [0, 1, 3, 4], 1], atol=2e-2)  # hip / knee velocities
+    np.testing.assert_allclose(sh[:, [2, 5], 1], so[:, [2, 5], 1], atol=0.2)  # wheel velocities: rim speed / 0.05 m, torque controlled
+    np.testing.assert_allclose(sh[:, [2, 5], 2], so[:, [2, 5], 2], atol=1e-3)  # wheel torques = clipped feedforward
+    assert np.abs(sh[:, [2, 5], 2]).max() <= 1.7 + 1e-6 and int(term.max()) == 0
+
+
+# ------------------------------------------- reference fixtures on the device
+@pytest.fixture(scope="module")
+def backend_golden():
+    with open(os.path.join(GOLDEN, "reference_backend.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def envs_golden():
+    with open(os.path.join(GOLDEN, "reference_envs.json")) as f:
+        return json.load(f)
+
+
+def test_device_observation_of_the_reference_backend_states(backend_golden):
+    """Every state the reference's PyBulletBackend observed, loaded into the
+    device state buffer (one env per golden case): `upkie_sim_observe` against
+    the reference's own observation blocks (pybullet_backend.py:313-490) at
+    fp32 resolution. No oracle involved."""
+    g = backend_golden
+    n = len(g["steps"])
+    model = Model()
+    cfg = abi.default_sim_config(n, frequency=1.0 / g["dt"])
+    sim = BatchedSim(cfg, model.struct)
+    s = np.zeros((abi.STATE_WORDS, n), dtype=np.float32)
+    for i, case in enumerate(g["steps"]):
+        base = case["base"]
+        s[abi.S_POS : abi.S_POS + 3, i] = base["pos"]
+        s[abi.S_QUAT : abi.S_QUAT + 4, i] = base["quat_wxyz"]
+        s[abi.S_LINVEL : abi.S_LINVEL + 3, i] = base["linvel"]
+        s[abi.S_ANGVEL : abi.S_ANGVEL + 3, i] = base["angvel"]
+        joints = np.array(case["final_joint_states"])
+        s[abi.S_Q : abi.S_Q + 6, i] = joints[:, 0]
+        s[abi.S_QD : abi.S_QD + 6, i] = joints[:, 1]
+        s[abi.S_TORQUE : abi.S_TORQUE + 6, i] = case["substep_torques"][-1]
+        s[abi.S_CONTACT, i] = 1.0 if any(case["contact"]) else 0.0
+    sim.state.copy_(torch.from_numpy(s))
+    first = sim.observe(update_imu=True)  # writes every case's IMU velocity into its own env
+    imu_velocity = sim.state[abi.S_IMUVEL : abi.S_IMUVEL + 3].clone()
+    # the reference observes the cases one after the other: case i differentiates against case i - 1 (:405-408)
+    sim.state[abi.S_IMUVEL : abi.S_IMUVEL + 3, 1:] = imu_velocity[:, :-1]
+    obs = {k: v.cpu().numpy().astype(np.float64) for k, v in sim.observe(update_imu=False).items()}
+    speed = 1.0 + np.abs(s[abi.S_LINVEL : abi.S_LINVEL + 3]).max()
+    for i, case in enumerate(g["steps"]):
+        ref = case["observation"]
+        bo = ref["base_orientation"]
+        assert obs["pitch"][i] == pytest.approx(bo["pitch"], abs=3e-7)
+        np.testing.assert_allclose(obs["angular_velocity"][i], bo["angular_velocity"], atol=1e-6)
+        np.testing.assert_allclose(obs["linear_velocity"][i], bo["linear_velocity"], atol=1e-6)
+        np.testing.assert_allclose(obs["rotation_base_to_world"][i].reshape(3, 3), bo["rotation_base_to_world"], atol=3e-7)
+        assert bool(obs["floor_contact"][i]) == ref["floor_contact"]["contact"]
+        imu = ref["imu"]
+        q_ref, q = np.array(imu["orientation"]), obs["imu_orientation"][i]
+        assert min(np.abs(q - q_ref).max(), np.abs(q + q_ref).max()) < 5e-7
+        np.testing.assert_allclose(obs["imu_angular_velocity"][i], imu["angular_velocity"], atol=1e-6)
+        if i > 0:
+            # finite difference of two fp32 velocities over dt: 2 ulp(v) / dt
+            atol = 4 * np.finfo(np.float32).eps * speed / g["dt"]
+            np.testing.assert_allclose(obs["imu_linear_acceleration"][i], imu["linear_acceleration"], atol=atol)
+            np.testing.assert_allclose(obs["imu_raw_linear_acceleration"][i], imu["raw_linear_acceleration"], atol=atol)
+        for j, joint in enumerate(JOINTS):
+            servo = ref["servo"][joint]
+            want = [servo["position"], servo["velocity"], servo["torque"], servo["temperature"], servo["voltage"]]
+            np.testing.assert_allclose(obs["servo"][i, j], want, rtol=2e-7, atol=1e-7)
+        odo = ref["wheel_odometry"]
+        np.testing.assert_allclose(obs["wheel_odometry"][i], [odo["position"], odo["velocity"]], rtol=1e-6, atol=1e-7)
+    assert first["pitch"].shape == (n,)
+
+
+def torque_law(q, qd, cmd, kp, kd, friction):
+    """compute_joint_torque as the reference states it (pybullet_backend.py:
+    492-553), in float64: the yardstick of the two tests below."""
+    tau = cmd["feedforward_torque"] + kd * cmd["kd_scale"] * (cmd["velocity"] - qd)
+    if not math.isnan(cmd["position"]):
+        tau += kp * cmd["kp_scale"] * (cmd["position"] - q)
+    if abs(qd) > 1e-3:
+        tau += -friction * (1.0 if qd > 0 else -1.0)
+    return min(max(tau, -cmd["maximum_torque"]), cmd["maximum_torque"])
+
+
+def test_device_torques_of_every_reference_substep(backend_golden):
+    """The 480 joint torques the reference's PyBulletBackend computed, one env
+    per (case, substep): the joint state Bullet reported at that substep is
+    loaded into the device state, the golden action sent through
+    `upkie_sim_step_servos` with ONE substep per step, so that the torque the
+    step reports is the torque law on exactly that state."""
+    g = backend_golden
+    cases, nsub = g["steps"], g["nb_substeps"]
+    n = len(cases) * nsub
+    cfg = abi.default_sim_config(n, frequency=1000.0, nb_substeps=1)
+    cfg.torque_control_kp, cfg.torque_control_kd = g["kp"], g["kd"]
+    for j in range(6):
+        cfg.joint_friction[j] = g["friction"][j]
+    cfg.init_pos[2] = 2.0  # in the air: contact plays no role in the torque law
+    model = Model().struct
+    # the backend applies no servo limits (UpkieServos does, upstream of it): the golden wheel commands carry
+    # maximum_torque up to 16 N.m, so the wheel effort of the model is lifted and the env-level clamp stays idle
+    model.joint_effort[2] = model.joint_effort[5] = 16.0
+    sim = BatchedSim(cfg, model)
+    sim.reset()
+    s = sim.state.cpu().numpy()
+    act = np.zeros((n, 6, 6), dtype=np.float32)
+    want = np.zeros((n, 6))
+    for i, case in enumerate(cases):
+        for sub in range(nsub):
+            e = i * nsub + sub
+            for j, joint in enumerate(JOINTS):
+                q, qd = case["substep_joint_states"][sub][j]
+                s[abi.S_Q + j, e], s[abi.S_QD + j, e] = q, qd
+                a = case["action"][joint]
+                act[e, j] = [num(a["position"]), a["velocity"], a.get("feedforward_torque", 0.0), a.get("kp_scale", 1.0),
+                             a.get("kd_scale", 1.0), a["maximum_torque"]]
+                want[e, j] = case["substep_torques"][sub][j]
+    sim.state.copy_(torch.from_numpy(s))
+    obs, _, _, _ = sim.step_servos(torch.from_numpy(act))
+    got = obs.cpu().numpy()[:, :, 2].astype(np.float64)
+    # the commanded torque is not continuous in the state (stiction threshold at |qd| = 1e-3, :541-543):
+    # states within fp32 rounding of it may land on the other branch
+    qd = s[abi.S_QD : abi.S_QD + 6].T
+    near_threshold = np.abs(np.abs(qd) - 1e-3) < 1e-9
+    ok = np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want))
+    assert np.all(ok | near_threshold), np.abs(got - want).max()
+    assert ok.mean() > 0.99 and np.abs(want).max() > 10.0
+
+
+@pytest.mark.parametrize("name", ["gyropod", "gyropod_scaled", "pendulum"])
+def test_device_replays_the_reference_wrapper_sequences(envs_golden, name):
+    """The 30-step sequences the reference's UpkieGyropod / UpkiePendulum ran
+    on a recording backend, replayed on the device: before step i the joint
+    state of the golden spine observation i is written into the state, the
+    golden action is sent through the Gyropod / Pendulum step with one substep,
+    and the torques the step reports must be the torque law on the servo
+    targets the REFERENCE sent (clamps, wheel / yaw map, leg low-pass with the
+    filter memory living on the device across the steps:
+    upkie_gyropod.py:246-331). Observations (:186-214, upkie_pendulum.py:17):
+    golden spine observation i + 1 loaded, reported by an untouched-env reset."""
+    g = envs_golden[name]
+    model = Model()
+    cfg = abi.default_sim_config(1, frequency=1.0 / g["dt"], nb_substeps=1)
+    for key, value in g["kwargs"].items():
+        setattr(cfg, key, value)
+    cfg.init_pos[2] = 2.0
+    sim = BatchedSim(cfg, model.struct)
+    from .test_reference_env_goldens import state_from_spine
+
+    spine = g["spine_observations"]
+    sim.reset()
+    first = state_from_spine(model, spine[0], 0.0, 0.0)
+    st = sim.state.cpu().numpy()
+    st[abi.S_LEGREF : abi.S_LEGREF + 4, 0] = np.array(spine[0]["servo"])[[0, 1, 3, 4], 0]  # upkie_gyropod.py:236-240
+    sim.state.copy_(torch.from_numpy(st))
+    none = torch.zeros(1, dtype=torch.uint8)
+    yaw, checked = 0.0, 0
+    for i, step in enumerate(g["steps"]):
+        servo = np.array(spine[i]["servo"])
+        sim.state[abi.S_Q : abi.S_Q + 6, 0] = torch.from_numpy(servo[:, 0]).float()
+        sim.state[abi.S_QD : abi.S_QD + 6, 0] = torch.from_numpy(servo[:, 1]).float()
+        q32, qd32 = sim.state[abi.S_Q : abi.S_Q + 6, 0].cpu().numpy().astype(np.float64), sim.state[abi.S_QD : abi.S_QD + 6, 0].cpu().numpy().astype(np.float64)
+        if name == "pendulum":
+            sim.step_pendulum(torch.tensor([step["action"][0]], dtype=torch.float32))
+            a1 = 0.0
+        else:
+            sim.step_gyropod(torch.tensor([step["action"]], dtype=torch.float32))
+            a1 = step["action"][1]
+        tau = sim.state[abi.S_TORQUE : abi.S_TORQUE + 6, 0].cpu().numpy().astype(np.float64)
+        for j in range(6):
+            ref_cmd = dict(zip(abi.ACTION_KEYS, (num(v) for v in step["spine_servo"][j])))
+            want = torque_law(q32[j], qd32[j], ref_cmd, 20.0, 1.0, 0.0)
+            if abs(abs(qd32[j]) - 1e-3) < 1e-9:
+                continue
+            assert tau[j] == pytest.approx(want, abs=2e-5 * max(1.0, abs(want))), (i, j)
+            checked += 1
+        # observation map: golden spine observation i + 1 in, the wrapper's vector out
+        yaw += a1 * g["dt"]
+        s = state_from_spine(model, spine[i + 1], yaw, a1).astype(np.float32)
+        keep = sim.state[:, 0].clone()
+        for w in (abi.S_QUAT, abi.S_Q, abi.S_QD, abi.S_ANGVEL, abi.S_YAW):
+            width = {abi.S_QUAT: 4, abi.S_Q: 6, abi.S_QD: 6, abi.S_ANGVEL: 3, abi.S_YAW: 2}[w]
+            sim.state[w : w + width, 0] = torch.from_numpy(s[w : w + width])
+        obs6 = sim.reset(mask=none).cpu().numpy()[0].astype(np.float64)
+        sim.state[:, 0] = keep
+        got = obs6[[1, 0, 4, 3]] if name == "pendulum" else obs6
+        np.testing.assert_allclose(got, step["observation"], rtol=2e-6, atol=5e-7)
+        assert (abs(obs6[1]) > cfg.fall_pitch) == step["terminated"]
+    assert checked > 150

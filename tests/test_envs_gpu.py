@@ -276,3 +276,41 @@ def test_same_step_autoreset_is_one_launch_and_matches_the_double(env_id, limit,
         cpu.sim._o.state[:] = gpu.sim.state.cpu().numpy().astype(np.float64)
     assert ended >= B // 4
     np.testing.assert_array_equal(gpu.sim.state[abi.S_EPISODE].cpu().numpy(), cpu.sim._o.state[abi.S_EPISODE])
+
+
+def test_base_velocity_same_step_autoreset_reports_the_dead_reckoned_pose():
+    """UpkieBaseVelocity with autoreset_mode="same_step" on the fused GPU path:
+    the dead-reckoned x, y live in the state words (upkie_base_velocity.py:
+    197-199); every step goes through reset(mask=done), whose observation must
+    carry them for the envs that did not restart and zeros for those that did."""
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    kw = dict(num_envs=48, frequency=200.0, nb_timesteps=16, fall_pitch=0.12, seed=3, autoreset_mode="same_step",
+              init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1)))
+    gpu = envs.make("Upkie-HIP-BaseVelocity-Vec", **kw)
+    cpu = envs.make("Upkie-HIP-BaseVelocity-Vec", sim_factory=oracle_sim_factory, mpc_factory=OracleMpc, **kw)
+    assert hasattr(gpu.sim, "step_base_velocity")
+    gpu.reset()
+    cpu.reset()
+    act = torch.zeros(48, 2)
+    act[:, 0] = torch.linspace(-1.0, 1.0, 48)
+    act[:, 1] = 0.3
+    in_sync = np.ones(48, dtype=bool)
+    ended = 0
+    for step in range(120):
+        og, _, tg, _, ig = gpu.step(act)
+        oc, _, tc, _, ic = cpu.step(act)
+        in_sync &= tg.cpu().numpy() == tc.numpy()
+        ended += int(tc.sum())
+        if step == 40:
+            moving = og[:, :2].abs().sum(dim=1).cpu().numpy() > 1e-3
+            assert moving[in_sync].mean() > 0.8  # the pose is reported, not zeros
+    assert ended > 0 and in_sync.mean() > 0.8
+    np.testing.assert_allclose(og.cpu().numpy()[in_sync], oc.numpy()[in_sync], atol=1e-4)
+    # explicit masked reset in any mode: untouched envs keep their pose
+    mask = torch.zeros(48, dtype=torch.uint8)
+    mask[::2] = 1
+    before = og.clone()
+    obs, _ = gpu.reset(mask=mask)
+    assert torch.equal(obs[1::2, :2].cpu(), before[1::2, :2].cpu()) and float(obs[::2, :2].abs().max()) == 0.0
