@@ -1,7 +1,7 @@
 """BASELINE.json's full batch sizes (4096, 16384, 65536 envs per GPU) through
-size-independent properties: the oracle cannot step 65536 envs in seconds, so
-correctness at scale is argued from invariants plus equality with small
-batches that ARE oracle-checked (tests/test_parity_gpu.py)."""
+size-independent properties (invariants, determinism, symmetry, equality of a
+large batch's prefix with a small batch). The direct oracle comparisons AT
+the BASELINE sizes are in tests/test_baseline_configs_gpu.py."""
 
 import numpy as np
 import pytest
