@@ -202,6 +202,14 @@ int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config);
 /* Size in bytes the caller must allocate for the state buffer. */
 int64_t upkie_sim_state_bytes(const UpkieSim* sim);
 
+/* Lanes of a wavefront that share one env in the step kernels of this handle:
+ * chosen from the batch size at creation (small batches spread every env over
+ * several lanes so that the chip's SIMDs all hold a wave; large ones keep one
+ * env per lane), or forced by the environment variable UPKIE_LANES_PER_ENV
+ * (tests, sweeps). Results agree across mappings to fp32 rounding and bit for
+ * bit within one. */
+int upkie_sim_lanes_per_env(const UpkieSim* sim);
+
 /* Optional per-env domain randomisation buffers (device pointers, may be
  * NULL): body_inertials[UPKIE_NB * UPKIE_INERTIAL_WORDS][B] replaces mass,
  * centre of mass and inertia of every composite body of every env (filled by

@@ -91,7 +91,36 @@ def ref_lib():
     return _ref
 
 
+_NATIVE_PATH = os.path.join(_HERE, "_build", "libupkie_oracle_native.so")
 _lib = None
+
+
+def use_native_build() -> bool:
+    """bench.py's cpu_baseline: (re)build the oracle with -O3 -march=native ON
+    THIS HOST and make it the library this process loads. Must be called
+    before the first use of the oracle. The tuned library never travels: a
+    sidecar remembers the CPU model it was built for."""
+    global _lib
+    if _lib is not None:
+        return False
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((line.split(":", 1)[1].strip() for line in f if line.startswith("model name")), cpu)
+    except OSError:
+        pass
+    stamp = _NATIVE_PATH + ".host"
+    built_for = open(stamp).read() if os.path.exists(stamp) else None
+    try:
+        if built_for != cpu or not os.path.exists(_NATIVE_PATH):
+            subprocess.run(["make", "-C", _HERE, "native", "-B"], check=True, capture_output=True)
+            with open(stamp, "w") as f:
+                f.write(cpu)
+        _load(_NATIVE_PATH)
+        return True
+    except (subprocess.CalledProcessError, OSError):
+        _lib = None
+        return False
 
 
 def lib():
@@ -99,23 +128,30 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.oracle_joint_torque.restype = C.c_double
-        _lib.oracle_joint_torque.argtypes = [
-            C.c_double,
-            C.c_double,
-            C.POINTER(ServoCommand),
-            C.c_double,
-            C.c_double,
-            C.c_double,
-        ]
-        _lib.oracle_total_mass.restype = C.c_double
-        _lib.oracle_energy.restype = C.c_double
-        _lib.oracle_substep.restype = C.c_int
-        _lib.oracle_substep_ext.restype = C.c_int
-        _lib.oracle_mpc_solve_exact.restype = C.c_int
-        _lib.oracle_observers_check.restype = C.c_int
-        _lib.oracle_pitch_frame_in_parent.restype = C.c_double
+        _load(_LIB_PATH)
+    return _lib
+
+
+def _load(path):
+    global _lib
+    _lib = C.CDLL(path)
+    _lib.oracle_joint_torque.restype = C.c_double
+    _lib.oracle_joint_torque.argtypes = [
+        C.c_double,
+        C.c_double,
+        C.POINTER(ServoCommand),
+        C.c_double,
+        C.c_double,
+        C.c_double,
+    ]
+    _lib.oracle_total_mass.restype = C.c_double
+    _lib.oracle_energy.restype = C.c_double
+    _lib.oracle_substep.restype = C.c_int
+    _lib.oracle_substep_ext.restype = C.c_int
+    _lib.oracle_mpc_solve_exact.restype = C.c_int
+    _lib.oracle_observers_check.restype = C.c_int
+    _lib.oracle_pitch_frame_in_parent.restype = C.c_double
+    _lib.oracle_rollout_pendulum_agent.restype = C.c_int64
     return _lib
 
 
@@ -255,6 +291,15 @@ class Oracle:
             self._rnd(),
         )
         return obs, rew, term, trunc
+
+    def rollout_pendulum_agent(self, obs, steps: int):
+        """`steps` consecutive `step_pendulum_agent` in one parallel region
+        (bench.py's cpu_baseline); returns (obs, terminations seen)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float64).copy()
+        falls = self._lib.oracle_rollout_pendulum_agent(
+            C.byref(self.model), C.byref(self.config), _ptr(self.state), _ptr(obs), C.c_int32(steps), self._rnd()
+        )
+        return obs, int(falls)
 
     def observe(self, update_imu: bool = True) -> dict:
         B = self.B

@@ -1215,6 +1215,44 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
   }
 }
 
+/* bench.py's cpu_baseline: `steps` consecutive env.step() of every env with
+ * the README agent, ONE parallel region for the whole rollout. Envs are
+ * independent, so each thread carries its chunk of envs through all the steps
+ * without meeting the others (no barrier per step, an env's state stays in
+ * the thread's cache between its steps); the per-step entry point above pays a
+ * fork/join and a strided SoA load/store per step instead. Same arithmetic,
+ * same results as `steps` calls of oracle_step_pendulum_agent. `obs` [B][4]
+ * in/out; returns the number of terminations seen. */
+int64_t oracle_rollout_pendulum_agent(const UpkieModel* model, const UpkieSimConfig* cfg, double* state,
+                                      double* obs, int32_t steps, const OracleRandomization* rnd) {
+  int B = cfg->num_envs;
+  int64_t falls = 0;
+#pragma omp parallel for schedule(static) reduction(+ : falls)
+  for (int e = 0; e < B; ++e) {
+    double s[NW], scale[NB * UPKIE_INERTIAL_WORDS], force[3 * UPKIE_MAX_EXTERNAL_FORCES], obs6[6], o4[4];
+    UpkieExternalForces slots;
+    const double *sp, *fp;
+    const UpkieExternalForces* pp;
+    uint8_t terminated, truncated;
+    load_env(state, B, e, s);
+    env_randomization(rnd, B, e, scale, force, &slots, &sp, &fp, &pp);
+    spine_begin(rnd, B, e);
+    for (int i = 0; i < 4; ++i) o4[i] = obs[4 * (int64_t)e + i];
+    for (int k = 0; k < steps; ++k) {
+      double a = 0.0;
+      for (int i = 0; i < 4; ++i) a += cfg->agent_gains[i] * o4[i];
+      a = clamp_like_reference(a, -cfg->agent_clip, cfg->agent_clip);
+      step_gyropod_env(model, cfg, s, cfg->env_id_offset + e, a, 0.0, obs6, &terminated, &truncated, sp, fp, pp);
+      for (int i = 0; i < 4; ++i) o4[i] = obs6[kPendulumObsIndices[i]];
+      falls += terminated;
+    }
+    for (int i = 0; i < 4; ++i) obs[4 * (int64_t)e + i] = o4[i];
+    spine_end(rnd, B, e);
+    store_env(state, B, e, s);
+  }
+  return falls;
+}
+
 /* upkie_servos.py:288-306 with pybullet_backend.py:448-474 */
 static void servo_observation(const UpkieSimConfig* cfg, int64_t env_global,
                               const double s[NW], double obs[30]) {

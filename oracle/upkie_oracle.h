@@ -122,6 +122,9 @@ void oracle_step_pendulum_agent(const UpkieModel* model,
                                 double* obs, double* reward,
                                 uint8_t* terminated, uint8_t* truncated,
                                 const OracleRandomization* rnd);
+/* `steps` env.step() of every env in one parallel region (bench.py's CPU baseline) */
+int64_t oracle_rollout_pendulum_agent(const UpkieModel* model, const UpkieSimConfig* cfg, double* state,
+                                      double* obs, int32_t steps, const OracleRandomization* rnd);
 
 /* PyBulletBackend.get_contact_points (pybullet_backend.py:660-716) of every
  * env: out [B][2][8] = per tire {exists, position in world (3), force in

@@ -172,3 +172,80 @@ def test_sharded_pendulum_two_ranks_equal_one_rank(tmp_path):
     out = tmp_path / "sharded.txt"
     mp.spawn(_sharded_worker, args=(2, free_port(), str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _shard_worker_8(rank: int, world: int, port: int, out_path: str):
+    """Eight ranks (gloo): the shard arithmetic of BASELINE configs[3] / [4]
+    (65536 = 8 x 8192, 32768 = 8 x 4096) on the real gather path, with tiny
+    per-rank batches standing for the full ones, and an uneven total."""
+    from upkie_amd.distributed import RolloutGather, shard_range
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_distributed(world, backend="gloo")
+    ok = True
+    # the configs' own numbers: contiguous, disjoint, complete
+    for total in (65536, 32768, 65536 + 5):
+        ranges = [shard_range(r, world, total) for r in range(world)]
+        ok = ok and ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        ok = ok and max(hi - lo for lo, hi in ranges) - min(hi - lo for lo, hi in ranges) <= 1
+    ok = ok and shard_range(3, 8, 65536) == (3 * 8192, 4 * 8192) and shard_range(7, 8, 32768) == (7 * 4096, 8 * 4096)
+    # the gather: 8 ranks x 3 envs, 11 steps in chunks of 4 (a partial chunk is flushed)
+    B = 3
+    gather = RolloutGather(B, rank, world, device="cpu", horizon=16, chunk=4)
+    for step in range(11):
+        out = gather.begin_step()
+        out.copy_(record_pattern(step, rank * B, (rank + 1) * B))
+        gather.end_step()
+    gather.flush()
+    if rank == 0:
+        for step in range(11):
+            got = gather.records(step)
+            for r in range(world):
+                ok = ok and torch.equal(got[r], record_pattern(step, r * B, (r + 1) * B))
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+def test_eight_ranks_shard_arithmetic_and_gather(tmp_path):
+    out = tmp_path / "eight.txt"
+    mp.spawn(_shard_worker_8, args=(8, free_port(), str(out)), nprocs=8, join=True)
+    assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world,flags,total,per_rank,ghosts", [
+    (2, ["--envs-per-gpu", "6"], 12, 6, 0),  # weak scaling
+    (3, ["--total-envs", "16"], 16, 6, 2),  # strong scaling, 3 does not divide 16: blocks of 6, two ghost envs on the last rank
+])
+def test_bench_launch_line_on_cpu_doubles(world, flags, total, per_rank, ghosts):
+    """The driver's launch line (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W`) with bench.py's `main` running on the oracle-backed
+    double over gloo (tests/bench_double.py): one JSON line from rank 0, whole-job
+    figures, the gather text, weak and strong scaling with a remainder."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "tests", "bench_double.py"), "--gpus", str(world), "--steps", "12", "--warmup", "3",
+           "--gather-chunk", "4"] + flags
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    result = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 12 and out["warmup"] == 3
+    cfg = out["config"]
+    assert cfg["total_envs"] == total and cfg["envs_per_gpu"] == per_rank and cfg["ghost_envs"] == ghosts
+    assert out["scaling"] == ("strong" if "--total-envs" in flags else "weak")
+    assert cfg["gather"].startswith("RCCL gather") and "4-step chunk" in cfg["gather"]
+    assert out["value"] == pytest.approx(total * 12 / (out["ms_per_step"] * 1e-3 * 12), rel=1e-6)
+    assert cfg["steps_per_launch"] == 1 and out["fused_rollout"]["value"] > 0  # (the double steps its rollouts one by one)
+    assert out["cpu_baseline"] is None  # N = 1 on a GPU only
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0

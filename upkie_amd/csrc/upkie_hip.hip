@@ -1153,6 +1153,8 @@ static bool uses_lane_pairs(const UpkieSim* sim) {
   return sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
 }
 
+extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : (uses_lane_pairs(sim) ? 2 : 1); }
+
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,

@@ -207,6 +207,21 @@ class ShardedPendulum:
         # the agent's first input: the reset observation, upkie_pendulum.py:17
         self.gather.previous[:, :4] = obs6[:, [1, 0, 4, 3]]
 
+    @property
+    def lanes_per_env(self) -> int:
+        return int(getattr(self.sim, "lanes_per_env", 1))
+
+    @property
+    def fused_rollouts(self) -> bool:
+        """True when `rollout_agent(n)` is ONE launch (the multi-lane mappings of small and medium batches)."""
+        return self.lanes_per_env > 1
+
+    @property
+    def kernel_name(self) -> str:
+        lanes = self.lanes_per_env
+        return {1: "step_kernel<MODE_PENDULUM_AGENT> (one env per lane)", 2: "step_kernel_pair<MODE_PENDULUM_AGENT / _ROLLOUT> (two lanes per env)"}.get(
+            lanes, f"step kernel, {lanes} lanes per env")
+
     def step_agent(self) -> None:
         """One env.step() of every local env with the on-device linear agent;
         the records of this step travel to rank 0 while the next step runs."""

@@ -386,6 +386,11 @@ class BatchedSim:
         envs' time limit, which the kernel knows nothing about)."""
         self.state[abi.S_DONE] = done.to(self.device, torch.float32)
 
+    @property
+    def lanes_per_env(self) -> int:
+        """Lanes of a wavefront sharing one env in this handle's step kernels."""
+        return int(self._lib.upkie_sim_lanes_per_env(self._handle))
+
     def restart_random_streams(self) -> None:
         """Zero the per-env episode and noise-step counters that key the Philox
         streams: (seed, env, episode = 0) is replayed by the next reset, as
