@@ -210,6 +210,20 @@ int64_t upkie_sim_state_bytes(const UpkieSim* sim);
  * bit within one. */
 int upkie_sim_lanes_per_env(const UpkieSim* sim);
 
+/* Rare-path census of the eight-lanes-per-env step kernel (octet.hpp): `counters`
+ * is the caller's device buffer of UPKIE_CENSUS_WORDS uint32 (zeroed by the
+ * caller) or NULL to switch the census off (the default). Env-substeps:
+ *   [0] a hip / knee at its stop (handed to the general two-lane substep)
+ *   [1] (unused: one tire in the air is handled by the eight-lane substep itself)
+ *   [2] contact impulses outside the friction cone / pulling: projected
+ *       Gauss-Seidel sweeps, run inside the eight-lane substep
+ *   [3] external forces on leg links (handed to the general two-lane substep)
+ * wavefront-substeps (what the paths cost): [4] ran the general two-lane substep
+ * for at least one of their eight envs, [5] ran Gauss-Seidel sweeps for at
+ * least one. Diagnostics only: no entry point of the reference corresponds to it. */
+#define UPKIE_CENSUS_WORDS 8
+int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters);
+
 /* Optional per-env domain randomisation buffers (device pointers, may be
  * NULL): body_inertials[UPKIE_NB * UPKIE_INERTIAL_WORDS][B] replaces mass,
  * centre of mass and inertia of every composite body of every env (filled by

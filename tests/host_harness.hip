@@ -48,3 +48,104 @@ extern "C" int harness_fuse_links(const UpkieModel* model, const float* factors,
   fuse_links(L, f, records, 1);
   return L.count;
 }
+
+// ---------------------------------------------------------------------------
+// The eight-lanes-per-env substep (octet.hpp) on the host: the eight lanes of ONE
+// env run as eight threads in lockstep; every lane exchange goes through a
+// shared slot array between two barriers (oct_host_get).
+#include <atomic>
+#include <thread>
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+
+namespace {
+struct SpinBarrier {
+  std::atomic<int> count{0};
+  std::atomic<int> generation{0};
+  int parties = 8;
+  void wait() {
+    const int gen = generation.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == parties) {
+      count.store(0, std::memory_order_relaxed);
+      generation.fetch_add(1, std::memory_order_release);
+    } else {
+      while (generation.load(std::memory_order_acquire) == gen) std::this_thread::yield();
+    }
+  }
+};
+void spin_barrier_wait(void* b) { static_cast<SpinBarrier*>(b)->wait(); }
+}  // namespace
+
+// st: one env's state words (in / out), tau: six commanded torques, records: [70] or null,
+// trunk_wrench: [6] (base frame, about the base origin) or null. Runs `substeps` substeps;
+// status[i] receives OCT_CONTACT / OCT_NO_CONTACT / OCT_NOT_MINE of substep i (the
+// run stops at the first OCT_NOT_MINE, state as before that substep).
+extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
+                                     const float* trunk_wrench, int substeps, int* status) {
+  DevModel M;
+  std::string why;
+  if (!convert_model(model, &M, &why)) return -1;
+  DevLimits Lm;
+  model_limits(M, &Lm);
+  DevConfig C;
+  std::memset(&C, 0, sizeof(C));
+  SpinBarrier barrier;
+  float slots[8];
+  OctPhys result[8];
+  int lane_status[8][64];
+  std::thread threads[8];
+  if (substeps > 64) substeps = 64;
+  for (int t = 0; t < 8; ++t) {
+    threads[t] = std::thread([&, t]() {
+      OctHostLane me{t, slots, spin_barrier_wait, &barrier};
+      g_oct_lane = &me;
+      const int l = t & 3, leg = t >> 2;
+      const OctLane L = load_oct_lane(M, Lm, C, l, leg, records, 1);
+      const int joint = 3 * leg + (l > 0 ? l - 1 : 0);
+      OctPhys s;
+      s.pos = v3(st[UPKIE_S_POS], st[UPKIE_S_POS + 1], st[UPKIE_S_POS + 2]);
+      s.qw = st[UPKIE_S_QUAT]; s.qx = st[UPKIE_S_QUAT + 1]; s.qy = st[UPKIE_S_QUAT + 2]; s.qz = st[UPKIE_S_QUAT + 3];
+      s.linvel = v3(st[UPKIE_S_LINVEL], st[UPKIE_S_LINVEL + 1], st[UPKIE_S_LINVEL + 2]);
+      s.angvel = v3(st[UPKIE_S_ANGVEL], st[UPKIE_S_ANGVEL + 1], st[UPKIE_S_ANGVEL + 2]);
+      s.q = l > 0 ? st[UPKIE_S_Q + joint] : 0.f;
+      s.qd = l > 0 ? st[UPKIE_S_QD + joint] : 0.f;
+      const float own_tau = l > 0 ? tau[joint] : 0.f;
+      for (int i = 0; i < substeps; ++i) {
+        const int r = physics_substep_octet(M, Lm, L, s, own_tau, h, trunk_wrench);
+        lane_status[t][i] = r;
+        if (r == OCT_NOT_MINE) {
+          for (int k = i + 1; k < substeps; ++k) lane_status[t][k] = OCT_NOT_MINE;
+          break;
+        }
+      }
+      result[t] = s;
+      g_oct_lane = nullptr;
+    });
+  }
+  for (int t = 0; t < 8; ++t) threads[t].join();
+  // every lane holds the same base; each joint lane its own joint
+  int consistent = 1;
+  for (int t = 1; t < 8; ++t) {
+    const OctPhys &a = result[0], &b = result[t];
+    if (a.pos.x != b.pos.x || a.pos.y != b.pos.y || a.pos.z != b.pos.z || a.qw != b.qw || a.qx != b.qx || a.qy != b.qy || a.qz != b.qz ||
+        a.linvel.x != b.linvel.x || a.linvel.y != b.linvel.y || a.linvel.z != b.linvel.z || a.angvel.x != b.angvel.x ||
+        a.angvel.y != b.angvel.y || a.angvel.z != b.angvel.z)
+      consistent = 0;
+    for (int i = 0; i < substeps; ++i)
+      if (lane_status[t][i] != lane_status[0][i]) consistent = 0;
+  }
+  const OctPhys& s = result[0];
+  st[UPKIE_S_POS] = s.pos.x; st[UPKIE_S_POS + 1] = s.pos.y; st[UPKIE_S_POS + 2] = s.pos.z;
+  st[UPKIE_S_QUAT] = s.qw; st[UPKIE_S_QUAT + 1] = s.qx; st[UPKIE_S_QUAT + 2] = s.qy; st[UPKIE_S_QUAT + 3] = s.qz;
+  st[UPKIE_S_LINVEL] = s.linvel.x; st[UPKIE_S_LINVEL + 1] = s.linvel.y; st[UPKIE_S_LINVEL + 2] = s.linvel.z;
+  st[UPKIE_S_ANGVEL] = s.angvel.x; st[UPKIE_S_ANGVEL + 1] = s.angvel.y; st[UPKIE_S_ANGVEL + 2] = s.angvel.z;
+  for (int t = 0; t < 8; ++t) {
+    const int l = t & 3, leg = t >> 2;
+    if (l == 0) continue;
+    st[UPKIE_S_Q + 3 * leg + l - 1] = result[t].q;
+    st[UPKIE_S_QD + 3 * leg + l - 1] = result[t].qd;
+  }
+  for (int i = 0; i < substeps; ++i) status[i] = lane_status[0][i];
+  return consistent;
+}
+#endif  // host pass only

@@ -62,7 +62,7 @@ def check_closed_loop(worst, report):
 
 
 # ------------------------------------------------------------------ C2
-@pytest.mark.parametrize("lanes", ["0", "1"])
+@pytest.mark.parametrize("lanes", ["0", "2", "1"])
 def test_c2_rollout_kernel_4096_envs_matches_oracle(lanes, monkeypatch):
     """bench.py's workload and entry point: 20 closed-loop env.step() of 4096
     envs in ONE launch of the rollout kernel, every step's records against
@@ -203,7 +203,8 @@ def test_c5_servos_share_4096_envs_matches_oracle():
     assert dv.max() <= 0.1 and np.quantile(dv, 0.999) <= 2e-2 and np.quantile(dv, 0.5) <= 1e-4, (dv.max(), np.quantile(dv, [0.5, 0.99, 0.999]))
     dw = np.abs(sh[:, [2, 5], 1] - so[:, [2, 5], 1])
     assert dw.max() <= 2.0 and np.quantile(dw, 0.999) <= 0.2, (dw.max(), np.quantile(dw, [0.5, 0.99, 0.999]))  # wheel velocities: rim speed / 0.05 m
-    np.testing.assert_allclose(sh[:, [2, 5], 2], so[:, [2, 5], 2], atol=1e-3)  # wheel torques = clipped feedforward
+    dt = np.abs(sh[:, [2, 5], 2] - so[:, [2, 5], 2])  # wheel torques = clipped feedforward -+ 0.1 N.m of friction, whose sign switches on at |qd| = 1e-3 rad/s
+    assert dt.max() <= 0.2 + 1e-3 and (dt > 1e-3).sum() <= 4, (dt.max(), (dt > 1e-3).sum())
     assert np.abs(sh[:, [2, 5], 2]).max() <= 1.7 + 1e-6 and int(term.max()) == 0
 
 

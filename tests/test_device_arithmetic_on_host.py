@@ -230,3 +230,206 @@ def test_substep_with_external_forces_on_any_link(harness):
     pushed, pushed32 = run_both(harness, model, s, np.zeros(6), force=np.array([[0.0, 0.0, 5.0]]), slots=make_slots([5], [[0.0, 0.0, -0.1]], [False]))
     assert np.abs(pushed[19 + 3 : 19 + 5] - free[19 + 3 : 19 + 5]).max() > 1e-3  # right hip / knee accelerate
     assert np.abs(pushed[19:25] - pushed32[19:25]).max() < 2e-2
+
+
+# ---------------------------------------------------------------------------
+# Eight lanes per env (octet.hpp): the lanes of one env run as eight host
+# threads in lockstep, lane exchanges go through a slot array.
+OCT_NOT_MINE, OCT_NO_CONTACT, OCT_CONTACT = -1, 0, 1
+
+
+def run_octet(harness, model, s64, tau, h=1e-3, records=None, wrench=None, substeps=1):
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    s32 = s64.astype(np.float32)
+    t32 = np.ascontiguousarray(tau, dtype=np.float32)
+    r32 = None if records is None else np.ascontiguousarray(records, dtype=np.float32)
+    w32 = None if wrench is None else np.ascontiguousarray(wrench, dtype=np.float32)
+    status = np.zeros(64, dtype=np.int32)
+    harness.harness_substep_octet.restype = C.c_int
+    ok = harness.harness_substep_octet(C.byref(model), p(s32), p(t32), C.c_float(h), p(r32), p(w32), C.c_int(substeps), p(status))
+    assert ok == 1, "the eight lanes disagree on the base state or on the status"
+    return s32.astype(np.float64), status[:substeps]
+
+
+def one_lane(harness, model, s64, tau, h=1e-3, records=None, force=None, slots=None):
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    s32 = s64.astype(np.float32)
+    t32 = np.ascontiguousarray(tau, dtype=np.float32)
+    r32 = None if records is None else np.ascontiguousarray(records, dtype=np.float32)
+    f32 = None if force is None else np.ascontiguousarray(force, dtype=np.float32)
+    harness.harness_substep.restype = C.c_int
+    rc = harness.harness_substep(C.byref(model), p(s32), p(t32), C.c_float(h), p(r32), p(f32), C.byref(slots) if slots is not None else None)
+    assert rc >= 0
+    return s32.astype(np.float64), rc
+
+
+def settle_on_floor(model, s):
+    """Lower the base until both tires are within the contact range (zero-time oracle probe of the tire heights is not
+    exposed: use the default standing height, legs near straight)."""
+    s[abi.S_Q : abi.S_Q + 6] *= 0.2
+    s[abi.S_QUAT : abi.S_QUAT + 4] = [np.cos(0.05), 0.0, np.sin(0.05), 0.0]
+    s[abi.S_POS + 2] = 0.6
+    return s
+
+
+@pytest.mark.parametrize("on_floor", [False, True])
+def test_octet_substep_matches_one_lane_and_oracle(harness, on_floor):
+    """Same substep, reassociated over eight lanes: against the one-lane device
+    arithmetic (fp32 rounding apart) and against the fp64 oracle with the
+    tolerances of test_substep_matches_oracle."""
+    rng = np.random.default_rng(11)
+    model = default_model()
+    worst_1 = np.zeros(25)
+    worst_o = np.zeros(25)
+    mine = 0
+    for _ in range(150):
+        s = random_state(rng, on_floor)
+        tau = rng.uniform(-1.5, 1.5, 6)
+        s8, status = run_octet(harness, model, s, tau)
+        s1, contact = one_lane(harness, model, s, tau)
+        so, _ = run_both(harness, model, s, tau)
+        if status[0] == OCT_NOT_MINE:
+            assert np.array_equal(s8[:25], s.astype(np.float32).astype(np.float64)[:25])  # state untouched
+            continue
+        mine += 1
+        assert (status[0] == OCT_CONTACT) == bool(contact)
+        worst_1 = np.maximum(worst_1, np.abs(s8[:25] - s1[:25]))
+        worst_o = np.maximum(worst_o, np.abs(s8[:25] - so[:25]))
+    assert mine > (100 if not on_floor else 15), mine  # (random states on the floor: often one tire only, or slipping)
+    assert worst_o[0:3].max() < 5e-7 and worst_o[3:7].max() < 5e-7
+    assert worst_o[7:10].max() < 2e-4 and worst_o[10:13].max() < 1e-3
+    assert worst_o[13:19].max() < 1e-6 and worst_o[19:25].max() < 2e-2
+    # the two device mappings agree more closely than either does with fp64
+    assert worst_1[0:7].max() < 5e-7 and worst_1[7:10].max() < 2e-4 and worst_1[10:13].max() < 1e-3
+    assert worst_1[13:19].max() < 1e-6 and worst_1[19:25].max() < 2e-2
+
+
+def test_octet_standing_robot_takes_the_fast_path(harness):
+    """A robot standing on both tires, legs held by the servos' PD law, wheels
+    driven by a balancing feedback: once it has landed every substep is the
+    eight-lane path's (contact, admissible solution), and 100 substeps of the
+    closed loop track the one-lane arithmetic."""
+    rng = np.random.default_rng(12)
+    model = default_model()
+
+    def torques(s):
+        tau = np.zeros(6)
+        for j in (0, 1, 3, 4):
+            tau[j] = np.clip(20.0 * (0.0 - s[abi.S_Q + j]) - 1.0 * s[abi.S_QD + j], -16.0, 16.0)
+        pitch = 2.0 * s[abi.S_QUAT + 2]
+        v = (10.0 * pitch) / 0.05  # wheel velocity target of the README agent
+        tau[2] = np.clip(1.0 * (v - s[abi.S_QD + 2]), -1.7, 1.7)
+        tau[5] = np.clip(1.0 * (-v - s[abi.S_QD + 5]), -1.7, 1.7)
+        return tau
+
+    fast = 0
+    for _ in range(4):
+        s = np.zeros(abi.STATE_WORDS)
+        pitch = rng.uniform(-0.03, 0.03)
+        s[abi.S_QUAT] = np.cos(pitch / 2)
+        s[abi.S_QUAT + 2] = np.sin(pitch / 2)
+        s[abi.S_POS + 2] = 0.6
+        for _ in range(300):  # land and settle (one-lane arithmetic)
+            s, _ = one_lane(harness, model, s, torques(s))
+        s8, s1 = s.copy(), s.copy()
+        for _ in range(100):
+            nxt, status = run_octet(harness, model, s8, torques(s8))
+            if status[0] == OCT_NOT_MINE:
+                nxt, _ = one_lane(harness, model, s8, torques(s8))
+            else:
+                assert status[0] == OCT_CONTACT
+                fast += 1
+            s8 = nxt
+            s1, contact = one_lane(harness, model, s1, torques(s1))
+            assert contact
+        assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-6
+        assert np.abs(s8[7:13] - s1[7:13]).max() < 5e-3
+        assert np.abs(s8[13:19] - s1[13:19]).max() < 2e-4
+    assert fast >= 390, fast
+
+
+def test_octet_per_env_inertials_and_trunk_wrench(harness):
+    rng = np.random.default_rng(13)
+    model = default_model()
+    checked = 0
+    for trial in range(40):
+        s = random_state(rng, trial % 2 == 0)
+        rec = records_of_model(model, rng.uniform(0.8, 1.2, 7))
+        for b in range(abi.NB):
+            if b in (3, 6):
+                rec[10 * b + 2] += rng.uniform(-0.01, 0.01)
+                continue
+            rec[10 * b + 1 : 10 * b + 4] += rng.uniform(-0.01, 0.01, 3)
+            rec[10 * b + 7 : 10 * b + 10] += rng.uniform(-0.1, 0.1, 3) * rec[10 * b + 4 : 10 * b + 7].min()
+        force = rng.uniform(-20, 20, 3)  # base frame (a "local" force on the trunk)
+        point = np.array([0.02, -0.01, -0.1])
+        wrench = np.concatenate([force, np.cross(point, force)])
+        tau = rng.uniform(-1, 1, 6)
+        s8, status = run_octet(harness, model, s, tau, records=rec, wrench=wrench)
+        if status[0] == OCT_NOT_MINE:
+            continue
+        s1, _ = one_lane(harness, model, s, tau, records=rec, force=force.reshape(1, 3), slots=make_slots([0], [point], [True]))
+        checked += 1
+        assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-7
+        assert np.abs(s8[7:10] - s1[7:10]).max() < 2e-4 and np.abs(s8[10:13] - s1[10:13]).max() < 1e-3
+        assert np.abs(s8[19:25] - s1[19:25]).max() < 2e-2
+    assert checked > 15
+
+
+def test_octet_rare_cases(harness):
+    """A joint at its stop: OCT_NOT_MINE with the state untouched (the caller
+    runs the two-lane substep). One tire in the air while the other touches
+    (identity rows for the missing tire) and contact impulses outside the
+    friction cone (projected Gauss-Seidel sweeps, contact_pgs6 on the gathered
+    system) stay inside the eight-lane substep: against the one-lane arithmetic."""
+    rng = np.random.default_rng(14)
+    model = default_model()
+    model.enforce_joint_limits = 1
+    s = random_state(rng, False)
+    s[abi.S_Q + 1] = 2.52  # left knee beyond its stop
+    s8, status = run_octet(harness, model, s, np.zeros(6))
+    assert status[0] == OCT_NOT_MINE and np.array_equal(s8, s.astype(np.float32).astype(np.float64))
+    model.enforce_joint_limits = 0
+    one_tire = 0
+    for roll in (0.2, 0.3, -0.3):
+        s = np.zeros(abi.STATE_WORDS)
+        s[abi.S_QUAT] = np.cos(roll / 2)
+        s[abi.S_QUAT + 1] = np.sin(roll / 2)
+        s[abi.S_POS + 2] = 0.66
+        for _ in range(200):  # falls onto one tire
+            nxt, contact = one_lane(harness, model, s, np.zeros(6))
+            if contact:
+                break
+            s = nxt
+        assert contact
+        s1, _ = one_lane(harness, model, s, np.zeros(6))
+        s8, status = run_octet(harness, model, s, np.zeros(6))
+        assert status[0] == OCT_CONTACT
+        one_tire += 1
+        assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-7 and np.abs(s8[7:13] - s1[7:13]).max() < 1e-3
+        assert np.abs(s8[19:25] - s1[19:25]).max() < 2e-2
+    assert one_tire == 3
+    # saturated wheel torques on a standing robot: the tires slip (friction cone active)
+    s = np.zeros(abi.STATE_WORDS)
+    s[abi.S_QUAT] = 1.0
+    s[abi.S_POS + 2] = 0.6
+
+    def hold(s, wheel):
+        tau = np.zeros(6)
+        for j in (0, 1, 3, 4):
+            tau[j] = np.clip(20.0 * (0.0 - s[abi.S_Q + j]) - 1.0 * s[abi.S_QD + j], -16.0, 16.0)
+        tau[2], tau[5] = wheel, -wheel
+        return tau
+
+    for _ in range(300):
+        s, _ = one_lane(harness, model, s, hold(s, 0.0))
+    model.friction_mu = 0.2  # 1.7 N.m / 0.05 m = 34 N at the rim against 0.2 x 26 N of grip
+    worst = np.zeros(25)
+    s1, s8 = s.copy(), s.copy()
+    for _ in range(20):
+        s1, contact = one_lane(harness, model, s1, hold(s1, 1.7))
+        s8, status = run_octet(harness, model, s8, hold(s8, 1.7))
+        assert contact and status[0] == OCT_CONTACT
+        worst = np.maximum(worst, np.abs(s8[:25] - s1[:25]))
+    assert abs(s1[abi.S_QD + 2]) > 20.0  # the wheels do spin up: the cone was active
+    assert worst[0:7].max() < 2e-6 and worst[7:13].max() < 5e-3 and worst[13:19].max() < 1e-4

@@ -236,7 +236,7 @@ def test_graph_captured_loop_equals_eager():
     assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs4, graphed.obs4)
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 @pytest.mark.parametrize("env_id,limit", [("Upkie-HIP-Pendulum-Vec", None), ("Upkie-HIP-Gyropod-Vec", 25), ("Upkie-HIP-Servos-Vec", 12)])
 def test_same_step_autoreset_is_one_launch_and_matches_the_double(env_id, limit, lanes, monkeypatch):
     """SAME_STEP autoreset through upkie_sim_autoreset_done (the reset branch

@@ -457,12 +457,13 @@ def test_sharded_pendulum_single_rank_rollout():
     env.shutdown()
 
 
+@pytest.mark.parametrize("wide", ["2", "8"])
 @pytest.mark.parametrize("mode", ["servos", "gyropod"])
-def test_two_lanes_per_env_equals_one_lane_per_env(mode, monkeypatch):
-    """The pair mapping (one leg per lane, DPP exchanges) and the one-lane
-    mapping are two schedules of the same arithmetic: same results up to fp32
-    summation order, with inertia randomisation, pushes, noise and joint
-    limits all active."""
+def test_two_lanes_per_env_equals_one_lane_per_env(mode, wide, monkeypatch):
+    """The pair mapping (one leg per lane, DPP exchanges), the eight-lane
+    mapping (one body per lane) and the one-lane mapping are schedules of the
+    same arithmetic: same results up to fp32 summation order, with inertia
+    randomisation, pushes, noise and joint limits all active."""
     from upkie_amd.sim import BatchedSim
 
     cfg = randomized_config(333, seed=17, autoreset=True)  # odd size: a half-filled last wave
@@ -472,9 +473,10 @@ def test_two_lanes_per_env_equals_one_lane_per_env(mode, monkeypatch):
         cfg.joint_friction[j] = 0.05
     cfg.torque_measurement_noise[4] = 0.03
     sims = []
-    for lanes in ("1", "2"):
+    for lanes in ("1", wide):
         monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
         sim = BatchedSim(cfg)
+        assert sim.lanes_per_env == int(lanes)
         sim.randomize_inertias(0.2)
         force = torch.zeros(3, 333)
         force[0] = torch.linspace(-8, 8, 333)
@@ -508,7 +510,7 @@ def test_two_lanes_per_env_equals_one_lane_per_env(mode, monkeypatch):
         assert_mostly_close(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-2, fraction=0.9)
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 def test_external_forces_on_any_link_match_oracle(lanes, monkeypatch):
     """Four simultaneous forces (pybullet_backend.py:603-658): world-frame on
     the trunk, link-frame on a calf, world-frame on the other leg's thigh and
@@ -558,7 +560,7 @@ def test_external_forces_on_any_link_match_oracle(lanes, monkeypatch):
     assert state_errors(oracle.state, sim.state_numpy())["pos"] < 3e-5
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 def test_joint_limit_on_one_leg_only(lanes, monkeypatch):
     """Asymmetric joint stops: only the RIGHT knee is driven into its stop (the
     left leg is held). In the two-lanes-per-env mapping the lane owning the left
@@ -591,7 +593,7 @@ def test_joint_limit_on_one_leg_only(lanes, monkeypatch):
     assert np.abs(oracle.state[legs] - s[legs]).max() < 2e-3 and err["pos"] < 1e-3 and err["q"] < 2e-2, err
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 def test_collapse_with_limp_joints_stays_finite(lanes, monkeypatch):
     """Every servo limp (no position feedback, zero damping gain): the robots
     fall, fold into hip and knee stops on one side or both and roll on their
@@ -761,7 +763,7 @@ def test_contact_points_in_the_air_and_on_one_wheel():
     assert sim.get_contact_points("torso", env=B - 1) == []
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 def test_per_link_inertia_randomisation_on_the_urdf_model(lanes, monkeypatch):
     """randomize_inertias on the URDF-derived model (13 links behind 7 bodies,
     pybullet_backend.py:555-601): link factors and fused body records equal the
@@ -797,7 +799,7 @@ def test_per_link_inertia_randomisation_on_the_urdf_model(lanes, monkeypatch):
     assert float((obs_p - obs_h).abs().max()) > 1e-3
 
 
-@pytest.mark.parametrize("lanes", ["1", "2"])
+@pytest.mark.parametrize("lanes", ["1", "2", "8"])
 def test_time_limit_in_the_kernel_matches_oracle(lanes, monkeypatch):
     """UpkieSimConfig.max_episode_steps (gymnasium's TimeLimit for the batch):
     `truncated` on the step that reaches the limit unless the robot fell in it,
@@ -833,7 +835,7 @@ def test_time_limit_in_the_kernel_matches_oracle(lanes, monkeypatch):
     assert sim.state_numpy()[abi.S_ELAPSED].max() <= 7
 
 
-@pytest.mark.parametrize("lanes", ["2", "1"])
+@pytest.mark.parametrize("lanes", ["8", "2", "1"])
 def test_rollout_in_one_launch_equals_step_by_step(lanes, monkeypatch):
     """upkie_sim_step_pendulum_agent_rollout: K fused-agent steps in one launch
     (two lanes per env: state carried in registers; one lane per env: K

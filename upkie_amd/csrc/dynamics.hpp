@@ -131,8 +131,35 @@ enum LegTableWord {
   LT_WORDS = 64
 };
 
+// Per-lane constants of the eight-lanes-per-env kernel (octet.hpp), one row per
+// (leg, lane of the quad): the lane's body and joint, and the 0 / 1 weights
+// that stand for its role.
+enum OctTableWord {
+  OT_MASS = 0,      // (the right quad's trunk lane: 0)
+  OT_COM = 1,       // 3
+  OT_INERTIA = 4,   // 6 (the right quad's trunk lane: 0)
+  OT_POS = 10,      // 3 joint origin in the parent's frame (trunk: 0)
+  OT_SIGN = 13,     // (trunk: 0)
+  OT_DAMPING = 14,
+  OT_LOWER = 15,
+  OT_UPPER = 16,
+  OT_BOUNDED = 17,  // 0.f / 1.f
+  OT_EFFORT = 18,
+  OT_VELOCITY = 19,
+  OT_WHEEL_CENTER = 20,  // 3
+  OT_WJ = 23,       // 1 on the joint lanes
+  OT_E = 24,        // 3: one-hot of the joint index
+  OT_W0 = 27,       // 1 on the trunk lane
+  OT_W0_ONCE = 28,  // 1 on the left quad's trunk lane
+  OT_KEEP_PSI = 29, // 0 on the wheel lane of an axisymmetric wheel
+  OT_KL = 30,       // base damping on the lane that owns the real trunk
+  OT_KA = 31,
+  OT_WORDS = 32
+};
+
 struct DevModel {
   alignas(16) float leg_table[2][LT_WORDS];
+  alignas(16) float oct_table[8][OT_WORDS];
   float mass[UPKIE_NB];
   float com[UPKIE_NB][3];
   float inertia[UPKIE_NB][6];
@@ -511,6 +538,59 @@ UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, flo
   l2 = fminf(fmaxf(0.5f * (s_new + d), -lim2), lim2);
   l5 = fminf(fmaxf(0.5f * (s_new - d), -lim5), lim5);
   return fabsf((l2 + l5) - s_old);
+}
+
+// Projected Gauss-Seidel on the 6 x 6 contact system of the two tires (rows 0-2
+// left: normal, rolling, lateral; rows 3-5 right), shared by every lane
+// mapping. A packed lower by rows, `lam` comes in as the projected direct
+// solution (the warm start). Normals of both wheels first, then the rolling
+// rows, then the lateral ones -- together (lateral_pair_sweep) when both tires
+// touch. Each env stops on its own criterion: lanes leave the loop one by one.
+template <class ModelT>
+UPKIE_HD void contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+  const float mu = M.friction_mu;
+  float idiag[6];
+  idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
+  idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+  for (int it = 0; it < M.pgs_iterations; ++it) {
+    float change = 0.f, scale = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const bool is_normal = (r % 3) == 0;
+        if (is_normal != (pass == 0) || ((r % 3) == 2 && pair)) continue;
+        float al = 0.f;  // (W + CFM) lam, row r
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          const int hi = r > b ? r : b, lo = r > b ? b : r;
+          al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
+        }
+        float x = lam[r] + (rhs[r] - al) * idiag[r];
+        if (is_normal) {
+          x = fmaxf(x, 0.f);
+        } else {
+          const float lim = mu * lam[3 * (r / 3)];
+          x = fminf(fmaxf(x, -lim), lim);
+        }
+        change = fmaxf(change, fabsf(x - lam[r]));
+        scale = fmaxf(scale, fabsf(x));
+        lam[r] = x;
+      }
+    }
+    if (pair) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
+      float r2 = rhs[2], r5 = rhs[5];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        if (b == 2 || b == 5) continue;
+        r2 -= A[(b > 2 ? b * (b + 1) / 2 + 2 : 2 * 3 / 2 + b)] * lam[b];
+        r5 -= A[5 * 6 / 2 + b] * lam[b];
+      }
+      change = fmaxf(change, lateral_pair_sweep(A[5], A[17], A[20], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
+      scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
+    }
+    if (change <= M.pgs_tolerance * scale) break;
+  }
 }
 
 // Rare path shared by both lane mappings: some hip/knee joint sits at its
@@ -1270,53 +1350,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
         if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
       }
     }
-    if (need_pgs) {
-      float idiag[6];
-      idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
-      idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
-      const bool pair = active[0] && active[1];  // both tires touch: their lateral rows are swept together
-      for (int it = 0; it < M.pgs_iterations; ++it) {
-        float change = 0.f, scale = 0.f;
-        // normals of both wheels first, then friction rows
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const bool is_normal = (r % 3) == 0;
-            if (is_normal != (pass == 0) || ((r % 3) == 2 && pair)) continue;
-            float al = 0.f;  // (W + CFM) lam, row r
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              const int hi = r > b ? r : b, lo = r > b ? b : r;
-              al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
-            }
-            float x = lam[r] + (rhs[r] - al) * idiag[r];
-            if (is_normal) {
-              x = fmaxf(x, 0.f);
-            } else {
-              const float lim = mu * lam[3 * (r / 3)];
-              x = fminf(fmaxf(x, -lim), lim);
-            }
-            change = fmaxf(change, fabsf(x - lam[r]));
-            scale = fmaxf(scale, fabsf(x));
-            lam[r] = x;
-          }
-        }
-        if (pair) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
-          float r2 = rhs[2], r5 = rhs[5];
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            if (b == 2 || b == 5) continue;
-            r2 -= A[sym(2, b)] * lam[b];
-            r5 -= A[sym(5, b)] * lam[b];
-          }
-          change = fmaxf(change, lateral_pair_sweep(A[sym(2, 2)], A[sym(5, 2)], A[sym(5, 5)], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
-          scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
-        }
-        // each env stops on its own criterion: lanes leave the loop one by one
-        if (change <= M.pgs_tolerance * scale) break;
-      }
-    }
+    if (need_pgs) contact_pgs6(M, A, rhs, lam, active[0] && active[1]);
     // t += J' lam
 #pragma unroll
     for (int c = 0; c < 6; ++c) {

@@ -1,0 +1,1268 @@
+// octet.hpp -- eight lanes per env: one quad of lanes per leg, one lane per body.
+//
+// At 4096 envs the two-lane kernel (pair.hpp) fills 128 of the chip's 1024
+// SIMDs and the launch lasts as long as one wave's instruction stream
+// (~11 k instructions per env.step()). Here an env owns two quads of a row of
+// 16 lanes (quads q and q + 2: the row holds two envs), one quad per leg:
+//
+//     lane of the quad   0            1      2      3
+//     body               trunk        thigh  calf   wheel
+//     joint              -            hip    knee   wheel
+//     contact row        (free vel.)  normal rolling lateral
+//
+// so that everything the reference does "per body", "per joint" and "per
+// contact row" is ONE instruction stream executed by four lanes side by side,
+// and the quantities a lane needs from its neighbours arrive through DPP
+// (quad_perm inside the quad, row_ror:8 between the legs), mostly folded into
+// the consuming multiply-add (v_fmac_f32_dpp). The real trunk lives in the left
+// quad's lane 0; the right quad's lane 0 carries a massless copy, so sums over
+// the eight lanes count it once. Nothing is staged through LDS.
+//
+// The algebra is that of physics_substep() (dynamics.hpp), reassociated:
+//   * kinematics and the Newton-Euler pass: chain quantities (cumulative joint
+//     angle, joint origins, joint-rate sums, origin accelerations) are prefix
+//     sums over the quad; the per-body wrench and inertia are lane-local;
+//   * composite inertias / wrenches of the subtrees: suffix sums over the quad;
+//   * the 3x3 leg block: rows by lane, Cholesky factor in every lane, one
+//     column of its inverse per lane; D = F Hinv one column per lane;
+//   * the 6x6 base block A = Mbb - sum D F': every lane adds its own body's
+//     spatial inertia minus its own column's outer product, one 8-lane sum per
+//     entry; LDL' in every lane (the structural zeros of a planar leg, F_y = 0,
+//     are skipped);
+//   * seven solves with A at once: the six contact rows (lanes 1-3 of both
+//     quads) and the free velocity A^-1 rt (lane 0);
+//   * the 6x6 contact system: one column per lane, solved by block elimination
+//     (each quad eliminates its own tire's 3x3 block by Gauss-Jordan across its
+//     lanes, the Schur complement couples the tires through one exchange);
+//   * nu+ = A^-1 rt + sum lam_b Y_b: the final solve is a weighted 8-lane sum.
+// Whatever is rare (a joint at its stop, a tire off the floor while the other
+// one touches, a contact solution outside its friction cone, forces on leg
+// links) is NOT restated here: the substep reports "not mine" before touching
+// the state and the caller runs physics_substep_pair on the same lanes
+// (LanesEightApart), every lane of a quad on identical data.
+//
+// Host build (tests/host_harness.hip): the same code, the eight lanes of one env
+// run as eight threads in lockstep and every exchange goes through a shared
+// slot array between two barriers.
+//
+// Included by upkie_hip.hip inside namespace upkie, after pair.hpp.
+#pragma once
+
+// ---------------------------------------------------------------- lane exchange
+#if !defined(__HIP_DEVICE_COMPILE__)
+struct OctHostLane {
+  int lane;      // 4 * leg + lane of the quad
+  float* slots;  // [8], shared by the env's threads
+  void (*barrier)(void*);
+  void* arg;
+};
+inline thread_local OctHostLane* g_oct_lane = nullptr;
+inline float oct_host_get(float x, int src) {
+  OctHostLane* L = g_oct_lane;
+  L->slots[L->lane] = x;
+  L->barrier(L->arg);
+  const float r = L->slots[src];
+  L->barrier(L->arg);
+  return r;
+}
+#endif
+
+// value of lane sel[l] of the own quad
+template <int S0, int S1, int S2, int S3>
+UPKIE_HD float oct_qperm(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xF, 0xF, true));
+#else
+  const int sel[4] = {S0, S1, S2, S3};
+  const int lane = g_oct_lane->lane;
+  return oct_host_get(x, (lane & 4) | sel[lane & 3]);
+#endif
+}
+template <int K>
+UPKIE_HD float oct_qb(float x) { return oct_qperm<K, K, K, K>(x); }
+// the parent's / grandparent's value along the chain trunk -> thigh -> calf -> wheel (the trunk reads itself)
+UPKIE_HD float oct_up1(float x) { return oct_qperm<0, 0, 1, 2>(x); }
+UPKIE_HD float oct_up2(float x) { return oct_qperm<0, 0, 0, 1>(x); }
+// same lane of the other leg's quad
+UPKIE_HD float oct_swp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));  // row_ror:8
+#else
+  return oct_host_get(x, g_oct_lane->lane ^ 4);
+#endif
+}
+// sum over the quad / over the env's eight lanes, in every lane
+UPKIE_HD float oct_qsum(float x) {
+#pragma clang fp contract(off)  // keep x + dpp(x) one v_add_f32_dpp (a contracted multiply-add costs a separate DPP move)
+  x += oct_qperm<1, 0, 3, 2>(x);
+  x += oct_qperm<2, 3, 0, 1>(x);
+  return x;
+}
+UPKIE_HD float oct_esum(float x) {
+#pragma clang fp contract(off)  // keep x + dpp(x) one v_add_f32_dpp (a contracted multiply-add costs a separate DPP move)
+  x = oct_qsum(x);
+  return x + oct_swp(x);
+}
+template <int N>
+UPKIE_HD void oct_esum(float (&x)[N]) {  // step by step over all values: independent chains between dependent DPP reads
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] += oct_qperm<1, 0, 3, 2>(x[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] += oct_qperm<2, 3, 0, 1>(x[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] += oct_swp(x[i]);
+}
+UPKIE_HD bool oct_env_any(bool b) { return oct_esum(b ? 1.f : 0.f) != 0.f; }
+// some lane of the wavefront (device) / of the env (host): a uniform branch guards the rare paths
+UPKIE_HD bool oct_wave_any(bool b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(b) != 0;
+#else
+  return oct_env_any(b);
+#endif
+}
+// inclusive prefix sum along the chain; the trunk lane's value must be 0
+UPKIE_HD float oct_chain(float x) {
+#pragma clang fp contract(off)  // keep x + dpp(x) one v_add_f32_dpp (a contracted multiply-add costs a separate DPP move)
+  x += oct_up1(x);
+  x += oct_up2(x);
+  return x;
+}
+// sum over the subtree of the own joint (lanes >= own, own >= 1) of a value that is 0 on the trunk lane
+UPKIE_HD float oct_subtree(float xm) {
+#pragma clang fp contract(off)  // keep x + dpp(x) one v_add_f32_dpp (a contracted multiply-add costs a separate DPP move)
+  const float s1 = xm + oct_qperm<1, 2, 3, 0>(xm);
+  return s1 + oct_qperm<0, 3, 0, 0>(xm);
+}
+
+// Multiply-accumulate blocks with the broadcast folded into the instruction
+// (v_fmac_f32_dpp: hipcc fuses DPP moves into adds and multiplies but not into
+// fused multiply-adds). The block opens with the two wait states a DPP read of
+// a freshly written VGPR needs; inside it only the accumulator is written.
+#define OCT_Q(k) " quad_perm:[" #k "," #k "," #k "," #k "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// init + qb<1>(x) y1 + qb<2>(x) y2 + qb<3>(x) y3: x as held by the three joint lanes
+UPKIE_HD float oct_sumj(float init, float x, float y1, float y2, float y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %1, %2" OCT_Q(1) "v_fmac_f32_dpp %0, %1, %3" OCT_Q(2) "v_fmac_f32_dpp %0, %1, %4" OCT_Q(3)
+      : "+v"(init)
+      : "v"(x), "v"(y1), "v"(y2), "v"(y3));
+  return init;
+#else
+  return fmaf(oct_qb<3>(x), y3, fmaf(oct_qb<2>(x), y2, fmaf(oct_qb<1>(x), y1, init)));
+#endif
+}
+UPKIE_HD float oct_sumj_neg(float init, float x, float y1, float y2, float y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, -%1, %2" OCT_Q(1) "v_fmac_f32_dpp %0, -%1, %3" OCT_Q(2) "v_fmac_f32_dpp %0, -%1, %4" OCT_Q(3)
+      : "+v"(init)
+      : "v"(x), "v"(y1), "v"(y2), "v"(y3));
+  return init;
+#else
+  return fmaf(-oct_qb<3>(x), y3, fmaf(-oct_qb<2>(x), y2, fmaf(-oct_qb<1>(x), y1, init)));
+#endif
+}
+// the same for five registers at once (one wait, fifteen multiply-adds): acc[i] -= sum_j qb<j>(x[i]) y_j
+UPKIE_HD void oct_sumj_neg5(float (&acc)[5], const float (&x)[5], float y1, float y2, float y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, -%5, %10" OCT_Q(1) "v_fmac_f32_dpp %1, -%6, %10" OCT_Q(1) "v_fmac_f32_dpp %2, -%7, %10" OCT_Q(1)
+      "v_fmac_f32_dpp %3, -%8, %10" OCT_Q(1) "v_fmac_f32_dpp %4, -%9, %10" OCT_Q(1)
+      "v_fmac_f32_dpp %0, -%5, %11" OCT_Q(2) "v_fmac_f32_dpp %1, -%6, %11" OCT_Q(2) "v_fmac_f32_dpp %2, -%7, %11" OCT_Q(2)
+      "v_fmac_f32_dpp %3, -%8, %11" OCT_Q(2) "v_fmac_f32_dpp %4, -%9, %11" OCT_Q(2)
+      "v_fmac_f32_dpp %0, -%5, %12" OCT_Q(3) "v_fmac_f32_dpp %1, -%6, %12" OCT_Q(3) "v_fmac_f32_dpp %2, -%7, %12" OCT_Q(3)
+      "v_fmac_f32_dpp %3, -%8, %12" OCT_Q(3) "v_fmac_f32_dpp %4, -%9, %12" OCT_Q(3)
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(y1), "v"(y2), "v"(y3));
+#else
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = fmaf(-oct_qb<3>(x[i]), y3, fmaf(-oct_qb<2>(x[i]), y2, fmaf(-oct_qb<1>(x[i]), y1, acc[i])));
+#endif
+}
+// init + sum_i qb<K>(x[i]) y[i]: a vector held by lane K of the quad against an own vector
+template <int K>
+UPKIE_HD float oct_dot3(float init, float x0, float x1, float x2, float y0, float y1, float y2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %1, %4 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %2, %5 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %3, %6 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(init)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2), "i"(K));
+  return init;
+#else
+  return fmaf(oct_qb<K>(x2), y2, fmaf(oct_qb<K>(x1), y1, fmaf(oct_qb<K>(x0), y0, init)));
+#endif
+}
+template <int K>
+UPKIE_HD float oct_dot3_neg(float init, float x0, float x1, float x2, float y0, float y1, float y2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, -%1, %4 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, -%2, %5 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, -%3, %6 quad_perm:[%7,%7,%7,%7] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(init)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2), "i"(K));
+  return init;
+#else
+  return fmaf(-oct_qb<K>(x2), y2, fmaf(-oct_qb<K>(x1), y1, fmaf(-oct_qb<K>(x0), y0, init)));
+#endif
+}
+template <int K>
+UPKIE_HD float oct_dot6(float init, const float (&x)[6], const float (&y)[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %1, %7 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %2, %8 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %3, %9 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %4, %10 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %5, %11 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %6, %12 quad_perm:[%13,%13,%13,%13] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(init)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]),
+        "v"(y[5]), "i"(K));
+  return init;
+#else
+  float acc = init;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc = fmaf(oct_qb<K>(x[i]), y[i], acc);
+  return acc;
+#endif
+}
+
+// h_k = qb<k>(x0) y0 + qb<k>(x1) y1 + qb<k>(x2) y2 for k = 1, 2, 3: the own vector against the three joint lanes' vectors
+UPKIE_HD void oct_dot3_all(float x0, float x1, float x2, float y0, float y1, float y2, float& h1, float& h2, float& h3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %3, %6" OCT_Q(1) "v_mul_f32_dpp %1, %3, %6" OCT_Q(2) "v_mul_f32_dpp %2, %3, %6" OCT_Q(3)
+      "v_fmac_f32_dpp %0, %4, %7" OCT_Q(1) "v_fmac_f32_dpp %1, %4, %7" OCT_Q(2) "v_fmac_f32_dpp %2, %4, %7" OCT_Q(3)
+      "v_fmac_f32_dpp %0, %5, %8" OCT_Q(1) "v_fmac_f32_dpp %1, %5, %8" OCT_Q(2) "v_fmac_f32_dpp %2, %5, %8" OCT_Q(3)
+      : "=&v"(h1), "=&v"(h2), "=&v"(h3)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2));
+#else
+  h1 = fmaf(oct_qb<1>(x2), y2, fmaf(oct_qb<1>(x1), y1, oct_qb<1>(x0) * y0));
+  h2 = fmaf(oct_qb<2>(x2), y2, fmaf(oct_qb<2>(x1), y1, oct_qb<2>(x0) * y0));
+  h3 = fmaf(oct_qb<3>(x2), y2, fmaf(oct_qb<3>(x1), y1, oct_qb<3>(x0) * y0));
+#endif
+}
+// out[i] = sum_j qb<j>(x[i]) y_j for five registers (one wait, fifteen instructions)
+UPKIE_HD void oct_sumj5(float (&out)[5], const float (&x)[5], float y1, float y2, float y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %5, %10" OCT_Q(1) "v_mul_f32_dpp %1, %6, %10" OCT_Q(1) "v_mul_f32_dpp %2, %7, %10" OCT_Q(1)
+      "v_mul_f32_dpp %3, %8, %10" OCT_Q(1) "v_mul_f32_dpp %4, %9, %10" OCT_Q(1)
+      "v_fmac_f32_dpp %0, %5, %11" OCT_Q(2) "v_fmac_f32_dpp %1, %6, %11" OCT_Q(2) "v_fmac_f32_dpp %2, %7, %11" OCT_Q(2)
+      "v_fmac_f32_dpp %3, %8, %11" OCT_Q(2) "v_fmac_f32_dpp %4, %9, %11" OCT_Q(2)
+      "v_fmac_f32_dpp %0, %5, %12" OCT_Q(3) "v_fmac_f32_dpp %1, %6, %12" OCT_Q(3) "v_fmac_f32_dpp %2, %7, %12" OCT_Q(3)
+      "v_fmac_f32_dpp %3, %8, %12" OCT_Q(3) "v_fmac_f32_dpp %4, %9, %12" OCT_Q(3)
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(y1), "v"(y2), "v"(y3));
+#else
+#pragma unroll
+  for (int i = 0; i < 5; ++i) out[i] = fmaf(oct_qb<3>(x[i]), y3, fmaf(oct_qb<2>(x[i]), y2, oct_qb<1>(x[i]) * y1));
+#endif
+}
+// out[a - 1] = sum_i qb<a>(x[i]) y[i] (+ sum_j qb<a>(u[j]) v[j]) for a = 1, 2, 3: a six-vector (and a three-vector)
+// held by each joint lane against own ones -- a 3-row slice of the contact matrix in one block
+#define OCT_ROW6(o, k) \
+  "v_mul_f32_dpp " o ", %3, %9" OCT_Q(k) "v_fmac_f32_dpp " o ", %4, %10" OCT_Q(k) "v_fmac_f32_dpp " o ", %5, %11" OCT_Q(k) \
+  "v_fmac_f32_dpp " o ", %6, %12" OCT_Q(k) "v_fmac_f32_dpp " o ", %7, %13" OCT_Q(k) "v_fmac_f32_dpp " o ", %8, %14" OCT_Q(k)
+#define OCT_ROW3(o, k) "v_fmac_f32_dpp " o ", %15, %18" OCT_Q(k) "v_fmac_f32_dpp " o ", %16, %19" OCT_Q(k) "v_fmac_f32_dpp " o ", %17, %20" OCT_Q(k)
+UPKIE_HD void oct_rows6(float (&out)[3], const float (&x)[6], const float (&y)[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t" OCT_ROW6("%0", 1) OCT_ROW6("%1", 2) OCT_ROW6("%2", 3)
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
+#else
+  out[0] = oct_dot6<1>(0.f, x, y);
+  out[1] = oct_dot6<2>(0.f, x, y);
+  out[2] = oct_dot6<3>(0.f, x, y);
+#endif
+}
+UPKIE_HD void oct_rows9(float (&out)[3], const float (&x)[6], const float (&y)[6], const float (&u)[3], const float (&v)[3]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t" OCT_ROW6("%0", 1) OCT_ROW3("%0", 1) OCT_ROW6("%1", 2) OCT_ROW3("%1", 2) OCT_ROW6("%2", 3) OCT_ROW3("%2", 3)
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]),
+        "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(v[0]), "v"(v[1]), "v"(v[2]));
+#else
+  out[0] = oct_dot3<1>(oct_dot6<1>(0.f, x, y), u[0], u[1], u[2], v[0], v[1], v[2]);
+  out[1] = oct_dot3<2>(oct_dot6<2>(0.f, x, y), u[0], u[1], u[2], v[0], v[1], v[2]);
+  out[2] = oct_dot3<3>(oct_dot6<3>(0.f, x, y), u[0], u[1], u[2], v[0], v[1], v[2]);
+#endif
+}
+// acc[i] -= sum_k qb<k>(x[i]) y_k for four registers
+UPKIE_HD void oct_sumj_neg4(float (&acc)[4], const float (&x)[4], float y1, float y2, float y3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, -%4, %8" OCT_Q(1) "v_fmac_f32_dpp %1, -%5, %8" OCT_Q(1) "v_fmac_f32_dpp %2, -%6, %8" OCT_Q(1) "v_fmac_f32_dpp %3, -%7, %8" OCT_Q(1)
+      "v_fmac_f32_dpp %0, -%4, %9" OCT_Q(2) "v_fmac_f32_dpp %1, -%5, %9" OCT_Q(2) "v_fmac_f32_dpp %2, -%6, %9" OCT_Q(2) "v_fmac_f32_dpp %3, -%7, %9" OCT_Q(2)
+      "v_fmac_f32_dpp %0, -%4, %10" OCT_Q(3) "v_fmac_f32_dpp %1, -%5, %10" OCT_Q(3) "v_fmac_f32_dpp %2, -%6, %10" OCT_Q(3) "v_fmac_f32_dpp %3, -%7, %10" OCT_Q(3)
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y1), "v"(y2), "v"(y3));
+#else
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = fmaf(-oct_qb<3>(x[i]), y3, fmaf(-oct_qb<2>(x[i]), y2, fmaf(-oct_qb<1>(x[i]), y1, acc[i])));
+#endif
+}
+
+// ---------------------------------------------------------------- per-lane constants
+// What a lane keeps in registers for the whole launch: the inertial record and
+// the joint of ITS body, and the 0 / 1 weights that stand for "if this lane is
+// ..." in a stream every lane executes.
+struct OctLane {
+  int l, leg;         // lane of the quad (0 trunk, 1 thigh, 2 calf, 3 wheel), leg (0 left, 1 right)
+  float m, c[3], I[6];  // mass, centre of mass in the body frame, inertia about it (xx yy zz xy xz yz); the right quad's trunk: 0
+  float p[3];         // joint origin in the parent's frame (trunk: 0)
+  float sg;           // joint axis = sg * y (trunk: 0)
+  float damping, lower, upper, effort, velocity, friction, control_noise, measurement_noise;
+  bool bounded;
+  float wheel_center[3];  // tire centre relative to the wheel joint of this leg
+  float wj;           // 1 on the joint lanes, 0 on the trunk lane
+  float e[3];         // one-hot of the joint index l - 1 (all 0 on the trunk lane)
+  float w0;           // 1 on the trunk lane
+  float w0_once;      // 1 on the trunk lane of the left quad
+  float keep_psi;     // 0 on the wheel lane when the wheel is axisymmetric
+  float kl, ka;       // Bullet-style base damping, on the lane that owns the real trunk
+};
+
+template <class ModelT>
+UPKIE_HD OctLane load_oct_lane(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int l, int leg, const float* records, size_t stride) {
+  // the lane's row of DevModel::oct_table: eight 16-byte loads issued together (cached: eight rows for the whole grid)
+  float t[OT_WORDS];
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    typedef float Vec4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) Vec4* GlobalVec;
+    GlobalVec row = (GlobalVec)(const void*)&M.oct_table[4 * leg + l][0];
+#pragma unroll
+    for (int i = 0; i < OT_WORDS / 4; ++i) {
+      const Vec4 v = row[i];
+      t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+  }
+#else
+  for (int i = 0; i < OT_WORDS; ++i) t[i] = M.oct_table[4 * leg + l][i];
+#endif
+  OctLane L;
+  L.l = l;
+  L.leg = leg;
+  const bool trunk = l == 0, real = !(trunk && leg == 1);
+  const int k = trunk ? 0 : l - 1, body = trunk ? 0 : 1 + 3 * leg + k, joint = 3 * leg + k;
+  L.m = t[OT_MASS];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    L.c[d] = t[OT_COM + d];
+    L.p[d] = t[OT_POS + d];
+    L.wheel_center[d] = t[OT_WHEEL_CENTER + d];
+    L.e[d] = t[OT_E + d];
+  }
+#pragma unroll
+  for (int d = 0; d < 6; ++d) L.I[d] = t[OT_INERTIA + d];
+  if (records) {  // this env's inertial record of the lane's body (randomize_inertias)
+    const float* r = records + (size_t)(UPKIE_INERTIAL_WORDS * body) * stride;
+    L.m = real ? r[0] : 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) L.c[d] = r[(size_t)(1 + d) * stride];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) L.I[d] = real ? r[(size_t)(4 + d) * stride] : 0.f;
+  }
+  L.sg = t[OT_SIGN];
+  L.damping = t[OT_DAMPING];
+  L.lower = t[OT_LOWER];
+  L.upper = t[OT_UPPER];
+  L.bounded = t[OT_BOUNDED] != 0.f;
+  L.effort = t[OT_EFFORT];
+  L.velocity = t[OT_VELOCITY];
+  L.wj = t[OT_WJ];
+  L.w0 = t[OT_W0];
+  L.w0_once = t[OT_W0_ONCE];
+  L.keep_psi = t[OT_KEEP_PSI];
+  L.kl = t[OT_KL];
+  L.ka = t[OT_KA];
+  // per-joint settings of the config (kernel arguments)
+  float fr = 0.f, cn = 0.f, mn = 0.f;
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    fr = j == joint ? C.joint_friction[j] : fr;
+    cn = j == joint ? C.control_noise[j] : cn;
+    mn = j == joint ? C.measurement_noise[j] : mn;
+  }
+  L.friction = trunk ? 0.f : fr;
+  L.control_noise = trunk ? 0.f : cn;
+  L.measurement_noise = trunk ? 0.f : mn;
+  (void)Lm;
+  return L;
+}
+
+// Physics state as a lane holds it: the base in every lane, the own joint.
+struct OctPhys {
+  V3 pos;
+  float qw, qx, qy, qz;
+  V3 linvel, angvel;
+  float q, qd;  // own joint (trunk lane: 0)
+};
+
+// 6x6 LDL' of the base block of a robot whose legs move in the sagittal plane:
+// F_y = 0 for every joint, so A(1,0) = A(2,1) = A(4,1) = 0 and with them
+// l10 = l21 = l41 = 0. A packed lower by rows as in ldl6_factor.
+struct Ldl6Planar {
+  float l20, l30, l31, l32, l40, l42, l43, l50, l51, l52, l53, l54;
+  float i0, i1, i2, i3, i4, i5;
+};
+UPKIE_HD void ldl6_factor_planar(const float (&A)[21], Ldl6Planar& f) {
+  f.i0 = fast_rcp(A[0]);
+  const float a20 = A[3], a30 = A[6], a40 = A[10], a50 = A[15];
+  f.l20 = a20 * f.i0; f.l30 = a30 * f.i0; f.l40 = a40 * f.i0; f.l50 = a50 * f.i0;
+  f.i1 = fast_rcp(A[2]);
+  const float a31 = A[7], a51 = A[16];
+  f.l31 = a31 * f.i1; f.l51 = a51 * f.i1;
+  const float d2 = A[5] - f.l20 * a20;
+  f.i2 = fast_rcp(d2);
+  const float a32 = A[8] - f.l30 * a20, a42 = A[12] - f.l40 * a20, a52 = A[17] - f.l50 * a20;
+  f.l32 = a32 * f.i2; f.l42 = a42 * f.i2; f.l52 = a52 * f.i2;
+  const float d3 = A[9] - f.l30 * a30 - f.l31 * a31 - f.l32 * a32;
+  f.i3 = fast_rcp(d3);
+  const float a43 = A[13] - f.l40 * a30 - f.l42 * a32, a53 = A[18] - f.l50 * a30 - f.l51 * a31 - f.l52 * a32;
+  f.l43 = a43 * f.i3; f.l53 = a53 * f.i3;
+  const float d4 = A[14] - f.l40 * a40 - f.l42 * a42 - f.l43 * a43;
+  f.i4 = fast_rcp(d4);
+  const float a54 = A[19] - f.l50 * a40 - f.l52 * a42 - f.l53 * a43;
+  f.l54 = a54 * f.i4;
+  const float d5 = A[20] - f.l50 * a50 - f.l51 * a51 - f.l52 * a52 - f.l53 * a53 - f.l54 * a54;
+  f.i5 = fast_rcp(d5);
+}
+UPKIE_HD void ldl6_solve_planar(const Ldl6Planar& f, float (&x)[6]) {
+  x[2] -= f.l20 * x[0];
+  x[3] -= f.l30 * x[0] + f.l31 * x[1] + f.l32 * x[2];
+  x[4] -= f.l40 * x[0] + f.l42 * x[2] + f.l43 * x[3];
+  x[5] -= f.l50 * x[0] + f.l51 * x[1] + f.l52 * x[2] + f.l53 * x[3] + f.l54 * x[4];
+  x[0] *= f.i0; x[1] *= f.i1; x[2] *= f.i2; x[3] *= f.i3; x[4] *= f.i4; x[5] *= f.i5;
+  x[4] -= f.l54 * x[5];
+  x[3] -= f.l43 * x[4] + f.l53 * x[5];
+  x[2] -= f.l32 * x[3] + f.l42 * x[4] + f.l52 * x[5];
+  x[1] -= f.l31 * x[3] + f.l51 * x[5];
+  x[0] -= f.l20 * x[2] + f.l30 * x[3] + f.l40 * x[4] + f.l50 * x[5];
+}
+
+// Gauss-Jordan across the three joint lanes of a quad: lane j + 1 holds row j of
+// [D (3x3) | E (NE extra columns)]; on return E holds row j of D^-1 E. D is
+// symmetric positive definite (a tire's own Delassus block or its Schur
+// complement): no pivoting. The trunk lane carries zeros along (its reciprocal
+// pivot is that of a unit diagonal).
+template <int NE>
+UPKIE_HD void oct_gauss_jordan(const OctLane& L, float (&D)[3], float (&E)[NE]) {
+  // pivot 0 (lane 1)
+  {
+    const float ip = fast_rcp(oct_qb<1>(D[0]));
+    const float f = (1.f - L.e[0]) * (D[0] * ip);  // 0 on the pivot lane itself
+    D[1] -= f * oct_qb<1>(D[1]);
+    D[2] -= f * oct_qb<1>(D[2]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) E[i] -= f * oct_qb<1>(E[i]);
+  }
+  {
+    const float ip = fast_rcp(oct_qb<2>(D[1]));
+    const float f = (1.f - L.e[1]) * (D[1] * ip);
+    D[2] -= f * oct_qb<2>(D[2]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) E[i] -= f * oct_qb<2>(E[i]);
+  }
+  {
+    const float ip = fast_rcp(oct_qb<3>(D[2]));
+    const float f = (1.f - L.e[2]) * (D[2] * ip);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) E[i] -= f * oct_qb<3>(E[i]);
+  }
+  const float diag = L.e[0] * D[0] + L.e[1] * D[1] + L.e[2] * D[2] + L.w0;
+  const float id = fast_rcp(diag);
+#pragma unroll
+  for (int i = 0; i < NE; ++i) E[i] *= id;
+}
+
+// Substep outcomes. The negative ones mean "not mine" (state untouched) and say why.
+enum { OCT_NOT_MINE_FORCES = -4, OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_ONE_TIRE = -2, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
+enum { OCT_NOT_MINE = OCT_NOT_MINE_LIMIT };
+
+// One physics substep, eight lanes per env. tau: commanded torque of the own
+// joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
+// in the BASE frame and their moment about the base origin, or nullptr.
+// Returns OCT_CONTACT / OCT_NO_CONTACT after advancing the state, or one of the
+// OCT_NOT_MINE_* codes with the state untouched (same answer in the env's eight lanes).
+template <class ModelT>
+UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const OctLane& L, OctPhys& s, float tau, float h,
+                                   const float* trunk_wrench, int* census = nullptr) {
+  // ---- a joint at its stop: not mine -------------------------------------
+  if (Lm.enforce) {
+    const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
+    if (oct_wave_any(own_limit)) {
+      if (oct_env_any(own_limit)) return OCT_NOT_MINE_LIMIT;
+    }
+  }
+
+  // ---- base frame ----------------------------------------------------------
+  const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+  const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
+  const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+  const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+  const V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
+                   r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
+  const V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
+                   r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
+  const V3 nB = v3(r20, r21, r22);
+  const V3 gn = M.gravity * nB;
+
+  // ---- kinematics along the chain (prefix sums over the quad) -----------------
+  const float psi = L.keep_psi * oct_chain(L.sg * s.q);
+  float sn, cs;
+  joint_sincos(psi, &sn, &cs);
+  const float pcs = oct_up1(cs), psn = oct_up1(sn);  // the parent's frame (trunk: identity)
+  const V3 r = v3(pcs * L.p[0] + psn * L.p[2], L.p[1], pcs * L.p[2] - psn * L.p[0]);  // joint origin minus the parent's
+  const V3 o = v3(oct_chain(r.x), oct_chain(r.y), oct_chain(r.z));
+  const float sq = L.sg * s.qd;
+  const float S = oct_chain(sq), Sp = S - sq;  // joint rates summed down to this body / to its parent
+  // parent's omega = wB + Sp y, alpha = Sp (wB x y): origin acceleration term of this joint offset
+  const V3 wp = v3(wB.x, wB.y + Sp, wB.z);
+  const V3 alp = v3(-Sp * wB.z, 0.f, Sp * wB.x);
+  const V3 e = cross(alp, r) + cross(wp, cross(wp, r));
+  const V3 ao = v3(oct_chain(e.x), oct_chain(e.y), oct_chain(e.z));
+
+  // ---- the own body: wrench and inertia about the base origin -----------------
+  const V3 w = v3(wB.x, wB.y + S, wB.z);
+  const V3 al = v3(-S * wB.z, 0.f, S * wB.x);
+  const V3 rc = rot_y(cs, sn, v3(L.c[0], L.c[1], L.c[2]));
+  const V3 c = o + rc;
+  const S3 Ic = rot_y(cs, sn, S3{L.I[0], L.I[1], L.I[2], L.I[3], L.I[4], L.I[5]});
+  const V3 ac = ao + cross(al, rc) + cross(w, cross(w, rc));
+  const V3 f = L.m * (ac + gn);
+  const V3 Iw = mul(Ic, w);
+  const V3 N = mul(Ic, al) + cross(w, Iw) + cross(c, f);
+  const V3 mc = L.m * c;
+  const S3 Ib = shift_to_origin(Ic, L.m, c);
+  // applied wrench on the body: Bullet-style damping of the trunk (kl, ka are 0 elsewhere), external forces on the trunk
+  V3 Fa, Na;
+  {
+    const V3 vc = vB + cross(w, rc);
+    const float vn = fast_sqrt(dot(vc, vc)), wn = fast_sqrt(dot(w, w));
+    Fa = (-L.m * (L.kl + L.kl * vn)) * vc;
+    Na = (-(L.ka + L.ka * wn)) * Iw + cross(rc, Fa);
+    if (trunk_wrench) {
+      Fa = Fa + L.w0_once * v3(trunk_wrench[0], trunk_wrench[1], trunk_wrench[2]);
+      Na = Na + L.w0_once * v3(trunk_wrench[3], trunk_wrench[4], trunk_wrench[5]);
+    }
+  }
+
+  // ---- subtree sums: composite wrench / inertia seen by the own joint -------
+  const float fcx = oct_subtree(L.wj * f.x), fcz = oct_subtree(L.wj * f.z), Ncy = oct_subtree(L.wj * N.y);
+  const float Cm = oct_subtree(L.wj * L.m);
+  const V3 Ch = v3(oct_subtree(L.wj * mc.x), oct_subtree(L.wj * mc.y), oct_subtree(L.wj * mc.z));
+  const float CIxy = oct_subtree(L.wj * Ib.xy), CIyy = oct_subtree(L.wj * Ib.yy), CIyz = oct_subtree(L.wj * Ib.yz);
+  // S = [a; o x a], a = sg y
+  const float oxa_x = -L.sg * o.z, oxa_z = L.sg * o.x;
+  const float bias = L.sg * Ncy + oxa_x * fcx + oxa_z * fcz;
+  // F = I^c S (F[1] = 0): force (x, z), moment (x, y, z)
+  float F[6];
+  F[0] = Cm * oxa_x + L.sg * Ch.z;
+  F[1] = 0.f;
+  F[2] = Cm * oxa_z - L.sg * Ch.x;
+  F[3] = L.sg * CIxy + Ch.y * oxa_z;
+  F[4] = L.sg * CIyy + (Ch.z * oxa_x - Ch.x * oxa_z);
+  F[5] = L.sg * CIyz - Ch.y * oxa_x;
+
+  // ---- leg block H (3x3): row of the own joint, factor in every lane, own column of the inverse
+  // H[j][k] = S_j . F_k for k >= j
+  float h1, h2, h3;
+  oct_dot3_all(F[4], F[0], F[2], L.sg, oxa_x, oxa_z, h1, h2, h3);
+  const float H00 = oct_qb<1>(h1), H01 = oct_qb<1>(h2), H02 = oct_qb<1>(h3), H11 = oct_qb<2>(h2), H12 = oct_qb<2>(h3), H22 = oct_qb<3>(h3);
+  const float i00 = fast_rsqrt(H00);
+  const float l10 = H01 * i00, l20 = H02 * i00;
+  const float i11 = fast_rsqrt(H11 - l10 * l10);
+  const float l21 = (H12 - l20 * l10) * i11;
+  const float i22 = fast_rsqrt(H22 - l20 * l20 - l21 * l21);
+  // x = H^-1 b through the factor (L y = b, L' x = y)
+  auto leg_solve = [&](float b0, float b1, float b2, float& x0, float& x1, float& x2) {
+    const float y0 = b0 * i00;
+    const float y1 = (b1 - l10 * y0) * i11;
+    const float y2 = (b2 - l20 * y0 - l21 * y1) * i22;
+    x2 = y2 * i22;
+    x1 = (y1 - l21 * x2) * i11;
+    x0 = (y0 - l10 * x1 - l20 * x2) * i00;
+  };
+  float hv0, hv1, hv2;  // column (= row) of Hinv of the own joint; the trunk lane: 0
+  leg_solve(L.e[0], L.e[1], L.e[2], hv0, hv1, hv2);
+  // D = F Hinv, own column: Dc[r] = sum_k F_k[r] Hinv[k][own]
+  float Dc[6];
+  {
+    const float f5[5] = {F[0], F[2], F[3], F[4], F[5]};
+    float d5[5];
+    oct_sumj5(d5, f5, hv0, hv1, hv2);
+    Dc[0] = d5[0]; Dc[1] = 0.f; Dc[2] = d5[1]; Dc[3] = d5[2]; Dc[4] = d5[3]; Dc[5] = d5[4];
+  }
+
+  // ---- base block: own body's spatial inertia minus own column's outer product, summed over the env
+  Ldl6Planar fac;
+  {
+    // the 18 entries that are not structurally zero, packed: see `at` below
+    float P[18];
+    P[0] = L.m - Dc[0] * F[0];          // (0,0)
+    P[1] = L.m;                         // (1,1)
+    P[2] = -Dc[2] * F[0];               // (2,0)
+    P[3] = L.m - Dc[2] * F[2];          // (2,2)
+    P[4] = -Dc[3] * F[0];               // (3,0)
+    P[5] = -mc.z;                       // (3,1)
+    P[6] = mc.y - Dc[3] * F[2];         // (3,2)
+    P[7] = Ib.xx - Dc[3] * F[3];        // (3,3)
+    P[8] = mc.z - Dc[4] * F[0];         // (4,0)
+    P[9] = -mc.x - Dc[4] * F[2];        // (4,2)
+    P[10] = Ib.xy - Dc[4] * F[3];       // (4,3)
+    P[11] = Ib.yy - Dc[4] * F[4];       // (4,4)
+    P[12] = -mc.y - Dc[5] * F[0];       // (5,0)
+    P[13] = mc.x;                       // (5,1)
+    P[14] = -Dc[5] * F[2];              // (5,2)
+    P[15] = Ib.xz - Dc[5] * F[3];       // (5,3)
+    P[16] = Ib.yz - Dc[5] * F[4];       // (5,4)
+    P[17] = Ib.zz - Dc[5] * F[5];       // (5,5)
+    oct_esum(P);
+    float A[21];
+    A[0] = P[0];
+    A[1] = 0.f; A[2] = P[1];
+    A[3] = P[2]; A[4] = 0.f; A[5] = P[3];
+    A[6] = P[4]; A[7] = P[5]; A[8] = P[6]; A[9] = P[7];
+    A[10] = P[8]; A[11] = 0.f; A[12] = P[9]; A[13] = P[10]; A[14] = P[11];
+    A[15] = P[12]; A[16] = P[13]; A[17] = P[14]; A[18] = P[15]; A[19] = P[16]; A[20] = P[17];
+    ldl6_factor_planar(A, fac);
+  }
+
+  // ---- impulses so far: own joint, and the base right-hand side reduced over the env
+  const float tl = h * (tau - L.damping * s.qd - bias);
+  float rt[6];
+  rt[0] = h * (Fa.x - f.x) - Dc[0] * tl;
+  rt[1] = h * (Fa.y - f.y);
+  rt[2] = h * (Fa.z - f.z) - Dc[2] * tl;
+  rt[3] = h * (Na.x - N.x) - Dc[3] * tl;
+  rt[4] = h * (Na.y - N.y) - Dc[4] * tl;
+  rt[5] = h * (Na.z - N.z) - Dc[5] * tl;
+  oct_esum(rt);
+
+  // ---- the tire of this leg: contact point, directions (every lane of the quad) --
+  const float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
+  const float iun = fast_rcp(fmaxf(un, 1e-12f));
+  const float denom = h * M.contact_stiffness + M.contact_damping;
+  const float ih = fast_rcp(h);
+  const float erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
+  const float cfm = denom > 0.f ? fast_rcp(denom * h) : 0.f;
+  const V3 ow = v3(oct_qb<3>(o.x), oct_qb<3>(o.y), oct_qb<3>(o.z));
+  const V3 center = ow + v3(L.wheel_center[0], L.wheel_center[1], L.wheel_center[2]);
+  const V3 Pc = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
+  const float dist = s.pos.z + dot(nB, Pc);
+  const bool active = un >= 1e-6f && dist <= M.contact_breaking_threshold;
+  const bool active_partner = oct_swp(active ? 1.f : 0.f) != 0.f;
+  const bool both = active && active_partner;
+
+  float xb[6];   // base velocity change
+  float tlc = tl;  // own joint impulse incl. contacts
+  if (active || active_partner) {
+    const float sa = oct_qb<3>(L.sg);
+    const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
+    const V3 t2 = cross(nB, t1);
+    // row of the lane: normal / rolling / lateral (the trunk lane: none, it solves for the free velocity)
+    const V3 d = L.e[0] * nB + L.e[1] * t1 + L.e[2] * t2;
+    const V3 Pxd = cross(Pc, d);
+    float Jb[6] = {d.x, d.y, d.z, Pxd.x, Pxd.y, Pxd.z};
+    // joint parts: Jl[row][j] = sg_j ((P - o_j) x d) . y-ish; lane j prepares its two factors, the row lanes combine
+    const float srz = L.sg * (Pc.z - o.z), srx = L.sg * (Pc.x - o.x);
+    const float Jl1 = oct_qb<1>(srz) * d.x - oct_qb<1>(srx) * d.z;
+    const float Jl2 = oct_qb<2>(srz) * d.x - oct_qb<2>(srx) * d.z;
+    const float Jl3 = oct_qb<3>(srz) * d.x - oct_qb<3>(srx) * d.z;
+    float vnow = Jb[0] * vB.x + Jb[1] * vB.y + Jb[2] * vB.z + Jb[3] * wB.x + Jb[4] * wB.y + Jb[5] * wB.z;
+    vnow = oct_sumj(vnow, s.qd, Jl1, Jl2, Jl3);
+    // row reduced onto the base: Jt = Jb - sum_j D[:, j] Jl[j]; the trunk lane takes rt instead
+    float Y[6];
+    {
+      float acc[5] = {Jb[0], Jb[2], Jb[3], Jb[4], Jb[5]};
+      const float dc[5] = {Dc[0], Dc[2], Dc[3], Dc[4], Dc[5]};
+      oct_sumj_neg5(acc, dc, Jl1, Jl2, Jl3);
+      Y[0] = acc[0]; Y[1] = Jb[1]; Y[2] = acc[1]; Y[3] = acc[2]; Y[4] = acc[3]; Y[5] = acc[4];
+    }
+    float Jt[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      Jt[i] = Y[i];
+      Y[i] = fmaf(L.w0, rt[i], Y[i]);
+    }
+    ldl6_solve_planar(fac, Y);  // contact rows: A^-1 Jt; trunk lane: A^-1 rt
+    float K1, K2, K3;
+    leg_solve(Jl1, Jl2, Jl3, K1, K2, K3);
+    float vf = vnow;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vf = fmaf(Y[i], rt[i], vf);
+    vf = oct_sumj(vf, tl, K1, K2, K3);
+    const float push = dist <= 0.f ? erp * (-dist) * ih : -dist * ih;
+    // (a tire without a contact point: identity rows, zero right-hand side, no coupling, as in physics_substep)
+    const float rhs = active ? L.e[0] * push - vf : 0.f;
+    // own tire's block and the coupling to the other tire, one column per lane:
+    // Dg[a] = Jt_a . Y + Jl_a . K for the rows a of this quad, X[a] for the rows of the other one
+    float Dg[3], X[3];
+    {
+      const float Jl[3] = {Jl1, Jl2, Jl3}, Kv[3] = {K1, K2, K3};
+      oct_rows9(Dg, Jt, Y, Jl, Kv);
+    }
+    Dg[0] = active ? fmaf(L.e[0], cfm, Dg[0]) : L.e[0];
+    Dg[1] = active ? fmaf(L.e[1], M.friction_cfm, Dg[1]) : L.e[1];
+    Dg[2] = active ? fmaf(L.e[2], M.friction_cfm, Dg[2]) : L.e[2];
+    float JtP[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) JtP[i] = oct_swp(Jt[i]);
+    oct_rows6(X, JtP, Y);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) X[i] = both ? X[i] : 0.f;
+    // block elimination: W = Dg^-1 [X | rhs] in this quad, exchanged; Schur complement of the other tire
+    float lam;
+    {
+      float Dw[3] = {Dg[0], Dg[1], Dg[2]};
+      float W[4] = {X[0], X[1], X[2], rhs};
+      oct_gauss_jordan<4>(L, Dw, W);
+      float WP[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) WP[i] = oct_swp(W[i]);
+      // S[a] = Dg[a] - sum_k X[k] WP_k[a] ; r' = rhs - sum_k X[k] WP_k[3]   (WP_k: row k of the other quad's W)
+      float Sd[3], rr[1];
+      {
+        float acc[4] = {Dg[0], Dg[1], Dg[2], rhs};
+        oct_sumj_neg4(acc, WP, X[0], X[1], X[2]);
+        Sd[0] = acc[0]; Sd[1] = acc[1]; Sd[2] = acc[2]; rr[0] = acc[3];
+      }
+      oct_gauss_jordan<1>(L, Sd, rr);
+      lam = rr[0];
+    }
+    // admissible? normal >= 0, friction inside the cone; otherwise the direct solution is projected and warm-starts
+    // projected Gauss-Seidel sweeps: the system is gathered into every lane and the sweeps of the other mappings run
+    // on it (contact_pgs6: same rows, same order), every lane of the env in lockstep on identical data
+    {
+      const float lam_n = oct_qb<1>(lam);
+      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
+      if (oct_wave_any(bad)) {
+        if (oct_env_any(bad)) {
+          if (census) *census = OCT_NOT_MINE_INFEASIBLE;
+          const bool left = L.leg == 0;
+          float A6[21], rhs6[6], lam6[6];
+          // diagonal blocks: entry (a, b) of the own tire's block sits in lane b + 1 of the own quad
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+              const float own = b == 0 ? oct_qb<1>(Dg[a]) : (b == 1 ? oct_qb<2>(Dg[a]) : oct_qb<3>(Dg[a]));
+              const float other = oct_swp(own);
+              A6[a * (a + 1) / 2 + b] = left ? own : other;
+              A6[(3 + a) * (4 + a) / 2 + 3 + b] = left ? other : own;
+            }
+          }
+          // coupling block (right tire's row a, left tire's column b): the left quad's lane b + 1 holds it as X[a]
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const float own = b == 0 ? oct_qb<1>(X[a]) : (b == 1 ? oct_qb<2>(X[a]) : oct_qb<3>(X[a]));
+              const float other = oct_swp(own);
+              A6[(3 + a) * (4 + a) / 2 + b] = left ? own : other;
+            }
+          }
+          {
+            const float r1 = oct_qb<1>(rhs), r2 = oct_qb<2>(rhs), r3 = oct_qb<3>(rhs);
+            const float p1 = oct_swp(r1), p2 = oct_swp(r2), p3 = oct_swp(r3);
+            rhs6[0] = left ? r1 : p1; rhs6[1] = left ? r2 : p2; rhs6[2] = left ? r3 : p3;
+            rhs6[3] = left ? p1 : r1; rhs6[4] = left ? p2 : r2; rhs6[5] = left ? p3 : r3;
+            const float l1 = oct_qb<1>(lam), l2 = oct_qb<2>(lam), l3 = oct_qb<3>(lam);
+            const float q1 = oct_swp(l1), q2 = oct_swp(l2), q3 = oct_swp(l3);
+            lam6[0] = left ? l1 : q1; lam6[1] = left ? l2 : q2; lam6[2] = left ? l3 : q3;
+            lam6[3] = left ? q1 : l1; lam6[4] = left ? q2 : l2; lam6[5] = left ? q3 : l3;
+          }
+          // projection of the direct solution (the warm start), as in physics_substep
+#pragma unroll
+          for (int w = 0; w < 2; ++w) lam6[3 * w] = fmaxf(lam6[3 * w], 0.f);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            if ((r % 3) == 0) continue;
+            const float lim = M.friction_mu * lam6[3 * (r / 3)];
+            lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
+          }
+          contact_pgs6(M, A6, rhs6, lam6, both);
+          const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
+          const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
+          lam = left ? mine_l : mine_r;
+        }
+      }
+    }
+    // nu+ = A^-1 rt + sum_b lam_b Y_b: the trunk lane's Y is the free part (counted once)
+    const float wgt = L.l == 0 ? L.w0_once : lam;  // (the trunk lane's own `lam` is the by-product of rows it does not have)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xb[i] = wgt * Y[i];
+    oct_esum(xb);
+    // own joint: t += sum_b Jl_b[own] lam_b, with Jl_b[own] rebuilt from the own factors (bit-identical to the row lanes')
+    const float JlT1 = srz * nB.x - srx * nB.z, JlT2 = srz * t1.x - srx * t1.z, JlT3 = srz * t2.x - srx * t2.z;
+    tlc = oct_sumj(tl, lam, JlT1, JlT2, JlT3);
+  } else {
+    // no contact: nu+ = A^-1 rt, every lane solves it
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xb[i] = rt[i];
+    ldl6_solve_planar(fac, xb);
+  }
+
+  // ---- joint velocity change: Hinv t - D' xb ------------------------------------
+  float xl = oct_sumj(0.f, tlc, hv0, hv1, hv2);
+  xl -= Dc[0] * xb[0] + Dc[2] * xb[2] + Dc[3] * xb[3] + Dc[4] * xb[4] + Dc[5] * xb[5];
+
+  // ---- integrate --------------------------------------------------------------------
+  {
+    const float v = fminf(fmaxf(s.qd + xl, -M.max_joint_velocity), M.max_joint_velocity);
+    s.qd = L.wj * v;
+    s.q = fmaf(h, s.qd, s.q);
+  }
+  const float n0 = vB.x + xb[0], n1 = vB.y + xb[1], n2 = vB.z + xb[2];
+  const float n3 = wB.x + xb[3], n4 = wB.y + xb[4], n5 = wB.z + xb[5];
+  s.linvel = v3(r00 * n0 + r01 * n1 + r02 * n2, r10 * n0 + r11 * n1 + r12 * n2, r20 * n0 + r21 * n1 + r22 * n2);
+  s.angvel = v3(r00 * n3 + r01 * n4 + r02 * n5, r10 * n3 + r11 * n4 + r12 * n5, r20 * n3 + r21 * n4 + r22 * n5);
+  s.pos = s.pos + h * s.linvel;
+  {
+    const float wn = fast_sqrt(dot(s.angvel, s.angvel));
+    const float half = 0.5f * h * wn;
+    float ch, k;
+    if (half < 0.5f) {
+      const float x2 = half * half;
+      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+    } else {
+      float sh;
+      sincosf(half, &sh, &ch);
+      k = sh * fast_rcp(wn);
+    }
+    const float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
+    const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+    const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+    const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+    const float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+    const float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
+    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
+  }
+  return (active || active_partner) ? OCT_CONTACT : OCT_NO_CONTACT;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// The rare path: the two-lane substep (pair.hpp) on the same lanes, every lane
+// of a quad holding its whole leg (identical data, identical results), the
+// other leg eight lanes away. Device only.
+template <class ModelT>
+__device__ __forceinline__ bool octet_general_substep(const ModelT& M, const DevLimits& Lm, const DevConfig& C, const OctLane& L, OctPhys& s,
+                                                   float tau, float h, const float* records, size_t stride, const ExtForces& ext) {
+  const PairLeg PL = load_pair_leg(M, Lm, C, L.leg, records, stride);
+  PhysPair p;
+  p.pos = s.pos; p.qw = s.qw; p.qx = s.qx; p.qy = s.qy; p.qz = s.qz;
+  p.linvel = s.linvel; p.angvel = s.angvel;
+  p.q[0] = oct_qb<1>(s.q); p.q[1] = oct_qb<2>(s.q); p.q[2] = oct_qb<3>(s.q);
+  p.qd[0] = oct_qb<1>(s.qd); p.qd[1] = oct_qb<2>(s.qd); p.qd[2] = oct_qb<3>(s.qd);
+  const float t3[3] = {oct_qb<1>(tau), oct_qb<2>(tau), oct_qb<3>(tau)};
+  TrunkInertial trunk;
+  if (records) {
+    trunk.m = records[0];
+    trunk.c = v3(records[(size_t)1 * stride], records[(size_t)2 * stride], records[(size_t)3 * stride]);
+    trunk.I = S3{records[(size_t)4 * stride], records[(size_t)5 * stride], records[(size_t)6 * stride],
+                 records[(size_t)7 * stride], records[(size_t)8 * stride], records[(size_t)9 * stride]};
+  }
+  const bool contact = physics_substep_pair<LanesEightApart>(M, Lm, PL, L.leg, p, t3, h, records ? &trunk : nullptr, ext);
+  s.pos = p.pos; s.qw = p.qw; s.qx = p.qx; s.qy = p.qy; s.qz = p.qz;
+  s.linvel = p.linvel; s.angvel = p.angvel;
+  s.q = L.l == 1 ? p.q[0] : (L.l == 2 ? p.q[1] : (L.l == 3 ? p.q[2] : 0.f));
+  s.qd = L.l == 1 ? p.qd[0] : (L.l == 2 ? p.qd[1] : (L.l == 3 ? p.qd[2] : 0.f));
+  return contact;
+}
+
+template <class T>
+__device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
+  return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : (j == 3 ? a[3] : (j == 4 ? a[4] : a[5]))));
+}
+
+// One env.step() of B envs on 8 B lanes. Same contract as step_kernel /
+// step_kernel_pair (the in-step spine observers are not restated here: launches
+// with observers attached use the two-lane kernel).
+template <int MODE, bool RAND>
+__global__ __launch_bounds__(64) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
+                                                         float* __restrict__ state, const float* __restrict__ act,
+                                                         float* __restrict__ obs, float* __restrict__ reward,
+                                                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                                                         const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
+                                                         const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
+                                                         float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census) {
+  typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
+  const int B = C.num_envs;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  // row of 16 lanes = quads [env 2r left, env 2r+1 left, env 2r right, env 2r+1 right]
+  const int l = tid & 3, quad = (tid >> 2) & 3, leg = quad >> 1;
+  const int e = (tid >> 4) * 2 + (quad & 1);
+  if (e >= B) return;  // the eight lanes of an env leave together
+  const bool lead = l == 0 && leg == 0;  // the lane that writes per-env words
+  const bool jointed = l != 0;
+  const int k = jointed ? l - 1 : 0;
+  const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
+  float* st = state + e;
+#define SW(w) st[(size_t)(w) * B]
+
+  // ---- load ----------------------------------------------------------
+  OctPhys s;
+  s.pos = v3(SW(UPKIE_S_POS), SW(UPKIE_S_POS + 1), SW(UPKIE_S_POS + 2));
+  s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
+  s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
+  s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
+  s.q = jointed ? SW(UPKIE_S_Q + joint) : 0.f;
+  s.qd = jointed ? SW(UPKIE_S_QD + joint) : 0.f;
+  const bool legged = l == 1 || l == 2;  // hip and knee lanes carry their low-pass target
+  float legref = legged ? SW(UPKIE_S_LEGREF + 2 * leg + k) : 0.f;
+  constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
+  float yaw = 0.f, yawvel = 0.f;
+  if (YAWING) {
+    yaw = SW(UPKIE_S_YAW);
+    yawvel = SW(UPKIE_S_YAWVEL);
+  }
+  const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
+  const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B);
+  const auto& M = *(ConstModelPtr)Mp;
+  // external forces: those on the trunk enter the eight-lane substep as one wrench; any force on a leg link sends
+  // every substep of the launch down the general path
+  const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
+  bool leg_forces = false;
+  if (RAND && ext.force) {
+    for (int i = 0; i < C.ext.count; ++i) leg_forces = leg_forces || C.ext.body[i] != 0;
+  }
+
+  float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
+  asm volatile("" : "+v"(done_word));
+  float act0 = 0.f, act1 = 0.f;
+  float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == MODE_PENDULUM) {
+    if (act) act0 = act[e];
+  } else if (fused_agent(MODE)) {
+    const float* prev = act ? act : obs;
+    prev_obs = reinterpret_cast<const float4*>(prev)[packed ? 2 * (size_t)e : (size_t)e];
+  } else if (MODE == MODE_GYROPOD) {
+    if (act) {
+      const float2 a = reinterpret_cast<const float2*>(act)[e];
+      act0 = a.x;
+      act1 = a.y;
+    }
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    act0 = bv.commanded[e];
+    act1 = act[2 * (size_t)e + 1];
+  }
+
+  constexpr bool ROLLOUT = MODE == MODE_PENDULUM_ROLLOUT;
+  int steps_left = ROLLOUT && packed && n_steps > 1 ? n_steps : 1;
+  float* records_out = obs;
+  float episode_word = ROLLOUT ? SW(UPKIE_S_EPISODE) : 0.f;
+  float elapsed_word = ROLLOUT && C.max_episode_steps > 0 ? SW(UPKIE_S_ELAPSED) : 0.f;
+  const bool any_noise = C.any_control_noise || C.any_measurement_noise;
+  unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
+  const float signed_radius = M.left_sign * M.wheel_radius;
+
+  // Gyropod observation (upkie_gyropod.py:186-214): the wheel lanes hold what it needs
+  auto observe6 = [&](float yaw_, float yawvel_, float (&o6)[6]) {
+    const float qo = oct_qb<3>(s.q), qdo = oct_qb<3>(s.qd);
+    const float qp = oct_swp(qo), qdp = oct_swp(qdo);
+    const float ql = leg ? qp : qo, qr = leg ? qo : qp;
+    const float qdl = leg ? qdp : qdo, qdr = leg ? qdo : qdp;
+    const float r01 = 2.f * (s.qx * s.qy - s.qz * s.qw), r11 = 1.f - 2.f * (s.qx * s.qx + s.qz * s.qz), r21 = 2.f * (s.qy * s.qz + s.qx * s.qw);
+    const float x = fminf(fmaxf(2.f * (s.qw * s.qy - s.qz * s.qx), -1.f), 1.f);
+    o6[0] = 0.5f * (ql - qr) * signed_radius;
+    o6[1] = asinf(x);
+    o6[2] = yaw_;
+    o6[3] = 0.5f * (qdl - qdr) * signed_radius;
+    o6[4] = r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z;
+    o6[5] = yawvel_;
+  };
+
+next_step:
+  bool do_reset;
+  if (MODE == MODE_RESET) {
+    do_reset = mask ? mask[e] != 0 : true;
+  } else {
+    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f;
+    if (C.autoreset_mode == AUTORESET_DONE_PASS) {
+      if (final_obs) {  // every env keeps its last observation (see step_kernel)
+        constexpr int W = ObsWords<MODE>::value;
+        if (MODE == MODE_SERVOS) {
+          if (jointed) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) final_obs[(size_t)30 * e + 5 * joint + i] = obs[(size_t)30 * e + 5 * joint + i];
+          }
+        } else if (lead) {
+          const float* last = obs + (size_t)(packed ? 8 : W) * e;
+#pragma unroll
+          for (int i = 0; i < W; ++i) final_obs[(size_t)W * e + i] = last[i];
+        }
+      }
+      if (!do_reset) return;
+    }
+  }
+
+  if (MODE == MODE_RESET && !do_reset) {
+    if (obs) {
+      float o6[6];
+      observe6(SW(UPKIE_S_YAW), SW(UPKIE_S_YAWVEL), o6);
+      if (lead) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = o6[i];
+      }
+    }
+    return;
+  }
+
+  // ---- action map: the own joint's servo target -----------------------------
+  Servo cmd{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float a0 = 0.f, a1 = 0.f;
+  unsigned episode = 0;
+  if (do_reset) {
+    episode = ROLLOUT ? (unsigned)episode_word : (unsigned)SW(UPKIE_S_EPISODE);
+    Phys full;
+    sample_init_state(C, (unsigned)e, episode, full);  // same draws in the eight lanes
+    s.pos = full.pos; s.qw = full.qw; s.qx = full.qx; s.qy = full.qy; s.qz = full.qz;
+    s.linvel = full.linvel; s.angvel = full.angvel;
+    s.q = jointed ? pick6(joint, full.q) : 0.f;
+    s.qd = 0.f;
+  } else if (MODE == MODE_SERVOS) {
+    if (jointed) {
+      const float* a = act + (size_t)36 * e + 6 * joint;
+      const float eff = L.effort, vel = L.velocity;
+      cmd.position = clamp_ref(a[0], L.lower, L.upper);
+      cmd.velocity = clamp_ref(a[1], -vel, vel);
+      cmd.feedforward_torque = clamp_ref(a[2], -eff, eff);
+      cmd.kp_scale = clamp_ref(a[3], 0.f, C.max_gain_scale);
+      cmd.kd_scale = clamp_ref(a[4], 0.f, C.max_gain_scale);
+      cmd.maximum_torque = clamp_ref(a[5], 0.f, eff);
+    }
+  } else if (MODE != MODE_RESET) {
+    if (fused_agent(MODE)) {
+      const float4 o = prev_obs;
+      a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
+      a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
+    } else {
+      a0 = act0;
+      a1 = act1;
+    }
+    const float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
+    const float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
+    const float inv_radius = fast_rcp(M.wheel_radius);
+    const float wheel_velocity = v * inv_radius;
+    float left = M.left_sign * wheel_velocity, right = -M.left_sign * wheel_velocity;
+    const float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) * inv_radius;
+    left = fmaf(yaw_to_wheel, yawd, left);
+    right = fmaf(yaw_to_wheel, yawd, right);
+    const float alpha = C.dt / 1.0f;
+    legref = legref + alpha * (0.f - legref);
+    if (legged) {
+      cmd.position = clamp_ref(legref, L.lower, L.upper);
+      cmd.kp_scale = clamp_ref(C.leg_gain_scale, 0.f, C.max_gain_scale);
+      cmd.kd_scale = cmd.kp_scale;
+      cmd.maximum_torque = L.effort;
+    } else if (l == 3) {
+      cmd.position = NAN;
+      cmd.velocity = clamp_ref(leg ? right : left, -L.velocity, L.velocity);
+      cmd.kp_scale = 1.f;
+      cmd.kd_scale = 1.f;
+      cmd.maximum_torque = L.effort;
+    }
+  }
+
+  // ---- substeps ------------------------------------------------------------
+  float tau = 0.f;
+  bool contact = false;
+  const int nsub = do_reset ? 1 : C.nb_substeps;
+  for (int sub = 0; sub < C.nb_substeps; ++sub) {
+    if (sub >= nsub) break;
+    float noise = 0.f;
+    if (C.any_control_noise && !do_reset) {
+      float zn[6];
+      philox_normal6(C, (unsigned)e, step_count, (unsigned)sub, zn);
+      noise = L.control_noise * pick6(joint, zn);
+    }
+    tau = jointed ? joint_torque(s.q, s.qd, cmd, C.kp, C.kd, L.friction, noise) : 0.f;
+    ConstModelPtr mp = (ConstModelPtr)Mp;
+    asm volatile("" : "+s"(mp));
+    int status = OCT_NOT_MINE_FORCES;
+    const bool forces = RAND && ext.force && !do_reset;  // the reset substep runs without external forces
+    if (!(forces && leg_forces)) {
+      float wrench[6];
+      if (forces) {  // forces on the trunk: one wrench about the base origin, base frame
+        const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+        const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
+        const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+        const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+        V3 Fs = v3(0.f, 0.f, 0.f), Ns = v3(0.f, 0.f, 0.f);
+        for (int i = 0; i < C.ext.count; ++i) {
+          const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride], ext.force[(size_t)(3 * i + 2) * ext.stride]);
+          const V3 pt = v3(C.ext.point[i][0], C.ext.point[i][1], C.ext.point[i][2]);
+          const V3 Fe = C.ext.local[i] != 0 ? f : v3(r00 * f.x + r10 * f.y + r20 * f.z, r01 * f.x + r11 * f.y + r21 * f.z, r02 * f.x + r12 * f.y + r22 * f.z);
+          Fs = Fs + Fe;
+          Ns = Ns + cross(pt, Fe);
+        }
+        wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
+      }
+      int swept = 0;
+      status = physics_substep_octet(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &swept : nullptr);
+      if (census && swept) {  // projected Gauss-Seidel inside the eight-lane substep
+        if (lead) atomicAdd(&census[2], 1u);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&census[5], 1u);
+      }
+    }
+    if (status < 0) {
+      if (census) {  // rare-path census (upkie_sim_set_census): env-substeps by reason, wavefront-substeps that took the path
+        if (lead) atomicAdd(&census[status == OCT_NOT_MINE_LIMIT ? 0 : (status == OCT_NOT_MINE_ONE_TIRE ? 1 : 3)], 1u);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&census[4], 1u);
+      }
+      const ExtForces ext_now{forces ? ext.force : nullptr, ext.stride, ext.slots};
+      contact = octet_general_substep(*mp, Lm, C, L, s, tau, C.h, records, (size_t)B, ext_now);
+    } else {
+      contact = status == OCT_CONTACT;
+    }
+  }
+
+  // ---- wrapper post-processing ---------------------------------------------
+  bool fallen = false, timeout = false;
+  float obs6[6];
+  if (do_reset) {
+    legref = s.q;
+    yaw = 0.f;
+    yawvel = 0.f;
+    if (lead) {
+      SW(UPKIE_S_YAW) = 0.f;
+      SW(UPKIE_S_YAWVEL) = 0.f;
+      SW(UPKIE_S_MPC_V) = 0.f;
+      SW(UPKIE_S_SE2_X) = 0.f;
+      SW(UPKIE_S_SE2_Y) = 0.f;
+      SW(UPKIE_S_EPISODE) = (float)((episode + 1u) & UPKIE_COUNTER_MASK);
+      SW(UPKIE_S_DONE) = 0.f;
+      SW(UPKIE_S_ELAPSED) = 0.f;
+    }
+    episode_word = (float)((episode + 1u) & UPKIE_COUNTER_MASK);
+    done_word = 0.f;
+    elapsed_word = 0.f;
+    observe6(yaw, yawvel, obs6);
+  } else {
+    if (YAWING) {
+      yaw = fmaf(a1, C.dt, yaw);
+      yawvel = a1;
+      if (lead) {
+        SW(UPKIE_S_YAW) = yaw;
+        SW(UPKIE_S_YAWVEL) = yawvel;
+      }
+    }
+    observe6(yaw, yawvel, obs6);
+    if (MODE != MODE_SERVOS) {
+      fallen = fabsf(obs6[1]) > C.fall_pitch;
+      if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
+    }
+    if (C.max_episode_steps > 0) {
+      const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
+      timeout = elapsed >= (float)C.max_episode_steps && !fallen;
+      elapsed_word = elapsed;
+      if (lead) {
+        SW(UPKIE_S_ELAPSED) = elapsed;
+        if (timeout) SW(UPKIE_S_DONE) = 1.f;
+      }
+    }
+    if (fallen || timeout) done_word = 1.f;
+    if (jointed) SW(UPKIE_S_TORQUE + joint) = tau;
+    if (any_noise) {
+      step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
+      if (lead) SW(UPKIE_S_STEP) = (float)step_count;
+    }
+  }
+
+  // ---- store (last step of the launch) --------------------------------------
+  if (steps_left > 1) {
+    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    if (lead) {
+      float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
+      rec[0] = o4;
+      rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+    }
+    prev_obs = o4;
+    records_out += (size_t)8 * B;
+    steps_left -= 1;
+    goto next_step;
+  }
+  if (lead) {
+    SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
+    SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
+    SW(UPKIE_S_LINVEL) = s.linvel.x; SW(UPKIE_S_LINVEL + 1) = s.linvel.y; SW(UPKIE_S_LINVEL + 2) = s.linvel.z;
+    SW(UPKIE_S_ANGVEL) = s.angvel.x; SW(UPKIE_S_ANGVEL + 1) = s.angvel.y; SW(UPKIE_S_ANGVEL + 2) = s.angvel.z;
+    SW(UPKIE_S_CONTACT) = contact ? 1.f : 0.f;
+  }
+  if (jointed) {
+    SW(UPKIE_S_Q + joint) = s.q;
+    SW(UPKIE_S_QD + joint) = s.qd;
+  }
+  if (MODE != MODE_SERVOS && legged) SW(UPKIE_S_LEGREF + 2 * leg + k) = legref;
+
+  if (MODE == MODE_RESET) {
+    if (obs && lead) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) obs[(size_t)6 * e + i] = obs6[i];
+    }
+    return;
+  }
+  if (MODE == MODE_SERVOS) {
+    // each joint lane reports its servo (upkie_servos.py:288-306)
+    float zm = 0.f;
+    if (C.any_measurement_noise) {
+      float z6[6];
+      philox_normal6(C, (unsigned)e, step_count, NOISE_SLOT_MEASUREMENT, z6);
+      zm = pick6(joint, z6);
+    }
+    if (jointed) {
+      float* o = obs + (size_t)30 * e + 5 * joint;
+      o[0] = s.q;
+      o[1] = s.qd;
+      o[2] = (do_reset ? SW(UPKIE_S_TORQUE + joint) : tau) + L.measurement_noise * zm;
+      o[3] = 42.0f;
+      o[4] = 18.0f;
+    }
+  }
+  if (!lead) return;
+  if (MODE == MODE_PENDULUM || fused_agent(MODE)) {
+    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+    if (packed) {
+      float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
+      rec[0] = o4;
+      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+      return;
+    }
+    reinterpret_cast<float4*>(obs)[e] = o4;
+  } else if (MODE == MODE_BASE_VELOCITY) {
+    float x = 0.f, y = 0.f;
+    if (!do_reset) {
+      const float lin = act[2 * (size_t)e];
+      float sy, cy;
+      sincosf(yaw, &sy, &cy);
+      x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
+      y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
+      SW(UPKIE_S_SE2_X) = x;
+      SW(UPKIE_S_SE2_Y) = y;
+    }
+    obs[(size_t)3 * e] = x;
+    obs[(size_t)3 * e + 1] = y;
+    obs[(size_t)3 * e + 2] = yaw;
+    reinterpret_cast<float4*>(bv.x0)[e] = make_float4(obs6[0], obs6[1], obs6[3], obs6[4]);
+    bv.contact[e] = contact ? 1 : 0;
+  } else if (MODE == MODE_GYROPOD) {
+    float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
+    o2[0] = make_float2(obs6[0], obs6[1]);
+    o2[1] = make_float2(obs6[2], obs6[3]);
+    o2[2] = make_float2(obs6[4], obs6[5]);
+  }
+  if (C.autoreset_mode == AUTORESET_DONE_PASS) return;
+  reward[e] = 0.f;
+  terminated[e] = fallen ? 1 : 0;
+  truncated[e] = timeout ? 1 : 0;
+#undef SW
+}
+#endif

@@ -21,12 +21,27 @@
 __device__ __forceinline__ float xchg(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float pair_sum(float x) { return x + xchg(x); }
-__device__ __forceinline__ V3 pair_sum(V3 a) { return V3{pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)}; }
+// Where the lane that owns the other leg sits: next to this one (the two-lane
+// kernel) or eight lanes away in the same row of 16 (the eight-lane kernel's
+// rare path, octet.hpp, where every lane of a leg's quad runs this substep on
+// identical data).
+struct AdjacentLanes {
+  static __device__ __forceinline__ float xchg(float x) { return upkie::xchg(x); }
+};
+struct LanesEightApart {
+  static __device__ __forceinline__ float xchg(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));  // row_ror:8
+  }
+};
+template <class X = AdjacentLanes>
+__device__ __forceinline__ float pair_sum(float x) { return x + X::xchg(x); }
+template <class X = AdjacentLanes>
+__device__ __forceinline__ V3 pair_sum(V3 a) { return V3{pair_sum<X>(a.x), pair_sum<X>(a.y), pair_sum<X>(a.z)}; }
 // (the exchange comes first: under `b || xchg(...)` a lane whose b is true would skip the DPP
 // move and its partner would read a disabled lane)
+template <class X = AdjacentLanes>
 __device__ __forceinline__ bool pair_any(bool b) {
-  const float partner = xchg(b ? 1.f : 0.f);
+  const float partner = X::xchg(b ? 1.f : 0.f);
   return b || partner != 0.f;
 }
 template <class T>
@@ -113,7 +128,7 @@ struct PhysPair {
 // One physics substep, two lanes per env. Mirrors physics_substep() step by
 // step; comments there apply. `leg` = 0 (left) / 1 (right) is the leg this lane
 // owns. Returns the floor-contact flag (identical in both lanes).
-template <class ModelT>
+template <class XL = AdjacentLanes, class ModelT>
 __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
                                                      const float (&tau)[3], float h, const TrunkInertial* trunk, const ExtForces& ext) {
   bool own_limit = false;
@@ -121,7 +136,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
 #pragma unroll
     for (int k = 0; k < 3; ++k) own_limit = own_limit || (PL.bounded[k] && (s.q[k] <= PL.lower[k] || s.q[k] >= PL.upper[k]));
   }
-  const bool any_limit = Lm.enforce ? pair_any(own_limit) : false;
+  const bool any_limit = Lm.enforce ? pair_any<XL>(own_limit) : false;
 
   float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
   float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
@@ -154,12 +169,12 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   Composite legs{0.f, v3(0.f, 0.f, 0.f), S3{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
   V3 lf = v3(0.f, 0.f, 0.f), ln = v3(0.f, 0.f, 0.f);
   leg_pass(PL.regs, M.wheel_axisymmetric != 0, s.q, s.qd, wB, gn, G, legs, lf, ln);
-  total.m += pair_sum(legs.m);
-  total.h = total.h + pair_sum(legs.h);
-  total.I = total.I + S3{pair_sum(legs.I.xx), pair_sum(legs.I.yy), pair_sum(legs.I.zz),
-                         pair_sum(legs.I.xy), pair_sum(legs.I.xz), pair_sum(legs.I.yz)};
-  bias_f = bias_f + pair_sum(lf);
-  bias_n = bias_n + pair_sum(ln);
+  total.m += pair_sum<XL>(legs.m);
+  total.h = total.h + pair_sum<XL>(legs.h);
+  total.I = total.I + S3{pair_sum<XL>(legs.I.xx), pair_sum<XL>(legs.I.yy), pair_sum<XL>(legs.I.zz),
+                         pair_sum<XL>(legs.I.xy), pair_sum<XL>(legs.I.xz), pair_sum<XL>(legs.I.yz)};
+  bias_f = bias_f + pair_sum<XL>(lf);
+  bias_n = bias_n + pair_sum<XL>(ln);
 
   Ldl6 fac;
   {
@@ -177,7 +192,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
         const float own = G.D[r][0] * G.F[0][c] + G.D[r][1] * G.F[1][c] + G.D[r][2] * G.F[2][c];
-        A[idx] -= pair_sum(own);
+        A[idx] -= pair_sum<XL>(own);
         ++idx;
       }
     }
@@ -215,8 +230,8 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
             Fe = v3(0.f, 0.f, 0.f);
             Ne = v3(0.f, 0.f, 0.f);
           }
-          F = F + pair_sum(Fe);
-          Ntot = Ntot + pair_sum(Ne);
+          F = F + pair_sum<XL>(Fe);
+          Ntot = Ntot + pair_sum<XL>(Ne);
 #pragma unroll
           for (int j = 0; j < 3; ++j) te[j] += mine ? t3[j] : 0.f;
         }
@@ -228,7 +243,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     for (int k = 0; k < 3; ++k) tl[k] = h * (tau[k] + te[k] - PL.damping[k] * s.qd[k] - G.bias[k]);
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) rt[c] = tb[c] - pair_sum(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
+  for (int c = 0; c < 6; ++c) rt[c] = tb[c] - pair_sum<XL>(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
 
   // ---- contact rows of the owned tire ------------------------------------
   float Jb[3][6], Jl[3][3], Jt[3][6], vnow[3];
@@ -269,7 +284,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       for (int c = 0; c < 6; ++c) Jt[k][c] = Jb[k][c] - (G.D[c][0] * Jl[k][0] + G.D[c][1] * Jl[k][1] + G.D[c][2] * Jl[k][2]);
     }
   }
-  const bool active_partner = xchg(active_own ? 1.f : 0.f) != 0.f;
+  const bool active_partner = XL::xchg(active_own ? 1.f : 0.f) != 0.f;
   const bool active_l = pick(leg, active_own, active_partner), active_r = pick(leg, active_partner, active_own);
   const bool any_contact = active_own || active_partner;
 
@@ -279,23 +294,23 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     S2.A = fac;
     Leg Gp = G;  // only Hinv and D of the partner are needed
 #pragma unroll
-    for (int i = 0; i < 6; ++i) Gp.Hinv[i] = xchg(G.Hinv[i]);
+    for (int i = 0; i < 6; ++i) Gp.Hinv[i] = XL::xchg(G.Hinv[i]);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Gp.D[r][c] = xchg(G.D[r][c]);
+      for (int c = 0; c < 3; ++c) Gp.D[r][c] = XL::xchg(G.D[r][c]);
     S2.leg[0] = pick(leg, G, Gp);
     S2.leg[1] = pick(leg, Gp, G);
     float lo6[6], up6[6], q6[6], qd6[6], vn6[6], Jt6[6][6], Jb6[6][6], Jl6[6][3], d2[2], tl2[3], tr2[3];
     int bd6[6];
     bool act2[2] = {active_l, active_r};
-    const float pdist = xchg(dist);
+    const float pdist = XL::xchg(dist);
     d2[0] = pick(leg, dist, pdist);
     d2[1] = pick(leg, pdist, dist);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float plo = xchg(PL.lower[k]), pup = xchg(PL.upper[k]), pq = xchg(s.q[k]), pqd = xchg(s.qd[k]), pvn = xchg(vnow[k]);
-      const float pb = xchg(PL.bounded[k] ? 1.f : 0.f), ptl = xchg(tl[k]);
+      const float plo = XL::xchg(PL.lower[k]), pup = XL::xchg(PL.upper[k]), pq = XL::xchg(s.q[k]), pqd = XL::xchg(s.qd[k]), pvn = XL::xchg(vnow[k]);
+      const float pb = XL::xchg(PL.bounded[k] ? 1.f : 0.f), ptl = XL::xchg(tl[k]);
       lo6[k] = pick(leg, PL.lower[k], plo); lo6[3 + k] = pick(leg, plo, PL.lower[k]);
       up6[k] = pick(leg, PL.upper[k], pup); up6[3 + k] = pick(leg, pup, PL.upper[k]);
       bd6[k] = pick(leg, PL.bounded[k], (int)(pb != 0.f)); bd6[3 + k] = pick(leg, (int)(pb != 0.f), PL.bounded[k]);
@@ -305,13 +320,13 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       tl2[k] = pick(leg, tl[k], ptl); tr2[k] = pick(leg, ptl, tl[k]);
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        const float pjt = xchg(Jt[k][c]), pjb = xchg(Jb[k][c]);
+        const float pjt = XL::xchg(Jt[k][c]), pjb = XL::xchg(Jb[k][c]);
         Jt6[k][c] = pick(leg, Jt[k][c], pjt); Jt6[3 + k][c] = pick(leg, pjt, Jt[k][c]);
         Jb6[k][c] = pick(leg, Jb[k][c], pjb); Jb6[3 + k][c] = pick(leg, pjb, Jb[k][c]);
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float pjl = xchg(Jl[k][j]);
+        const float pjl = XL::xchg(Jl[k][j]);
         Jl6[k][j] = pick(leg, Jl[k][j], pjl); Jl6[3 + k][j] = pick(leg, pjl, Jl[k][j]);
       }
     }
@@ -354,7 +369,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     for (int b = 0; b < 3; ++b) {
       float pY[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) pY[c] = xchg(Y[b][c]);
+      for (int c = 0; c < 6; ++c) pY[c] = XL::xchg(Y[b][c]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         float acc = 0.f;
@@ -368,14 +383,14 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        const float px = xchg(X[a][b]);
+        const float px = XL::xchg(X[a][b]);
         const float v = pick(leg, px, X[a][b]);  // the right lane's product
         A[(3 + a) * (4 + a) / 2 + b] = (active_l && active_r) ? v : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const float pd = xchg(Dg[i]);
+      const float pd = XL::xchg(Dg[i]);
       // packed index i of a 3x3 lower triangle: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
       const int a = i < 1 ? 0 : (i < 3 ? 1 : 2), b = i - a * (a + 1) / 2;
       const float dl = pick(leg, Dg[i], pd), dr = pick(leg, pd, Dg[i]);
@@ -384,7 +399,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float pr = xchg(rhs_own[k]);
+      const float pr = XL::xchg(rhs_own[k]);
       rhs[k] = pick(leg, rhs_own[k], pr);
       rhs[3 + k] = pick(leg, pr, rhs_own[k]);
     }
@@ -412,57 +427,13 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
         if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
       }
     }
-    if (need_pgs) {  // identical data in both lanes: they iterate in lockstep
-      float idiag[6];
-      idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
-      idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
-      const bool both = active_l && active_r;  // both tires touch: their lateral rows are swept together
-      for (int it = 0; it < M.pgs_iterations; ++it) {
-        float change = 0.f, scale = 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const bool is_normal = (r % 3) == 0;
-            if (is_normal != (pass == 0) || ((r % 3) == 2 && both)) continue;
-            float al = 0.f;
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              const int hi = r > b ? r : b, lo = r > b ? b : r;
-              al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
-            }
-            float x = lam[r] + (rhs[r] - al) * idiag[r];
-            if (is_normal) {
-              x = fmaxf(x, 0.f);
-            } else {
-              const float lim = mu * lam[3 * (r / 3)];
-              x = fminf(fmaxf(x, -lim), lim);
-            }
-            change = fmaxf(change, fabsf(x - lam[r]));
-            scale = fmaxf(scale, fabsf(x));
-            lam[r] = x;
-          }
-        }
-        if (both) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep, dynamics.hpp)
-          float r2 = rhs[2], r5 = rhs[5];
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            if (b == 2 || b == 5) continue;
-            r2 -= A[sym(2, b)] * lam[b];
-            r5 -= A[sym(5, b)] * lam[b];
-          }
-          change = fmaxf(change, lateral_pair_sweep(A[sym(2, 2)], A[sym(5, 2)], A[sym(5, 5)], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
-          scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
-        }
-        if (change <= M.pgs_tolerance * scale) break;
-      }
-    }
+    if (need_pgs) contact_pgs6(M, A, rhs, lam, active_l && active_r);  // identical data in both lanes: they iterate in lockstep
     // t += J' lam: own rows locally, base part as own + partner
     float lo_[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) lo_[k] = pick(leg, lam[k], lam[3 + k]);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tb[c] += pair_sum(Jb[0][c] * lo_[0] + Jb[1][c] * lo_[1] + Jb[2][c] * lo_[2]);
+    for (int c = 0; c < 6; ++c) tb[c] += pair_sum<XL>(Jb[0][c] * lo_[0] + Jb[1][c] * lo_[1] + Jb[2][c] * lo_[2]);
 #pragma unroll
     for (int j = 0; j < 3; ++j) tl[j] += Jl[0][j] * lo_[0] + Jl[1][j] * lo_[1] + Jl[2][j] * lo_[2];
   }
@@ -470,7 +441,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   // nu+ = nu + M^-1 t
   float xb[6], xl[3];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) xb[c] = tb[c] - pair_sum(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
+  for (int c = 0; c < 6; ++c) xb[c] = tb[c] - pair_sum<XL>(G.D[c][0] * tl[0] + G.D[c][1] * tl[1] + G.D[c][2] * tl[2]);
   ldl6_solve(fac, xb);
   {
     const float* hv = G.Hinv;

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
 }
 
 #include "pair.hpp"
+#include "octet.hpp"
 
 // Full spine observation, pybullet_backend.py:313-490.
 struct ObsPtrs {
@@ -829,6 +830,7 @@ struct UpkieSim {
   DevLinks links;
   const float* ext_force = nullptr;
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
+  unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   std::string error;
 };
 
@@ -939,6 +941,34 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
       t[LT_LOWER + k] = d->joint_lower[j];
       t[LT_UPPER + k] = d->joint_upper[j];
       t[LT_BOUNDED + k] = (d->joint_lower[j] > -1e30f && d->joint_upper[j] < 1e30f) ? 1.f : 0.f;
+    }
+  }
+  for (int leg = 0; leg < 2; ++leg) {
+    for (int l = 0; l < 4; ++l) {
+      float* t = d->oct_table[4 * leg + l];
+      const bool trunk = l == 0, real = !(trunk && leg == 1);
+      const int k = trunk ? 0 : l - 1, b = trunk ? 0 : 1 + 3 * leg + k, j = 3 * leg + k;
+      t[OT_MASS] = real ? d->mass[b] : 0.f;
+      for (int a = 0; a < 3; ++a) {
+        t[OT_COM + a] = d->com[b][a];
+        t[OT_POS + a] = trunk ? 0.f : d->joint_pos[j][a];
+        t[OT_WHEEL_CENTER + a] = d->wheel_center[leg][a];
+        t[OT_E + a] = (!trunk && k == a) ? 1.f : 0.f;
+      }
+      for (int a = 0; a < 6; ++a) t[OT_INERTIA + a] = real ? d->inertia[b][a] : 0.f;
+      t[OT_SIGN] = trunk ? 0.f : d->joint_sign[j];
+      t[OT_DAMPING] = trunk ? 0.f : d->joint_damping[j];
+      t[OT_LOWER] = d->joint_lower[j];
+      t[OT_UPPER] = d->joint_upper[j];
+      t[OT_BOUNDED] = (!trunk && d->joint_lower[j] > -1e30f && d->joint_upper[j] < 1e30f) ? 1.f : 0.f;
+      t[OT_EFFORT] = d->joint_effort[j];
+      t[OT_VELOCITY] = d->joint_velocity[j];
+      t[OT_WJ] = trunk ? 0.f : 1.f;
+      t[OT_W0] = trunk ? 1.f : 0.f;
+      t[OT_W0_ONCE] = (trunk && leg == 0) ? 1.f : 0.f;
+      t[OT_KEEP_PSI] = (l == 3 && d->wheel_axisymmetric) ? 0.f : 1.f;
+      t[OT_KL] = (trunk && leg == 0) ? d->base_linear_damping : 0.f;
+      t[OT_KA] = (trunk && leg == 0) ? d->base_angular_damping : 0.f;
     }
   }
   return true;
@@ -1148,12 +1178,31 @@ static const int kDenseBatch = 131072;
 // up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
 static const int kPairBatch = 32768;
 
-// up to this many envs a launch maps two lanes to every env (step_kernel_pair)
-static bool uses_lane_pairs(const UpkieSim* sim) {
-  return sim->lanes_per_env == 2 || (sim->lanes_per_env == 0 && sim->config.num_envs <= kPairBatch);
-}
+// up to this many envs eight lanes per env (step_kernel_octet) are at most two waves per SIMD (1024 SIMDs x 64 lanes x 2 / 8)
+static const int kOctetBatch = 16384;
 
-extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : (uses_lane_pairs(sim) ? 2 : 1); }
+// Lanes per env of a step launch: eight (one quad per leg, one lane per body:
+// octet.hpp) while that leaves the chip under-subscribed, two (one lane per
+// leg: pair.hpp) up to one wave per SIMD, one beyond. The in-step spine
+// observers exist in the one- and two-lane kernels only.
+static int mapped_lanes(const UpkieSim* sim) {
+  if (sim->lanes_per_env == 8 || sim->lanes_per_env == 2 || sim->lanes_per_env == 1) {
+    if (sim->lanes_per_env == 8 && sim->spine_state) return 2;
+    return sim->lanes_per_env;
+  }
+  if (sim->config.num_envs <= kOctetBatch && !sim->spine_state) return 8;
+  return sim->config.num_envs <= kPairBatch ? 2 : 1;
+}
+// fewer lanes than envs x 2: several env.step() of the fused agent can share a launch (state in registers)
+static bool uses_lane_pairs(const UpkieSim* sim) { return mapped_lanes(sim) >= 2; }
+
+extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : mapped_lanes(sim); }
+
+extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  sim->census = counters;
+  return UPKIE_OK;
+}
 
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
@@ -1189,8 +1238,14 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
                      n_steps)
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
+#define UPKIE_LAUNCH_OCTET(R)                                                                                                \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+                     sim->d_model, sim->limits, config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, \
+                     final_obs, n_steps, sim->census)
   const bool spine = sim->spine_state != nullptr;
-  if (paired) {
+  if (mapped_lanes(sim) == 8) {
+    if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
+  } else if (paired) {
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
   } else if constexpr (MODE == MODE_PENDULUM_ROLLOUT) {
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "several steps per launch need the two-lane mapping");
@@ -1199,6 +1254,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   } else {
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
+#undef UPKIE_LAUNCH_OCTET
 #undef UPKIE_LAUNCH_PAIR_S
 #undef UPKIE_LAUNCH_S
 #undef UPKIE_LAUNCH_PAIR

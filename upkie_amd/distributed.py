@@ -219,7 +219,8 @@ class ShardedPendulum:
     @property
     def kernel_name(self) -> str:
         lanes = self.lanes_per_env
-        return {1: "step_kernel<MODE_PENDULUM_AGENT> (one env per lane)", 2: "step_kernel_pair<MODE_PENDULUM_AGENT / _ROLLOUT> (two lanes per env)"}.get(
+        return {1: "step_kernel<MODE_PENDULUM_AGENT> (one env per lane)", 2: "step_kernel_pair<MODE_PENDULUM_AGENT / _ROLLOUT> (two lanes per env)",
+                8: "step_kernel_octet<MODE_PENDULUM_AGENT / _ROLLOUT> (eight lanes per env: one quad per leg, one lane per body)"}.get(
             lanes, f"step kernel, {lanes} lanes per env")
 
     def step_agent(self) -> None:

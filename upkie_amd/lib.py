@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_last_error",
     "upkie_sim_state_bytes",
     "upkie_sim_lanes_per_env",
+    "upkie_sim_set_census",
     "upkie_sim_set_randomization",
     "upkie_sim_set_external_forces",
     "upkie_sim_sample_body_inertials",
@@ -147,6 +148,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_state_bytes.argtypes = [vp]
     lib.upkie_sim_lanes_per_env.restype = C.c_int
     lib.upkie_sim_lanes_per_env.argtypes = [vp]
+    lib.upkie_sim_set_census.restype = C.c_int
+    lib.upkie_sim_set_census.argtypes = [vp, vp]
     lib.upkie_sim_set_randomization.restype = C.c_int
     lib.upkie_sim_set_randomization.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
     lib.upkie_sim_set_external_forces.restype = C.c_int

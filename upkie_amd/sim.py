@@ -391,6 +391,21 @@ class BatchedSim:
         """Lanes of a wavefront sharing one env in this handle's step kernels."""
         return int(self._lib.upkie_sim_lanes_per_env(self._handle))
 
+    CENSUS_FIELDS = ("joint_limit", "one_tire", "friction_cone", "leg_forces", "wavefront_substeps_general", "wavefront_substeps_pgs")
+
+    def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
+        """Rare-path census of the eight-lane step kernel (`upkie_sim_set_census`):
+        a zeroed device buffer the kernels count into, or None when switched off."""
+        self.census = torch.zeros(8, dtype=torch.int32, device=self.device) if on else None
+        self._check(self._lib.upkie_sim_set_census(self._handle, _ptr(self.census)))
+        return self.census
+
+    def census_counts(self) -> dict:
+        """Counters of `enable_census` so far: env-substeps handed to the general
+        substep by reason, and wavefront-substeps that ran it."""
+        values = self.census.cpu().tolist()
+        return dict(zip(self.CENSUS_FIELDS, values))
+
     def restart_random_streams(self) -> None:
         """Zero the per-env episode and noise-step counters that key the Philox
         streams: (seed, env, episode = 0) is replayed by the next reset, as
