@@ -43,10 +43,10 @@ def test_invariants_at_full_size(B):
     assert bool((st[abi.S_EPISODE] == 1).all())
 
 
-@pytest.mark.parametrize("big_b,small_b", [(65536, 40000), (32768, 20000), (16384, 1000)])
+@pytest.mark.parametrize("big_b,small_b", [(65536, 40000), (32768, 20000), (8192, 1000)])
 def test_prefix_of_a_large_batch_equals_a_small_batch(big_b, small_b):
     """Env i does not depend on how many envs share the launch. (Batches up to
-    16384 envs use the eight-lanes-per-env mapping, up to 32768 two lanes per
+    8192 envs use the eight-lanes-per-env mapping, up to 32768 two lanes per
     env, larger ones one lane per env: bit equality holds within a mapping,
     tolerance across, see test_two_lanes_per_env_equals_one_lane_per_env.)"""
     big = BatchedSim(randomized_config(big_b, seed=9, autoreset=True))

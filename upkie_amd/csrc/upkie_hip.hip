@@ -1178,8 +1178,9 @@ static const int kDenseBatch = 131072;
 // up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
 static const int kPairBatch = 32768;
 
-// up to this many envs eight lanes per env (step_kernel_octet) are at most two waves per SIMD (1024 SIMDs x 64 lanes x 2 / 8)
-static const int kOctetBatch = 16384;
+// up to this many envs eight lanes per env (step_kernel_octet) are one wave per SIMD (1024 SIMDs x 64 lanes / 8): the
+// kernel carries the two-lane substep for its rarest cases and with it 384 registers, one wave per SIMD
+static const int kOctetBatch = 8192;
 
 // Lanes per env of a step launch: eight (one quad per leg, one lane per body:
 // octet.hpp) while that leaves the chip under-subscribed, two (one lane per
