@@ -121,3 +121,60 @@ def test_reference_mpc_balancer_test_restated():
     v_before = v.copy()
     O.lib().oracle_mpc_step(C.byref(cfg), p(ws), p(x0), p(np.array([0.2])), p(contact), C.c_double(0.01), p(v), p(first))
     assert v[0] == pytest.approx(v_before[0] * (1 - 0.01 / 0.1), abs=1e-15)
+
+
+@pytest.mark.parametrize("N", [16, 50])
+def test_condensed_qp_equals_the_cost_of_a_forward_simulation(N):
+    """An independent derivation of P and q: no Phi / Psi
+    stacks. The discrete model comes from the matrix exponential of the
+    continuous wheeled inverted pendulum (p'' = a, theta'' = (g / l) theta -
+    a / l), the trajectory from stepping x+ = A x + B u through a random input
+    sequence, and the cost from the reference's own definition: target states
+    of get_target_states (mpc_balancer.py:18-37: position p0 + k T v*, velocity
+    v*, zero pitch and pitch rate), stage state / stage input / terminal
+    weights of mpc_balancer.py:176-178 as qpmpc's MPCProblem applies them
+    (states 0 .. N-1 against the stage weight, state N against the terminal
+    one, every input against the input weight). J(U) - J(0) must be the
+    quadratic form of the condensed QP, U'PU / 2 + q'U up to the one constant
+    factor a least-squares cost may carry (1 or 2), for every U, x0, v*: a
+    sign, ordering or weighting slip in the condensing would show here while
+    passing every test that shares the condensing with the kernel."""
+    from scipy.linalg import expm
+
+    cfg, P, Kx, kv = build(N)
+    T, l, g = cfg.sampling_period, cfg.leg_length, 9.81
+    Ac = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [0, 0, 0, 0], [0, g / l, 0, 0]], dtype=np.float64)
+    Bc = np.array([0, 0, 1, -1 / l], dtype=np.float64)
+    aug = np.zeros((5, 5))
+    aug[:4, :4], aug[:4, 4] = Ac, Bc
+    E = expm(aug * T)
+    A, B = E[:4, :4], E[:4, 4]
+    wx, wu, wT = cfg.stage_state_cost_weight, cfg.stage_input_cost_weight, cfg.terminal_cost_weight
+
+    def cost(x0, vt, U):
+        x, J = x0.copy(), 0.0
+        for k in range(N + 1):
+            ref = np.array([x0[0] + k * T * vt, 0.0, vt, 0.0])
+            J += (wT if k == N else wx) * float((x - ref) @ (x - ref))
+            if k == N:
+                break
+            J += wu * U[k] ** 2
+            x = A @ x + B * U[k]
+        return J
+
+    rng = np.random.default_rng(1)
+    factors = []
+    for _ in range(12):
+        x0, vt = rng.normal(size=4) * np.array([1.0, 0.2, 0.5, 0.5]), rng.normal()
+        q = Kx @ x0 + kv * vt
+        U = rng.uniform(-cfg.max_ground_accel, cfg.max_ground_accel, N)
+        lhs = cost(x0, vt, U) - cost(x0, vt, np.zeros(N))
+        rhs = 0.5 * U @ P @ U + q @ U
+        factors.append(lhs / rhs)
+        # ... and the gradient at a random point, which pins q on its own
+        eps = 1e-6
+        grad = np.array([(cost(x0, vt, U + eps * e) - cost(x0, vt, U - eps * e)) / (2 * eps) for e in np.eye(N)])
+        np.testing.assert_allclose(grad / factors[-1], P @ U + q, rtol=1e-6, atol=1e-7)
+    factors = np.array(factors)
+    assert np.abs(factors - factors[0]).max() < 1e-9 * abs(factors[0])
+    assert min(abs(factors[0] - 1.0), abs(factors[0] - 2.0)) < 1e-9

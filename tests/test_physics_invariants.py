@@ -1,0 +1,308 @@
+"""Invariants a rigid-body engine with rolling contacts satisfies whatever its
+solver -- what Bullet's stepSimulation() would satisfy too -- checked on the
+fp64 oracle (CPU) and on the device kernels in every lane mapping (VERDICT r1,
+item 7b). Bullet itself is absent: these do not pin trajectories,
+they pin the physics the trajectories must obey:
+
+* rolling without slipping: the tire centre moves at radius x the wheel's
+  absolute spin, sideways not at all;
+* statics: the normal forces of the two tires carry the robot's weight;
+* the linearised falling mode of the robot on free wheels has the rate the
+  model's masses and inertias give (wheeled inverted pendulum);
+* free flight conserves energy up to the integrator's own drift.
+"""
+
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from upkie_amd import abi
+from upkie_amd.model.default_model import default_model
+
+G = 9.81
+B = 8  # a handful of envs with different initial conditions
+
+
+# ---------------------------------------------------------------- rigs
+class OracleRig:
+    def __init__(self, model, cfg):
+        self.o = O.Oracle(model, cfg)
+        self.model = model
+
+    def reset(self):
+        self.o.reset()
+
+    def state(self):
+        return self.o.state.copy()
+
+    def set_state(self, s):
+        self.o.state[:] = s
+
+    def step_servos(self, act):
+        self.o.step_servos(act)
+
+    def contact_points(self):
+        return self.o.contact_points()
+
+
+class DeviceRig:
+    def __init__(self, model, cfg):
+        import torch
+
+        from upkie_amd.sim import BatchedSim
+
+        self.torch = torch
+        self.sim = BatchedSim(cfg, model)
+        self.model = model
+
+    def reset(self):
+        self.sim.reset()
+
+    def state(self):
+        return self.sim.state_numpy().astype(np.float64)
+
+    def set_state(self, s):
+        self.sim.state.copy_(self.torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)))
+
+    def step_servos(self, act):
+        self.sim.step_servos(self.torch.from_numpy(np.ascontiguousarray(act, dtype=np.float32)))
+
+    def contact_points(self):
+        return self.sim.contact_points().cpu().numpy().astype(np.float64)
+
+
+RIGS = [
+    pytest.param("oracle", id="oracle-fp64"),
+    pytest.param("1", marks=pytest.mark.gpu, id="device-1-lane"),
+    pytest.param("2", marks=pytest.mark.gpu, id="device-2-lanes"),
+    pytest.param("8", marks=pytest.mark.gpu, id="device-8-lanes"),
+]
+
+
+def make_rig(kind, model, cfg, monkeypatch):
+    if kind == "oracle":
+        return OracleRig(model, cfg)
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", kind)
+    rig = DeviceRig(model, cfg)
+    assert rig.sim.lanes_per_env == int(kind)
+    return rig
+
+
+def quiet_model():
+    m = default_model()
+    m.base_linear_damping = 0.0
+    m.base_angular_damping = 0.0
+    return m
+
+
+# ---------------------------------------------------------------- kinematics of the model at a given state
+def rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (w * y + x * z)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def roty(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def wheel_center_motion(model, s, leg):
+    """World velocity of the tire centre of `leg`, the wheel's absolute spin
+    about its axle, and the axle direction, from one env's state words."""
+    R = rot(s[abi.S_QUAT : abi.S_QUAT + 4])
+    v, w = s[abi.S_LINVEL : abi.S_LINVEL + 3], s[abi.S_ANGVEL : abi.S_ANGVEL + 3]
+    q, qd = s[abi.S_Q + 3 * leg : abi.S_Q + 3 * leg + 3], s[abi.S_QD + 3 * leg : abi.S_QD + 3 * leg + 3]
+    sign = [float(model.joint_axis[3 * leg + k][1]) for k in range(3)]
+    pos = [np.array(model.joint_pos[3 * leg + k][:]) for k in range(3)]
+    # joint origins in the base frame and their velocities relative to the base
+    o = [pos[0]]
+    psi = sign[0] * q[0]
+    o.append(o[0] + roty(psi) @ pos[1])
+    psi2 = psi + sign[1] * q[1]
+    o.append(o[1] + roty(psi2) @ pos[2])
+    center = o[2] + np.array(model.wheel_center[leg][:])
+    y = np.array([0.0, 1.0, 0.0])
+    rel = np.zeros(3)
+    for j in range(2):  # hip and knee move the axle relative to the base
+        rel += np.cross(sign[j] * qd[j] * y, center - o[j])
+    vc = v + np.cross(w, R @ center) + R @ rel
+    axle = R @ y
+    spin = float(w @ axle) + sum(sign[k] * qd[k] for k in range(3))
+    return vc, spin, axle
+
+
+def balancing_action(state, model, target=0.0):
+    """Legs held at zero by the servos, wheels on the README's feedback
+    (velocity targets), for every env of a state array."""
+    n = state.shape[1]
+    act = np.zeros((n, 6, 6))
+    act[:, :, 3] = 1.0
+    act[:, :, 4] = 1.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = np.nan
+    act[:, [2, 5], 5] = 1.7
+    qw, qx, qy, qz = state[abi.S_QUAT : abi.S_QUAT + 4]
+    pitch = np.arcsin(np.clip(2 * (qw * qy - qz * qx), -1, 1))
+    r = model.wheel_radius
+    pos = 0.5 * (state[abi.S_Q + 2] - state[abi.S_Q + 5]) * r * model.left_sign
+    vel = 0.5 * (state[abi.S_QD + 2] - state[abi.S_QD + 5]) * r * model.left_sign
+    v = np.clip(10.0 * pitch + (pos - target) + 0.1 * vel, -0.9, 0.9) / r
+    act[:, 2, 1] = model.left_sign * v
+    act[:, 5, 1] = -model.left_sign * v
+    return act
+
+
+def standing_rig(kind, monkeypatch, model=None, **rand):
+    model = model or quiet_model()
+    cfg = abi.default_sim_config(B, seed=3)
+    for k, v in rand.items():
+        setattr(cfg, k, v)
+    rig = make_rig(kind, model, cfg, monkeypatch)
+    rig.reset()
+    return rig, model
+
+
+# ---------------------------------------------------------------- tests
+@pytest.mark.parametrize("kind", RIGS)
+def test_rolling_without_slipping(kind, monkeypatch):
+    """In traction the contact point of a tire is at rest: the tire centre moves
+    at r x (absolute spin of the wheel) along axle x vertical, and not along the
+    axle. Robots balancing while they track a 0.3 m position offset."""
+    rig, model = standing_rig(kind, monkeypatch, rand_pitch=0.05, rand_x=0.05)
+    r = model.wheel_radius
+    worst_roll = worst_side = 0.0
+    speeds = []
+    for step in range(300):
+        s = rig.state()
+        rig.step_servos(balancing_action(s, model, target=0.3))
+        if step < 100:  # landing and the first saturated commands
+            continue
+        s = rig.state()
+        for e in range(B):
+            for leg in (0, 1):
+                vc, spin, axle = wheel_center_motion(model, s[:, e], leg)
+                forward = np.cross(axle, [0.0, 0.0, 1.0])
+                worst_roll = max(worst_roll, abs(vc @ forward - r * spin))
+                worst_side = max(worst_side, abs(vc @ axle))
+                speeds.append(abs(vc @ forward))
+    assert max(speeds) > 0.05  # the robots did move
+    # (friction rows carry a CFM of 0.01 / kg: a slip of 0.01 x the tangential impulse, ~1e-4 m/s at most here)
+    assert worst_roll < 2e-3 and worst_side < 2e-3, (worst_roll, worst_side)
+
+
+@pytest.mark.parametrize("kind", RIGS)
+def test_normal_forces_carry_the_weight(kind, monkeypatch):
+    """A balanced robot at rest: the two normal forces reported by
+    get_contact_points (pybullet_backend.py:660-716) add up to m g, shared
+    evenly, and the friction forces are a small fraction of them."""
+    rig, model = standing_rig(kind, monkeypatch)
+    for _ in range(600):
+        rig.step_servos(balancing_action(rig.state(), model))
+    cp = rig.contact_points()
+    weight = O.total_mass(model) * G
+    assert np.all(cp[:, :, 0] == 1.0)
+    normal = cp[:, :, 6]
+    np.testing.assert_allclose(normal.sum(axis=1), weight, rtol=0.02)
+    np.testing.assert_allclose(normal[:, 0], normal[:, 1], rtol=0.05)
+    assert np.abs(cp[:, :, 4:6]).max() < 0.1 * weight
+
+
+@pytest.mark.parametrize("kind", RIGS)
+def test_falling_rate_of_the_wheeled_inverted_pendulum(kind, monkeypatch):
+    """Legs locked by stiff servos, wheels free (no torque, no friction): the
+    pitch leaves its equilibrium like cosh(lambda t) with
+    lambda^2 = m g l / (I + m l^2 - (m l)^2 / (m + m_w + I_w / r^2)),
+    m, l, I the locked body's mass, centre-of-mass distance from the axle and
+    inertia about its centre of mass, m_w, I_w the wheels'. All from the model."""
+    model = quiet_model()
+    for j in (2, 5):
+        model.joint_damping[j] = 0.0
+    rig, model = standing_rig(kind, monkeypatch, model=model)
+    # first-principles rate
+    y = np.array([0.0, 1.0, 0.0])
+    pos = [np.array(model.joint_pos[j][:]) for j in range(6)]
+    origin = {0: np.zeros(3)}
+    for leg in (0, 1):
+        o = np.zeros(3)
+        for k in range(3):
+            o = o + pos[3 * leg + k]
+            origin[1 + 3 * leg + k] = o
+    axle = 0.5 * (origin[3] + origin[6])
+    body = [0, 1, 2, 4, 5]
+    m = sum(model.mass[b] for b in body)
+    com = sum(model.mass[b] * (origin[b] + np.array(model.com[b][:])) for b in body) / m
+    I = sum(model.inertia[b][1] + model.mass[b] * np.sum((origin[b] + np.array(model.com[b][:]) - com)[[0, 2]] ** 2) for b in body)
+    arm = (com - axle)[[0, 2]]
+    l = float(np.linalg.norm(arm))
+    pitch_eq = -math.atan2(arm[0], arm[1])  # the pitch that puts the centre of mass above the axle
+    r = model.wheel_radius
+    m_t = m + model.mass[3] + model.mass[6] + (model.inertia[3][1] + model.inertia[6][1]) / r**2
+    lam = math.sqrt(m * G * l / (I + m * l * l - (m * l) ** 2 / m_t))
+    # settle on the floor at the equilibrium pitch, at rest, then let go
+    s = rig.state()
+    offset = 0.01
+    s[abi.S_QUAT : abi.S_QUAT + 4] = np.array([math.cos((pitch_eq + offset) / 2), 0.0, math.sin((pitch_eq + offset) / 2), 0.0])[:, None]
+    s[abi.S_LINVEL : abi.S_ANGVEL + 3] = 0.0
+    s[abi.S_QD : abi.S_QD + 6] = 0.0
+    height = float(-(roty(pitch_eq + offset) @ axle)[2] + r)
+    s[abi.S_POS + 2] = height - 1e-4
+    rig.set_state(s)
+    act = np.zeros((B, 6, 6))
+    act[:, :, 3] = 5.0  # stiff legs
+    act[:, :, 4] = 5.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = np.nan
+    act[:, [2, 5], 3:5] = 0.0  # free wheels
+    act[:, [2, 5], 5] = 0.0
+    steps = 50  # 0.25 s
+    for _ in range(steps):
+        rig.step_servos(act)
+    s = rig.state()
+    pitch = np.arcsin(np.clip(2 * (s[abi.S_QUAT] * s[abi.S_QUAT + 2] - s[abi.S_QUAT + 3] * s[abi.S_QUAT + 1]), -1, 1))
+    measured = np.arccosh((pitch - pitch_eq) / offset) / (steps * 0.005)
+    assert 5.0 < lam < 15.0  # (9.35 / s for the default model: free wheels roll away under the falling body)
+    np.testing.assert_allclose(measured, lam, rtol=0.03)
+
+
+@pytest.mark.parametrize("kind", RIGS)
+def test_free_flight_conserves_energy(kind, monkeypatch):
+    """No contact, no damping, no torques: kinetic + potential energy stays put
+    up to the drift of semi-implicit Euler at 1 ms (spinning trunk, swinging
+    legs), over 0.5 s."""
+    model = quiet_model()
+    for j in range(6):
+        model.joint_damping[j] = 0.0
+    model.enforce_joint_limits = 0
+    cfg = abi.default_sim_config(B, seed=4)
+    rig = make_rig(kind, model, cfg, monkeypatch)
+    rig.reset()
+    rng = np.random.default_rng(2)
+    s = rig.state()
+    s[abi.S_POS + 2] = 50.0
+    s[abi.S_LINVEL : abi.S_LINVEL + 3] = rng.uniform(-1, 1, (3, B))
+    s[abi.S_ANGVEL : abi.S_ANGVEL + 3] = rng.uniform(-2, 2, (3, B))
+    s[abi.S_Q : abi.S_Q + 6] = rng.uniform(-0.4, 0.4, (6, B))
+    s[abi.S_QD : abi.S_QD + 6] = rng.uniform(-3, 3, (6, B))
+    rig.set_state(s)
+    act = np.zeros((B, 6, 6))
+    act[:, :, 0] = np.nan  # no position term, zero gains, zero feedforward: no torque
+
+    def energies(s):
+        return np.array([O.energy(model, s[abi.S_POS : abi.S_POS + 3, e], s[abi.S_QUAT : abi.S_QUAT + 4, e], s[abi.S_LINVEL : abi.S_LINVEL + 3, e],
+                                  s[abi.S_ANGVEL : abi.S_ANGVEL + 3, e], s[abi.S_Q : abi.S_Q + 6, e], s[abi.S_QD : abi.S_QD + 6, e]) for e in range(B)])
+
+    s0 = rig.state()
+    e0 = energies(s0)
+    kinetic0 = e0 - O.total_mass(model) * G * 50.0  # (potential is dominated by the 50 m of height)
+    for _ in range(100):
+        rig.step_servos(act)
+    s1 = rig.state()
+    drift = np.abs(energies(s1) - e0)
+    assert np.all(s1[abi.S_POS + 2] > 40.0)
+    # fp32 state at z = 50 m: one ulp of height is 4e-6 m = 2e-4 J; the integrator's drift is ~1e-3 of the kinetic energy
+    assert np.all(drift < 0.02 * np.abs(kinetic0) + 0.02), (drift, kinetic0)
