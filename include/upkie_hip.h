@@ -343,6 +343,32 @@ int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* act,
                           float* obs, float* reward, uint8_t* terminated,
                           uint8_t* truncated, void* stream);
 
+/* On-device servo-level policy for UpkieServos: ONE small launch that writes the
+ * action buffer act[B][6][6] of the next upkie_sim_step_servos from the state,
+ * so that a servo-level agent needs no host round trip (BASELINE.json
+ * configs[4]). The law is examples/pybullet/torque_balancing.py:15-37 with
+ * room for the README's velocity feedback: every joint j starts from
+ * `action[j]` (ACTION_KEYS order) and gets
+ *   feedforward_torque += pitch_to_torque[j] * pitch
+ *   velocity           += clip(pitch_to_velocity[j] * pitch + position_to_velocity[j] * p + velocity_to_velocity[j] * pdot,
+ *                               +-velocity_feedback_clip[j])        (no clipping where velocity_feedback_clip[j] <= 0)
+ * with pitch = base_orientation.pitch of the spine observation and p, pdot the
+ * ground position / velocity of upkie_gyropod.py:186-214 (wheel odometry).
+ * Envs with |pitch| > fall_pitch get their UPKIE_S_DONE word set: with
+ * UPKIE_AUTORESET_NEXT_STEP the step that follows re-initialises them (what the
+ * example's `if terminated or truncated: env.reset()` does); fall_pitch <= 0
+ * switches that off. */
+typedef struct UpkieServoPolicy {
+  float action[UPKIE_NJ][6];
+  float pitch_to_torque[UPKIE_NJ];
+  float pitch_to_velocity[UPKIE_NJ];
+  float position_to_velocity[UPKIE_NJ];
+  float velocity_to_velocity[UPKIE_NJ];
+  float velocity_feedback_clip[UPKIE_NJ];
+  float fall_pitch;
+} UpkieServoPolicy;
+int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, void* stream);
+
 /* Full spine observation (pybullet_backend.py:313-490), materialised lazily.
  * Any pointer may be NULL. */
 typedef struct UpkieSpineObservation {

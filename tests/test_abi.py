@@ -41,6 +41,7 @@ def test_struct_layouts_match_header():
       printf("%zu %zu %zu %zu %zu\n", offsetof(UpkieSimConfig, dt), offsetof(UpkieSimConfig, fall_pitch), offsetof(UpkieSimConfig, init_pos), offsetof(UpkieSimConfig, seed), offsetof(UpkieSimConfig, agent_clip));
       printf("%zu %zu\n", offsetof(UpkieMpcConfig, sampling_period), offsetof(UpkieMpcConfig, admm_rho));
       printf("%d %d %d %d\n", UPKIE_STATE_WORDS, UPKIE_S_TORQUE, UPKIE_S_DONE, UPKIE_S_CONTACT);
+      printf("%zu %zu %zu %d\n", sizeof(UpkieServoPolicy), offsetof(UpkieServoPolicy, velocity_feedback_clip), offsetof(UpkieServoPolicy, fall_pitch), UPKIE_CENSUS_WORDS);
       printf("%zu %zu %zu %d %d %d\n", offsetof(UpkieObserverConfig, dt), offsetof(UpkieObserverConfig, signed_radius), offsetof(UpkieObserverConfig, rotation_ars_to_world), UPKIE_OBSERVER_STATE_WORDS, UPKIE_O_UPPER_LEG_TORQUE, UPKIE_O_ODOMETRY_VELOCITY);
       return 0;
     }
@@ -69,8 +70,10 @@ def test_struct_layouts_match_header():
     p = abi.UpkieMpcConfig
     assert [int(x) for x in out[3].split()] == [p.sampling_period.offset, p.admm_rho.offset]
     assert [int(x) for x in out[4].split()] == [abi.STATE_WORDS, abi.S_TORQUE, abi.S_DONE, abi.S_CONTACT]
+    sp = abi.UpkieServoPolicy
+    assert [int(x) for x in out[5].split()] == [C.sizeof(sp), sp.velocity_feedback_clip.offset, sp.fall_pitch.offset, 8]
     o = abi.UpkieObserverConfig
-    assert [int(x) for x in out[5].split()] == [
+    assert [int(x) for x in out[6].split()] == [
         o.dt.offset,
         o.signed_radius.offset,
         o.rotation_ars_to_world.offset,

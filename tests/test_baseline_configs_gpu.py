@@ -393,3 +393,55 @@ def test_device_replays_the_reference_wrapper_sequences(envs_golden, name):
         np.testing.assert_allclose(got, step["observation"], rtol=2e-6, atol=5e-7)
         assert (abs(obs6[1]) > cfg.fall_pitch) == step["terminated"]
     assert checked >= 5 * len(g["steps"])  # six torques per step, minus the few at the stiction threshold
+
+
+def test_c5_share_with_the_servo_policy_on_the_device_matches_oracle():
+    """C5 as an RL loop runs it, with nothing on the host between two steps:
+    `upkie_sim_servo_policy` (examples/pybullet/torque_balancing.py:15-37 on the
+    device: legs held, wheel torques +-10 x pitch, fallen robots flagged) then
+    `upkie_sim_step_servos` with NEXT_STEP autoreset, per-link inertia
+    randomisation 0.2 and a push on the torso, 4096 envs x 40 steps -- against
+    the same law written in numpy on the fp64 oracle's state."""
+    B = 4096
+    cfg = randomized_config(B, seed=4, autoreset=True)
+    cfg.rand_pitch = 0.3  # some robots start beyond the policy's fall threshold
+    cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
+    model = Model().struct
+    oracle, sim = make_pair(B, cfg=cfg, model=model)
+    rec_o = oracle.sample_body_inertials(0.2)
+    sim.randomize_inertias(0.2)
+    oracle.body_inertials = rec_o
+    rng = np.random.default_rng(6)
+    force = np.stack([rng.uniform(-5.0, 5.0, B), np.zeros(B), np.zeros(B)])
+    oracle.ext_force = force
+    oracle.ext_point = np.array([0.0, 0.0, -0.1])
+    sim.set_external_force(torch.from_numpy(force).float(), point=(0.0, 0.0, -0.1))
+    oracle.reset()
+    sim.reset()
+    policy = abi.torque_balancing_policy(gain=10.0, fall_pitch=0.25, left_sign=float(model.left_sign))  # (a low threshold: falls happen within the test)
+    template = np.array([[policy.action[j][k] for k in range(6)] for j in range(6)], dtype=np.float64)
+    r = float(model.left_sign * model.wheel_radius)
+    worst = np.zeros(3)
+    for step in range(40):
+        st = oracle.state
+        pitch = np.arcsin(np.clip(2.0 * (st[abi.S_QUAT] * st[abi.S_QUAT + 2] - st[abi.S_QUAT + 3] * st[abi.S_QUAT + 1]), -1, 1))
+        act_o = np.broadcast_to(template, (B, 6, 6)).copy()
+        act_o[:, 2, 2] += policy.pitch_to_torque[2] * pitch
+        act_o[:, 5, 2] += policy.pitch_to_torque[5] * pitch
+        st[abi.S_DONE][np.abs(pitch) > policy.fall_pitch] = 1.0
+        act_h = sim.servo_policy(policy)
+        # the device policy sees the device state: compare the actions on the envs whose states still agree closely
+        dq = np.abs(sim.state_numpy()[abi.S_QUAT : abi.S_QUAT + 4].astype(np.float64) - st[abi.S_QUAT : abi.S_QUAT + 4]).max(axis=0)
+        close = dq < 1e-5
+        a_h = act_h.cpu().numpy().astype(np.float64)
+        assert np.array_equal(np.isnan(a_h), np.isnan(act_o))
+        np.testing.assert_allclose(np.nan_to_num(a_h[close]), np.nan_to_num(act_o[close]), atol=2e-4)
+        assert np.array_equal(sim.state_numpy()[abi.S_DONE][close] != 0, st[abi.S_DONE][close] != 0)
+        oracle.step_servos(act_o)
+        sim.step_servos(act_h)
+        err = np.abs(sim.state_numpy()[:13].astype(np.float64) - oracle.state[:13])
+        worst = np.maximum(worst, [np.quantile(err[:7].max(axis=0), 0.5), np.quantile(err[:7].max(axis=0), 0.99), np.mean(err[:7].max(axis=0) > 1e-2)])
+    episodes_o, episodes_h = oracle.state[abi.S_EPISODE], sim.state_numpy()[abi.S_EPISODE]
+    assert episodes_o.sum() > B + 50  # robots did fall and were re-initialised by the step that followed
+    assert np.mean(episodes_o == episodes_h) > 0.99  # (a threshold crossing can land one step apart in fp32)
+    assert worst[0] < 2e-5 and worst[1] < 2e-3 and worst[2] < 0.01, worst

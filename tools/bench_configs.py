@@ -56,4 +56,27 @@ loop = GraphedLoop(servo_step, unroll=8)
 dt = timeit(loop.replay, 100, 10) / 8
 out.append(dict(config="C5 share: UpkieServos, inertia_variation 0.2, +-5 N torso push, wheel friction 0.1, PyTorch balancing law, fallen robots reset; hipGraph, 8 steps per launch",
                 envs=B, us_per_step=dt * 1e6, env_steps_per_s=B / dt, eager_python_us_per_step=dt_eager * 1e6, algorithmic_bytes_per_env_step=630))
+# C5 share with the servo-level policy on the device (upkie_sim_servo_policy, fallen robots flagged for the NEXT_STEP
+# autoreset): two launches per step, nothing on the host in between; same randomisation and push. Two laws: the README's
+# balancer through the wheels' velocity loop (what the PyTorch law above does), and examples/pybullet/torque_balancing.py:15-37
+# (wheel torques +-10 x pitch, no velocity feedback: the robots run away, slip and fall -- most substeps go through the
+# Gauss-Seidel sweeps, see the census).
+for label, make_policy in (("README balancer through the wheel velocity loop", lambda m: abi.velocity_balancing_policy(float(m.wheel_radius), 1.0, float(m.left_sign))),
+                           ("examples/pybullet/torque_balancing.py (pitch -> wheel torque)", lambda m: abi.torque_balancing_policy(10.0, 1.0, float(m.left_sign)))):
+    env2 = envs.make("Upkie-HIP-Servos-Vec", num_envs=B, frequency=200.0, inertia_variation=0.2, init_state=rand_state(), autoreset_mode="next_step",
+                     joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
+    env2.reset(seed=0)
+    env2.set_external_forces("torso", push)
+    policy = make_policy(env2.model.struct)
+    census = env2.sim.enable_census()
+    def policy_step():
+        env2.sim.step_servos(env2.sim.servo_policy(policy))
+    timeit(policy_step, 200, 200)
+    census.zero_()
+    dt_policy = timeit(policy_step, 2000, 0)
+    c = env2.sim.census_counts()
+    out.append(dict(config=f"C5 share, servo-level policy on the device ({label}): upkie_sim_servo_policy + upkie_sim_step_servos, NEXT_STEP autoreset of fallen robots, two launches per step, Python loop",
+                    envs=B, us_per_step=dt_policy * 1e6, env_steps_per_s=B / dt_policy, lanes_per_env=env2.sim.lanes_per_env, episodes=int(env2.sim.state[40].sum()),
+                    env_substeps_in_gauss_seidel_sweeps=c["friction_cone"] / (B * 5 * 2000), env_substeps_on_the_general_path=(c["joint_limit"] + c["leg_forces"]) / (B * 5 * 2000),
+                    algorithmic_bytes_per_env_step=630 + 2 * 144))
 for line in out: print(json.dumps(line))

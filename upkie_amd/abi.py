@@ -192,6 +192,53 @@ class UpkieExternalForces(C.Structure):
     ]
 
 
+class UpkieServoPolicy(C.Structure):
+    """On-device servo-level policy (include/upkie_hip.h, upkie_sim_servo_policy)."""
+
+    _fields_ = [
+        ("action", (C.c_float * 6) * NJ),
+        ("pitch_to_torque", C.c_float * NJ),
+        ("pitch_to_velocity", C.c_float * NJ),
+        ("position_to_velocity", C.c_float * NJ),
+        ("velocity_to_velocity", C.c_float * NJ),
+        ("velocity_feedback_clip", C.c_float * NJ),
+        ("fall_pitch", C.c_float),
+    ]
+
+
+def torque_balancing_policy(gain: float = 10.0, fall_pitch: float = 1.0, left_sign: float = 1.0) -> "UpkieServoPolicy":
+    """examples/pybullet/torque_balancing.py:15-37: legs held at zero, no
+    velocity feedback in the wheels, wheel torques +-gain x pitch."""
+    policy = UpkieServoPolicy()
+    for j in range(NJ):
+        wheel = j in (2, 5)
+        policy.action[j][0] = float("nan") if wheel else 0.0  # position
+        policy.action[j][1] = 0.0  # velocity
+        policy.action[j][2] = 0.0  # feedforward torque
+        policy.action[j][3] = 1.0  # kp_scale
+        policy.action[j][4] = 0.0 if wheel else 1.0  # kd_scale
+        policy.action[j][5] = 1.7 if wheel else 16.0  # maximum torque (clamped to the joint's effort limit by the step)
+    policy.pitch_to_torque[2] = left_sign * gain
+    policy.pitch_to_torque[5] = -left_sign * gain
+    policy.fall_pitch = fall_pitch
+    return policy
+
+
+def velocity_balancing_policy(wheel_radius: float, fall_pitch: float = 1.0, left_sign: float = 1.0, gains=(10.0, 1.0, 0.1),
+                              clip: float = 0.99) -> "UpkieServoPolicy":
+    """The README's balancer at the servo level: legs held at zero, wheel
+    velocity targets +-clip(g0 pitch + g1 p + g2 pdot, +-clip) / wheel_radius
+    through the servos' velocity loop (kd_scale 1, no position target)."""
+    policy = torque_balancing_policy(gain=0.0, fall_pitch=fall_pitch, left_sign=left_sign)
+    for j, sign in ((2, left_sign), (5, -left_sign)):
+        policy.action[j][4] = 1.0
+        policy.pitch_to_velocity[j] = sign * gains[0] / wheel_radius
+        policy.position_to_velocity[j] = sign * gains[1] / wheel_radius
+        policy.velocity_to_velocity[j] = sign * gains[2] / wheel_radius
+        policy.velocity_feedback_clip[j] = clip / wheel_radius
+    return policy
+
+
 class UpkieObserverConfig(C.Structure):
     _fields_ = [
         ("num_envs", C.c_int32),

@@ -1326,6 +1326,41 @@ extern "C" int upkie_sim_step_servos(UpkieSim* sim, float* state, const float* a
   return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
 }
 
+// Servo-level policy on the device (include/upkie_hip.h, upkie_sim_servo_policy): HBM bound, 12 state words in,
+// 36 action words out per env; the row-major action rows leave as 16-byte stores (one env = nine of them).
+__global__ __launch_bounds__(64) void servo_policy_kernel(int B, float signed_radius, UpkieServoPolicy P, float* __restrict__ state,
+                                                           float* __restrict__ act) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+#define SW(w) state[(size_t)(w) * B + e]
+  const float qw = SW(UPKIE_S_QUAT), qx = SW(UPKIE_S_QUAT + 1), qy = SW(UPKIE_S_QUAT + 2), qz = SW(UPKIE_S_QUAT + 3);
+  const float pitch = asinf(fminf(fmaxf(2.f * (qw * qy - qz * qx), -1.f), 1.f));
+  const float p = 0.5f * (SW(UPKIE_S_Q + 2) - SW(UPKIE_S_Q + 5)) * signed_radius;
+  const float pd = 0.5f * (SW(UPKIE_S_QD + 2) - SW(UPKIE_S_QD + 5)) * signed_radius;
+  float a[36];
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[6 * j + k] = P.action[j][k];
+    float fb = P.pitch_to_velocity[j] * pitch + P.position_to_velocity[j] * p + P.velocity_to_velocity[j] * pd;
+    if (P.velocity_feedback_clip[j] > 0.f) fb = fminf(fmaxf(fb, -P.velocity_feedback_clip[j]), P.velocity_feedback_clip[j]);
+    a[6 * j + 1] += fb;
+    a[6 * j + 2] += P.pitch_to_torque[j] * pitch;
+  }
+  float4* out = reinterpret_cast<float4*>(act + (size_t)36 * e);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+  if (P.fall_pitch > 0.f && fabsf(pitch) > P.fall_pitch) SW(UPKIE_S_DONE) = 1.f;
+#undef SW
+}
+
+extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, void* stream) {
+  if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  hipLaunchKernelGGL(servo_policy_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config.num_envs,
+                     sim->model.left_sign * sim->model.wheel_radius, *policy, state, act);
+  return check_hip(sim, hipGetLastError(), "servo_policy_kernel");
+}
+
 extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state, float* obs, float* final_obs, void* stream) {
   const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
   switch (observation) {

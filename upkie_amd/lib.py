@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_pendulum_agent_rollout",
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
+    "upkie_sim_servo_policy",
     "upkie_sim_step_base_velocity",
     "upkie_sim_observe",
     "upkie_sim_contact_points",
@@ -150,6 +151,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_lanes_per_env.argtypes = [vp]
     lib.upkie_sim_set_census.restype = C.c_int
     lib.upkie_sim_set_census.argtypes = [vp, vp]
+    lib.upkie_sim_servo_policy.restype = C.c_int
+    lib.upkie_sim_servo_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp]
     lib.upkie_sim_set_randomization.restype = C.c_int
     lib.upkie_sim_set_randomization.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
     lib.upkie_sim_set_external_forces.restype = C.c_int

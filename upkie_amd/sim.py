@@ -217,6 +217,19 @@ class BatchedSim:
             )
         return self._step(self._lib.upkie_sim_step_servos, act, self.obs_servos)
 
+    def servo_policy(self, policy: "abi.UpkieServoPolicy", act: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Write the next `step_servos` action ``[B, 6, 6]`` from the state with
+        the on-device servo-level policy (`upkie_sim_servo_policy`: one small
+        launch, no host round trip); fallen envs are flagged for the NEXT_STEP
+        autoreset."""
+        if act is None:
+            if getattr(self, "_policy_act", None) is None:
+                self._policy_act = torch.zeros((self.num_envs, 6, 6), dtype=torch.float32, device=self.device)
+            act = self._policy_act
+        with torch.cuda.device(self.device):
+            self._check(self._lib.upkie_sim_servo_policy(self._handle, _ptr(self.state), C.byref(policy), _ptr(act), self._stream()))
+        return act
+
     def step_base_velocity(self, act, commanded_velocity, mpc_x0, mpc_contact):
         """Second half of the fused UpkieBaseVelocity step: ``act[B, 2]`` =
         [linear velocity, yaw velocity], ground velocity from the MPC
