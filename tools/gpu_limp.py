@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from upkie_amd import abi  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-for lanes in ("1", "2"):
+for lanes in ("1", "2", "8"):
     os.environ["UPKIE_LANES_PER_ENV"] = lanes
     import upkie_amd.envs as envs
 

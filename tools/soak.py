@@ -44,7 +44,7 @@ def config(seed):
     return cfg
 
 
-for lanes in ("2", "1"):
+for lanes in ("8", "2", "1"):
     os.environ["UPKIE_LANES_PER_ENV"] = lanes
     t0 = time.time()
     # Pendulum with the README agent, randomised inertias, random pushes renewed every 500 steps
