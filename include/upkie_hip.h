@@ -335,6 +335,20 @@ int upkie_sim_step_base_velocity(UpkieSim* sim, float* state, const float* act,
                                  float* reward, uint8_t* terminated,
                                  uint8_t* truncated, void* stream);
 
+/* The same step with MPCBalancer.step() in front of it in ONE launch
+ * (upkie_base_velocity.py:164-202 as a whole): equivalent to
+ * upkie_mpc_step_env(mpc, workspace, mpc_x0, act, mpc_contact, <done words of
+ * the state when autoreset is on>, dt, commanded_velocity) followed by
+ * upkie_sim_step_base_velocity(...), bit for bit. One kernel when envs are
+ * mapped two lanes each and the horizon fits one 16-row tile (the wavefront
+ * that steps 32 envs first solves their condensed QPs on the matrix cores and
+ * hands the velocities over through LDS); the two launches otherwise. */
+struct UpkieMpc;
+int upkie_sim_step_base_velocity_mpc(UpkieSim* sim, struct UpkieMpc* mpc, float* state, float* workspace,
+                                     const float* act, float* commanded_velocity, float* obs,
+                                     float* mpc_x0, uint8_t* mpc_contact, float* reward,
+                                     uint8_t* terminated, uint8_t* truncated, void* stream);
+
 /* One env.step() of UpkieServos (upkie_servos.py:316-344 + upkie_env.py:
  * 196-242): act[B][6][6] in ACTION_KEYS order (position, velocity,
  * feedforward_torque, kp_scale, kd_scale, maximum_torque) -> obs[B][6][5]

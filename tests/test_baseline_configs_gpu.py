@@ -445,3 +445,35 @@ def test_c5_share_with_the_servo_policy_on_the_device_matches_oracle():
     assert episodes_o.sum() > B + 50  # robots did fall and were re-initialised by the step that followed
     assert np.mean(episodes_o == episodes_h) > 0.99  # (a threshold crossing can land one step apart in fp32)
     assert worst[0] < 2e-5 and worst[1] < 2e-3 and worst[2] < 0.01, worst
+
+
+@pytest.mark.parametrize("B,lanes", [(16384, "0"), (2000, "2"), (1000, "8")])
+def test_c3_balancer_and_step_in_one_launch_equal_two_launches(B, lanes, monkeypatch):
+    """`upkie_sim_step_base_velocity_mpc` (the wavefront that steps 32 envs
+    first solves their condensed QPs on the matrix cores; two launches under
+    the lane mappings that cannot) against `upkie_mpc_step_env` +
+    `upkie_sim_step_base_velocity`: same bits, with autoreset on so that the
+    balancer's reset-instead-of-solve branch is taken too."""
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    kw = dict(num_envs=B, frequency=200.0, nb_timesteps=16, seed=0, fall_pitch=0.3,
+              init_state=RobotState(randomization=RobotStateRandomization(pitch=0.25, x=0.05, omega_y=0.3, linear_velocity=np.array([0.2, 0.0, 0.0]))))
+    one = envs.make("Upkie-HIP-BaseVelocity-Vec", **kw)
+    two = envs.make("Upkie-HIP-BaseVelocity-Vec", **kw)
+    one.fuse_mpc, two.fuse_mpc = True, False
+    one.reset(seed=0)
+    two.reset(seed=0)
+    rng = np.random.default_rng(1)
+    act = torch.zeros(B, 2)
+    for step in range(30):
+        act[:, 0] = torch.from_numpy(rng.uniform(-0.8, 0.8, B)).float()
+        act[:, 1] = torch.from_numpy(rng.uniform(-0.5, 0.5, B)).float()
+        o1, _, t1, _, _ = one.step(act)
+        o2, _, t2, _, _ = two.step(act)
+        assert torch.equal(o1, o2) and torch.equal(t1, t2), step
+    assert torch.equal(one.sim.state, two.sim.state)
+    assert torch.equal(one.mpc_balancer.commanded_velocity, two.mpc_balancer.commanded_velocity)
+    assert torch.equal(one.mpc_balancer.workspace, two.mpc_balancer.workspace)
+    assert float(one.mpc_balancer.commanded_velocity.abs().max()) > 0.05  # the balancer did act

@@ -22,10 +22,14 @@ out = []
 B = 16384
 env = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=B, frequency=200.0, nb_timesteps=16, init_state=rand_state())
 env.reset(seed=0)
+env.fuse_mpc = True
 act = torch.zeros(B, 2, device="cuda:0"); act[:, 0] = torch.empty(B, device="cuda:0").uniform_(-0.5, 0.5)
 dt = timeit(lambda: env.step(act), 1000, 100)
-out.append(dict(config="C3 UpkieBaseVelocity + MPC N=16 (ADMM 30 it, MFMA)", envs=B, us_per_step=dt * 1e6, env_steps_per_s=B / dt,
-                episodes=int(env.sim.state[40].sum()), algorithmic_bytes_per_env_step=554))
+out.append(dict(config="C3 UpkieBaseVelocity + MPC N=16 (ADMM 30 it, MFMA), balancer and step in ONE launch (upkie_sim_step_base_velocity_mpc)", envs=B, us_per_step=dt * 1e6, env_steps_per_s=B / dt,
+                episodes=int(env.sim.state[40].sum()), lanes_per_env=env.sim.lanes_per_env, algorithmic_bytes_per_env_step=554))
+env.fuse_mpc = False
+dt = timeit(lambda: env.step(act), 1000, 100)
+out.append(dict(config="C3, two launches (upkie_mpc_step_env + upkie_sim_step_base_velocity)", envs=B, us_per_step=dt * 1e6, env_steps_per_s=B / dt))
 # C5 share: UpkieServos 4096 envs (one GPU's share of 32768 over 8), inertia randomisation 0.2, wheel
 # friction 0.1, a +-5 N push on the torso per env; a servo-level balancing law written as PyTorch
 # ops; fallen robots are reset (as an RL loop does). Captured in a hipGraph (8 steps per launch) so

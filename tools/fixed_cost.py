@@ -1,0 +1,26 @@
+"""Fixed and per-substep cost of a step launch: the same Pendulum step with 1 .. 5 physics substeps
+(frequency adjusted so that h stays 1 ms), per lane mapping."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from upkie_amd import abi
+from upkie_amd.sim import BatchedSim
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+for lanes in ("2", "8"):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
+    times = {}
+    for n in (1, 2, 3, 5):
+        cfg = abi.default_sim_config(B, frequency=1000.0 / n, nb_substeps=n, seed=0)
+        cfg.rand_pitch = 0.05
+        sim = BatchedSim(cfg)
+        sim.reset()
+        sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+        for _ in range(100): sim.step_pendulum_agent()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); s.record()
+        for _ in range(400): sim.step_pendulum_agent()
+        e.record(); torch.cuda.synchronize()
+        times[n] = s.elapsed_time(e) * 1e3 / 400
+    per = (times[5] - times[1]) / 4
+    print(f"lanes {lanes}: " + "  ".join(f"{n} substeps {t:.2f} us" for n, t in times.items()) + f"   per substep {per:.2f} us, fixed {times[1] - per:.2f} us", flush=True)

@@ -50,6 +50,15 @@
 #define SMOV(i) "s_mov_b32 s20, s21\n"
 #define MIX1(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_mov_b32 s20, s21\n"
 
+#define FMAC_DPP(i) "v_fmac_f32_dpp %" #i ", %16, %17 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define FMAC_DPP_NEG(i) "v_fmac_f32_dpp %" #i ", -%16, %17 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define MUL_DPP(i) "v_mul_f32_dpp %" #i ", %16, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define ADD_ROR8(i) "v_add_f32_dpp %" #i ", %16, %" #i " row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define DEP_FMAC_DPP(i) "v_fmac_f32_dpp %0, %16, %17 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define DPP_THEN_FMA(i) "v_fmac_f32_dpp %" #i ", %16, %17 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_fmac_f32_e32 %" #i ", %16, %17\n"
+#define NOP1(i) "s_nop 1\n"
+#define MFMA4(i) "v_mfma_f32_4x4x1_16b_f32 a[0:3], %16, %17, a[0:3]\n"
+#define MFMA4_IND(i) "v_mfma_f32_4x4x1_16b_f32 a[" "4*(" #i "%4)" ":" "4*(" #i "%4)+3" "], %16, %17, a[0:3]\n"
 #define KERNEL(NAME, STR)                                                          \
   __global__ void NAME(float* out, long long* cyc, int iters, float b, float c) { \
     float a[16];                                                                   \
@@ -104,6 +113,15 @@ KERNEL(k_mulabs, MUL_E64ABS)
 KERNEL(k_smov, SMOV)
 KERNEL(k_mix1, MIX1)
 
+KERNEL(k_fmac_dpp, FMAC_DPP)
+KERNEL(k_fmac_dpp_neg, FMAC_DPP_NEG)
+KERNEL(k_mul_dpp, MUL_DPP)
+KERNEL(k_add_ror8, ADD_ROR8)
+KERNEL(k_dep_fmac_dpp, DEP_FMAC_DPP)
+KERNEL(k_dpp_then_fma, DPP_THEN_FMA)
+KERNEL(k_nop1, NOP1)
+KERNEL(k_mfma4, MFMA4)
+
 typedef void (*kern_t)(float*, long long*, int, float, float);
 
 int main() {
@@ -138,7 +156,15 @@ int main() {
       {"v_sub_f32_e32", k_sub},
       {"v_mul_f32_e64 |abs|", k_mulabs},
       {"s_mov_b32", k_smov},
-      {"v_fmac + s_mov interleaved (per pair)", k_mix1}};
+      {"v_fmac + s_mov interleaved (per pair)", k_mix1},
+      {"v_fmac_f32_dpp quad_perm broadcast", k_fmac_dpp},
+      {"v_fmac_f32_dpp with neg modifier", k_fmac_dpp_neg},
+      {"v_mul_f32_dpp quad_perm broadcast", k_mul_dpp},
+      {"v_add_f32_dpp row_ror:8", k_add_ror8},
+      {"v_fmac_f32_dpp dependent accumulator", k_dep_fmac_dpp},
+      {"v_fmac_f32_dpp + v_fmac_f32_e32 (per pair)", k_dpp_then_fma},
+      {"s_nop 1", k_nop1},
+      {"v_mfma_f32_4x4x1_16b_f32 same accumulator", k_mfma4}};
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_fma_vop3, dim3(256), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
   (void)hipDeviceSynchronize();
   for (int wps : {1}) {

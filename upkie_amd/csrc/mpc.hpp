@@ -43,17 +43,20 @@ struct MpcDev {
 // logical horizon index held by (tile t, lane group g, register r)
 __device__ __forceinline__ int mpc_index(int t, int g, int r) { return 16 * t + 4 * r + g; }
 
+// MPCBalancer.step of the 16 envs env0 .. env0 + 15 by one wavefront (all 64
+// lanes must be active). `handover`: 16 floats (LDS) that receive the commanded
+// velocities as well, for a step fused behind the solve in the same launch.
 template <int T>
-__global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
-                                                       const float* __restrict__ v_target, int v_target_stride,
-                                                       const uint8_t* __restrict__ contact,
-                                                       const float* __restrict__ done, float dt,
-                                                       float* __restrict__ commanded, float* __restrict__ first_input) {
+__device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
+                                         const float* __restrict__ v_target, int v_target_stride,
+                                         const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
+                                         float* __restrict__ commanded, float* __restrict__ first_input, int env0,
+                                         float* handover) {
   constexpr int NP = 16 * T;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int col = lane & 15, g = lane >> 4;
   const int B = P.num_envs;
-  const int env = blockIdx.x * 16 + col;
+  const int env = env0 + col;
   const bool live = env < B;
   const int N = P.n;
 
@@ -132,8 +135,19 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
       v = fminf(fmaxf(v, -P.max_ground_velocity), P.max_ground_velocity);
     }
     commanded[env] = v;
+    if (handover) handover[col] = v;
   }
 }
+
+template <int T>
+__global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
+                                                       const float* __restrict__ v_target, int v_target_stride,
+                                                       const uint8_t* __restrict__ contact,
+                                                       const float* __restrict__ done, float dt,
+                                                       float* __restrict__ commanded, float* __restrict__ first_input) {
+  mpc_tile<T>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, blockIdx.x * 16, nullptr);
+}
+
 
 __global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __restrict__ ws, float* __restrict__ commanded,
                                                         const uint8_t* __restrict__ mask) {

@@ -503,6 +503,17 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = tid >> 1, leg = tid & 1;
+  // UpkieBaseVelocity with its MPC balancer in the same launch (upkie_sim_step_base_velocity_mpc): the wavefront first
+  // solves the condensed QPs of its 32 envs, 16 at a time on the matrix cores (mpc_tile, all 64 lanes), and hands the
+  // commanded velocities to the lanes that step those envs through LDS
+  __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 32 : 1];
+  if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
+    const int env0 = 32 * blockIdx.x;
+    const float* done_row = C.autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
+    mpc_tile<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0, mpc_velocity);
+    mpc_tile<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0 + 16, mpc_velocity + 16);
+    __syncthreads();
+  }
   if (e >= B) return;  // both lanes of a pair leave together
   const bool lead = leg == 0;  // the lane that writes per-env (not per-leg) words
   float* st = state + e;
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
       act1 = a.y;
     }
   } else if (MODE == MODE_BASE_VELOCITY) {
-    act0 = bv.commanded[e];
+    act0 = bv.mpc_fused ? mpc_velocity[e & 31] : bv.commanded[e];
     act1 = act[2 * (size_t)e + 1];
   }
 

@@ -72,6 +72,12 @@ struct BaseVelocityPtrs {
   const float* commanded;  // [B] ground velocity out of the MPC balancer
   float* x0;               // [B][4] next MPC state: position, pitch, velocity, pitch rate
   uint8_t* contact;        // [B] next MPC floor-contact flag
+  // MPCBalancer.step in front of the step, in the same launch (two-lane kernel, horizon <= 16:
+  // upkie_sim_step_base_velocity_mpc): the balancer's constants, its warm start, its velocity state
+  int mpc_fused = 0;
+  MpcDev mpc{};
+  float* mpc_ws = nullptr;
+  float* mpc_commanded = nullptr;
 };
 
 // ------------------------------------------------------------------ Philox
@@ -1208,7 +1214,7 @@ extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
-                       BaseVelocityPtrs bv = BaseVelocityPtrs{nullptr, nullptr, nullptr}, bool done_pass = false,
+                       BaseVelocityPtrs bv = BaseVelocityPtrs{}, bool done_pass = false,
                        float* final_obs = nullptr, int n_steps = 1) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (MODE != MODE_RESET && (!obs || (!packed && !done_pass && (!reward || !terminated || !truncated))))
@@ -1295,7 +1301,7 @@ extern "C" int upkie_sim_step_pendulum_agent_rollout(UpkieSim* sim, float* state
                                                     int32_t num_steps, void* stream) {
   if (!prev_records || !records || num_steps < 1) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument or num_steps < 1");
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
-  const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
+  const BaseVelocityPtrs none{};
   if (uses_lane_pairs(sim))  // one launch: the state stays in registers from step to step
     return launch_step<MODE_PENDULUM_ROLLOUT>(sim, state, prev_records, records, nullptr, nullptr, nullptr, nullptr, stream, 1, none, false,
                                               nullptr, num_steps);
@@ -1362,7 +1368,7 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
 }
 
 extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state, float* obs, float* final_obs, void* stream) {
-  const BaseVelocityPtrs none{nullptr, nullptr, nullptr};
+  const BaseVelocityPtrs none{};
   switch (observation) {
     case UPKIE_OBSERVATION_PENDULUM:
       return launch_step<MODE_PENDULUM>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, none, true, final_obs);
@@ -1511,6 +1517,30 @@ extern "C" int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0, 
 extern "C" int upkie_mpc_step_env(UpkieMpc* mpc, float* workspace, const float* x0, const float* act, const uint8_t* contact,
                                   const float* done, double dt, float* commanded_velocity, void* stream) {
   return mpc_launch(mpc, workspace, x0, act, 2, contact, done, dt, commanded_velocity, nullptr, stream);
+}
+
+// UpkieBaseVelocity's step with its balancer in front, ONE launch where the mapping allows it (two lanes per env,
+// horizon <= 16: the wavefront that steps 32 envs first solves their QPs), two launches otherwise: same results.
+extern "C" int upkie_sim_step_base_velocity_mpc(UpkieSim* sim, UpkieMpc* mpc, float* state, float* workspace, const float* act,
+                                                float* commanded_velocity, float* obs, float* mpc_x0, uint8_t* mpc_contact,
+                                                float* reward, uint8_t* terminated, uint8_t* truncated, void* stream) {
+  if (!sim || !mpc || !state || !workspace || !act || !commanded_velocity || !mpc_x0 || !mpc_contact)
+    return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (mpc->dev.num_envs != sim->config.num_envs) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "balancer and simulation differ in num_envs");
+  if (!(sim->config.dt / 0.1 < 0.5)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
+  if (mapped_lanes(sim) == 2 && mpc->tiles == 1) {
+    BaseVelocityPtrs bv{commanded_velocity, mpc_x0, mpc_contact};
+    bv.mpc_fused = 1;
+    bv.mpc = mpc->dev;
+    bv.mpc_ws = workspace;
+    bv.mpc_commanded = commanded_velocity;
+    return launch_step<MODE_BASE_VELOCITY>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream, 0, bv);
+  }
+  const float* done = sim->config.autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * sim->config.num_envs : nullptr;
+  const int status = mpc_launch(mpc, workspace, mpc_x0, act, 2, mpc_contact, done, sim->config.dt, commanded_velocity, nullptr, stream);
+  if (status != UPKIE_OK) return fail(sim, status, mpc->error);
+  return launch_step<MODE_BASE_VELOCITY>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream, 0,
+                                         BaseVelocityPtrs{commanded_velocity, mpc_x0, mpc_contact});
 }
 
 // =========================================================== observer pipeline

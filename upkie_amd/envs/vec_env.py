@@ -473,6 +473,10 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         self._x0 = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
         self._contact = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._xy = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
+        # balancer and step in ONE launch (upkie_sim_step_base_velocity_mpc) instead of two: same bits, but measured SLOWER at
+        # 16384 envs (37.9 vs 35.6 us: the wavefront that steps 32 envs solves their two MPC tiles one after the other, the
+        # separate kernel spreads them over twice as many wavefronts; profiles/r02_secondary_configs_c.jsonl): off by default
+        self.fuse_mpc = False
 
     def _remember(self, obs6: torch.Tensor) -> None:
         # MPC state [ground position, pitch, ground velocity, pitch rate] of the
@@ -499,6 +503,10 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
 
     def step(self, action):
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2).contiguous()
+        if self.fuse_mpc and hasattr(self.sim, "step_base_velocity_mpc") and hasattr(self.mpc_balancer, "_handle"):
+            # balancer and step in one call (one launch with two lanes per env and a horizon <= 16), everything on device
+            obs, reward, terminated, truncated = self.sim.step_base_velocity_mpc(self.mpc_balancer, act, self._x0, self._contact)
+            return self._finish_step(obs, reward, terminated, truncated)
         if hasattr(self.sim, "step_base_velocity") and hasattr(self.mpc_balancer, "step_env"):
             # fused path: two launches per env.step(), everything stays on device
             done = self.sim.state[abi.S_DONE] if self.config.autoreset_mode else None

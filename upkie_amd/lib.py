@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_servos",
     "upkie_sim_servo_policy",
     "upkie_sim_step_base_velocity",
+    "upkie_sim_step_base_velocity_mpc",
     "upkie_sim_observe",
     "upkie_sim_contact_points",
     "upkie_sim_autoreset_done",
@@ -181,6 +182,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_step_pendulum_agent_rollout.argtypes = [vp, vp, vp, vp, C.c_int32, vp]
     lib.upkie_sim_step_base_velocity.restype = C.c_int
     lib.upkie_sim_step_base_velocity.argtypes = [vp] * 11
+    lib.upkie_sim_step_base_velocity_mpc.restype = C.c_int
+    lib.upkie_sim_step_base_velocity_mpc.argtypes = [vp] * 13
     lib.upkie_sim_observe.restype = C.c_int
     lib.upkie_sim_observe.argtypes = [
         vp,

@@ -217,6 +217,23 @@ class BatchedSim:
             )
         return self._step(self._lib.upkie_sim_step_servos, act, self.obs_servos)
 
+    def step_base_velocity_mpc(self, mpc, act, mpc_x0, mpc_contact):
+        """UpkieBaseVelocity's whole step in one call (`upkie_sim_step_base_velocity_mpc`):
+        the MPC balancer `mpc` (a `BatchedMpc`) on the previous observation, then
+        the step; one launch where the lane mapping and the horizon allow it."""
+        act = self._as_action(act, (self.num_envs, 2))
+        if getattr(self, "obs3", None) is None:
+            self.obs3 = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(
+                self._lib.upkie_sim_step_base_velocity_mpc(
+                    self._handle, mpc._handle, _ptr(self.state), _ptr(mpc.workspace), _ptr(act), _ptr(mpc.commanded_velocity),
+                    _ptr(self.obs3), _ptr(mpc_x0), _ptr(mpc_contact), _ptr(self.reward), _ptr(self.terminated), _ptr(self.truncated),
+                    self._stream(),
+                )
+            )
+        return self.obs3, self.reward, self.terminated, self.truncated
+
     def servo_policy(self, policy: "abi.UpkieServoPolicy", act: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Write the next `step_servos` action ``[B, 6, 6]`` from the state with
         the on-device servo-level policy (`upkie_sim_servo_policy`: one small
