@@ -213,14 +213,13 @@ int upkie_sim_lanes_per_env(const UpkieSim* sim);
 /* Rare-path census of the eight-lanes-per-env step kernel (octet.hpp): `counters`
  * is the caller's device buffer of UPKIE_CENSUS_WORDS uint32 (zeroed by the
  * caller) or NULL to switch the census off (the default). Env-substeps:
- *   [0] a hip / knee at its stop (handed to the general two-lane substep)
- *   [1] (unused: one tire in the air is handled by the eight-lane substep itself)
- *   [2] contact impulses outside the friction cone / pulling: projected
- *       Gauss-Seidel sweeps, run inside the eight-lane substep
- *   [3] external forces on leg links (handed to the general two-lane substep)
- * wavefront-substeps (what the paths cost): [4] ran the general two-lane substep
- * for at least one of their eight envs, [5] ran Gauss-Seidel sweeps for at
- * least one. Diagnostics only: no entry point of the reference corresponds to it. */
+ *   [0] a hip / knee at its stop (contacts and limit rows through the general
+ *       solver over scratch memory)
+ *   [2] contact impulses outside the friction cone / pulling (projected
+ *       Gauss-Seidel sweeps)
+ * wavefront-substeps (what the paths cost) that took, for at least one of their
+ * eight envs, [4] the joint-stop path, [5] the sweeps. The other words are
+ * unused. Diagnostics only: no entry point of the reference corresponds to it. */
 #define UPKIE_CENSUS_WORDS 8
 int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters);
 

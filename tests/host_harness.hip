@@ -78,8 +78,7 @@ void spin_barrier_wait(void* b) { static_cast<SpinBarrier*>(b)->wait(); }
 
 // st: one env's state words (in / out), tau: six commanded torques, records: [70] or null,
 // trunk_wrench: [6] (base frame, about the base origin) or null. Runs `substeps` substeps;
-// status[i] receives OCT_CONTACT / OCT_NO_CONTACT / OCT_NOT_MINE of substep i (the
-// run stops at the first OCT_NOT_MINE, state as before that substep).
+// status[i] receives OCT_CONTACT / OCT_NO_CONTACT of substep i.
 extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
                                      const float* trunk_wrench, int substeps, int* status) {
   DevModel M;
@@ -113,10 +112,6 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
       for (int i = 0; i < substeps; ++i) {
         const int r = physics_substep_octet(M, Lm, L, s, own_tau, h, trunk_wrench);
         lane_status[t][i] = r;
-        if (r == OCT_NOT_MINE) {
-          for (int k = i + 1; k < substeps; ++k) lane_status[t][k] = OCT_NOT_MINE;
-          break;
-        }
       }
       result[t] = s;
       g_oct_lane = nullptr;

@@ -235,7 +235,7 @@ def test_substep_with_external_forces_on_any_link(harness):
 # ---------------------------------------------------------------------------
 # Eight lanes per env (octet.hpp): the lanes of one env run as eight host
 # threads in lockstep, lane exchanges go through a slot array.
-OCT_NOT_MINE, OCT_NO_CONTACT, OCT_CONTACT = -1, 0, 1
+OCT_NO_CONTACT, OCT_CONTACT = 0, 1
 
 
 def run_octet(harness, model, s64, tau, h=1e-3, records=None, wrench=None, substeps=1):
@@ -288,14 +288,11 @@ def test_octet_substep_matches_one_lane_and_oracle(harness, on_floor):
         s8, status = run_octet(harness, model, s, tau)
         s1, contact = one_lane(harness, model, s, tau)
         so, _ = run_both(harness, model, s, tau)
-        if status[0] == OCT_NOT_MINE:
-            assert np.array_equal(s8[:25], s.astype(np.float32).astype(np.float64)[:25])  # state untouched
-            continue
         mine += 1
         assert (status[0] == OCT_CONTACT) == bool(contact)
         worst_1 = np.maximum(worst_1, np.abs(s8[:25] - s1[:25]))
         worst_o = np.maximum(worst_o, np.abs(s8[:25] - so[:25]))
-    assert mine > (100 if not on_floor else 15), mine  # (random states on the floor: often one tire only, or slipping)
+    assert mine == 150
     assert worst_o[0:3].max() < 5e-7 and worst_o[3:7].max() < 5e-7
     assert worst_o[7:10].max() < 2e-4 and worst_o[10:13].max() < 1e-3
     assert worst_o[13:19].max() < 1e-6 and worst_o[19:25].max() < 2e-2
@@ -333,13 +330,9 @@ def test_octet_standing_robot_takes_the_fast_path(harness):
             s, _ = one_lane(harness, model, s, torques(s))
         s8, s1 = s.copy(), s.copy()
         for _ in range(100):
-            nxt, status = run_octet(harness, model, s8, torques(s8))
-            if status[0] == OCT_NOT_MINE:
-                nxt, _ = one_lane(harness, model, s8, torques(s8))
-            else:
-                assert status[0] == OCT_CONTACT
-                fast += 1
-            s8 = nxt
+            s8, status = run_octet(harness, model, s8, torques(s8))
+            assert status[0] == OCT_CONTACT
+            fast += 1
             s1, contact = one_lane(harness, model, s1, torques(s1))
             assert contact
         assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-6
@@ -366,29 +359,40 @@ def test_octet_per_env_inertials_and_trunk_wrench(harness):
         wrench = np.concatenate([force, np.cross(point, force)])
         tau = rng.uniform(-1, 1, 6)
         s8, status = run_octet(harness, model, s, tau, records=rec, wrench=wrench)
-        if status[0] == OCT_NOT_MINE:
-            continue
         s1, _ = one_lane(harness, model, s, tau, records=rec, force=force.reshape(1, 3), slots=make_slots([0], [point], [True]))
         checked += 1
         assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-7
         assert np.abs(s8[7:10] - s1[7:10]).max() < 2e-4 and np.abs(s8[10:13] - s1[10:13]).max() < 1e-3
         assert np.abs(s8[19:25] - s1[19:25]).max() < 2e-2
-    assert checked > 15
+    assert checked == 40
 
 
 def test_octet_rare_cases(harness):
-    """A joint at its stop: OCT_NOT_MINE with the state untouched (the caller
-    runs the two-lane substep). One tire in the air while the other touches
-    (identity rows for the missing tire) and contact impulses outside the
-    friction cone (projected Gauss-Seidel sweeps, contact_pgs6 on the gathered
-    system) stay inside the eight-lane substep: against the one-lane arithmetic."""
+    """The rare cases stay inside the eight-lane substep, against the one-lane
+    arithmetic: a hip / knee at its stop (the general solver over scratch memory
+    on the system gathered from the lanes, as limit_path_scratch builds it),
+    one tire in the air while the other touches (identity rows), contact
+    impulses outside the friction cone (projected Gauss-Seidel sweeps,
+    contact_pgs6 on the gathered system)."""
     rng = np.random.default_rng(14)
     model = default_model()
     model.enforce_joint_limits = 1
-    s = random_state(rng, False)
-    s[abi.S_Q + 1] = 2.52  # left knee beyond its stop
-    s8, status = run_octet(harness, model, s, np.zeros(6))
-    assert status[0] == OCT_NOT_MINE and np.array_equal(s8, s.astype(np.float32).astype(np.float64))
+    hits = 0
+    for trial in range(60):
+        s = random_state(rng, on_floor=trial % 2 == 0)
+        for j, lim in ((0, 1.26), (1, 2.51), (3, 1.26), (4, 2.51)):
+            if rng.uniform() < 0.5:
+                s[abi.S_Q + j] = rng.choice([-1, 1]) * (lim + rng.uniform(0.0, 0.01))
+                s[abi.S_QD + j] = rng.uniform(-3, 3)
+                hits += 1
+        tau = rng.uniform(-3.0, 3.0, 6)
+        s8, status = run_octet(harness, model, s, tau)
+        s1, contact = one_lane(harness, model, s, tau)
+        assert (status[0] == OCT_CONTACT) == bool(contact)
+        assert np.abs(s8[0:7] - s1[0:7]).max() < 1e-6
+        assert np.abs(s8[7:10] - s1[7:10]).max() < 5e-4 and np.abs(s8[10:13] - s1[10:13]).max() < 3e-3
+        assert np.abs(s8[13:19] - s1[13:19]).max() < 1e-5 and np.abs(s8[19:25] - s1[19:25]).max() < 5e-2
+    assert hits > 80
     model.enforce_joint_limits = 0
     one_tire = 0
     for roll in (0.2, 0.3, -0.3):

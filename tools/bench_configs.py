@@ -81,6 +81,6 @@ for label, make_policy in (("README balancer through the wheel velocity loop", l
     c = env2.sim.census_counts()
     out.append(dict(config=f"C5 share, servo-level policy on the device ({label}): upkie_sim_servo_policy + upkie_sim_step_servos, NEXT_STEP autoreset of fallen robots, two launches per step, Python loop",
                     envs=B, us_per_step=dt_policy * 1e6, env_steps_per_s=B / dt_policy, lanes_per_env=env2.sim.lanes_per_env, episodes=int(env2.sim.state[40].sum()),
-                    env_substeps_in_gauss_seidel_sweeps=c["friction_cone"] / (B * 5 * 2000), env_substeps_on_the_general_path=(c["joint_limit"] + c["leg_forces"]) / (B * 5 * 2000),
+                    env_substeps_in_gauss_seidel_sweeps=c["friction_cone"] / (B * 5 * 2000), env_substeps_with_a_joint_at_its_stop=c["joint_limit"] / (B * 5 * 2000),
                     algorithmic_bytes_per_env_step=630 + 2 * 144))
 for line in out: print(json.dumps(line))

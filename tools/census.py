@@ -29,5 +29,5 @@ while done < steps:
     env_sub = B * 5 * window
     wave_sub = (B * 8 // 64) * 5 * window
     done += window
-    print(f"steps {done - window:5d}-{done:5d}: {start.elapsed_time(stop) * 1e3 / window:6.2f} us/step  env-substeps: limit {c['joint_limit'] / env_sub:.4%} one tire {c['one_tire'] / env_sub:.4%} "
-          f"cone {c['friction_cone'] / env_sub:.4%}  wavefront-substeps: general path {c['wavefront_substeps_general'] / wave_sub:.3%} sweeps {c['wavefront_substeps_pgs'] / wave_sub:.3%}  episodes {int(sim.state[40].sum())}", flush=True)
+    print(f"steps {done - window:5d}-{done:5d}: {start.elapsed_time(stop) * 1e3 / window:6.2f} us/step  env-substeps: limit {c['joint_limit'] / env_sub:.4%} "
+          f"cone {c['friction_cone'] / env_sub:.4%}  wavefront-substeps: joint-stop path {c['wavefront_substeps_limit'] / wave_sub:.3%} sweeps {c['wavefront_substeps_sweeps'] / wave_sub:.3%}  episodes {int(sim.state[40].sum())}", flush=True)

@@ -35,11 +35,13 @@
 //     (each quad eliminates its own tire's 3x3 block by Gauss-Jordan across its
 //     lanes, the Schur complement couples the tires through one exchange);
 //   * nu+ = A^-1 rt + sum lam_b Y_b: the final solve is a weighted 8-lane sum.
-// Whatever is rare (a joint at its stop, a tire off the floor while the other
-// one touches, a contact solution outside its friction cone, forces on leg
-// links) is NOT restated here: the substep reports "not mine" before touching
-// the state and the caller runs physics_substep_pair on the same lanes
-// (LanesEightApart), every lane of a quad on identical data.
+// The rare cases gather their system into every lane of the env and run the
+// code the other mappings run, every lane on identical data: a contact solution
+// outside its friction cone -> the projected Gauss-Seidel sweeps (contact_pgs6);
+// a hip or knee at its stop -> the general solver over scratch memory
+// (general_constraint_solve), so that the path costs no registers. A tire off
+// the floor is masked with identity rows. Forces on leg links are not handled
+// here: launch_step gives such launches to the two-lane kernel.
 //
 // Host build (tests/host_harness.hip): the same code, the eight lanes of one env
 // run as eight threads in lockstep and every exchange goes through a shared
@@ -482,23 +484,188 @@ UPKIE_HD void oct_gauss_jordan(const OctLane& L, float (&D)[3], float (&E)[NE]) 
   for (int i = 0; i < NE; ++i) E[i] *= id;
 }
 
-// Substep outcomes. The negative ones mean "not mine" (state untouched) and say why.
-enum { OCT_NOT_MINE_FORCES = -4, OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_ONE_TIRE = -2, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
-enum { OCT_NOT_MINE = OCT_NOT_MINE_LIMIT };
+// A hip or knee at its stop (rare): contacts and joint-limit rows are solved
+// together by the general solver the one-lane kernel of very large batches uses
+// (general_constraint_solve: rows listed in scratch memory, Cholesky, projected
+// Gauss-Seidel when infeasible; same rows, order and numerics as limit_path).
+// The system is gathered into every lane of the env -- both legs' D and Hinv,
+// the contact rows of the touching tires in wheel order, one row per limited
+// joint in joint order -- straight into the solver's scratch structures, so
+// the path costs the kernel no registers; every lane then runs the same
+// solve on identical data and keeps the base velocity change and its own
+// joint's. Slow (a few thousand instructions), by design.
+template <int K>
+UPKIE_HD float oct_from_joint(float x) { return oct_qb<K + 1>(x); }
+
+template <class ModelT>
+UPKIE_HD void octet_limit_path(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
+                               V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active, bool active_partner, float qd,
+                               float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_err,
+                               float (&xb)[6], float& xl) {
+  const bool left = L.leg == 0;
+  System S;
+  S.A.l10 = 0.f; S.A.l20 = fac.l20; S.A.l21 = 0.f; S.A.l30 = fac.l30; S.A.l31 = fac.l31; S.A.l32 = fac.l32;
+  S.A.l40 = fac.l40; S.A.l41 = 0.f; S.A.l42 = fac.l42; S.A.l43 = fac.l43;
+  S.A.l50 = fac.l50; S.A.l51 = fac.l51; S.A.l52 = fac.l52; S.A.l53 = fac.l53; S.A.l54 = fac.l54;
+  S.A.i0 = fac.i0; S.A.i1 = fac.i1; S.A.i2 = fac.i2; S.A.i3 = fac.i3; S.A.i4 = fac.i4; S.A.i5 = fac.i5;
+  // both legs' D (6 x 3) and Hinv (symmetric: 00 11 22 01 02 12), column k from joint lane k
+  float tl6[2][3];
+  {
+    const float hv[3] = {hv0, hv1, hv2};
+    auto column = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const float own = oct_from_joint<k>(Dc[r]), other = oct_swp(own);
+        S.leg[0].D[r][k] = left ? own : other;
+        S.leg[1].D[r][k] = left ? other : own;
+      }
+#pragma unroll
+      for (int a = 0; a <= k; ++a) {  // Hinv[a][k], a <= k
+        const float own = oct_from_joint<k>(hv[a]), other = oct_swp(own);
+        const int idx = a == k ? a : (a == 0 ? (k == 1 ? 3 : 4) : 5);
+        S.leg[0].Hinv[idx] = left ? own : other;
+        S.leg[1].Hinv[idx] = left ? other : own;
+      }
+      const float own = oct_from_joint<k>(tl), other = oct_swp(own);
+      tl6[0][k] = left ? own : other;
+      tl6[1][k] = left ? other : own;
+    };
+    column(std::integral_constant<int, 0>{});
+    column(std::integral_constant<int, 1>{});
+    column(std::integral_constant<int, 2>{});
+  }
+  // contact rows of the own tire (lanes 1-3 of the quad), as in the eight-lane path
+  const float sa = oct_qb<3>(L.sg);
+  const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
+  const V3 t2 = cross(nB, t1);
+  const V3 d = L.e[0] * nB + L.e[1] * t1 + L.e[2] * t2;
+  const V3 Pxd = cross(Pc, d);
+  const float Jb[6] = {d.x, d.y, d.z, Pxd.x, Pxd.y, Pxd.z};
+  const float srz = L.sg * (Pc.z - o.z), srx = L.sg * (Pc.x - o.x);
+  const float Jl[3] = {oct_qb<1>(srz) * d.x - oct_qb<1>(srx) * d.z, oct_qb<2>(srz) * d.x - oct_qb<2>(srx) * d.z,
+                       oct_qb<3>(srz) * d.x - oct_qb<3>(srx) * d.z};
+  float vnow = Jb[0] * vB.x + Jb[1] * vB.y + Jb[2] * vB.z + Jb[3] * wB.x + Jb[4] * wB.y + Jb[5] * wB.z;
+  vnow = oct_sumj(vnow, qd, Jl[0], Jl[1], Jl[2]);
+  float Jt[6];
+  {
+    float acc[5] = {Jb[0], Jb[2], Jb[3], Jb[4], Jb[5]};
+    const float dc[5] = {Dc[0], Dc[2], Dc[3], Dc[4], Dc[5]};
+    oct_sumj_neg5(acc, dc, Jl[0], Jl[1], Jl[2]);
+    Jt[0] = acc[0]; Jt[1] = Jb[1]; Jt[2] = acc[1]; Jt[3] = acc[2]; Jt[4] = acc[3]; Jt[5] = acc[4];
+  }
+  const float dist_other = oct_swp(dist);
+  GeneralRows R;
+  R.n = 0;
+  // rows of the touching tires in wheel order (left, right); each tire's rows come from its own quad
+  auto tire = [&](int w) {
+    const bool mine = (w == 0) == left;  // the quad this lane sits in owns tire w
+    const bool touching = mine ? active : active_partner;
+    const float dw = mine ? dist : dist_other;
+    auto row = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const int i = R.n;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float own_t = oct_from_joint<k>(Jt[c]), other_t = oct_swp(own_t);
+        const float own_b = oct_from_joint<k>(Jb[c]), other_b = oct_swp(own_b);
+        if (touching) {
+          R.Jt[i][c] = mine ? own_t : other_t;
+          R.Jb[i][c] = mine ? own_b : other_b;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float own = oct_from_joint<k>(Jl[j]), other = oct_swp(own);
+        if (touching) R.Jl[i][j] = mine ? own : other;
+      }
+      const float own_v = oct_from_joint<k>(vnow), other_v = oct_swp(own_v);
+      if (touching) {
+        R.vnow[i] = mine ? own_v : other_v;
+        R.leg[i] = w;
+        R.kind[i] = k == 0 ? 0 : 1;
+        R.normal_row[i] = i - k;
+        R.cfm[i] = k == 0 ? cfm : M.friction_cfm;
+        R.bias[i] = k == 0 ? (dw <= 0.f ? erp * (-dw) * ih : -dw * ih) : 0.f;
+        R.n = i + 1;
+      }
+    };
+    row(std::integral_constant<int, 0>{});
+    row(std::integral_constant<int, 1>{});
+    row(std::integral_constant<int, 2>{});
+  };
+  tire(0);
+  tire(1);
+  // one row per limited joint in joint order (left hip, left knee, right hip, right knee)
+  auto limit = [&](int w, auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const bool mine = (w == 0) == left;
+    const float own_s = oct_from_joint<k>(lim_sign), other_s = oct_swp(own_s);
+    const float own_e = oct_from_joint<k>(lim_err), other_e = oct_swp(own_e);
+    const float own_q = oct_from_joint<k>(qd), other_q = oct_swp(own_q);
+    const float sign = mine ? own_s : other_s, err = mine ? own_e : other_e, qdj = mine ? own_q : other_q;
+    if (sign != 0.f) {
+      const int i = R.n;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        R.Jb[i][c] = 0.f;
+        R.Jt[i][c] = -sign * S.leg[w].D[c][k];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R.Jl[i][j] = j == k ? sign : 0.f;
+      R.vnow[i] = sign * qdj;
+      R.leg[i] = w;
+      R.kind[i] = 2;
+      R.normal_row[i] = i;
+      R.cfm[i] = 0.f;
+      R.bias[i] = 0.2f * err * ih;  // Bullet's default ERP
+      R.n = i + 1;
+    }
+  };
+  limit(0, std::integral_constant<int, 0>{});
+  limit(0, std::integral_constant<int, 1>{});
+  limit(1, std::integral_constant<int, 0>{});
+  limit(1, std::integral_constant<int, 1>{});
+  // base impulse before the constraints: rt is tb reduced by the legs' impulses
+  float tb[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float v = rt[c];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v = fmaf(S.leg[w].D[c][k], tl6[w][k], v);
+    tb[c] = v;
+  }
+  float lam_rows[10];
+  general_constraint_solve(M, S, R, rt, tb, tl6[0], tl6[1], lam_rows);
+  system_solve<true, true>(S, tb, tl6[0], tl6[1]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xb[c] = tb[c];
+  const float mine_l = L.l == 1 ? tl6[0][0] : (L.l == 2 ? tl6[0][1] : tl6[0][2]);
+  const float mine_r = L.l == 1 ? tl6[1][0] : (L.l == 2 ? tl6[1][1] : tl6[1][2]);
+  xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
+}
+
+// Substep outcomes (returned) and rare paths taken (reported through `census`).
+enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
 
 // One physics substep, eight lanes per env. tau: commanded torque of the own
 // joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
 // in the BASE frame and their moment about the base origin, or nullptr.
-// Returns OCT_CONTACT / OCT_NO_CONTACT after advancing the state, or one of the
-// OCT_NOT_MINE_* codes with the state untouched (same answer in the env's eight lanes).
+// Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
 template <class ModelT>
 UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const OctLane& L, OctPhys& s, float tau, float h,
                                    const float* trunk_wrench, int* census = nullptr) {
-  // ---- a joint at its stop: not mine -------------------------------------
+  // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
+  bool at_a_stop = false;
+  float lim_sign = 0.f, lim_err = 0.f;
   if (Lm.enforce) {
-    const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
-    if (oct_wave_any(own_limit)) {
-      if (oct_env_any(own_limit)) return OCT_NOT_MINE_LIMIT;
+    const bool low = L.bounded && s.q <= L.lower, high = L.bounded && !low && s.q >= L.upper;
+    if (oct_wave_any(low || high)) {
+      at_a_stop = oct_env_any(low || high);
+      lim_sign = low ? 1.f : (high ? -1.f : 0.f);
+      lim_err = low ? L.lower - s.q : (high ? s.q - L.upper : 0.f);
     }
   }
 
@@ -663,7 +830,12 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
 
   float xb[6];   // base velocity change
   float tlc = tl;  // own joint impulse incl. contacts
-  if (active || active_partner) {
+  float xl = 0.f;  // own joint velocity change
+  if (at_a_stop) {
+    if (census) *census = OCT_NOT_MINE_LIMIT;
+    octet_limit_path(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih, lim_sign,
+                     lim_err, xb, xl);
+  } else if (active || active_partner) {
     const float sa = oct_qb<3>(L.sg);
     const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
     const V3 t2 = cross(nB, t1);
@@ -811,8 +983,10 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   }
 
   // ---- joint velocity change: Hinv t - D' xb ------------------------------------
-  float xl = oct_sumj(0.f, tlc, hv0, hv1, hv2);
-  xl -= Dc[0] * xb[0] + Dc[2] * xb[2] + Dc[3] * xb[3] + Dc[4] * xb[4] + Dc[5] * xb[5];
+  if (!at_a_stop) {
+    xl = oct_sumj(0.f, tlc, hv0, hv1, hv2);
+    xl -= Dc[0] * xb[0] + Dc[2] * xb[2] + Dc[3] * xb[3] + Dc[4] * xb[4] + Dc[5] * xb[5];
+  }
 
   // ---- integrate --------------------------------------------------------------------
   {
@@ -850,34 +1024,6 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-// The rare path: the two-lane substep (pair.hpp) on the same lanes, every lane
-// of a quad holding its whole leg (identical data, identical results), the
-// other leg eight lanes away. Device only.
-template <class ModelT>
-__device__ __forceinline__ bool octet_general_substep(const ModelT& M, const DevLimits& Lm, const DevConfig& C, const OctLane& L, OctPhys& s,
-                                                   float tau, float h, const float* records, size_t stride, const ExtForces& ext) {
-  const PairLeg PL = load_pair_leg(M, Lm, C, L.leg, records, stride);
-  PhysPair p;
-  p.pos = s.pos; p.qw = s.qw; p.qx = s.qx; p.qy = s.qy; p.qz = s.qz;
-  p.linvel = s.linvel; p.angvel = s.angvel;
-  p.q[0] = oct_qb<1>(s.q); p.q[1] = oct_qb<2>(s.q); p.q[2] = oct_qb<3>(s.q);
-  p.qd[0] = oct_qb<1>(s.qd); p.qd[1] = oct_qb<2>(s.qd); p.qd[2] = oct_qb<3>(s.qd);
-  const float t3[3] = {oct_qb<1>(tau), oct_qb<2>(tau), oct_qb<3>(tau)};
-  TrunkInertial trunk;
-  if (records) {
-    trunk.m = records[0];
-    trunk.c = v3(records[(size_t)1 * stride], records[(size_t)2 * stride], records[(size_t)3 * stride]);
-    trunk.I = S3{records[(size_t)4 * stride], records[(size_t)5 * stride], records[(size_t)6 * stride],
-                 records[(size_t)7 * stride], records[(size_t)8 * stride], records[(size_t)9 * stride]};
-  }
-  const bool contact = physics_substep_pair<LanesEightApart>(M, Lm, PL, L.leg, p, t3, h, records ? &trunk : nullptr, ext);
-  s.pos = p.pos; s.qw = p.qw; s.qx = p.qx; s.qy = p.qy; s.qz = p.qz;
-  s.linvel = p.linvel; s.angvel = p.angvel;
-  s.q = L.l == 1 ? p.q[0] : (L.l == 2 ? p.q[1] : (L.l == 3 ? p.q[2] : 0.f));
-  s.qd = L.l == 1 ? p.qd[0] : (L.l == 2 ? p.qd[1] : (L.l == 3 ? p.qd[2] : 0.f));
-  return contact;
-}
-
 template <class T>
 __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
   return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : (j == 3 ? a[3] : (j == 4 ? a[4] : a[5]))));
@@ -887,7 +1033,7 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
 template <int MODE, bool RAND>
-__global__ __launch_bounds__(64) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
+__global__ __launch_bounds__(64, 2) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
                                                          float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -927,13 +1073,9 @@ __global__ __launch_bounds__(64) void step_kernel_octet(const DevModel* __restri
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B);
   const auto& M = *(ConstModelPtr)Mp;
-  // external forces: those on the trunk enter the eight-lane substep as one wrench; any force on a leg link sends
-  // every substep of the launch down the general path
+  // external forces: those on the trunk enter the substep as one wrench (launches with a force on a leg link use the
+  // two-lane kernel: launch_step)
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
-  bool leg_forces = false;
-  if (RAND && ext.force) {
-    for (int i = 0; i < C.ext.count; ++i) leg_forces = leg_forces || C.ext.body[i] != 0;
-  }
 
   float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
   asm volatile("" : "+v"(done_word));
@@ -1087,42 +1229,31 @@ next_step:
     tau = jointed ? joint_torque(s.q, s.qd, cmd, C.kp, C.kd, L.friction, noise) : 0.f;
     ConstModelPtr mp = (ConstModelPtr)Mp;
     asm volatile("" : "+s"(mp));
-    int status = OCT_NOT_MINE_FORCES;
     const bool forces = RAND && ext.force && !do_reset;  // the reset substep runs without external forces
-    if (!(forces && leg_forces)) {
-      float wrench[6];
-      if (forces) {  // forces on the trunk: one wrench about the base origin, base frame
-        const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
-        const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
-        const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
-        const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-        V3 Fs = v3(0.f, 0.f, 0.f), Ns = v3(0.f, 0.f, 0.f);
-        for (int i = 0; i < C.ext.count; ++i) {
-          const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride], ext.force[(size_t)(3 * i + 2) * ext.stride]);
-          const V3 pt = v3(C.ext.point[i][0], C.ext.point[i][1], C.ext.point[i][2]);
-          const V3 Fe = C.ext.local[i] != 0 ? f : v3(r00 * f.x + r10 * f.y + r20 * f.z, r01 * f.x + r11 * f.y + r21 * f.z, r02 * f.x + r12 * f.y + r22 * f.z);
-          Fs = Fs + Fe;
-          Ns = Ns + cross(pt, Fe);
-        }
-        wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
+    float wrench[6];
+    if (forces) {  // forces on the trunk: one wrench about the base origin, base frame
+      const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
+      const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
+      const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+      const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+      V3 Fs = v3(0.f, 0.f, 0.f), Ns = v3(0.f, 0.f, 0.f);
+      for (int i = 0; i < C.ext.count; ++i) {
+        const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride], ext.force[(size_t)(3 * i + 2) * ext.stride]);
+        const V3 pt = v3(C.ext.point[i][0], C.ext.point[i][1], C.ext.point[i][2]);
+        const V3 Fe = C.ext.local[i] != 0 ? f : v3(r00 * f.x + r10 * f.y + r20 * f.z, r01 * f.x + r11 * f.y + r21 * f.z, r02 * f.x + r12 * f.y + r22 * f.z);
+        Fs = Fs + Fe;
+        Ns = Ns + cross(pt, Fe);
       }
-      int swept = 0;
-      status = physics_substep_octet(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &swept : nullptr);
-      if (census && swept) {  // projected Gauss-Seidel inside the eight-lane substep
-        if (lead) atomicAdd(&census[2], 1u);
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&census[5], 1u);
-      }
+      wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
     }
-    if (status < 0) {
-      if (census) {  // rare-path census (upkie_sim_set_census): env-substeps by reason, wavefront-substeps that took the path
-        if (lead) atomicAdd(&census[status == OCT_NOT_MINE_LIMIT ? 0 : (status == OCT_NOT_MINE_ONE_TIRE ? 1 : 3)], 1u);
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&census[4], 1u);
-      }
-      const ExtForces ext_now{forces ? ext.force : nullptr, ext.stride, ext.slots};
-      contact = octet_general_substep(*mp, Lm, C, L, s, tau, C.h, records, (size_t)B, ext_now);
-    } else {
-      contact = status == OCT_CONTACT;
+    int rare = 0;
+    const int status = physics_substep_octet(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &rare : nullptr);
+    if (census && rare) {  // rare-path census (upkie_sim_set_census): env-substeps by path, wavefront-substeps that took it
+      const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+      if (lead) atomicAdd(&census[rare == OCT_NOT_MINE_LIMIT ? 0 : 2], 1u);
+      if (first) atomicAdd(&census[rare == OCT_NOT_MINE_LIMIT ? 4 : 5], 1u);
     }
+    contact = status == OCT_CONTACT;
   }
 
   // ---- wrapper post-processing ---------------------------------------------

@@ -21,17 +21,9 @@
 __device__ __forceinline__ float xchg(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
-// Where the lane that owns the other leg sits: next to this one (the two-lane
-// kernel) or eight lanes away in the same row of 16 (the eight-lane kernel's
-// rare path, octet.hpp, where every lane of a leg's quad runs this substep on
-// identical data).
+// Where the lane that owns the other leg sits (a policy, so that the substep below does not depend on the lane layout).
 struct AdjacentLanes {
   static __device__ __forceinline__ float xchg(float x) { return upkie::xchg(x); }
-};
-struct LanesEightApart {
-  static __device__ __forceinline__ float xchg(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));  // row_ror:8
-  }
 };
 template <class X = AdjacentLanes>
 __device__ __forceinline__ float pair_sum(float x) { return x + X::xchg(x); }

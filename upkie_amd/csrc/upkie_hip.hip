@@ -1184,8 +1184,9 @@ static const int kDenseBatch = 131072;
 // up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
 static const int kPairBatch = 32768;
 
-// up to this many envs eight lanes per env (step_kernel_octet) are one wave per SIMD (1024 SIMDs x 64 lanes / 8): the
-// kernel carries the two-lane substep for its rarest cases and with it 384 registers, one wave per SIMD
+// up to this many envs eight lanes per env (step_kernel_octet) are one wave per SIMD (1024 SIMDs x 64 lanes / 8). The kernel
+// fits 256 registers, but a second wave per SIMD buys little (the stream is issue bound): 26.1 us at 16384 envs against the
+// two-lane kernel's 25.7 (profiles/r02_batch_sweep_lanes.txt)
 static const int kOctetBatch = 8192;
 
 // Lanes per env of a step launch: eight (one quad per leg, one lane per body:
@@ -1193,11 +1194,15 @@ static const int kOctetBatch = 8192;
 // leg: pair.hpp) up to one wave per SIMD, one beyond. The in-step spine
 // observers exist in the one- and two-lane kernels only.
 static int mapped_lanes(const UpkieSim* sim) {
+  // the eight-lane kernel restates neither the in-step spine observers nor forces on leg links
+  bool eight = !sim->spine_state;
+  if (sim->ext_force)
+    for (int i = 0; i < sim->config.ext.count; ++i) eight = eight && sim->config.ext.body[i] == 0;
   if (sim->lanes_per_env == 8 || sim->lanes_per_env == 2 || sim->lanes_per_env == 1) {
-    if (sim->lanes_per_env == 8 && sim->spine_state) return 2;
+    if (sim->lanes_per_env == 8 && !eight) return 2;
     return sim->lanes_per_env;
   }
-  if (sim->config.num_envs <= kOctetBatch && !sim->spine_state) return 8;
+  if (sim->config.num_envs <= kOctetBatch && eight) return 8;
   return sim->config.num_envs <= kPairBatch ? 2 : 1;
 }
 // fewer lanes than envs x 2: several env.step() of the fused agent can share a launch (state in registers)

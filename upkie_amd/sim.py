@@ -421,7 +421,7 @@ class BatchedSim:
         """Lanes of a wavefront sharing one env in this handle's step kernels."""
         return int(self._lib.upkie_sim_lanes_per_env(self._handle))
 
-    CENSUS_FIELDS = ("joint_limit", "one_tire", "friction_cone", "leg_forces", "wavefront_substeps_general", "wavefront_substeps_pgs")
+    CENSUS_FIELDS = ("joint_limit", "unused_1", "friction_cone", "unused_3", "wavefront_substeps_limit", "wavefront_substeps_sweeps")
 
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
         """Rare-path census of the eight-lane step kernel (`upkie_sim_set_census`):
@@ -431,8 +431,8 @@ class BatchedSim:
         return self.census
 
     def census_counts(self) -> dict:
-        """Counters of `enable_census` so far: env-substeps handed to the general
-        substep by reason, and wavefront-substeps that ran it."""
+        """Counters of `enable_census` so far: env-substeps on the eight-lane
+        kernel's rare paths, and wavefront-substeps that ran them."""
         values = self.census.cpu().tolist()
         return dict(zip(self.CENSUS_FIELDS, values))
 
