@@ -33,6 +33,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of the GPU boxes only supports dmabuf IPC: without this RCCL's intra-node transport fails with
+# `hipIpcGetMemHandle: invalid argument` (already exported on the boxes; kept here for any env that drops it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ENVS_PER_GPU = 4096
 STEPS_PER_LAUNCH = 32  # the state stays in registers between the steps of a launch; 1 = one launch per env.step()
