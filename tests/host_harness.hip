@@ -80,7 +80,7 @@ void spin_barrier_wait(void* b) { static_cast<SpinBarrier*>(b)->wait(); }
 // trunk_wrench: [6] (base frame, about the base origin) or null. Runs `substeps` substeps;
 // status[i] receives OCT_CONTACT / OCT_NO_CONTACT of substep i.
 extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
-                                     const float* trunk_wrench, int substeps, int* status) {
+                                     const float* trunk_wrench, int substeps, int* status, int limits_in_registers) {
   DevModel M;
   std::string why;
   if (!convert_model(model, &M, &why)) return -1;
@@ -110,7 +110,8 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
       s.qd = l > 0 ? st[UPKIE_S_QD + joint] : 0.f;
       const float own_tau = l > 0 ? tau[joint] : 0.f;
       for (int i = 0; i < substeps; ++i) {
-        const int r = physics_substep_octet(M, Lm, L, s, own_tau, h, trunk_wrench);
+        const int r = limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench)
+                                          : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench);
         lane_status[t][i] = r;
       }
       result[t] = s;

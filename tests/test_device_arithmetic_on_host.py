@@ -238,7 +238,7 @@ def test_substep_with_external_forces_on_any_link(harness):
 OCT_NO_CONTACT, OCT_CONTACT = 0, 1
 
 
-def run_octet(harness, model, s64, tau, h=1e-3, records=None, wrench=None, substeps=1):
+def run_octet(harness, model, s64, tau, h=1e-3, records=None, wrench=None, substeps=1, limits_in_registers=False):
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
     s32 = s64.astype(np.float32)
     t32 = np.ascontiguousarray(tau, dtype=np.float32)
@@ -246,7 +246,7 @@ def run_octet(harness, model, s64, tau, h=1e-3, records=None, wrench=None, subst
     w32 = None if wrench is None else np.ascontiguousarray(wrench, dtype=np.float32)
     status = np.zeros(64, dtype=np.int32)
     harness.harness_substep_octet.restype = C.c_int
-    ok = harness.harness_substep_octet(C.byref(model), p(s32), p(t32), C.c_float(h), p(r32), p(w32), C.c_int(substeps), p(status))
+    ok = harness.harness_substep_octet(C.byref(model), p(s32), p(t32), C.c_float(h), p(r32), p(w32), C.c_int(substeps), p(status), C.c_int(1 if limits_in_registers else 0))
     assert ok == 1, "the eight lanes disagree on the base state or on the status"
     return s32.astype(np.float64), status[:substeps]
 
@@ -386,12 +386,13 @@ def test_octet_rare_cases(harness):
                 s[abi.S_QD + j] = rng.uniform(-3, 3)
                 hits += 1
         tau = rng.uniform(-3.0, 3.0, 6)
-        s8, status = run_octet(harness, model, s, tau)
         s1, contact = one_lane(harness, model, s, tau)
-        assert (status[0] == OCT_CONTACT) == bool(contact)
-        assert np.abs(s8[0:7] - s1[0:7]).max() < 1e-6
-        assert np.abs(s8[7:10] - s1[7:10]).max() < 5e-4 and np.abs(s8[10:13] - s1[10:13]).max() < 3e-3
-        assert np.abs(s8[13:19] - s1[13:19]).max() < 1e-5 and np.abs(s8[19:25] - s1[19:25]).max() < 5e-2
+        for in_registers in (False, True):  # the scratch-memory solve (Pendulum / Gyropod kernels) and the register one (Servos kernels)
+            s8, status = run_octet(harness, model, s, tau, limits_in_registers=in_registers)
+            assert (status[0] == OCT_CONTACT) == bool(contact)
+            assert np.abs(s8[0:7] - s1[0:7]).max() < 1e-6
+            assert np.abs(s8[7:10] - s1[7:10]).max() < 5e-4 and np.abs(s8[10:13] - s1[10:13]).max() < 3e-3
+            assert np.abs(s8[13:19] - s1[13:19]).max() < 1e-5 and np.abs(s8[19:25] - s1[19:25]).max() < 5e-2
     assert hits > 80
     model.enforce_joint_limits = 0
     one_tire = 0

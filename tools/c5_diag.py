@@ -8,7 +8,9 @@ from upkie_amd.utils.robot_state import RobotState
 from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 B=4096
 init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
-for variant in ("full", "no_push", "no_inertia", "plain"):
+import os
+for variant, lanes in (("full", "8"), ("full", "2"), ("plain", "8"), ("plain", "2")):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
     kw = dict(num_envs=B, frequency=200.0, init_state=init, autoreset_mode="next_step")
     if variant in ("full", "no_push"): kw["inertia_variation"] = 0.2
     if variant != "plain": kw["joint_properties"] = {n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")}
@@ -19,6 +21,7 @@ for variant in ("full", "no_push", "no_inertia", "plain"):
         env.set_external_forces("torso", push)
     policy = abi.torque_balancing_policy(gain=10.0, fall_pitch=1.0, left_sign=float(env.model.struct.left_sign))
     census = env.sim.enable_census()
+    print('mapping', env.sim.lanes_per_env)
     for w in range(4):
         census.zero_()
         torch.cuda.synchronize(); t0=time.perf_counter()

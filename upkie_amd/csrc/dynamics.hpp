@@ -546,8 +546,8 @@ UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, flo
 // solution (the warm start). Normals of both wheels first, then the rolling
 // rows, then the lateral ones -- together (lateral_pair_sweep) when both tires
 // touch. Each env stops on its own criterion: lanes leave the loop one by one.
-template <class ModelT>
-UPKIE_HD void contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+template <bool pair, class ModelT>
+UPKIE_HD void contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   const float mu = M.friction_mu;
   float idiag[6];
   idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
@@ -591,6 +591,15 @@ UPKIE_HD void contact_pgs6(const ModelT& M, const float (&A)[21], const float (&
     }
     if (change <= M.pgs_tolerance * scale) break;
   }
+}
+// (`pair` is a compile-time parameter of the sweeps: decided inside the unrolled loops at run time, the compiler
+// if-converts the row updates of both cases in some instantiations -- 361 instead of 151 instructions per sweep)
+template <class ModelT>
+UPKIE_HD void contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+  if (pair)
+    contact_pgs6_sweeps<true>(M, A, rhs, lam);
+  else
+    contact_pgs6_sweeps<false>(M, A, rhs, lam);
 }
 
 // Rare path shared by both lane mappings: some hip/knee joint sits at its

@@ -38,9 +38,10 @@
 // The rare cases gather their system into every lane of the env and run the
 // code the other mappings run, every lane on identical data: a contact solution
 // outside its friction cone -> the projected Gauss-Seidel sweeps (contact_pgs6);
-// a hip or knee at its stop -> the general solver over scratch memory
-// (general_constraint_solve), so that the path costs no registers. A tire off
-// the floor is masked with identity rows. Forces on leg links are not handled
+// a hip or knee at its stop -> the ten-row solve of the other mappings
+// (limit_path in registers for the Servos kernels, limit_path_scratch over
+// scratch memory for the others: octet_limit_path). A tire off the floor is
+// masked with identity rows. Forces on leg links are not handled
 // here: launch_step gives such launches to the two-lane kernel.
 //
 // Host build (tests/host_harness.hip): the same code, the eight lanes of one env
@@ -485,20 +486,116 @@ UPKIE_HD void oct_gauss_jordan(const OctLane& L, float (&D)[3], float (&E)[NE]) 
 }
 
 // A hip or knee at its stop (rare): contacts and joint-limit rows are solved
-// together by the general solver the one-lane kernel of very large batches uses
-// (general_constraint_solve: rows listed in scratch memory, Cholesky, projected
-// Gauss-Seidel when infeasible; same rows, order and numerics as limit_path).
-// The system is gathered into every lane of the env -- both legs' D and Hinv,
-// the contact rows of the touching tires in wheel order, one row per limited
-// joint in joint order -- straight into the solver's scratch structures, so
-// the path costs the kernel no registers; every lane then runs the same
-// solve on identical data and keeps the base velocity change and its own
-// joint's. Slow (a few thousand instructions), by design.
+// together, as in the other mappings. The system is gathered into every lane of
+// the env -- both legs' D and Hinv, the six contact rows, joint angles and
+// rates -- and every lane runs the shared solve on identical data, then keeps
+// the base velocity change and its own joint's:
+//   REGISTERS (the Servos instantiations, whose agents may drive joints into
+//   their stops all the time): limit_path, the ten-row solve in registers of
+//   the two-lane kernel (about 8 us per substep; the kernel then needs 512
+//   registers, its common path pays a few AGPR moves);
+//   otherwise octet_limit_path_scratch / general_constraint_solve: rows listed
+//   in scratch memory (about ten times slower, costs the kernel no registers:
+//   the Pendulum / Gyropod kernels, whose legs are held by the servos, keep a
+//   clean 256-register common path).
 template <int K>
 UPKIE_HD float oct_from_joint(float x) { return oct_qb<K + 1>(x); }
 
 template <class ModelT>
-UPKIE_HD void octet_limit_path(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
+UPKIE_HD void octet_limit_path_registers(const ModelT& M, const DevLimits& Lm, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0,
+                               float hv1, float hv2, V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active,
+                               bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih,
+                               float (&xb)[6], float& xl) {
+  const bool left = L.leg == 0;
+  System S;
+  S.A.l10 = 0.f; S.A.l20 = fac.l20; S.A.l21 = 0.f; S.A.l30 = fac.l30; S.A.l31 = fac.l31; S.A.l32 = fac.l32;
+  S.A.l40 = fac.l40; S.A.l41 = 0.f; S.A.l42 = fac.l42; S.A.l43 = fac.l43;
+  S.A.l50 = fac.l50; S.A.l51 = fac.l51; S.A.l52 = fac.l52; S.A.l53 = fac.l53; S.A.l54 = fac.l54;
+  S.A.i0 = fac.i0; S.A.i1 = fac.i1; S.A.i2 = fac.i2; S.A.i3 = fac.i3; S.A.i4 = fac.i4; S.A.i5 = fac.i5;
+  // contact rows of the own tire (lanes 1-3 of the quad), as in the eight-lane path
+  const float sa = oct_qb<3>(L.sg);
+  const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
+  const V3 t2 = cross(nB, t1);
+  const V3 d = L.e[0] * nB + L.e[1] * t1 + L.e[2] * t2;
+  const V3 Pxd = cross(Pc, d);
+  const float Jb[6] = {d.x, d.y, d.z, Pxd.x, Pxd.y, Pxd.z};
+  const float srz = L.sg * (Pc.z - o.z), srx = L.sg * (Pc.x - o.x);
+  const float Jl[3] = {oct_qb<1>(srz) * d.x - oct_qb<1>(srx) * d.z, oct_qb<2>(srz) * d.x - oct_qb<2>(srx) * d.z,
+                       oct_qb<3>(srz) * d.x - oct_qb<3>(srx) * d.z};
+  float vnow = Jb[0] * vB.x + Jb[1] * vB.y + Jb[2] * vB.z + Jb[3] * wB.x + Jb[4] * wB.y + Jb[5] * wB.z;
+  vnow = oct_sumj(vnow, qd, Jl[0], Jl[1], Jl[2]);
+  float Jt[6];
+  {
+    float acc[5] = {Jb[0], Jb[2], Jb[3], Jb[4], Jb[5]};
+    const float dc[5] = {Dc[0], Dc[2], Dc[3], Dc[4], Dc[5]};
+    oct_sumj_neg5(acc, dc, Jl[0], Jl[1], Jl[2]);
+    Jt[0] = acc[0]; Jt[1] = Jb[1]; Jt[2] = acc[1]; Jt[3] = acc[2]; Jt[4] = acc[3]; Jt[5] = acc[4];
+  }
+  // everything of both legs, in the fixed (left, right) order of the shared solve
+  float Jt6[6][6], Jb6[6][6], Jl6[6][3], vn6[6], q6[6], qd6[6], tl6[2][3], d2[2];
+  bool act2[2];
+  {
+    const float hv[3] = {hv0, hv1, hv2};
+    const float other_dist = oct_swp(dist);
+    d2[0] = left ? dist : other_dist;
+    d2[1] = left ? other_dist : dist;
+    act2[0] = left ? active : active_partner;
+    act2[1] = left ? active_partner : active;
+    auto joint = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      auto both = [&](float x, float& l_, float& r_) {
+        const float own = oct_from_joint<k>(x), other = oct_swp(own);
+        l_ = left ? own : other;
+        r_ = left ? other : own;
+      };
+#pragma unroll
+      for (int r = 0; r < 6; ++r) both(Dc[r], S.leg[0].D[r][k], S.leg[1].D[r][k]);
+#pragma unroll
+      for (int a = 0; a <= k; ++a) {  // Hinv[a][k], a <= k (symmetric storage 00 11 22 01 02 12)
+        const int idx = a == k ? a : (a == 0 ? (k == 1 ? 3 : 4) : 5);
+        both(hv[a], S.leg[0].Hinv[idx], S.leg[1].Hinv[idx]);
+      }
+      both(tl, tl6[0][k], tl6[1][k]);
+      both(q, q6[k], q6[3 + k]);
+      both(qd, qd6[k], qd6[3 + k]);
+      both(vnow, vn6[k], vn6[3 + k]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        both(Jt[c], Jt6[k][c], Jt6[3 + k][c]);
+        both(Jb[c], Jb6[k][c], Jb6[3 + k][c]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) both(Jl[j], Jl6[k][j], Jl6[3 + k][j]);
+    };
+    joint(std::integral_constant<int, 0>{});
+    joint(std::integral_constant<int, 1>{});
+    joint(std::integral_constant<int, 2>{});
+  }
+  // base impulse before the constraints: rt is tb reduced by the legs' impulses
+  float tb[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float v = rt[c];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v = fmaf(S.leg[w].D[c][k], tl6[w][k], v);
+    tb[c] = v;
+  }
+  float contact_lam[6];
+  limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl6[0], tl6[1], contact_lam);
+  system_solve<true, true>(S, tb, tl6[0], tl6[1]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xb[c] = tb[c];
+  const float mine_l = L.l == 1 ? tl6[0][0] : (L.l == 2 ? tl6[0][1] : tl6[0][2]);
+  const float mine_r = L.l == 1 ? tl6[1][0] : (L.l == 2 ? tl6[1][1] : tl6[1][2]);
+  xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
+}
+
+// The same path with the rows written straight into the general solver's scratch structures (no register arrays in
+// between: gathered into registers first, they cost the common path of a 256-register kernel spills).
+template <class ModelT>
+UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
                                V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active, bool active_partner, float qd,
                                float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_err,
                                float (&xb)[6], float& xl) {
@@ -654,19 +751,14 @@ enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0
 // joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
 // in the BASE frame and their moment about the base origin, or nullptr.
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
-template <class ModelT>
+template <bool LIMITS_IN_REGISTERS = false, class ModelT>
 UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const OctLane& L, OctPhys& s, float tau, float h,
                                    const float* trunk_wrench, int* census = nullptr) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
-  float lim_sign = 0.f, lim_err = 0.f;
   if (Lm.enforce) {
-    const bool low = L.bounded && s.q <= L.lower, high = L.bounded && !low && s.q >= L.upper;
-    if (oct_wave_any(low || high)) {
-      at_a_stop = oct_env_any(low || high);
-      lim_sign = low ? 1.f : (high ? -1.f : 0.f);
-      lim_err = low ? L.lower - s.q : (high ? s.q - L.upper : 0.f);
-    }
+    const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
+    if (oct_wave_any(own_limit)) at_a_stop = oct_env_any(own_limit);
   }
 
   // ---- base frame ----------------------------------------------------------
@@ -833,8 +925,14 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   float xl = 0.f;  // own joint velocity change
   if (at_a_stop) {
     if (census) *census = OCT_NOT_MINE_LIMIT;
-    octet_limit_path(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih, lim_sign,
-                     lim_err, xb, xl);
+    if (LIMITS_IN_REGISTERS) {
+      octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
+                                 erp, ih, xb, xl);
+    } else {
+      const bool low = L.bounded && s.q <= L.lower, high = L.bounded && !low && s.q >= L.upper;
+      octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
+                               low ? 1.f : (high ? -1.f : 0.f), low ? L.lower - s.q : (high ? s.q - L.upper : 0.f), xb, xl);
+    }
   } else if (active || active_partner) {
     const float sa = oct_qb<3>(L.sg);
     const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
@@ -1033,7 +1131,7 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
 template <int MODE, bool RAND>
-__global__ __launch_bounds__(64, 2) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
+__global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
                                                          float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -1247,11 +1345,20 @@ next_step:
       wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
     }
     int rare = 0;
-    const int status = physics_substep_octet(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &rare : nullptr);
-    if (census && rare) {  // rare-path census (upkie_sim_set_census): env-substeps by path, wavefront-substeps that took it
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &rare : nullptr);
+    if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
+                   // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)
+      const unsigned long long limited = __builtin_amdgcn_ballot_w64(lead && rare == OCT_NOT_MINE_LIMIT);
+      const unsigned long long swept = __builtin_amdgcn_ballot_w64(lead && rare == OCT_NOT_MINE_INFEASIBLE);
       const bool first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
-      if (lead) atomicAdd(&census[rare == OCT_NOT_MINE_LIMIT ? 0 : 2], 1u);
-      if (first) atomicAdd(&census[rare == OCT_NOT_MINE_LIMIT ? 4 : 5], 1u);
+      if (first && limited) {
+        atomicAdd(&census[0], (unsigned)__builtin_popcountll(limited));
+        atomicAdd(&census[4], 1u);
+      }
+      if (first && swept) {
+        atomicAdd(&census[2], (unsigned)__builtin_popcountll(swept));
+        atomicAdd(&census[5], 1u);
+      }
     }
     contact = status == OCT_CONTACT;
   }
