@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXAMPLES = ["pd_balancing", "batched_balancing", "domain_randomization", "count_wheel_contacts", "mpc_balancing", "ppo_rollout"]
+EXAMPLES = ["pd_balancing", "batched_balancing", "domain_randomization", "count_wheel_contacts", "mpc_balancing", "ppo_rollout", "torque_balancing"]
 
 
 @pytest.mark.parametrize("name", EXAMPLES)
@@ -21,5 +21,7 @@ def test_example_runs(name):
     assert out.strip(), "the example prints what it did"
     if name == "count_wheel_contacts":
         assert "left tire 1 contact(s), right tire 1 contact(s)" in out and "PointContact(link_name='left_wheel_tire'" in out
+    if name == "torque_balancing":
+        assert "torque_balancing:" in out and "velocity_balancing:" in out
     if name == "domain_randomization":
         assert out.count("inertia_variation") == 3
