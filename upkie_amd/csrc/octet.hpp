@@ -132,7 +132,25 @@ UPKIE_HD float oct_chain(float x) {
   x += oct_up2(x);
   return x;
 }
+// the same for several values at once, step by step over all of them (no wait states between dependent DPP reads)
+template <int N>
+UPKIE_HD void oct_chain(float (&x)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] += oct_up1(x[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] += oct_up2(x[i]);
+}
 // sum over the subtree of the own joint (lanes >= own, own >= 1) of a value that is 0 on the trunk lane
+template <int N>
+UPKIE_HD void oct_subtree(float (&xm)[N]) {
+#pragma clang fp contract(off)
+  float s1[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) s1[i] = xm[i] + oct_qperm<1, 2, 3, 0>(xm[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) xm[i] = s1[i] + oct_qperm<0, 3, 0, 0>(xm[i]);
+}
 UPKIE_HD float oct_subtree(float xm) {
 #pragma clang fp contract(off)  // keep x + dpp(x) one v_add_f32_dpp (a contracted multiply-add costs a separate DPP move)
   const float s1 = xm + oct_qperm<1, 2, 3, 0>(xm);
@@ -779,14 +797,18 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   joint_sincos(psi, &sn, &cs);
   const float pcs = oct_up1(cs), psn = oct_up1(sn);  // the parent's frame (trunk: identity)
   const V3 r = v3(pcs * L.p[0] + psn * L.p[2], L.p[1], pcs * L.p[2] - psn * L.p[0]);  // joint origin minus the parent's
-  const V3 o = v3(oct_chain(r.x), oct_chain(r.y), oct_chain(r.z));
   const float sq = L.sg * s.qd;
-  const float S = oct_chain(sq), Sp = S - sq;  // joint rates summed down to this body / to its parent
+  float along[4] = {r.x, r.y, r.z, sq};
+  oct_chain(along);
+  const V3 o = v3(along[0], along[1], along[2]);
+  const float S = along[3], Sp = S - sq;  // joint rates summed down to this body / to its parent
   // parent's omega = wB + Sp y, alpha = Sp (wB x y): origin acceleration term of this joint offset
   const V3 wp = v3(wB.x, wB.y + Sp, wB.z);
   const V3 alp = v3(-Sp * wB.z, 0.f, Sp * wB.x);
   const V3 e = cross(alp, r) + cross(wp, cross(wp, r));
-  const V3 ao = v3(oct_chain(e.x), oct_chain(e.y), oct_chain(e.z));
+  float ao3[3] = {e.x, e.y, e.z};
+  oct_chain(ao3);
+  const V3 ao = v3(ao3[0], ao3[1], ao3[2]);
 
   // ---- the own body: wrench and inertia about the base origin -----------------
   const V3 w = v3(wB.x, wB.y + S, wB.z);
@@ -814,10 +836,11 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   }
 
   // ---- subtree sums: composite wrench / inertia seen by the own joint -------
-  const float fcx = oct_subtree(L.wj * f.x), fcz = oct_subtree(L.wj * f.z), Ncy = oct_subtree(L.wj * N.y);
-  const float Cm = oct_subtree(L.wj * L.m);
-  const V3 Ch = v3(oct_subtree(L.wj * mc.x), oct_subtree(L.wj * mc.y), oct_subtree(L.wj * mc.z));
-  const float CIxy = oct_subtree(L.wj * Ib.xy), CIyy = oct_subtree(L.wj * Ib.yy), CIyz = oct_subtree(L.wj * Ib.yz);
+  float sub[10] = {L.wj * f.x, L.wj * f.z, L.wj * N.y, L.wj * L.m, L.wj * mc.x, L.wj * mc.y, L.wj * mc.z, L.wj * Ib.xy, L.wj * Ib.yy, L.wj * Ib.yz};
+  oct_subtree(sub);
+  const float fcx = sub[0], fcz = sub[1], Ncy = sub[2], Cm = sub[3];
+  const V3 Ch = v3(sub[4], sub[5], sub[6]);
+  const float CIxy = sub[7], CIyy = sub[8], CIyz = sub[9];
   // S = [a; o x a], a = sg y
   const float oxa_x = -L.sg * o.z, oxa_z = L.sg * o.x;
   const float bias = L.sg * Ncy + oxa_x * fcx + oxa_z * fcz;
