@@ -210,6 +210,57 @@ struct Phys {
   float qd[UPKIE_NJ];
 };
 
+// Base frame of a substep, shared by every lane mapping: rotation base -> world
+// from the quaternion (upkie/utils/rotations.py:52-71), the base velocities in
+// base coordinates, world z in base coordinates.
+struct BaseFrame {
+  float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+  V3 vB, wB, nB;
+};
+UPKIE_HD BaseFrame base_frame(float qw, float qx, float qy, float qz, V3 linvel, V3 angvel) {
+  BaseFrame f;
+  f.r00 = 1.f - 2.f * (qy * qy + qz * qz); f.r01 = 2.f * (qx * qy - qz * qw); f.r02 = 2.f * (qw * qy + qx * qz);
+  f.r10 = 2.f * (qx * qy + qz * qw); f.r11 = 1.f - 2.f * (qx * qx + qz * qz); f.r12 = 2.f * (qy * qz - qx * qw);
+  f.r20 = 2.f * (qx * qz - qy * qw); f.r21 = 2.f * (qy * qz + qx * qw); f.r22 = 1.f - 2.f * (qx * qx + qy * qy);
+  f.vB = v3(f.r00 * linvel.x + f.r10 * linvel.y + f.r20 * linvel.z, f.r01 * linvel.x + f.r11 * linvel.y + f.r21 * linvel.z,
+            f.r02 * linvel.x + f.r12 * linvel.y + f.r22 * linvel.z);
+  f.wB = v3(f.r00 * angvel.x + f.r10 * angvel.y + f.r20 * angvel.z, f.r01 * angvel.x + f.r11 * angvel.y + f.r21 * angvel.z,
+            f.r02 * angvel.x + f.r12 * angvel.y + f.r22 * angvel.z);
+  f.nB = v3(f.r20, f.r21, f.r22);
+  return f;
+}
+// End of a substep, shared by every lane mapping (semi-implicit Euler: the new
+// velocities move the positions): n = new base velocity in base coordinates
+// (linear 0-2, angular 3-5) -> world velocities, position, orientation.
+// dq = (cos(half), sin(half) w / |w|) with sin(half) / |w| = h/2 sinc(half); half
+// is a few 1e-3 at most in practice: series to x^8 (exact to fp32 below 0.5 rad),
+// libm beyond; q <- dq * q (world-frame angular velocity), renormalised.
+UPKIE_HD void integrate_base(const BaseFrame& f, float n0, float n1, float n2, float n3, float n4, float n5, float h, V3& pos, float& qw,
+                             float& qx, float& qy, float& qz, V3& linvel, V3& angvel) {
+  linvel = v3(f.r00 * n0 + f.r01 * n1 + f.r02 * n2, f.r10 * n0 + f.r11 * n1 + f.r12 * n2, f.r20 * n0 + f.r21 * n1 + f.r22 * n2);
+  angvel = v3(f.r00 * n3 + f.r01 * n4 + f.r02 * n5, f.r10 * n3 + f.r11 * n4 + f.r12 * n5, f.r20 * n3 + f.r21 * n4 + f.r22 * n5);
+  pos = pos + h * linvel;
+  const float wn = fast_sqrt(dot(angvel, angvel));
+  const float half = 0.5f * h * wn;
+  float ch, k;
+  if (half < 0.5f) {
+    const float x2 = half * half;
+    k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+    ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+  } else {
+    float sh;
+    sincosf(half, &sh, &ch);
+    k = sh * fast_rcp(wn);
+  }
+  const float dw = ch, dx = k * angvel.x, dy = k * angvel.y, dz = k * angvel.z;
+  const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+  const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+  const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+  const float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+  const float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
+  qw = nw * inv; qx = nx * inv; qy = ny * inv; qz = nz * inv;
+}
+
 // 6x6 symmetric LDL' factorisation, unit lower L (15) + inverse pivots (6).
 struct Ldl6 {
   float l10, l20, l21, l30, l31, l32, l40, l41, l42, l43, l50, l51, l52, l53, l54;
@@ -1104,17 +1155,9 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     for (int j = 0; j < UPKIE_NJ; ++j)
       any_limit = any_limit || (Lm.bounded[j] && (s.q[j] <= Lm.lower[j] || s.q[j] >= Lm.upper[j]));
   }
-  // rotation base -> world (upkie/utils/rotations.py:52-71)
-  float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
-  float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
-  float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
-  float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-  // base-frame velocities
-  V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
-             r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
-  V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
-             r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
-  V3 nB = v3(r20, r21, r22);  // world z in base coordinates
+  const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
+  const float r00 = bf.r00, r01 = bf.r01, r02 = bf.r02, r10 = bf.r10, r11 = bf.r11, r12 = bf.r12, r20 = bf.r20, r21 = bf.r21, r22 = bf.r22;
+  const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
   V3 gn = M.gravity * nB;
 
   // trunk
@@ -1392,34 +1435,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     s.qd[j] = v;
     s.q[j] = fmaf(h, v, s.q[j]);
   }
-  s.linvel = v3(r00 * nu[0] + r01 * nu[1] + r02 * nu[2], r10 * nu[0] + r11 * nu[1] + r12 * nu[2], r20 * nu[0] + r21 * nu[1] + r22 * nu[2]);
-  s.angvel = v3(r00 * nu[3] + r01 * nu[4] + r02 * nu[5], r10 * nu[3] + r11 * nu[4] + r12 * nu[5], r20 * nu[3] + r21 * nu[4] + r22 * nu[5]);
-  s.pos = s.pos + h * s.linvel;
-  {
-    float wn = fast_sqrt(dot(s.angvel, s.angvel));
-    float half = 0.5f * h * wn;
-    // dq = (cos(half), sin(half) w / |w|) with sin(half) / |w| = h/2 sinc(half);
-    // half is a few 1e-3 at most in practice: series to x^8 (exact to fp32
-    // below 0.5 rad), libm beyond
-    float ch, k;
-    if (half < 0.5f) {
-      float x2 = half * half;
-      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
-      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
-    } else {
-      float sh;
-      sincosf(half, &sh, &ch);
-      k = sh * fast_rcp(wn);
-    }
-    float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
-    // q <- dq * q (world-frame angular velocity)
-    float nw = dw * qw - dx * qx - dy * qy - dz * qz;
-    float nx = dw * qx + dx * qw + dy * qz - dz * qy;
-    float ny = dw * qy - dx * qz + dy * qw + dz * qx;
-    float nz = dw * qz + dx * qy - dy * qx + dz * qw;
-    float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
-    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
-  }
+  integrate_base(bf, nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   if (report) {
 #pragma unroll
     for (int w = 0; w < 2; ++w)

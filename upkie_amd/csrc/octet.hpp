@@ -780,15 +780,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   }
 
   // ---- base frame ----------------------------------------------------------
-  const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
-  const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
-  const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
-  const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-  const V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
-                   r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
-  const V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
-                   r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
-  const V3 nB = v3(r20, r21, r22);
+  const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
+  const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
   const V3 gn = M.gravity * nB;
 
   // ---- kinematics along the chain (prefix sums over the quad) -----------------
@@ -1117,30 +1110,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   }
   const float n0 = vB.x + xb[0], n1 = vB.y + xb[1], n2 = vB.z + xb[2];
   const float n3 = wB.x + xb[3], n4 = wB.y + xb[4], n5 = wB.z + xb[5];
-  s.linvel = v3(r00 * n0 + r01 * n1 + r02 * n2, r10 * n0 + r11 * n1 + r12 * n2, r20 * n0 + r21 * n1 + r22 * n2);
-  s.angvel = v3(r00 * n3 + r01 * n4 + r02 * n5, r10 * n3 + r11 * n4 + r12 * n5, r20 * n3 + r21 * n4 + r22 * n5);
-  s.pos = s.pos + h * s.linvel;
-  {
-    const float wn = fast_sqrt(dot(s.angvel, s.angvel));
-    const float half = 0.5f * h * wn;
-    float ch, k;
-    if (half < 0.5f) {
-      const float x2 = half * half;
-      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
-      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
-    } else {
-      float sh;
-      sincosf(half, &sh, &ch);
-      k = sh * fast_rcp(wn);
-    }
-    const float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
-    const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
-    const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
-    const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
-    const float nz = dw * qz + dx * qy - dy * qx + dz * qw;
-    const float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
-    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
-  }
+  integrate_base(bf, n0, n1, n2, n3, n4, n5, h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   return (active || active_partner) ? OCT_CONTACT : OCT_NO_CONTACT;
 }
 
@@ -1353,10 +1323,8 @@ next_step:
     const bool forces = RAND && ext.force && !do_reset;  // the reset substep runs without external forces
     float wrench[6];
     if (forces) {  // forces on the trunk: one wrench about the base origin, base frame
-      const float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
-      const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
-      const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
-      const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+      const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
+      const float r00 = bf.r00, r01 = bf.r01, r02 = bf.r02, r10 = bf.r10, r11 = bf.r11, r12 = bf.r12, r20 = bf.r20, r21 = bf.r21, r22 = bf.r22;
       V3 Fs = v3(0.f, 0.f, 0.f), Ns = v3(0.f, 0.f, 0.f);
       for (int i = 0; i < C.ext.count; ++i) {
         const V3 f = v3(ext.force[(size_t)(3 * i) * ext.stride], ext.force[(size_t)(3 * i + 1) * ext.stride], ext.force[(size_t)(3 * i + 2) * ext.stride]);

@@ -130,15 +130,9 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   }
   const bool any_limit = Lm.enforce ? pair_any<XL>(own_limit) : false;
 
-  float qw = s.qw, qx = s.qx, qy = s.qy, qz = s.qz;
-  float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qw * qy + qx * qz);
-  float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
-  float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
-  V3 vB = v3(r00 * s.linvel.x + r10 * s.linvel.y + r20 * s.linvel.z, r01 * s.linvel.x + r11 * s.linvel.y + r21 * s.linvel.z,
-             r02 * s.linvel.x + r12 * s.linvel.y + r22 * s.linvel.z);
-  V3 wB = v3(r00 * s.angvel.x + r10 * s.angvel.y + r20 * s.angvel.z, r01 * s.angvel.x + r11 * s.angvel.y + r21 * s.angvel.z,
-             r02 * s.angvel.x + r12 * s.angvel.y + r22 * s.angvel.z);
-  V3 nB = v3(r20, r21, r22);
+  const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
+  const float r00 = bf.r00, r01 = bf.r01, r02 = bf.r02, r10 = bf.r10, r11 = bf.r11, r12 = bf.r12, r20 = bf.r20, r21 = bf.r21, r22 = bf.r22;
+  const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
   V3 gn = M.gravity * nB;
 
   // trunk (both lanes, identical)
@@ -455,30 +449,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
     s.qd[j] = v;
     s.q[j] = fmaf(h, v, s.q[j]);
   }
-  s.linvel = v3(r00 * n0 + r01 * n1 + r02 * n2, r10 * n0 + r11 * n1 + r12 * n2, r20 * n0 + r21 * n1 + r22 * n2);
-  s.angvel = v3(r00 * n3 + r01 * n4 + r02 * n5, r10 * n3 + r11 * n4 + r12 * n5, r20 * n3 + r21 * n4 + r22 * n5);
-  s.pos = s.pos + h * s.linvel;
-  {
-    float wn = fast_sqrt(dot(s.angvel, s.angvel));
-    float half = 0.5f * h * wn;
-    float ch, k;
-    if (half < 0.5f) {
-      float x2 = half * half;
-      k = 0.5f * h * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
-      ch = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
-    } else {
-      float sh;
-      sincosf(half, &sh, &ch);
-      k = sh * fast_rcp(wn);
-    }
-    float dw = ch, dx = k * s.angvel.x, dy = k * s.angvel.y, dz = k * s.angvel.z;
-    float nw = dw * qw - dx * qx - dy * qy - dz * qz;
-    float nx = dw * qx + dx * qw + dy * qz - dz * qy;
-    float ny = dw * qy - dx * qz + dy * qw + dz * qx;
-    float nz = dw * qz + dx * qy - dy * qx + dz * qw;
-    float inv = fast_rsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
-    s.qw = nw * inv; s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv;
-  }
+  integrate_base(bf, n0, n1, n2, n3, n4, n5, h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   return any_contact;
 }
 

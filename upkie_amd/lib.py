@@ -19,6 +19,7 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "dynamics.hpp"),
     os.path.join(_HERE, "csrc", "mpc.hpp"),
     os.path.join(_HERE, "csrc", "pair.hpp"),
+    os.path.join(_HERE, "csrc", "octet.hpp"),
     os.path.join(_HERE, "csrc", "observers.hpp"),
     os.path.join(_HERE, "csrc", "rollout.hpp"),
     os.path.join(_HERE, "csrc", "wave_io.hpp"),
