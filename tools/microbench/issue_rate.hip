@@ -59,6 +59,14 @@
 #define NOP1(i) "s_nop 1\n"
 #define MFMA4(i) "v_mfma_f32_4x4x1_16b_f32 a[0:3], %16, %17, a[0:3]\n"
 #define MFMA4_IND(i) "v_mfma_f32_4x4x1_16b_f32 a[" "4*(" #i "%4)" ":" "4*(" #i "%4)+3" "], %16, %17, a[0:3]\n"
+// branches (exec is never zero here): not taken, taken to the next instruction, taken over 8 skipped instructions
+#define BR_NOT_TAKEN(i) "s_cbranch_execz .Lnt%=_" #i "\n.Lnt%=_" #i ":\n"
+#define BR_TAKEN(i) "s_cbranch_execnz .Ltk%=_" #i "\n.Ltk%=_" #i ":\n"
+#define BR_TAKEN_FAR(i) "s_cbranch_execnz .Ltf%=_" #i "\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\n.Ltf%=_" #i ":\n"
+#define BR_NT_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execz .Lnv%=_" #i "\n.Lnv%=_" #i ":\n"
+#define BR_TK_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execnz .Ltv%=_" #i "\n.Ltv%=_" #i ":\n"
+#define SAVEEXEC(i) "s_and_saveexec_b64 s[20:21], -1\ns_or_b64 exec, exec, s[20:21]\n"
+#define CMP_SAVEEXEC_VALU(i) "v_cmp_lt_f32_e32 vcc, %16, %17\ns_and_saveexec_b64 s[20:21], vcc\nv_fmac_f32_e32 %" #i ", %16, %17\ns_or_b64 exec, exec, s[20:21]\n"
 #define KERNEL(NAME, STR)                                                          \
   __global__ void NAME(float* out, long long* cyc, int iters, float b, float c) { \
     float a[16];                                                                   \
@@ -122,6 +130,14 @@ KERNEL(k_dpp_then_fma, DPP_THEN_FMA)
 KERNEL(k_nop1, NOP1)
 KERNEL(k_mfma4, MFMA4)
 
+KERNEL(k_br_nt, BR_NOT_TAKEN)
+KERNEL(k_br_tk, BR_TAKEN)
+KERNEL(k_br_tf, BR_TAKEN_FAR)
+KERNEL(k_br_nt_valu, BR_NT_VALU)
+KERNEL(k_br_tk_valu, BR_TK_VALU)
+KERNEL(k_saveexec, SAVEEXEC)
+KERNEL(k_cmp_saveexec, CMP_SAVEEXEC_VALU)
+
 typedef void (*kern_t)(float*, long long*, int, float, float);
 
 int main() {
@@ -164,7 +180,14 @@ int main() {
       {"v_fmac_f32_dpp dependent accumulator", k_dep_fmac_dpp},
       {"v_fmac_f32_dpp + v_fmac_f32_e32 (per pair)", k_dpp_then_fma},
       {"s_nop 1", k_nop1},
-      {"v_mfma_f32_4x4x1_16b_f32 same accumulator", k_mfma4}};
+      {"v_mfma_f32_4x4x1_16b_f32 same accumulator", k_mfma4},
+      {"s_cbranch_execz not taken", k_br_nt},
+      {"s_cbranch_execnz taken (to the next instruction)", k_br_tk},
+      {"s_cbranch_execnz taken over 8 skipped instructions", k_br_tf},
+      {"v_fmac + s_cbranch_execz not taken (per pair)", k_br_nt_valu},
+      {"v_fmac + s_cbranch_execnz taken (per pair)", k_br_tk_valu},
+      {"s_and_saveexec + s_or exec (per pair)", k_saveexec},
+      {"v_cmp, s_and_saveexec, v_fmac, s_or exec (per 4)", k_cmp_saveexec}};
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_fma_vop3, dim3(256), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
   (void)hipDeviceSynchronize();
   for (int wps : {1}) {

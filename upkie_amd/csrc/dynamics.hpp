@@ -210,6 +210,30 @@ struct Phys {
   float qd[UPKIE_NJ];
 };
 
+// The step kernels take ~1 KB of arguments by value (DevLimits, DevConfig) and the compiler loads them piece by piece,
+// with a wait after each piece. The argument block sits in device memory the CPU wrote over PCIe: its lines are not
+// in L2, a dependent miss costs 177 ns against 34 ns for a scalar-cache hit (tools/microbench/kernarg_latency.hip).
+// First thing in a kernel: touch every line (20 x 64 B covers the 1272-byte segment) with all the misses in flight
+// together; the loads that follow hit the scalar cache.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void warm_kernel_arguments() {
+  auto args = __builtin_amdgcn_kernarg_segment_ptr();
+  int sink;
+  asm volatile(
+      "s_load_dword %0, %1, 0x0\n s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n"
+      "s_load_dword %0, %1, 0x100\n s_load_dword %0, %1, 0x140\n s_load_dword %0, %1, 0x180\n s_load_dword %0, %1, 0x1c0\n"
+      "s_load_dword %0, %1, 0x200\n s_load_dword %0, %1, 0x240\n s_load_dword %0, %1, 0x280\n s_load_dword %0, %1, 0x2c0\n"
+      "s_load_dword %0, %1, 0x300\n s_load_dword %0, %1, 0x340\n s_load_dword %0, %1, 0x380\n s_load_dword %0, %1, 0x3c0\n"
+      "s_load_dword %0, %1, 0x400\n s_load_dword %0, %1, 0x440\n s_load_dword %0, %1, 0x480\n s_load_dword %0, %1, 0x4c0\n"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(sink)
+      : "s"(args)
+      : "memory");
+}
+#else
+__device__ inline void warm_kernel_arguments() {}
+#endif
+
 // Base frame of a substep, shared by every lane mapping: rotation base -> world
 // from the quaternion (upkie/utils/rotations.py:52-71), the base velocities in
 // base coordinates, world z in base coordinates.

@@ -776,7 +776,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   bool at_a_stop = false;
   if (Lm.enforce) {
     const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
-    if (oct_wave_any(own_limit)) at_a_stop = oct_env_any(own_limit);
+    if (__builtin_expect(oct_wave_any(own_limit), 0)) at_a_stop = oct_env_any(own_limit);
   }
 
   // ---- base frame ----------------------------------------------------------
@@ -939,7 +939,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   float xb[6];   // base velocity change
   float tlc = tl;  // own joint impulse incl. contacts
   float xl = 0.f;  // own joint velocity change
-  if (at_a_stop) {
+  if (__builtin_expect(at_a_stop, 0)) {
     if (census) *census = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
@@ -949,7 +949,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
       octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
                                low ? 1.f : (high ? -1.f : 0.f), low ? L.lower - s.q : (high ? s.q - L.upper : 0.f), xb, xl);
     }
-  } else if (active || active_partner) {
+  } else if (__builtin_expect(active || active_partner, 1)) {
     const float sa = oct_qb<3>(L.sg);
     const V3 t1 = (sa * iun) * v3(nB.z, 0.f, -nB.x);
     const V3 t2 = cross(nB, t1);
@@ -1029,7 +1029,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
     {
       const float lam_n = oct_qb<1>(lam);
       const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
-      if (oct_wave_any(bad)) {
+      if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
           if (census) *census = OCT_NOT_MINE_INFEASIBLE;
           const bool left = L.leg == 0;
@@ -1097,7 +1097,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   }
 
   // ---- joint velocity change: Hinv t - D' xb ------------------------------------
-  if (!at_a_stop) {
+  if (__builtin_expect(!at_a_stop, 1)) {
     xl = oct_sumj(0.f, tlc, hv0, hv1, hv2);
     xl -= Dc[0] * xb[0] + Dc[2] * xb[2] + Dc[3] * xb[3] + Dc[4] * xb[4] + Dc[5] * xb[5];
   }
@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                          const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                          float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census) {
+  warm_kernel_arguments();
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;

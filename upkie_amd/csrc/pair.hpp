@@ -462,6 +462,7 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
                                                         const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                         const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                         float* __restrict__ spine_state, float* __restrict__ final_obs, int n_steps) {
+  warm_kernel_arguments();
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;

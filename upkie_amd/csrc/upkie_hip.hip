@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
                                                    const float* __restrict__ body_inertials,
                                                    const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                    float* __restrict__ spine_state, float* __restrict__ final_obs) {
+  warm_kernel_arguments();
   const DevModel& M = *Mp;
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,7 +13,8 @@ from . import abi
 from .exceptions import UpkieRuntimeError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libupkie_hip.so")
+# UPKIE_HIP_LIBRARY: another build of the same sources (A/B measurements of a kernel change on one GPU box)
+LIB_PATH = os.environ.get("UPKIE_HIP_LIBRARY") or os.path.join(_HERE, "_lib", "libupkie_hip.so")
 SOURCES = [
     os.path.join(_HERE, "csrc", "upkie_hip.hip"),
     os.path.join(_HERE, "csrc", "dynamics.hpp"),

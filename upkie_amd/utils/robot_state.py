@@ -61,23 +61,41 @@ class RobotState:
         cfg.rand_omega_x, cfg.rand_omega_y = r.omega_x, r.omega_y
         cfg.rand_linvel[:] = list(r.linear_velocity)
 
+    def _base_rotation(self):
+        """The base orientation as a scipy Rotation (kept as given when one was given)."""
+        from scipy.spatial.transform import Rotation
+
+        if self._rotation is not None:
+            return self._rotation
+        w, x, y, z = self.orientation_base_in_world
+        return Rotation.from_quat([x, y, z, w])
+
+    def sample_angular_velocity(self, np_random: np.random.Generator) -> np.ndarray:
+        """Angular velocity around this state's (robot_state.py:109-125): offset added in the base frame."""
+        return self.angular_velocity_base_in_base + self.randomization.sample_angular_velocity(np_random)
+
+    def sample_linear_velocity(self, np_random: np.random.Generator) -> np.ndarray:
+        """Linear velocity around this state's (robot_state.py:127-143), world frame."""
+        return self.linear_velocity_base_to_world_in_world + self.randomization.sample_linear_velocity(np_random)
+
+    def sample_orientation(self, np_random: np.random.Generator):
+        """Orientation around this state's, a scipy Rotation (robot_state.py:145-160): the random offset is composed
+        on the right of the base orientation."""
+        return self._base_rotation() * self.randomization.sample_orientation(np_random)
+
+    def sample_position(self, np_random: np.random.Generator) -> np.ndarray:
+        """Position around this state's (robot_state.py:162-173)."""
+        return self.position_base_in_world + self.randomization.sample_position(np_random)
+
     def sample_state(self, np_random: np.random.Generator) -> "RobotState":
         """A state drawn around this one as `RobotState.sample_state` draws it
         (robot_state.py:175-196): angular velocity, linear velocity,
-        orientation (offset composed on the right of the base orientation,
-        :158-160), position, in that order, from the env's seeded generator.
+        orientation, position, in that order, from the env's seeded generator.
         Used by the single-robot envs; batched envs draw on the device."""
-        from scipy.spatial.transform import Rotation
-
-        r = self.randomization
-        angular_velocity = self.angular_velocity_base_in_base + r.sample_angular_velocity(np_random)
-        linear_velocity = self.linear_velocity_base_to_world_in_world + r.sample_linear_velocity(np_random)
-        base = self._rotation
-        if base is None:
-            w, x, y, z = self.orientation_base_in_world
-            base = Rotation.from_quat([x, y, z, w])
-        orientation = base * r.sample_orientation(np_random)
-        position = self.position_base_in_world + r.sample_position(np_random)
+        angular_velocity = self.sample_angular_velocity(np_random)
+        linear_velocity = self.sample_linear_velocity(np_random)
+        orientation = self.sample_orientation(np_random)
+        position = self.sample_position(np_random)
         return RobotState(
             angular_velocity_base_in_base=angular_velocity,
             joint_configuration=self.joint_configuration,
