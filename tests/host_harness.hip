@@ -88,6 +88,7 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
   model_limits(M, &Lm);
   DevConfig C;
   std::memset(&C, 0, sizeof(C));
+  C.h = h;  // load_oct_lane derives the launch's contact constants from it
   SpinBarrier barrier;
   float slots[8];
   OctPhys result[8];

@@ -142,6 +142,8 @@ UPKIE_HD void oct_chain(float (&x)[N]) {
   for (int i = 0; i < N; ++i) x[i] += oct_up2(x[i]);
 }
 // sum over the subtree of the own joint (lanes >= own, own >= 1) of a value that is 0 on the trunk lane
+// (DPP bank masks select quads of a row, not lanes of a quad: the zero on the trunk lane is what keeps the wheel and
+// calf lanes' sums clean)
 template <int N>
 UPKIE_HD void oct_subtree(float (&xm)[N]) {
 #pragma clang fp contract(off)
@@ -347,6 +349,9 @@ struct OctLane {
   float w0_once;      // 1 on the trunk lane of the left quad
   float keep_psi;     // 0 on the wheel lane when the wheel is axisymmetric
   float kl, ka;       // Bullet-style base damping, on the lane that owns the real trunk
+  // the same in every lane and every substep of a launch
+  float inv_h, erp, cfm;  // 1 / h, the normal rows' error reduction and constraint force mixing (from the contact stiffness / damping)
+  float total_mass;       // sum of the env's link masses: entry (1,1) of the base block
 };
 
 template <class ModelT>
@@ -414,6 +419,13 @@ UPKIE_HD OctLane load_oct_lane(const ModelT& M, const DevLimits& Lm, const DevCo
   L.friction = trunk ? 0.f : fr;
   L.control_noise = trunk ? 0.f : cn;
   L.measurement_noise = trunk ? 0.f : mn;
+  {
+    const float h = C.h, denom = h * M.contact_stiffness + M.contact_damping;
+    L.inv_h = fast_rcp(h);
+    L.erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
+    L.cfm = denom > 0.f ? fast_rcp(denom * h) : 0.f;
+  }
+  L.total_mass = oct_esum(L.m);
   (void)Lm;
   return L;
 }
@@ -879,34 +891,33 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   // ---- base block: own body's spatial inertia minus own column's outer product, summed over the env
   Ldl6Planar fac;
   {
-    // the 18 entries that are not structurally zero, packed: see `at` below
-    float P[18];
+    // the 17 configuration-dependent entries that are not structurally zero, packed ((1,1) is the total mass)
+    float P[17];
     P[0] = L.m - Dc[0] * F[0];          // (0,0)
-    P[1] = L.m;                         // (1,1)
-    P[2] = -Dc[2] * F[0];               // (2,0)
-    P[3] = L.m - Dc[2] * F[2];          // (2,2)
-    P[4] = -Dc[3] * F[0];               // (3,0)
-    P[5] = -mc.z;                       // (3,1)
-    P[6] = mc.y - Dc[3] * F[2];         // (3,2)
-    P[7] = Ib.xx - Dc[3] * F[3];        // (3,3)
-    P[8] = mc.z - Dc[4] * F[0];         // (4,0)
-    P[9] = -mc.x - Dc[4] * F[2];        // (4,2)
-    P[10] = Ib.xy - Dc[4] * F[3];       // (4,3)
-    P[11] = Ib.yy - Dc[4] * F[4];       // (4,4)
-    P[12] = -mc.y - Dc[5] * F[0];       // (5,0)
-    P[13] = mc.x;                       // (5,1)
-    P[14] = -Dc[5] * F[2];              // (5,2)
-    P[15] = Ib.xz - Dc[5] * F[3];       // (5,3)
-    P[16] = Ib.yz - Dc[5] * F[4];       // (5,4)
-    P[17] = Ib.zz - Dc[5] * F[5];       // (5,5)
+    P[1] = -Dc[2] * F[0];               // (2,0)
+    P[2] = L.m - Dc[2] * F[2];          // (2,2)
+    P[3] = -Dc[3] * F[0];               // (3,0)
+    P[4] = -mc.z;                       // (3,1)
+    P[5] = mc.y - Dc[3] * F[2];         // (3,2)
+    P[6] = Ib.xx - Dc[3] * F[3];        // (3,3)
+    P[7] = mc.z - Dc[4] * F[0];         // (4,0)
+    P[8] = -mc.x - Dc[4] * F[2];        // (4,2)
+    P[9] = Ib.xy - Dc[4] * F[3];        // (4,3)
+    P[10] = Ib.yy - Dc[4] * F[4];       // (4,4)
+    P[11] = -mc.y - Dc[5] * F[0];       // (5,0)
+    P[12] = mc.x;                       // (5,1)
+    P[13] = -Dc[5] * F[2];              // (5,2)
+    P[14] = Ib.xz - Dc[5] * F[3];       // (5,3)
+    P[15] = Ib.yz - Dc[5] * F[4];       // (5,4)
+    P[16] = Ib.zz - Dc[5] * F[5];       // (5,5)
     oct_esum(P);
     float A[21];
     A[0] = P[0];
-    A[1] = 0.f; A[2] = P[1];
-    A[3] = P[2]; A[4] = 0.f; A[5] = P[3];
-    A[6] = P[4]; A[7] = P[5]; A[8] = P[6]; A[9] = P[7];
-    A[10] = P[8]; A[11] = 0.f; A[12] = P[9]; A[13] = P[10]; A[14] = P[11];
-    A[15] = P[12]; A[16] = P[13]; A[17] = P[14]; A[18] = P[15]; A[19] = P[16]; A[20] = P[17];
+    A[1] = 0.f; A[2] = L.total_mass;
+    A[3] = P[1]; A[4] = 0.f; A[5] = P[2];
+    A[6] = P[3]; A[7] = P[4]; A[8] = P[5]; A[9] = P[6];
+    A[10] = P[7]; A[11] = 0.f; A[12] = P[8]; A[13] = P[9]; A[14] = P[10];
+    A[15] = P[11]; A[16] = P[12]; A[17] = P[13]; A[18] = P[14]; A[19] = P[15]; A[20] = P[16];
     ldl6_factor_planar(A, fac);
   }
 
@@ -924,10 +935,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   // ---- the tire of this leg: contact point, directions (every lane of the quad) --
   const float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
   const float iun = fast_rcp(fmaxf(un, 1e-12f));
-  const float denom = h * M.contact_stiffness + M.contact_damping;
-  const float ih = fast_rcp(h);
-  const float erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
-  const float cfm = denom > 0.f ? fast_rcp(denom * h) : 0.f;
+  const float ih = L.inv_h, erp = L.erp, cfm = L.cfm;  // of this launch's h (load_oct_lane)
   const V3 ow = v3(oct_qb<3>(o.x), oct_qb<3>(o.y), oct_qb<3>(o.z));
   const V3 center = ow + v3(L.wheel_center[0], L.wheel_center[1], L.wheel_center[2]);
   const V3 Pc = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
