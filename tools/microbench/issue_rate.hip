@@ -65,8 +65,6 @@
 #define BR_TAKEN_FAR(i) "s_cbranch_execnz .Ltf%=_" #i "\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\n.Ltf%=_" #i ":\n"
 #define BR_NT_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execz .Lnv%=_" #i "\n.Lnv%=_" #i ":\n"
 #define BR_TK_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execnz .Ltv%=_" #i "\n.Ltv%=_" #i ":\n"
-#define SAVEEXEC(i) "s_and_saveexec_b64 s[20:21], -1\ns_or_b64 exec, exec, s[20:21]\n"
-#define CMP_SAVEEXEC_VALU(i) "v_cmp_lt_f32_e32 vcc, %16, %17\ns_and_saveexec_b64 s[20:21], vcc\nv_fmac_f32_e32 %" #i ", %16, %17\ns_or_b64 exec, exec, s[20:21]\n"
 #define KERNEL(NAME, STR)                                                          \
   __global__ void NAME(float* out, long long* cyc, int iters, float b, float c) { \
     float a[16];                                                                   \
@@ -135,8 +133,6 @@ KERNEL(k_br_tk, BR_TAKEN)
 KERNEL(k_br_tf, BR_TAKEN_FAR)
 KERNEL(k_br_nt_valu, BR_NT_VALU)
 KERNEL(k_br_tk_valu, BR_TK_VALU)
-KERNEL(k_saveexec, SAVEEXEC)
-KERNEL(k_cmp_saveexec, CMP_SAVEEXEC_VALU)
 
 typedef void (*kern_t)(float*, long long*, int, float, float);
 
@@ -185,9 +181,7 @@ int main() {
       {"s_cbranch_execnz taken (to the next instruction)", k_br_tk},
       {"s_cbranch_execnz taken over 8 skipped instructions", k_br_tf},
       {"v_fmac + s_cbranch_execz not taken (per pair)", k_br_nt_valu},
-      {"v_fmac + s_cbranch_execnz taken (per pair)", k_br_tk_valu},
-      {"s_and_saveexec + s_or exec (per pair)", k_saveexec},
-      {"v_cmp, s_and_saveexec, v_fmac, s_or exec (per 4)", k_cmp_saveexec}};
+      {"v_fmac + s_cbranch_execnz taken (per pair)", k_br_tk_valu}};
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_fma_vop3, dim3(256), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
   (void)hipDeviceSynchronize();
   for (int wps : {1}) {
