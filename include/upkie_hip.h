@@ -121,7 +121,8 @@ typedef struct UpkieModel {
   double base_angular_damping;     /* Bullet default 0.04                   */
   double max_joint_velocity;       /* Bullet maxCoordinateVelocity, 100     */
   double pgs_tolerance;            /* sweeps stop once no impulse moved by more
-                                      than this fraction of the largest one  */
+                                      than this fraction of the largest one;
+                                      the fp32 kernels do not go below 1e-5  */
   int32_t pgs_iterations;          /* Bullet numSolverIterations, 50        */
   int32_t enforce_joint_limits;    /* hip/knee limit rows in the solver     */
   /* The URDF links each composite body was fused from: what Bullet keeps as
@@ -218,8 +219,10 @@ int upkie_sim_lanes_per_env(const UpkieSim* sim);
  *   [2] contact impulses outside the friction cone / pulling (projected
  *       Gauss-Seidel sweeps)
  * wavefront-substeps (what the paths cost) that took, for at least one of their
- * eight envs, [4] the joint-stop path, [5] the sweeps. The other words are
- * unused. Diagnostics only: no entry point of the reference corresponds to it. */
+ * eight envs, [4] the joint-stop path, [5] the sweeps. Sweeps run by the
+ * env-substeps of [2]: [6] their sum, [7] the largest count, [1] how many
+ * stopped at the iteration cap. Word [3] is unused. Diagnostics only: no entry
+ * point of the reference corresponds to it. */
 #define UPKIE_CENSUS_WORDS 8
 int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters);
 

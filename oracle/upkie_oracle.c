@@ -22,6 +22,11 @@
 
 long oracle_debug_sweeps = 0, oracle_debug_fallbacks = 0, oracle_debug_substeps = 0;
 long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they needed */
+/* the first systems whose sweeps ran into the iteration cap (diagnostics of the solver, tools/pgs_cap_cases.py):
+ * per case nrows, then W + CFM row-major [6][6], rhs [6], the warm start [6], the result [6] */
+#define ORACLE_CAPTURE_CASES 64
+double oracle_debug_capture[ORACLE_CAPTURE_CASES][1 + 36 + 18] = {{0}};
+long oracle_debug_captured = 0;
 
 /* ------------------------------------------------------------------ vec3 */
 static void v3_cross(const double a[3], const double b[3], double c[3]) {
@@ -672,6 +677,8 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       }
     }
     int sweeps_here = 0;
+    double warm_start[MAXROWS];
+    memcpy(warm_start, lam, sizeof(warm_start));
     for (int it = 0; need_pgs && it < model->pgs_iterations; ++it) {
       double change = 0.0, scale = 0.0;
       for (int pass = 0; pass < 3; ++pass) { /* normals, friction, limits */
@@ -700,6 +707,21 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       /* converged: the sweep moved no impulse by more than pgs_tolerance of
        * the largest one (each env stops on its own criterion) */
       if (change <= model->pgs_tolerance * scale) break;
+    }
+    if (need_pgs && sweeps_here >= model->pgs_iterations && nrows <= 6) {
+      long slot;
+#pragma omp atomic capture
+      slot = oracle_debug_captured++;
+      if (slot < ORACLE_CAPTURE_CASES) {
+        double* c = oracle_debug_capture[slot];
+        c[0] = nrows;
+        for (int a = 0; a < nrows; ++a) {
+          for (int b = 0; b < nrows; ++b) c[1 + 6 * a + b] = W[a][b] + (a == b ? cfm[a] : 0.0);
+          c[37 + a] = rhs_c[a];
+          c[43 + a] = warm_start[a];
+          c[49 + a] = lam[a];
+        }
+      }
     }
     if (need_pgs) {
       oracle_debug_fallbacks += 1;

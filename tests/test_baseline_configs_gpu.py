@@ -435,7 +435,8 @@ def test_c5_share_with_the_servo_policy_on_the_device_matches_oracle():
         close = dq < 1e-5
         a_h = act_h.cpu().numpy().astype(np.float64)
         assert np.array_equal(np.isnan(a_h), np.isnan(act_o))
-        np.testing.assert_allclose(np.nan_to_num(a_h[close]), np.nan_to_num(act_o[close]), atol=2e-4)
+        # (quaternion words within 1e-5 -> pitch within 4e-5 -> a torque of 10 x pitch within 4e-4)
+        np.testing.assert_allclose(np.nan_to_num(a_h[close]), np.nan_to_num(act_o[close]), atol=5e-4)
         assert np.array_equal(sim.state_numpy()[abi.S_DONE][close] != 0, st[abi.S_DONE][close] != 0)
         oracle.step_servos(act_o)
         sim.step_servos(act_h)

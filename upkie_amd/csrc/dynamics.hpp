@@ -210,6 +210,14 @@ struct Phys {
   float qd[UPKIE_NJ];
 };
 
+// A wavefront-uniform value that must stay in a scalar register from here on (the compiler may otherwise reload it
+// from the constant model next to each use).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UPKIE_KEEP_IN_SGPR(x) asm volatile("" : "+s"(x))
+#else
+#define UPKIE_KEEP_IN_SGPR(x) (void)0
+#endif
+
 // The step kernels take ~1 KB of arguments by value (DevLimits, DevConfig) and the compiler loads them piece by piece,
 // with a wait after each piece. The argument block sits in device memory the CPU wrote over PCIe: its lines are not
 // in L2, a dependent miss costs 177 ns against 34 ns for a scalar-cache hit (tools/microbench/kernarg_latency.hip).
@@ -622,12 +630,18 @@ UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, flo
 // rows, then the lateral ones -- together (lateral_pair_sweep) when both tires
 // touch. Each env stops on its own criterion: lanes leave the loop one by one.
 template <bool pair, class ModelT>
-UPKIE_HD void contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
+UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   const float mu = M.friction_mu;
+  // read before the loop and held in a scalar register: left to the compiler, the tolerance is re-fetched from the
+  // model inside every sweep, a scalar-cache round trip the lone wavefront waits out each time
+  float tolerance = M.pgs_tolerance;
+  UPKIE_KEEP_IN_SGPR(tolerance);
   float idiag[6];
   idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
   idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+  int sweeps = 0;
   for (int it = 0; it < M.pgs_iterations; ++it) {
+    sweeps = it + 1;
     float change = 0.f, scale = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -664,17 +678,15 @@ UPKIE_HD void contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const f
       change = fmaxf(change, lateral_pair_sweep(A[5], A[17], A[20], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
       scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));
     }
-    if (change <= M.pgs_tolerance * scale) break;
+    if (change <= tolerance * scale) break;
   }
+  return sweeps;  // for the census (upkie_sim_set_census)
 }
 // (`pair` is a compile-time parameter of the sweeps: decided inside the unrolled loops at run time, the compiler
 // if-converts the row updates of both cases in some instantiations -- 361 instead of 151 instructions per sweep)
 template <class ModelT>
-UPKIE_HD void contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
-  if (pair)
-    contact_pgs6_sweeps<true>(M, A, rhs, lam);
-  else
-    contact_pgs6_sweeps<false>(M, A, rhs, lam);
+UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+  return pair ? contact_pgs6_sweeps<true>(M, A, rhs, lam) : contact_pgs6_sweeps<false>(M, A, rhs, lam);
 }
 
 // Rare path shared by both lane mappings: some hip/knee joint sits at its
@@ -831,6 +843,8 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
     float idiag[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) idiag[r] = fast_rcp(A[sym(r, r)]);
+    float tolerance = M.pgs_tolerance;  // held in a scalar register across the sweeps (see contact_pgs6_sweeps)
+    UPKIE_KEEP_IN_SGPR(tolerance);
     for (int it = 0; it < M.pgs_iterations; ++it) {
       float change = 0.f, scale = 0.f;
 #pragma unroll
@@ -866,7 +880,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
           lam[r] = x;
         }
       }
-      if (change <= M.pgs_tolerance * scale) break;
+      if (change <= tolerance * scale) break;
     }
   }
   // t += J' lam (limit rows have no base part)

@@ -948,7 +948,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   float tlc = tl;  // own joint impulse incl. contacts
   float xl = 0.f;  // own joint velocity change
   if (__builtin_expect(at_a_stop, 0)) {
-    if (census) *census = OCT_NOT_MINE_LIMIT;
+    if (census) census[0] = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
                                  erp, ih, xb, xl);
@@ -1039,7 +1039,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
       const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
       if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
-          if (census) *census = OCT_NOT_MINE_INFEASIBLE;
+          if (census) census[0] = OCT_NOT_MINE_INFEASIBLE;
           const bool left = L.leg == 0;
           float A6[21], rhs6[6], lam6[6];
           // diagonal blocks: entry (a, b) of the own tire's block sits in lane b + 1 of the own quad
@@ -1082,7 +1082,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
             const float lim = M.friction_mu * lam6[3 * (r / 3)];
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
-          contact_pgs6(M, A6, rhs6, lam6, both);
+          const int sweeps = contact_pgs6(M, A6, rhs6, lam6, both);
+          if (census) census[1] = sweeps;
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
           lam = left ? mine_l : mine_r;
@@ -1344,8 +1345,9 @@ next_step:
       }
       wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
     }
-    int rare = 0;
-    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? &rare : nullptr);
+    int rare_path[2] = {0, 0};  // which rare path the env took this substep, Gauss-Seidel sweeps it ran
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? rare_path : nullptr);
+    const int rare = rare_path[0];
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)
       const unsigned long long limited = __builtin_amdgcn_ballot_w64(lead && rare == OCT_NOT_MINE_LIMIT);
@@ -1358,6 +1360,11 @@ next_step:
       if (first && swept) {
         atomicAdd(&census[2], (unsigned)__builtin_popcountll(swept));
         atomicAdd(&census[5], 1u);
+      }
+      if (lead && rare == OCT_NOT_MINE_INFEASIBLE) {  // 1 % of the env-substeps at most: per-env atomics are affordable here
+        atomicAdd(&census[6], (unsigned)rare_path[1]);
+        atomicMax(&census[7], (unsigned)rare_path[1]);
+        if (rare_path[1] >= M.pgs_iterations) atomicAdd(&census[1], 1u);
       }
     }
     contact = status == OCT_CONTACT;

@@ -864,6 +864,8 @@ extern "C" int upkie_hip_device_count(void) {
   return n;
 }
 
+// smallest relative change of an impulse the fp32 Gauss-Seidel sweeps can resolve (see convert_model)
+constexpr float kSweepToleranceFloor = 1e-5f;
 static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   std::memset(d, 0, sizeof(*d));
   for (int i = 0; i < UPKIE_NB; ++i) {
@@ -928,7 +930,11 @@ static bool convert_model(const UpkieModel* m, DevModel* d, std::string* why) {
   d->base_angular_damping = (float)m->base_angular_damping;
   d->max_joint_velocity = (float)m->max_joint_velocity;
   d->pgs_iterations = m->pgs_iterations;
-  d->pgs_tolerance = (float)m->pgs_tolerance;
+  // The sweeps run in fp32: a six-term residual cannot be told from zero below ~1e-5 of the largest impulse. With the
+  // model's default 1e-6 (the fp64 oracle reaches it within 26 sweeps on the C5 workload) 2.5 % of the infeasible
+  // substeps ran into the iteration cap, 50 sweeps that changed nothing, and a launch lasts as long as its slowest
+  // wavefront: 4e-6 leaves 0.03 % of them at the cap, 1e-5 none (profiles/r02_sweep_tolerance.txt).
+  d->pgs_tolerance = fmaxf((float)m->pgs_tolerance, kSweepToleranceFloor);
   d->enforce_joint_limits = m->enforce_joint_limits ? 1 : 0;
   for (int leg = 0; leg < 2; ++leg) {
     float* t = d->leg_table[leg];

@@ -421,7 +421,7 @@ class BatchedSim:
         """Lanes of a wavefront sharing one env in this handle's step kernels."""
         return int(self._lib.upkie_sim_lanes_per_env(self._handle))
 
-    CENSUS_FIELDS = ("joint_limit", "unused_1", "friction_cone", "unused_3", "wavefront_substeps_limit", "wavefront_substeps_sweeps")
+    CENSUS_FIELDS = ("joint_limit", "sweep_cap_hits", "friction_cone", "unused_3", "wavefront_substeps_limit", "wavefront_substeps_sweeps", "sweeps_total", "sweeps_max")
 
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
         """Rare-path census of the eight-lane step kernel (`upkie_sim_set_census`):
