@@ -24,9 +24,10 @@ long oracle_debug_sweeps = 0, oracle_debug_fallbacks = 0, oracle_debug_substeps 
 long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they needed */
 /* the first systems whose sweeps ran into the iteration cap (diagnostics of the solver, tools/pgs_cap_cases.py):
  * per case nrows, then W + CFM row-major [6][6], rhs [6], the warm start [6], the result [6] */
-#define ORACLE_CAPTURE_CASES 64
+#define ORACLE_CAPTURE_CASES 4096
 double oracle_debug_capture[ORACLE_CAPTURE_CASES][1 + 36 + 18] = {{0}};
 long oracle_debug_captured = 0;
+long oracle_debug_capture_threshold = 0; /* capture systems that needed at least this many sweeps (0: the iteration cap) */
 
 /* ------------------------------------------------------------------ vec3 */
 static void v3_cross(const double a[3], const double b[3], double c[3]) {
@@ -708,7 +709,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
        * the largest one (each env stops on its own criterion) */
       if (change <= model->pgs_tolerance * scale) break;
     }
-    if (need_pgs && sweeps_here >= model->pgs_iterations && nrows <= 6) {
+    if (need_pgs && sweeps_here >= (oracle_debug_capture_threshold > 0 ? oracle_debug_capture_threshold : model->pgs_iterations) && nrows <= 6) {
       long slot;
 #pragma omp atomic capture
       slot = oracle_debug_captured++;

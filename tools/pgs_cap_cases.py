@@ -1,7 +1,7 @@
 """Which contact systems run the projected Gauss-Seidel sweeps into their iteration cap? Runs one GPU's share of
 BASELINE's C5 (Servos, randomised inertias, +-5 N pushes, README balancer through the wheel velocity loop, fallen
 robots reset) on the fp64 oracle (CPU), prints the sweep histogram and saves the captured systems.
-Usage: python tools/pgs_cap_cases.py [envs] [steps] [out.npz]"""
+Usage: python tools/pgs_cap_cases.py [envs] [steps] [out.npz] [sweeps threshold]"""
 import ctypes as C
 import os
 import sys
@@ -17,6 +17,7 @@ from upkie_amd.model.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/pgs_cap_cases.npz"
+threshold = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # capture the systems that needed at least this many sweeps (0: the cap)
 cfg = randomized_config(B, seed=0)
 cfg.rand_pitch = 0.1
 cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
@@ -32,6 +33,7 @@ lib = O.load() if hasattr(O, "load") else O._lib
 hist = (C.c_long * 64).in_dll(lib, "oracle_debug_sweep_hist")
 for i in range(64): hist[i] = 0
 C.c_long.in_dll(lib, "oracle_debug_captured").value = 0
+C.c_long.in_dll(lib, "oracle_debug_capture_threshold").value = threshold
 r = float(model.wheel_radius)
 act = np.zeros((B, 6, 6)); act[:, :, 3] = 1.0; act[:, :, 4] = 1.0; act[:, :, 5] = 16.0
 act[:, [2, 5], 0] = np.nan
@@ -52,7 +54,7 @@ h = np.array(list(hist))
 n = h.sum()
 print(f"{B} envs x {steps} steps, {resets} resets; infeasible substeps {n} ({n / (B * steps * 5):.3%}); mean sweeps {np.dot(h, np.arange(64)) / max(n, 1):.1f}; at the cap {h[50:].sum()} ({h[50:].sum() / max(n, 1):.2%})")
 print("sweeps histogram (1..50):", h[1:51].tolist())
-captured = min(C.c_long.in_dll(lib, "oracle_debug_captured").value, 64)
-cases = np.ctypeslib.as_array((C.c_double * (64 * 55)).in_dll(lib, "oracle_debug_capture")).reshape(64, 55)[:captured].copy()
+captured = min(C.c_long.in_dll(lib, "oracle_debug_captured").value, 4096)
+cases = np.ctypeslib.as_array((C.c_double * (4096 * 55)).in_dll(lib, "oracle_debug_capture")).reshape(4096, 55)[:captured].copy()
 np.savez(out, cases=cases, mu=float(model.friction_mu))
 print("captured", captured, "cases ->", out)
