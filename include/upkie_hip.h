@@ -222,7 +222,8 @@ int upkie_sim_lanes_per_env(const UpkieSim* sim);
  * eight envs, [4] the joint-stop path, [5] the sweeps. Sweeps run by the
  * env-substeps of [2]: [6] their sum, [7] the largest count, [1] how many
  * stopped at the iteration cap. Word [3] is unused. Diagnostics only: no entry
- * point of the reference corresponds to it. */
+ * point of the reference corresponds to it, and its atomics (up to five per
+ * wavefront and substep on a rare path) are not free: time without it. */
 #define UPKIE_CENSUS_WORDS 8
 int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters);
 

@@ -483,6 +483,16 @@ def test_two_lanes_per_env_equals_one_lane_per_env(mode, wide, monkeypatch):
         sim.set_external_force(force, point=(0.0, 0.0, -0.1))
         sim.reset()
         sims.append(sim)
+    def compare(outs, hard_q):
+        a, b = sims[0].state, sims[1].state
+        assert_mostly_close(a[:7].t().cpu().numpy(), b[:7].t().cpu().numpy(), atol=2e-4, fraction=0.9, hard_atol=2e-2)
+        # (knees resting on their stops under noise: a stiff, rounding-sensitive regime)
+        assert_mostly_close(a[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), b[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), atol=5e-3, fraction=0.95, hard_atol=hard_q)
+        if mode == "servos":  # velocities / torques chatter on the stops: compare the reported positions
+            assert_mostly_close(outs[0][0][:, :, 0].cpu().numpy(), outs[1][0][:, :, 0].cpu().numpy(), atol=5e-3, fraction=0.95)
+        else:
+            assert_mostly_close(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-2, fraction=0.9)
+
     rng = np.random.default_rng(0)
     for step in range(40):
         if mode == "servos":
@@ -499,15 +509,16 @@ def test_two_lanes_per_env_equals_one_lane_per_env(mode, wide, monkeypatch):
             act = rng.uniform(-0.3, 0.3, (333, 2)).astype(np.float32)
             outs = [s.step_gyropod(torch.from_numpy(act)) for s in sims]
         assert torch.equal(outs[0][2], outs[1][2])  # terminated flags
+        if step == 25:
+            compare(outs, hard_q=0.05)
     a, b = sims[0].state, sims[1].state
     assert torch.equal(a[abi.S_EPISODE], b[abi.S_EPISODE]) and torch.equal(a[abi.S_STEP], b[abi.S_STEP])
-    assert_mostly_close(a[:7].t().cpu().numpy(), b[:7].t().cpu().numpy(), atol=2e-4, fraction=0.9, hard_atol=2e-2)
-    # (knees resting on their stops under noise: a stiff, rounding-sensitive regime)
-    assert_mostly_close(a[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), b[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), atol=5e-3, fraction=0.9, hard_atol=0.2)
-    if mode == "servos":  # velocities / torques chatter on the stops: compare the reported positions
-        assert_mostly_close(outs[0][0][:, :, 0].cpu().numpy(), outs[1][0][:, :, 0].cpu().numpy(), atol=5e-3, fraction=0.9)
-    else:
-        assert_mostly_close(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-2, fraction=0.9)
+    # Knees pushed against their stops by 6 N.m under torque noise: a stiff regime in which two schedules of the same
+    # arithmetic drift apart tenfold every five steps (1e-8 -> 1e-3 between steps 10 and 39 for the pair mapping, from
+    # 5e-7 for the eight-lane one, whose sums associate differently from the start). Held tightly 14 steps into that
+    # regime (above) and loosely at the end.
+    assert_mostly_close(a[:7].t().cpu().numpy(), b[:7].t().cpu().numpy(), atol=2e-3, fraction=0.9, hard_atol=5e-2)
+    assert_mostly_close(a[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), b[abi.S_Q : abi.S_Q + 6].t().cpu().numpy(), atol=1e-2, fraction=0.9, hard_atol=0.2)
 
 
 @pytest.mark.parametrize("lanes", ["1", "2", "8"])

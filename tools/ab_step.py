@@ -2,7 +2,7 @@
 step) or, with --c5, one GPU's share of BASELINE's C5 (Servos, randomised inertias, pushes, servo policy on the
 device: plenty of Gauss-Seidel sweeps); each build in its own process, interleaved, several rounds (box-to-box
 differences are larger than the few-percent effects this is for).
-Usage: python tools/ab_step.py libA.so libB.so ... [--rounds N] [--c5]"""
+Usage: python tools/ab_step.py libA.so libB.so ... [--rounds N] [--c5] [--fall]"""
 import os, subprocess, sys
 
 CHILD_C5 = r'''
@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "
 import torch, bench
 from upkie_amd.sim import BatchedSim
 sim = BatchedSim(bench.make_config(4096)); sim.reset(); sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
-for _ in range(100): sim.step_pendulum_agent()
+for _ in range(int(os.environ.get("AB_WARMUP", "100"))): sim.step_pendulum_agent()
 out = []
 for rep in range(3):
     a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,6 +60,9 @@ if "--rounds" in args:
 c5 = "--c5" in args
 if c5:
     args.remove("--c5")
+if "--fall" in args:  # the windows of the bench workload in which robots fall (steps 1200-2400)
+    args.remove("--fall")
+    os.environ["AB_WARMUP"] = "1200"
 libs = args
 for r in range(rounds):
     for lib in libs:

@@ -1,7 +1,7 @@
 """Which contact systems run the projected Gauss-Seidel sweeps into their iteration cap? Runs one GPU's share of
 BASELINE's C5 (Servos, randomised inertias, +-5 N pushes, README balancer through the wheel velocity loop, fallen
 robots reset) on the fp64 oracle (CPU), prints the sweep histogram and saves the captured systems.
-Usage: python tools/pgs_cap_cases.py [envs] [steps] [out.npz] [sweeps threshold]"""
+Usage: python tools/pgs_cap_cases.py [envs] [steps] [out.npz] [sweeps threshold] [torque]"""
 import ctypes as C
 import os
 import sys
@@ -18,6 +18,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/pgs_cap_cases.npz"
 threshold = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # capture the systems that needed at least this many sweeps (0: the cap)
+torque_law = len(sys.argv) > 5 and sys.argv[5] == "torque"  # examples/pybullet/torque_balancing.py instead of the README balancer
 cfg = randomized_config(B, seed=0)
 cfg.rand_pitch = 0.1
 cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
@@ -43,8 +44,13 @@ for k in range(steps):
     pitch = 2.0 * st[abi.S_QUAT + 2]
     pos = 0.5 * (st[abi.S_Q + 2] - st[abi.S_Q + 5]) * r * float(model.left_sign)
     v = np.clip(10.0 * pitch + pos, -0.99, 0.99) / r
-    act[:, 2, 1] = float(model.left_sign) * v
-    act[:, 5, 1] = -float(model.left_sign) * v
+    if torque_law:  # wheel torques +-10 x pitch, no velocity feedback (kd_scale 0 on the wheels)
+        act[:, [2, 5], 4] = 0.0
+        act[:, 2, 2] = float(model.left_sign) * 10.0 * pitch
+        act[:, 5, 2] = -float(model.left_sign) * 10.0 * pitch
+    else:
+        act[:, 2, 1] = float(model.left_sign) * v
+        act[:, 5, 1] = -float(model.left_sign) * v
     oracle.step_servos(act)
     fallen = np.abs(2.0 * oracle.state[abi.S_QUAT + 2]) > 1.0
     if fallen.any():

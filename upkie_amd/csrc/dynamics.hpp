@@ -636,9 +636,33 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
   // model inside every sweep, a scalar-cache round trip the lone wavefront waits out each time
   float tolerance = M.pgs_tolerance;
   UPKIE_KEEP_IN_SGPR(tolerance);
-  float idiag[6];
-  idiag[0] = fast_rcp(A[0]); idiag[1] = fast_rcp(A[2]); idiag[2] = fast_rcp(A[5]);
-  idiag[3] = fast_rcp(A[9]); idiag[4] = fast_rcp(A[14]); idiag[5] = fast_rcp(A[20]);
+  // Rows scaled by their diagonal once, so that a row update is x_r = b_r - sum_{c != r} a_rc lam_c: five multiply-adds
+  // (the unscaled form costs eight instructions a row; a launch with many skidding robots is bound by these sweeps).
+  // In pair mode the lateral rows 2 and 5 are swept together from the unscaled entries (lateral_pair_sweep).
+  float a[6][6], b[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    if ((r % 3) == 2 && pair) continue;
+    const float inv = fast_rcp(A[r * (r + 1) / 2 + r]);
+    b[r] = rhs[r] * inv;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int hi = r > c ? r : c, lo = r > c ? c : r;
+      a[r][c] = A[hi * (hi + 1) / 2 + lo] * inv;
+    }
+  }
+  // A rolling row that slides sits on its bound and moves with the normal impulse, lam_t = +-mu lam_n. Stepping the
+  // normal row as if the rolling one stayed put (it follows only in the next pass) makes the pair converge like
+  // 0.36^sweeps on a robot that skids (mu = 1: 9-13 sweeps for 1e-5). With the step scaled to the diagonal of the row
+  // solved for both, A_nn +- mu A_nt, the same fixed point is reached in about half the sweeps
+  // (profiles/r02_sweep_tolerance.txt). slide[tire][0 / 1]: A_nn / that diagonal for a rolling impulse > 0 / < 0.
+  float slide[2][2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const float coupling = mu * a[3 * w][3 * w + 1];
+    slide[w][0] = 1.f + coupling > 0.25f ? fast_rcp(1.f + coupling) : 1.f;
+    slide[w][1] = 1.f - coupling > 0.25f ? fast_rcp(1.f - coupling) : 1.f;
+  }
   int sweeps = 0;
   for (int it = 0; it < M.pgs_iterations; ++it) {
     sweeps = it + 1;
@@ -649,32 +673,18 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
       for (int r = 0; r < 6; ++r) {
         const bool is_normal = (r % 3) == 0;
         if (is_normal != (pass == 0) || ((r % 3) == 2 && pair)) continue;
-        float al = 0.f;  // (W + CFM) lam, row r
+        float x = b[r];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          const int hi = r > b ? r : b, lo = r > b ? b : r;
-          al = fmaf(A[hi * (hi + 1) / 2 + lo], lam[b], al);
-        }
-        float x;
+        for (int c = 0; c < 6; ++c)
+          if (c != r) x = fmaf(-a[r][c], lam[c], x);
         if (is_normal) {
-          // A rolling row that slides sits on its bound and moves with the normal impulse, lam_t = +-mu lam_n. Updating
-          // the normal row alone ignores that (the rolling row follows only in the next pass) and the pair then
-          // converges like 0.36^sweeps on a robot that skids (mu = 1: 9-13 sweeps for 1e-5). Solved for both at once
-          // -- effective diagonal A_nn +- mu A_nt, the rolling impulse set with the normal one -- the same fixed
-          // point is reached in about half the sweeps (profiles/r02_sweep_tolerance.txt).
-          const int t = r + 1;
-          const float lt = lam[t], smu = lt > 0.f ? mu : -mu;
-          const float eff = fmaf(smu, A[t * (t + 1) / 2 + r], A[r * (r + 1) / 2 + r]);
-          const bool together = lam[r] > 0.f && fabsf(lt) >= mu * lam[r] && eff > 0.25f * A[r * (r + 1) / 2 + r];
-          x = fmaxf(lam[r] + (rhs[r] - al) * (together ? fast_rcp(eff) : idiag[r]), 0.f);
-          if (together) {
-            const float xt = smu * x;
-            change = fmaxf(change, fabsf(xt - lt));
-            lam[t] = xt;
-          }
+          const int w = r / 3, t = r + 1;
+          const bool sliding = lam[r] > 0.f && fabsf(lam[t]) >= mu * lam[r];
+          const float step = sliding ? (lam[t] > 0.f ? slide[w][0] : slide[w][1]) : 1.f;
+          x = fmaxf(fmaf(x - lam[r], step, lam[r]), 0.f);
         } else {
           const float lim = mu * lam[3 * (r / 3)];
-          x = fminf(fmaxf(lam[r] + (rhs[r] - al) * idiag[r], -lim), lim);
+          x = fminf(fmaxf(x, -lim), lim);
         }
         change = fmaxf(change, fabsf(x - lam[r]));
         scale = fmaxf(scale, fabsf(x));
@@ -684,10 +694,10 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
     if (pair) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
       float r2 = rhs[2], r5 = rhs[5];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        if (b == 2 || b == 5) continue;
-        r2 -= A[(b > 2 ? b * (b + 1) / 2 + 2 : 2 * 3 / 2 + b)] * lam[b];
-        r5 -= A[5 * 6 / 2 + b] * lam[b];
+      for (int c = 0; c < 6; ++c) {
+        if (c == 2 || c == 5) continue;
+        r2 -= A[(c > 2 ? c * (c + 1) / 2 + 2 : 2 * 3 / 2 + c)] * lam[c];
+        r5 -= A[5 * 6 / 2 + c] * lam[c];
       }
       change = fmaxf(change, lateral_pair_sweep(A[5], A[17], A[20], r2, r5, mu * lam[0], mu * lam[3], lam[2], lam[5]));
       scale = fmaxf(scale, fmaxf(fabsf(lam[2]), fabsf(lam[5])));

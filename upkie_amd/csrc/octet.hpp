@@ -1361,10 +1361,19 @@ next_step:
         atomicAdd(&census[2], (unsigned)__builtin_popcountll(swept));
         atomicAdd(&census[5], 1u);
       }
-      if (lead && rare == OCT_NOT_MINE_INFEASIBLE) {  // 1 % of the env-substeps at most: per-env atomics are affordable here
-        atomicAdd(&census[6], (unsigned)rare_path[1]);
-        atomicMax(&census[7], (unsigned)rare_path[1]);
-        if (rare_path[1] >= M.pgs_iterations) atomicAdd(&census[1], 1u);
+      if (swept) {  // the sweeps those envs ran, summed over the wavefront first (at most eight envs: a scalar loop over their lead lanes)
+        unsigned total = 0, most = 0, capped = 0;
+        for (unsigned long long left = swept; left; left &= left - 1) {
+          const unsigned count = (unsigned)__builtin_amdgcn_readlane(rare_path[1], __builtin_ctzll(left));
+          total += count;
+          most = count > most ? count : most;
+          capped += count >= (unsigned)M.pgs_iterations ? 1u : 0u;
+        }
+        if (first) {
+          atomicAdd(&census[6], total);
+          atomicMax(&census[7], most);
+          if (capped) atomicAdd(&census[1], capped);
+        }
       }
     }
     contact = status == OCT_CONTACT;
