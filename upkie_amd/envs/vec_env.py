@@ -313,8 +313,7 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
         return obs, self._info()
 
     def step(self, action):
-        act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs)
-        obs, reward, terminated, truncated = self.sim.step_pendulum(act)
+        obs, reward, terminated, truncated = self.sim.step_pendulum(action)  # (converted / reshaped to [B] there)
         return self._finish_step(obs, reward, terminated, truncated)
 
 

@@ -18,7 +18,12 @@ from .model.default_model import default_model
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    # (a plain integer: ctypes turns it into the c_void_p the argtypes ask for, without an object per argument)
+    return t.data_ptr() if t is not None else None
+
+
+# the raw handle of torch's current stream on a device without building a torch.cuda.Stream object per call
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 class BatchedSim:
@@ -37,6 +42,7 @@ class BatchedSim:
             )
         self._lib = lib.load()
         self.device = torch.device(device)
+        self._device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.config = config
         self.model = model if model is not None else default_model()
         self.num_envs = int(config.num_envs)
@@ -77,10 +83,24 @@ class BatchedSim:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if _raw_stream is not None:
+            return _raw_stream(self._device_index)
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def _check(self, status: int) -> None:
-        lib.check(status, self._handle)
+        if status < 0:
+            lib.check(status, self._handle)
+
+    def _launch(self, fn, *args) -> None:
+        """One call into the library on torch's current stream of this handle's device. A Python-level RL loop pays
+        this once per `env.step()`: no device context manager when the device is already current, no stream object."""
+        if torch.cuda.current_device() == self._device_index:
+            status = fn(self._handle, *args, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                status = fn(self._handle, *args, self._stream())
+        if status < 0:
+            lib.check(status, self._handle)
 
     def push_config(self) -> None:
         """Hand the (mutated) ``self.config`` to the library."""
@@ -180,26 +200,16 @@ class BatchedSim:
         return self.obs6
 
     def _step(self, fn, act, obs):
-        with torch.cuda.device(self.device):
-            self._check(
-                fn(
-                    self._handle,
-                    _ptr(self.state),
-                    _ptr(act),
-                    _ptr(obs),
-                    _ptr(self.reward),
-                    _ptr(self.terminated),
-                    _ptr(self.truncated),
-                    self._stream(),
-                )
-            )
+        self._launch(fn, self.state.data_ptr(), act.data_ptr(), obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                     self.truncated.data_ptr())
         return obs, self.reward, self.terminated, self.truncated
 
     def _as_action(self, act, shape):
-        act = torch.as_tensor(act, dtype=torch.float32, device=self.device)
-        if tuple(act.shape) != shape:
+        if not (type(act) is torch.Tensor and act.dtype is torch.float32 and act.device == self.device):
+            act = torch.as_tensor(act, dtype=torch.float32, device=self.device)
+        if act.shape != shape:
             act = act.reshape(shape)
-        return act.contiguous()
+        return act if act.is_contiguous() else act.contiguous()
 
     def step_pendulum(self, act):
         act = self._as_action(act, (self.num_envs,))
@@ -243,8 +253,7 @@ class BatchedSim:
             if getattr(self, "_policy_act", None) is None:
                 self._policy_act = torch.zeros((self.num_envs, 6, 6), dtype=torch.float32, device=self.device)
             act = self._policy_act
-        with torch.cuda.device(self.device):
-            self._check(self._lib.upkie_sim_servo_policy(self._handle, _ptr(self.state), C.byref(policy), _ptr(act), self._stream()))
+        self._launch(self._lib.upkie_sim_servo_policy, self.state.data_ptr(), C.byref(policy), act.data_ptr())
         return act
 
     def step_base_velocity(self, act, commanded_velocity, mpc_x0, mpc_contact):
@@ -276,18 +285,8 @@ class BatchedSim:
     def step_pendulum_agent(self):
         """Pendulum step with the README's linear agent evaluated on-device
         from the observation currently held in ``self.obs4``."""
-        with torch.cuda.device(self.device):
-            self._check(
-                self._lib.upkie_sim_step_pendulum_agent(
-                    self._handle,
-                    _ptr(self.state),
-                    _ptr(self.obs4),
-                    _ptr(self.reward),
-                    _ptr(self.terminated),
-                    _ptr(self.truncated),
-                    self._stream(),
-                )
-            )
+        self._launch(self._lib.upkie_sim_step_pendulum_agent, self.state.data_ptr(), self.obs4.data_ptr(), self.reward.data_ptr(),
+                     self.terminated.data_ptr(), self.truncated.data_ptr())
         return self.obs4, self.reward, self.terminated, self.truncated
 
     def step_pendulum_records(self, prev_records: torch.Tensor, records: torch.Tensor) -> torch.Tensor:
@@ -374,8 +373,7 @@ class BatchedSim:
         set are re-initialised; their rows of ``obs`` (what the step of layout
         `abi.OBSERVATION_*` just wrote) go to ``final_obs`` and are replaced
         by the reset observation. Returns ``obs``."""
-        with torch.cuda.device(self.device):
-            self._check(self._lib.upkie_sim_autoreset_done(self._handle, int(layout), _ptr(self.state), _ptr(obs), _ptr(final_obs), self._stream()))
+        self._launch(self._lib.upkie_sim_autoreset_done, int(layout), self.state.data_ptr(), obs.data_ptr(), _ptr(final_obs))
         return obs
 
     def contact_points(self) -> torch.Tensor:
