@@ -211,6 +211,20 @@ int64_t upkie_sim_state_bytes(const UpkieSim* sim);
  * bit within one. */
 int upkie_sim_lanes_per_env(const UpkieSim* sim);
 
+/* gymnasium's SAME_STEP autoreset completed by the step calls themselves: with
+ * `final_obs` set (a device buffer shaped like the step's observation output:
+ * [B][4] Pendulum, [B][6] Gyropod, [B][6][5] Servos) and
+ * UpkieSimConfig::autoreset_mode == UPKIE_AUTORESET_DISABLED (no NEXT_STEP reset),
+ * upkie_sim_step_pendulum / _gyropod / _servos return with every env's last
+ * observation in `final_obs`, the finished envs re-initialised and their rows
+ * of the observation output replaced by the reset observation (reward and flags
+ * are those of the step) -- what upkie_sim_autoreset_done does as a second call,
+ * inside the same launch where the lane mapping allows it (batches up to 8192
+ * envs), as a second launch otherwise. NULL (the default): the step calls only
+ * flag the finished envs. Mirrors gymnasium.vector's AutoresetMode.SAME_STEP
+ * (the reference's envs are single robots: no counterpart there). */
+int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
+
 /* Rare-path census of the eight-lanes-per-env step kernel (octet.hpp): `counters`
  * is the caller's device buffer of UPKIE_CENSUS_WORDS uint32 (zeroed by the
  * caller) or NULL to switch the census off (the default). Env-substeps:

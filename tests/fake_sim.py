@@ -104,14 +104,25 @@ class OracleSim:
         self.truncated = torch.from_numpy(trunc)
         return getattr(self, holder), self.reward, self.terminated, self.truncated
 
+    final_obs = None
+
+    def set_final_observation(self, final_obs):
+        """`BatchedSim.set_final_observation`: the step calls complete a SAME_STEP autoreset themselves."""
+        self.final_obs = final_obs
+
+    def _same_step(self, out, layout):
+        if self.final_obs is not None and self.config.autoreset_mode == abi.AUTORESET_DISABLED:
+            self.autoreset_done(layout, out[0], self.final_obs)
+        return out
+
     def step_pendulum(self, act):
-        return self._out(*self._o.step_pendulum(torch.as_tensor(act).double().numpy().reshape(-1)), "obs4")
+        return self._same_step(self._out(*self._o.step_pendulum(torch.as_tensor(act).double().numpy().reshape(-1)), "obs4"), abi.OBSERVATION_PENDULUM)
 
     def step_gyropod(self, act):
-        return self._out(*self._o.step_gyropod(torch.as_tensor(act).double().numpy().reshape(-1, 2)), "obs6")
+        return self._same_step(self._out(*self._o.step_gyropod(torch.as_tensor(act).double().numpy().reshape(-1, 2)), "obs6"), abi.OBSERVATION_GYROPOD)
 
     def step_servos(self, act):
-        return self._out(*self._o.step_servos(torch.as_tensor(act).double().numpy().reshape(-1, 6, 6)), "obs_servos")
+        return self._same_step(self._out(*self._o.step_servos(torch.as_tensor(act).double().numpy().reshape(-1, 6, 6)), "obs_servos"), abi.OBSERVATION_SERVOS)
 
     def step_pendulum_agent(self):
         return self._out(*self._o.step_pendulum_agent(self.obs4.double().numpy()), "obs4")

@@ -12,6 +12,7 @@ from upkie_amd.utils.robot_state import RobotState
 from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 
 from .fake_sim import OracleMpc, oracle_sim_factory
+from .helpers import randomized_config
 
 pytestmark = pytest.mark.gpu
 
@@ -314,3 +315,60 @@ def test_base_velocity_same_step_autoreset_reports_the_dead_reckoned_pose():
     before = og.clone()
     obs, _ = gpu.reset(mask=mask)
     assert torch.equal(obs[1::2, :2].cpu(), before[1::2, :2].cpu()) and float(obs[::2, :2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("lanes", ["2", "8"])
+@pytest.mark.parametrize("mode", ["pendulum", "gyropod", "servos"])
+def test_same_step_autoreset_inside_the_step_equals_the_two_calls(mode, lanes, monkeypatch):
+    """`upkie_sim_set_final_observation`: the step call completes a SAME_STEP
+    autoreset itself -- inside the launch on eight lanes per env (the finished
+    env's lanes go through the reset branch once more), by a second launch
+    behind the first on the other mappings -- with the bits of an explicit
+    `upkie_sim_step_*` + `upkie_sim_autoreset_done` pair: observations, last
+    observations, flags, state, falls and time limits alike."""
+    from upkie_amd.sim import BatchedSim
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 333  # a half-filled last wavefront
+    cfg = randomized_config(B, seed=9)
+    cfg.autoreset_mode = abi.AUTORESET_DISABLED
+    cfg.fall_pitch = 0.12
+    cfg.rand_pitch = 0.1
+    cfg.max_episode_steps = 17
+    cfg.torque_measurement_noise[1] = 0.02
+    layout, shape = {"pendulum": (abi.OBSERVATION_PENDULUM, (B, 4)), "gyropod": (abi.OBSERVATION_GYROPOD, (B, 6)), "servos": (abi.OBSERVATION_SERVOS, (B, 6, 5))}[mode]
+    fused, pair = BatchedSim(cfg), BatchedSim(cfg)
+    assert fused.lanes_per_env == int(lanes)
+    for sim in (fused, pair):
+        sim.reset()
+    final_fused = torch.full(shape, -7.0, device="cuda:0")
+    final_pair = torch.full(shape, -7.0, device="cuda:0")
+    fused.set_final_observation(final_fused)
+    rng = np.random.default_rng(1)
+    restarted = 0
+    for step in range(50):
+        if mode == "pendulum":
+            act = torch.from_numpy(rng.uniform(-0.5, 0.5, B).astype(np.float32))
+            a, b = fused.step_pendulum(act), pair.step_pendulum(act)
+        elif mode == "gyropod":
+            act = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, 2)).astype(np.float32))
+            a, b = fused.step_gyropod(act), pair.step_gyropod(act)
+        else:
+            act = np.zeros((B, 6, 6), dtype=np.float32)
+            act[:, :, 0] = rng.uniform(-0.2, 0.2, (B, 6))
+            act[:, [2, 5], 0] = np.nan
+            act[:, :, 3:5] = 0.3  # soft joints: some robots sag and the time limit takes the rest
+            act[:, :, 5] = 16.0
+            a, b = fused.step_servos(torch.from_numpy(act)), pair.step_servos(torch.from_numpy(act))
+        restarted += int((pair.state[abi.S_DONE] != 0).sum())
+        pair.autoreset_done(layout, b[0], final_pair)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (mode, step)
+        assert torch.equal(final_fused, final_pair), (mode, step)
+        assert torch.equal(fused.state, pair.state), (mode, step)
+    assert restarted > B  # every env ran into the time limit at least once, some fell before
+    fused.set_final_observation(None)  # back to flag-only steps
+    act0 = torch.zeros(shape[:1] if mode == "pendulum" else ((B, 2) if mode == "gyropod" else (B, 6, 6)), device="cuda:0")
+    before = final_fused.clone()
+    (fused.step_pendulum if mode == "pendulum" else fused.step_gyropod if mode == "gyropod" else fused.step_servos)(act0)
+    assert torch.equal(final_fused, before)

@@ -1223,12 +1223,18 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
     o6[5] = yawvel_;
   };
 
+  // gymnasium's SAME_STEP autoreset inside the launch (upkie_sim_set_final_observation): an env that finishes keeps its
+  // last observation in `final_obs` and goes through the reset branch once more before the kernel returns -- its eight
+  // lanes together, the other envs of the wavefront wait masked.
+  constexpr bool CAN_RESET_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
+  const bool same_step = CAN_RESET_IN_PLACE && C.autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && !packed;
+  bool second_pass = false;
 next_step:
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = (C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f;
+    do_reset = second_pass || ((C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f);
     if (C.autoreset_mode == AUTORESET_DONE_PASS) {
       if (final_obs) {  // every env keeps its last observation (see step_kernel)
         constexpr int W = ObsWords<MODE>::value;
@@ -1464,6 +1470,7 @@ next_step:
     }
     return;
   }
+  const bool keep_last = same_step && !second_pass;  // this pass's observation is also the env's `final_obs` row
   if (MODE == MODE_SERVOS) {
     // each joint lane reports its servo (upkie_servos.py:288-306)
     float zm = 0.f;
@@ -1473,50 +1480,72 @@ next_step:
       zm = pick6(joint, z6);
     }
     if (jointed) {
+      const float o2 = (do_reset ? SW(UPKIE_S_TORQUE + joint) : tau) + L.measurement_noise * zm;
       float* o = obs + (size_t)30 * e + 5 * joint;
       o[0] = s.q;
       o[1] = s.qd;
-      o[2] = (do_reset ? SW(UPKIE_S_TORQUE + joint) : tau) + L.measurement_noise * zm;
+      o[2] = o2;
       o[3] = 42.0f;
       o[4] = 18.0f;
+      if (keep_last) {
+        float* f = final_obs + (size_t)30 * e + 5 * joint;
+        f[0] = s.q;
+        f[1] = s.qd;
+        f[2] = o2;
+        f[3] = 42.0f;
+        f[4] = 18.0f;
+      }
     }
   }
-  if (!lead) return;
-  if (MODE == MODE_PENDULUM || fused_agent(MODE)) {
-    const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
-    if (packed) {
-      float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
-      rec[0] = o4;
-      if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
-      return;
+  if (lead) {
+    if (MODE == MODE_PENDULUM || fused_agent(MODE)) {
+      const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
+      if (packed) {
+        float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
+        rec[0] = o4;
+        if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+        return;
+      }
+      reinterpret_cast<float4*>(obs)[e] = o4;
+      if (keep_last) reinterpret_cast<float4*>(final_obs)[e] = o4;
+    } else if (MODE == MODE_BASE_VELOCITY) {
+      float x = 0.f, y = 0.f;
+      if (!do_reset) {
+        const float lin = act[2 * (size_t)e];
+        float sy, cy;
+        sincosf(yaw, &sy, &cy);
+        x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
+        y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
+        SW(UPKIE_S_SE2_X) = x;
+        SW(UPKIE_S_SE2_Y) = y;
+      }
+      obs[(size_t)3 * e] = x;
+      obs[(size_t)3 * e + 1] = y;
+      obs[(size_t)3 * e + 2] = yaw;
+      reinterpret_cast<float4*>(bv.x0)[e] = make_float4(obs6[0], obs6[1], obs6[3], obs6[4]);
+      bv.contact[e] = contact ? 1 : 0;
+    } else if (MODE == MODE_GYROPOD) {
+      float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
+      o2[0] = make_float2(obs6[0], obs6[1]);
+      o2[1] = make_float2(obs6[2], obs6[3]);
+      o2[2] = make_float2(obs6[4], obs6[5]);
+      if (keep_last) {
+        float2* f2 = reinterpret_cast<float2*>(final_obs) + (size_t)3 * e;
+        f2[0] = make_float2(obs6[0], obs6[1]);
+        f2[1] = make_float2(obs6[2], obs6[3]);
+        f2[2] = make_float2(obs6[4], obs6[5]);
+      }
     }
-    reinterpret_cast<float4*>(obs)[e] = o4;
-  } else if (MODE == MODE_BASE_VELOCITY) {
-    float x = 0.f, y = 0.f;
-    if (!do_reset) {
-      const float lin = act[2 * (size_t)e];
-      float sy, cy;
-      sincosf(yaw, &sy, &cy);
-      x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
-      y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
-      SW(UPKIE_S_SE2_X) = x;
-      SW(UPKIE_S_SE2_Y) = y;
+    if (C.autoreset_mode != AUTORESET_DONE_PASS && !second_pass) {  // (the flags are those of the step, not of the reset behind it)
+      reward[e] = 0.f;
+      terminated[e] = fallen ? 1 : 0;
+      truncated[e] = timeout ? 1 : 0;
     }
-    obs[(size_t)3 * e] = x;
-    obs[(size_t)3 * e + 1] = y;
-    obs[(size_t)3 * e + 2] = yaw;
-    reinterpret_cast<float4*>(bv.x0)[e] = make_float4(obs6[0], obs6[1], obs6[3], obs6[4]);
-    bv.contact[e] = contact ? 1 : 0;
-  } else if (MODE == MODE_GYROPOD) {
-    float2* o2 = reinterpret_cast<float2*>(obs) + (size_t)3 * e;
-    o2[0] = make_float2(obs6[0], obs6[1]);
-    o2[1] = make_float2(obs6[2], obs6[3]);
-    o2[2] = make_float2(obs6[4], obs6[5]);
   }
-  if (C.autoreset_mode == AUTORESET_DONE_PASS) return;
-  reward[e] = 0.f;
-  terminated[e] = fallen ? 1 : 0;
-  truncated[e] = timeout ? 1 : 0;
+  if (keep_last && done_word != 0.f) {
+    second_pass = true;
+    goto next_step;
+  }
 #undef SW
 }
 #endif

@@ -838,6 +838,7 @@ struct UpkieSim {
   const float* ext_force = nullptr;
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
+  float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
   std::string error;
 };
 
@@ -1223,6 +1224,12 @@ extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
   return UPKIE_OK;
 }
 
+extern "C" int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  sim->final_obs = final_obs;
+  return UPKIE_OK;
+}
+
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
@@ -1235,6 +1242,12 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null action buffer");
   DevConfig config = sim->config;
   if (done_pass) config.autoreset_mode = AUTORESET_DONE_PASS;
+  // SAME_STEP autoreset completed by the step call itself (upkie_sim_set_final_observation): inside the launch on the
+  // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
+  constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
+  const bool same_step = RESETS_IN_PLACE && !done_pass && !packed && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
+  const bool same_step_in_kernel = same_step && mapped_lanes(sim) == 8;
+  if (same_step_in_kernel) final_obs = sim->final_obs;
   const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   const float* scale = rnd ? sim->body_inertials : nullptr;
@@ -1278,7 +1291,12 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
 #undef UPKIE_LAUNCH_S
 #undef UPKIE_LAUNCH_PAIR
 #undef UPKIE_LAUNCH
-  return check_hip(sim, hipGetLastError(), "step_kernel");
+  const int status = check_hip(sim, hipGetLastError(), "step_kernel");
+  if constexpr (RESETS_IN_PLACE) {
+    if (status == UPKIE_OK && same_step && !same_step_in_kernel)
+      return launch_step<MODE>(sim, state, nullptr, obs, nullptr, nullptr, nullptr, nullptr, stream, 0, BaseVelocityPtrs{}, true, sim->final_obs);
+  }
+  return status;
 }
 
 extern "C" int upkie_sim_reset(UpkieSim* sim, float* state, const uint8_t* mask, float* obs6, void* stream) {

@@ -205,11 +205,13 @@ class UpkieVecEnv:
         if self.autoreset_mode != "same_step":
             return obs, reward, terminated, truncated, self._info()
         done = terminated | truncated
-        if self._same_step_layout is not None and hasattr(self.sim, "autoreset_done"):
-            # one launch: envs whose DONE word is set restart, their terminal observation kept aside
+        if self._same_step_layout is not None and hasattr(self.sim, "set_final_observation"):
+            # the step call itself restarted the envs whose DONE word it set and kept every env's last observation
+            # aside (inside the same launch up to 8192 envs): armed on the first step, see below
             if self._final_obs is None:
-                self._final_obs = torch.empty_like(obs)
-            self.sim.autoreset_done(self._same_step_layout, obs, self._final_obs)
+                self._final_obs = obs.clone()
+                self.sim.set_final_observation(self._final_obs)
+                self.sim.autoreset_done(self._same_step_layout, obs, self._final_obs)  # this first step's own resets
             info = dict(self._info())
             info["final_obs"] = self._final_obs
             info["_final_obs"] = done

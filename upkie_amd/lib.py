@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_state_bytes",
     "upkie_sim_lanes_per_env",
     "upkie_sim_set_census",
+    "upkie_sim_set_final_observation",
     "upkie_sim_set_randomization",
     "upkie_sim_set_external_forces",
     "upkie_sim_sample_body_inertials",
@@ -154,6 +155,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_lanes_per_env.argtypes = [vp]
     lib.upkie_sim_set_census.restype = C.c_int
     lib.upkie_sim_set_census.argtypes = [vp, vp]
+    lib.upkie_sim_set_final_observation.restype = C.c_int
+    lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
     lib.upkie_sim_servo_policy.restype = C.c_int
     lib.upkie_sim_servo_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp]
     lib.upkie_sim_set_randomization.restype = C.c_int

@@ -368,6 +368,16 @@ class BatchedSim:
             )
         return out
 
+    def set_final_observation(self, final_obs: Optional[torch.Tensor]) -> None:
+        """SAME_STEP autoreset completed by the step calls themselves
+        (`upkie_sim_set_final_observation`): `final_obs`, shaped like the step's
+        observation output, receives every env's last observation; finished
+        envs come back re-initialised. ``None`` switches it off."""
+        if final_obs is not None:
+            assert final_obs.is_contiguous() and final_obs.dtype == torch.float32 and final_obs.device == self.device
+        self.final_obs = final_obs  # (kept alive here: the library holds the raw pointer)
+        self._check(self._lib.upkie_sim_set_final_observation(self._handle, _ptr(final_obs)))
+
     def autoreset_done(self, layout: int, obs: torch.Tensor, final_obs: Optional[torch.Tensor]) -> torch.Tensor:
         """gymnasium SAME_STEP autoreset in one launch: envs whose DONE word is
         set are re-initialised; their rows of ``obs`` (what the step of layout
