@@ -713,7 +713,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       long slot;
 #pragma omp atomic capture
       slot = oracle_debug_captured++;
-      if (slot < ORACLE_CAPTURE_CASES) {
+      if (slot >= 0 && slot < ORACLE_CAPTURE_CASES) { /* (a negative start skips the first cases) */
         double* c = oracle_debug_capture[slot];
         c[0] = nrows;
         for (int a = 0; a < nrows; ++a) {

@@ -33,7 +33,7 @@ oracle.reset()
 lib = O.load() if hasattr(O, "load") else O._lib
 hist = (C.c_long * 64).in_dll(lib, "oracle_debug_sweep_hist")
 for i in range(64): hist[i] = 0
-C.c_long.in_dll(lib, "oracle_debug_captured").value = 0
+C.c_long.in_dll(lib, "oracle_debug_captured").value = -int(os.environ.get("PGS_SKIP_CASES", "0"))  # skip the first cases (landing after the initial reset)
 C.c_long.in_dll(lib, "oracle_debug_capture_threshold").value = threshold
 r = float(model.wheel_radius)
 act = np.zeros((B, 6, 6)); act[:, :, 3] = 1.0; act[:, :, 4] = 1.0; act[:, :, 5] = 16.0
@@ -60,7 +60,7 @@ h = np.array(list(hist))
 n = h.sum()
 print(f"{B} envs x {steps} steps, {resets} resets; infeasible substeps {n} ({n / (B * steps * 5):.3%}); mean sweeps {np.dot(h, np.arange(64)) / max(n, 1):.1f}; at the cap {h[50:].sum()} ({h[50:].sum() / max(n, 1):.2%})")
 print("sweeps histogram (1..50):", h[1:51].tolist())
-captured = min(C.c_long.in_dll(lib, "oracle_debug_captured").value, 4096)
+captured = max(0, min(C.c_long.in_dll(lib, "oracle_debug_captured").value, 4096))
 cases = np.ctypeslib.as_array((C.c_double * (4096 * 55)).in_dll(lib, "oracle_debug_capture")).reshape(4096, 55)[:captured].copy()
 np.savez(out, cases=cases, mu=float(model.friction_mu))
 print("captured", captured, "cases ->", out)

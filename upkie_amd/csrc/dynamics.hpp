@@ -710,6 +710,13 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
 // if-converts the row updates of both cases in some instantiations -- 361 instead of 151 instructions per sweep)
 template <class ModelT>
 UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+  // both tires leaving the floor (neither normal row asks for an impulse): lam = 0 is the solution, what the sweeps
+  // return after one pass over the projected zeros (a tire without a contact point has an identity row and rhs 0)
+  if (rhs[0] <= 0.f && rhs[3] <= 0.f) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) lam[r] = 0.f;
+    return 0;
+  }
   return pair ? contact_pgs6_sweeps<true>(M, A, rhs, lam) : contact_pgs6_sweeps<false>(M, A, rhs, lam);
 }
 
