@@ -1,8 +1,8 @@
 """The reference's examples/pybullet/torque_balancing.py for a batch, with the
 agent on the device: legs held at zero by the servos, wheel torques
 +-10 N.m/rad x pitch, no velocity feedback in the wheels. The law itself is a
-one-launch policy (`upkie_sim_servo_policy`) that writes the next servo action
-from the state and flags fallen robots, which the NEXT_STEP autoreset
+servo-level policy evaluated inside the step's own launch
+(`upkie_sim_step_servos_policy`): it flags fallen robots, which the NEXT_STEP autoreset
 re-initialises: nothing returns to the host between two steps. As on the real
 robot the pure pitch-to-torque law does not hold a position: the robots run
 away, the tires slip, they fall and start again. The README balancer sent
@@ -29,7 +29,7 @@ if __name__ == "__main__":
             else:
                 policy = abi.velocity_balancing_policy(float(model.wheel_radius), fall_pitch=1.0, left_sign=float(model.left_sign))
             for _ in range(n):
-                env.sim.step_servos(env.sim.servo_policy(policy))
+                env.sim.step_servos_policy(policy)  # the policy inside the step's launch (one launch per step up to 8192 envs)
             torch.cuda.synchronize()
             falls = int(env.sim.state[abi.S_EPISODE].sum()) - B
             pitch = 2.0 * env.sim.state[abi.S_QUAT + 2]

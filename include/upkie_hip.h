@@ -399,6 +399,14 @@ typedef struct UpkieServoPolicy {
   float fall_pitch;
 } UpkieServoPolicy;
 int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, void* stream);
+/* upkie_sim_servo_policy + upkie_sim_step_servos as one call: on the
+ * eight-lanes-per-env mapping (batches up to 8192 envs) the policy is evaluated
+ * inside the step's launch, each joint lane computing its own command from the
+ * state the step starts from, and `act` is left untouched; on the other
+ * mappings the two launches run one behind the other through `act` ([B][6][6],
+ * caller's scratch). Same results up to the rounding of the feedback sum. */
+int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
+                                 uint8_t* terminated, uint8_t* truncated, void* stream);
 
 /* Full spine observation (pybullet_backend.py:313-490), materialised lazily.
  * Any pointer may be NULL. */

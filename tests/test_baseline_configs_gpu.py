@@ -478,3 +478,45 @@ def test_c3_balancer_and_step_in_one_launch_equal_two_launches(B, lanes, monkeyp
     assert torch.equal(one.mpc_balancer.commanded_velocity, two.mpc_balancer.commanded_velocity)
     assert torch.equal(one.mpc_balancer.workspace, two.mpc_balancer.workspace)
     assert float(one.mpc_balancer.commanded_velocity.abs().max()) > 0.05  # the balancer did act
+
+
+@pytest.mark.parametrize("lanes", ["8", "2"])
+def test_servo_policy_inside_the_step_equals_the_two_launches(lanes, monkeypatch):
+    """`upkie_sim_step_servos_policy`: the servo-level policy evaluated by the
+    step's own lanes (eight lanes per env) against `upkie_sim_servo_policy` +
+    `upkie_sim_step_servos`, the C5 share's loop: same commands (the feedback
+    sum may round differently: two compilations of one expression), same
+    NEXT_STEP resets of the robots the policy flags as fallen; on two lanes per
+    env the one call IS the two launches (same bits)."""
+    from upkie_amd.sim import BatchedSim
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = 1000
+    cfg = randomized_config(B, seed=6, autoreset=True)
+    cfg.rand_pitch = 0.3
+    cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
+    model = Model().struct
+    one, two = BatchedSim(cfg, model), BatchedSim(cfg, model)
+    force = torch.zeros(3, B)
+    force[0] = torch.linspace(-5, 5, B)
+    for sim in (one, two):
+        sim.randomize_inertias(0.2)
+        sim.set_external_force(force, point=(0.0, 0.0, -0.1))
+        sim.reset()
+    resets = 0
+    for make in (lambda: abi.velocity_balancing_policy(float(model.wheel_radius), 0.4, float(model.left_sign)),
+                 lambda: abi.torque_balancing_policy(gain=10.0, fall_pitch=0.3, left_sign=float(model.left_sign))):
+        policy = make()
+        for step in range(30):
+            a = one.step_servos_policy(policy)
+            b = two.step_servos(two.servo_policy(policy))
+            assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), step
+            assert torch.equal(one.state[abi.S_EPISODE], two.state[abi.S_EPISODE]), step
+            if lanes == "2":
+                assert torch.equal(a[0], b[0]) and torch.equal(one.state, two.state), step
+            else:
+                torch.testing.assert_close(a[0][:, :, :2], b[0][:, :, :2], atol=2e-5, rtol=0)  # positions, velocities
+                torch.testing.assert_close(one.state[:13], two.state[:13], atol=2e-5, rtol=0)
+                one.state.copy_(two.state)  # (fp32 closed loops part ways: compare step by step)
+        resets = int(two.state[abi.S_EPISODE].sum()) - B
+    assert resets > 20  # robots beyond the policies' fall thresholds were restarted by the step that followed

@@ -73,7 +73,10 @@ for label, make_policy in (("README balancer through the wheel velocity loop", l
     env2.set_external_forces("torso", push)
     policy = make_policy(env2.model.struct)
     def policy_step():
+        env2.sim.step_servos_policy(policy)  # the policy inside the step's launch (eight lanes per env)
+    def two_launches():
         env2.sim.step_servos(env2.sim.servo_policy(policy))
+    dt_two = timeit(two_launches, 1000, 400)
     dt_policy = timeit(policy_step, 2000, 400)
     # the rare-path census afterwards, on its own steps: its atomics (five per wavefront-substep that sweeps) are not free
     census = env2.sim.enable_census()
@@ -81,7 +84,8 @@ for label, make_policy in (("README balancer through the wheel velocity loop", l
     timeit(policy_step, census_steps, 0)
     c = env2.sim.census_counts()
     env2.sim.enable_census(False)
-    out.append(dict(config=f"C5 share, servo-level policy on the device ({label}): upkie_sim_servo_policy + upkie_sim_step_servos, NEXT_STEP autoreset of fallen robots, two launches per step, Python loop",
+    out.append(dict(config=f"C5 share, servo-level policy on the device ({label}): upkie_sim_step_servos_policy (policy evaluated inside the step's launch), NEXT_STEP autoreset of fallen robots, ONE launch per step, Python loop",
+                    us_per_step_as_two_launches=dt_two * 1e6,
                     envs=B, us_per_step=dt_policy * 1e6, env_steps_per_s=B / dt_policy, lanes_per_env=env2.sim.lanes_per_env, episodes=int(env2.sim.state[40].sum()),
                     env_substeps_in_gauss_seidel_sweeps=c["friction_cone"] / (B * 5 * census_steps), env_substeps_with_a_joint_at_its_stop=c["joint_limit"] / (B * 5 * census_steps),
                     sweeps_per_infeasible_env_substep=c["sweeps_total"] / max(c["friction_cone"], 1), infeasible_env_substeps_at_the_sweep_cap=c["sweep_cap_hits"] / max(c["friction_cone"], 1),

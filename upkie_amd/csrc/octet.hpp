@@ -1231,6 +1231,23 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
     o6[5] = yawvel_;
   };
 
+  // UpkieServos with the servo-level policy evaluated here instead of by a launch of its own in front of this one
+  // (upkie_sim_step_servos_policy: `packed` == 2, `act` is the device copy of the UpkieServoPolicy): what
+  // servo_policy_kernel computes from the state the step starts from, the own joint's row only.
+  const UpkieServoPolicy* policy = MODE == MODE_SERVOS && packed == 2 ? reinterpret_cast<const UpkieServoPolicy*>(act) : nullptr;
+  float policy_pitch = 0.f, policy_position = 0.f, policy_velocity = 0.f;
+  if (MODE == MODE_SERVOS && policy) {
+    policy_pitch = asinf(fminf(fmaxf(2.f * (s.qw * s.qy - s.qz * s.qx), -1.f), 1.f));
+    const float qo = oct_qb<3>(s.q), qdo = oct_qb<3>(s.qd);
+    const float qp = oct_swp(qo), qdp = oct_swp(qdo);
+    policy_position = 0.5f * ((leg ? qp : qo) - (leg ? qo : qp)) * signed_radius;
+    policy_velocity = 0.5f * ((leg ? qdp : qdo) - (leg ? qdo : qdp)) * signed_radius;
+    const float fall_pitch = policy->fall_pitch;
+    if (fall_pitch > 0.f && fabsf(policy_pitch) > fall_pitch) {  // flagged for the NEXT_STEP autoreset: this very launch
+      done_word = 1.f;
+      if (lead) SW(UPKIE_S_DONE) = 1.f;
+    }
+  }
   // gymnasium's SAME_STEP autoreset inside the launch (upkie_sim_set_final_observation): an env that finishes keeps its
   // last observation in `final_obs` and goes through the reset branch once more before the kernel returns -- its eight
   // lanes together, the other envs of the wavefront wait masked.
@@ -1287,7 +1304,21 @@ next_step:
     s.qd = 0.f;
   } else if (MODE == MODE_SERVOS) {
     if (jointed) {
-      const float* a = act + (size_t)36 * e + 6 * joint;
+      float a[6];
+      if (policy) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = policy->action[joint][i];
+        float fb = policy->pitch_to_velocity[joint] * policy_pitch + policy->position_to_velocity[joint] * policy_position +
+                   policy->velocity_to_velocity[joint] * policy_velocity;
+        const float clip = policy->velocity_feedback_clip[joint];
+        if (clip > 0.f) fb = fminf(fmaxf(fb, -clip), clip);
+        a[1] += fb;
+        a[2] += policy->pitch_to_torque[joint] * policy_pitch;
+      } else {
+        const float* given = act + (size_t)36 * e + 6 * joint;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = given[i];
+      }
       const float eff = L.effort, vel = L.velocity;
       cmd.position = clamp_ref(a[0], L.lower, L.upper);
       cmd.velocity = clamp_ref(a[1], -vel, vel);

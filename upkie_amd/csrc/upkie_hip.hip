@@ -839,6 +839,9 @@ struct UpkieSim {
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
+  UpkieServoPolicy* d_policy = nullptr;  // device copy of the policy of upkie_sim_step_servos_policy, uploaded when it changes
+  UpkieServoPolicy policy_cache{};
+  bool policy_cached = false;
   std::string error;
 };
 
@@ -1130,6 +1133,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
+  if (sim && sim->d_policy) (void)hipFree(sim->d_policy);
   delete sim;
   return UPKIE_OK;
 }
@@ -1395,6 +1399,26 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
   hipLaunchKernelGGL(servo_policy_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config.num_envs,
                      sim->model.left_sign * sim->model.wheel_radius, *policy, state, act);
   return check_hip(sim, hipGetLastError(), "servo_policy_kernel");
+}
+
+extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
+                                            uint8_t* terminated, uint8_t* truncated, void* stream) {
+  if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (mapped_lanes(sim) != 8) {  // the other mappings: the policy's own launch into `act`, then the step
+    const int status = upkie_sim_servo_policy(sim, state, policy, act, stream);
+    if (status != UPKIE_OK) return status;
+    return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
+  }
+  if (!sim->d_policy && hipMalloc((void**)&sim->d_policy, sizeof(UpkieServoPolicy)) != hipSuccess)
+    return fail(sim, UPKIE_ERR_HIP, "hipMalloc of the servo policy failed");
+  if (!sim->policy_cached || std::memcmp(&sim->policy_cache, policy, sizeof(UpkieServoPolicy)) != 0) {
+    sim->policy_cache = *policy;
+    sim->policy_cached = true;
+    const hipError_t err = hipMemcpyAsync(sim->d_policy, &sim->policy_cache, sizeof(UpkieServoPolicy), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err != hipSuccess) return check_hip(sim, err, "upload of the servo policy");
+  }
+  // (`packed` == 2 tells the eight-lane Servos kernel that `act` is the policy)
+  return launch_step<MODE_SERVOS>(sim, state, reinterpret_cast<const float*>(sim->d_policy), obs, reward, terminated, truncated, nullptr, stream, 2);
 }
 
 extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state, float* obs, float* final_obs, void* stream) {

@@ -51,6 +51,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_step_gyropod",
     "upkie_sim_step_servos",
     "upkie_sim_servo_policy",
+    "upkie_sim_step_servos_policy",
     "upkie_sim_step_base_velocity",
     "upkie_sim_step_base_velocity_mpc",
     "upkie_sim_observe",
@@ -159,6 +160,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
     lib.upkie_sim_servo_policy.restype = C.c_int
     lib.upkie_sim_servo_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp]
+    lib.upkie_sim_step_servos_policy.restype = C.c_int
+    lib.upkie_sim_step_servos_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp, vp, vp, vp, vp]
     lib.upkie_sim_set_randomization.restype = C.c_int
     lib.upkie_sim_set_randomization.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
     lib.upkie_sim_set_external_forces.restype = C.c_int

@@ -256,6 +256,18 @@ class BatchedSim:
         self._launch(self._lib.upkie_sim_servo_policy, self.state.data_ptr(), C.byref(policy), act.data_ptr())
         return act
 
+    def step_servos_policy(self, policy: "abi.UpkieServoPolicy"):
+        """`servo_policy` + `step_servos` as one call (`upkie_sim_step_servos_policy`):
+        one launch up to 8192 envs (the policy evaluated by the step's own lanes),
+        two otherwise."""
+        if getattr(self, "_policy_act", None) is None:
+            self._policy_act = torch.zeros((self.num_envs, 6, 6), dtype=torch.float32, device=self.device)
+        if self.obs_servos is None:
+            self.obs_servos = torch.zeros((self.num_envs, 6, 5), dtype=torch.float32, device=self.device)
+        self._launch(self._lib.upkie_sim_step_servos_policy, self.state.data_ptr(), C.byref(policy), self._policy_act.data_ptr(),
+                     self.obs_servos.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr())
+        return self.obs_servos, self.reward, self.terminated, self.truncated
+
     def step_base_velocity(self, act, commanded_velocity, mpc_x0, mpc_contact):
         """Second half of the fused UpkieBaseVelocity step: ``act[B, 2]`` =
         [linear velocity, yaw velocity], ground velocity from the MPC
