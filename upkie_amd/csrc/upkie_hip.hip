@@ -1401,6 +1401,12 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
   return check_hip(sim, hipGetLastError(), "servo_policy_kernel");
 }
 
+__global__ void store_servo_policy_kernel(UpkieServoPolicy policy, UpkieServoPolicy* out) {
+  const float* from = reinterpret_cast<const float*>(&policy);
+  float* to = reinterpret_cast<float*>(out);
+  for (int i = threadIdx.x; i < (int)(sizeof(UpkieServoPolicy) / sizeof(float)); i += blockDim.x) to[i] = from[i];
+}
+
 extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
                                             uint8_t* terminated, uint8_t* truncated, void* stream) {
   if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
@@ -1414,8 +1420,10 @@ extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const U
   if (!sim->policy_cached || std::memcmp(&sim->policy_cache, policy, sizeof(UpkieServoPolicy)) != 0) {
     sim->policy_cache = *policy;
     sim->policy_cached = true;
-    const hipError_t err = hipMemcpyAsync(sim->d_policy, &sim->policy_cache, sizeof(UpkieServoPolicy), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (err != hipSuccess) return check_hip(sim, err, "upload of the servo policy");
+    // (as a kernel argument, not a host-to-device copy: capturable in a hipGraph, no host buffer to keep alive)
+    hipLaunchKernelGGL(store_servo_policy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sim->policy_cache, sim->d_policy);
+    const int stored = check_hip(sim, hipGetLastError(), "store_servo_policy_kernel");
+    if (stored != UPKIE_OK) return stored;
   }
   // (`packed` == 2 tells the eight-lane Servos kernel that `act` is the policy)
   return launch_step<MODE_SERVOS>(sim, state, reinterpret_cast<const float*>(sim->d_policy), obs, reward, terminated, truncated, nullptr, stream, 2);
