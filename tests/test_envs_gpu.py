@@ -372,3 +372,40 @@ def test_same_step_autoreset_inside_the_step_equals_the_two_calls(mode, lanes, m
     before = final_fused.clone()
     (fused.step_pendulum if mode == "pendulum" else fused.step_gyropod if mode == "gyropod" else fused.step_servos)(act0)
     assert torch.equal(final_fused, before)
+
+
+def test_fused_servo_policy_step_and_same_step_resets_replay_from_a_graph():
+    """The calls added in round 2 are plain kernel launches on the caller's
+    stream (the policy reaches the device as a kernel argument, the SAME_STEP
+    buffer is a pointer held by the handle): captured in a hipGraph they
+    replay the trajectory of the eager loop bit for bit."""
+    from upkie_amd.graphs import GraphedLoop
+    from upkie_amd.sim import BatchedSim
+
+    def make():
+        cfg = randomized_config(640, seed=12)
+        cfg.autoreset_mode = abi.AUTORESET_DISABLED
+        cfg.rand_pitch = 0.2
+        cfg.max_episode_steps = 9
+        sim = BatchedSim(cfg)
+        sim.reset()
+        sim.set_final_observation(torch.zeros(640, 6, 5, device="cuda:0"))
+        return sim
+
+    eager, graphed = make(), make()
+    policy = abi.velocity_balancing_policy(float(eager.model.wheel_radius), 0.5, float(eager.model.left_sign))
+    changed = abi.torque_balancing_policy(gain=8.0, fall_pitch=0.5, left_sign=float(eager.model.left_sign))
+    loop = GraphedLoop(lambda: graphed.step_servos_policy(policy), unroll=3, warmup=1)
+    eager.state.copy_(graphed.state)
+    eager.final_obs.copy_(graphed.final_obs)
+    for _ in range(8):
+        loop.replay()
+    for _ in range(24):
+        eager.step_servos_policy(policy)
+    assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs_servos, graphed.obs_servos)
+    assert torch.equal(eager.final_obs, graphed.final_obs)
+    assert int(eager.state[abi.S_EPISODE].sum()) > 640 * 2  # the time limit restarted every env, inside the step's launch
+    # another policy afterwards: uploaded by the next call, eagerly or not
+    for sim in (eager, graphed):
+        sim.step_servos_policy(changed)
+    assert torch.equal(eager.state, graphed.state)

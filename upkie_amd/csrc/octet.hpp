@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   // last observation in `final_obs` and goes through the reset branch once more before the kernel returns -- its eight
   // lanes together, the other envs of the wavefront wait masked.
   constexpr bool CAN_RESET_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
-  const bool same_step = CAN_RESET_IN_PLACE && C.autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && !packed;
+  const bool same_step = CAN_RESET_IN_PLACE && C.autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
   bool second_pass = false;
 next_step:
   bool do_reset;

@@ -1249,7 +1249,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // SAME_STEP autoreset completed by the step call itself (upkie_sim_set_final_observation): inside the launch on the
   // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
   constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
-  const bool same_step = RESETS_IN_PLACE && !done_pass && !packed && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
+  const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
   const bool same_step_in_kernel = same_step && mapped_lanes(sim) == 8;
   if (same_step_in_kernel) final_obs = sim->final_obs;
   const bool rnd = sim->body_inertials || sim->ext_force;
