@@ -520,3 +520,40 @@ def test_servo_policy_inside_the_step_equals_the_two_launches(lanes, monkeypatch
                 one.state.copy_(two.state)  # (fp32 closed loops part ways: compare step by step)
         resets = int(two.state[abi.S_EPISODE].sum()) - B
     assert resets > 20  # robots beyond the policies' fall thresholds were restarted by the step that followed
+
+
+def test_c5_share_sweeps_converge_in_fp32():
+    """Guards what round 2 found on the C5 share (profiles/r02_sweep_tolerance.txt):
+    the projected Gauss-Seidel sweeps run in fp32, so a tolerance below what a
+    six-term fp32 residual resolves (the model's 1e-6, or 1e-8 here) must not
+    send them to the 50-sweep cap -- the kernels stop at max(tolerance, 1e-5)
+    -- and robots whose tires both leave the floor must not sweep at all."""
+    from upkie_amd.model.joint_properties import JointProperties
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    B = 4096
+    model = Model()
+    model.struct.pgs_tolerance = 1e-8
+    env = envs.make("Upkie-HIP-Servos-Vec", num_envs=B, frequency=200.0, inertia_variation=0.2, autoreset_mode="next_step", model=model,
+                    init_state=RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0]))),
+                    joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
+    env.reset(seed=0)
+    assert env.sim.lanes_per_env == 8
+    torch.manual_seed(0)
+    push = torch.zeros(B, 3, device="cuda:0")
+    push[:, 0] = torch.empty(B, device="cuda:0").uniform_(-5, 5)
+    env.set_external_forces("torso", push)
+    policy = abi.velocity_balancing_policy(float(env.model.struct.wheel_radius), 1.0, float(env.model.struct.left_sign))
+    for _ in range(100):
+        env.sim.step_servos_policy(policy)
+    census = env.sim.enable_census()
+    steps = 300
+    for _ in range(steps):
+        env.sim.step_servos_policy(policy)
+    c = env.sim.census_counts()
+    infeasible = c["friction_cone"]
+    assert infeasible > 0.003 * B * 5 * steps  # pushed robots do skid, tip over and land: the rare path is exercised
+    assert c["sweep_cap_hits"] <= 0.002 * infeasible, c  # (2.5 % of them before the tolerance floor)
+    assert c["sweeps_total"] <= 3.5 * infeasible, c  # 2.3 sweeps on average (6.9 before)
+    assert c["sweeps_max"] <= 50 and torch.isfinite(env.sim.state).all()
