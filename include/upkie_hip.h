@@ -282,6 +282,18 @@ int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inertials,
                                     float* link_scale,
                                     double inertia_variation, void* stream);
 
+/* Push domain randomisation (BASELINE.json configs[4] "push-domain-randomisation";
+ * the reference applies pushes through PyBulletBackend.set_external_forces,
+ * pybullet_backend.py:603-658, with forces the user script draws:
+ * examples/pybullet/apply_external_forces.py:37-43): push number `push_index`
+ * of every env, a world-frame force with norm ~ U(0, max_norm) and a uniformly
+ * random horizontal direction, drawn on the device from the Philox stream
+ * keyed by (seed, global env id, push_index) into force[3][B] -- the buffer
+ * upkie_sim_set_randomization / upkie_sim_set_external_forces read at every
+ * substep. Zero the buffer to end the push. */
+int upkie_sim_sample_pushes(UpkieSim* sim, float* force, uint32_t push_index,
+                            double max_norm, void* stream);
+
 /* Reset the envs whose mask byte is non-zero (all when mask is NULL):
  * sample the initial state in the reference's draw order (robot_state.py:
  * 182-187), zero joint velocities, run the one extra torque-free physics

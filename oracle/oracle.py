@@ -232,6 +232,13 @@ class Oracle:
         self.link_scale = link_scale
         return records
 
+    def sample_pushes(self, push_index: int, max_norm: float):
+        """Push number `push_index` of every env: world-frame force ``[3, B]``,
+        norm ~ U(0, max_norm), random horizontal direction."""
+        force = np.zeros((3, self.B))
+        self._lib.oracle_sample_pushes(C.byref(self.config), C.c_uint32(int(push_index) & 0xFFFFFFFF), C.c_double(max_norm), _ptr(force))
+        return force
+
     # -- env API -----------------------------------------------------------
     def reset(self, mask=None):
         obs6 = np.zeros((self.B, 6))

@@ -144,7 +144,7 @@ void oracle_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2 };
+enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2, STREAM_PUSH = 3 };
 
 /* 24-bit uniforms in [0, 1): identical values in fp32 and fp64. */
 static void philox_uniform4(uint64_t seed, int64_t env, uint32_t episode,
@@ -936,6 +936,24 @@ static void reset_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   s[UPKIE_S_EPISODE] = (double)((episode + 1u) & UPKIE_COUNTER_MASK); /* counters live in fp32 words on the device: exact up to 2^24, then wrap */
   s[UPKIE_S_DONE] = 0.0;
   s[UPKIE_S_ELAPSED] = 0.0;
+}
+
+/* Push domain randomisation of BASELINE.json configs[4]:
+ * the force a user script would hand to PyBulletBackend.set_external_forces
+ * (pybullet_backend.py:603-658; examples/pybullet/apply_external_forces.py:37-43)
+ * -- world frame, on the torso, norm ~ U(0, max_norm), uniformly random
+ * horizontal direction -- for push number `push_index` of every env: one
+ * Philox block keyed by (seed, global env id, push_index). force[3][B]. */
+void oracle_sample_pushes(const UpkieSimConfig* cfg, uint32_t push_index, double max_norm, double* force) {
+  int B = cfg->num_envs;
+  for (int e = 0; e < B; ++e) {
+    double u[4];
+    philox_uniform4(cfg->seed, cfg->env_id_offset + e, push_index, STREAM_PUSH, 0, u);
+    double norm = max_norm * u[0], phi = 6.283185307179586 * u[1];
+    force[e] = norm * cos(phi);
+    force[(int64_t)B + e] = norm * sin(phi);
+    force[(int64_t)2 * B + e] = 0.0;
+  }
 }
 
 /* PyBulletBackend.randomize_inertias, pybullet_backend.py:571-601, for every

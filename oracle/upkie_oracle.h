@@ -102,6 +102,8 @@ int oracle_substep_ext(const UpkieModel* model, double* state, const double tau[
 void oracle_sample_body_inertials(const UpkieModel* model, const UpkieSimConfig* cfg,
                                   double inertia_variation, double* records /* [70][B] */,
                                   double* link_scale /* [UPKIE_MAX_LINKS][B] or NULL */);
+void oracle_sample_pushes(const UpkieSimConfig* cfg, uint32_t push_index, double max_norm,
+                          double* force /* [3][B] */);
 void oracle_reset(const UpkieModel* model, const UpkieSimConfig* cfg,
                   double* state, const uint8_t* mask,
                   const OracleRandomization* rnd, double* obs6);

@@ -70,6 +70,13 @@ class OracleSim:
         self.link_scale = torch.from_numpy(self._o.link_scale.astype(np.float32))
         return self.body_inertials
 
+    def sample_pushes(self, push_index, max_norm, out=None):
+        force = torch.from_numpy(self._o.sample_pushes(push_index, max_norm).astype(np.float32))
+        if out is None:
+            return force
+        out.copy_(force)
+        return out
+
     def set_external_force(self, force, point=(0.0, 0.0, 0.0)):
         self.ext_force = force
         self._o.ext_slots = None

@@ -567,8 +567,8 @@ struct System {
 };
 
 // x overwrites b. `has_leg[l]` false means the leg part of b is zero.
-template <bool LEFT, bool RIGHT>
-UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], float (&br)[3]) {
+template <bool LEFT, bool RIGHT, class SystemT>
+UPKIE_HD void system_solve(const SystemT& S, float (&bb)[6], float (&bl)[3], float (&br)[3]) {
   // y = b_base - D_L b_L - D_R b_R
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -582,7 +582,7 @@ UPKIE_HD void system_solve(const System& S, float (&bb)[6], float (&bl)[3], floa
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     float(&b)[3] = l == 0 ? bl : br;
-    const Leg& G = S.leg[l];
+    const auto& G = S.leg[l];
     const float* h = G.Hinv;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if ((l == 0 && LEFT) || (l == 1 && RIGHT)) {
@@ -953,11 +953,26 @@ struct GeneralRows {
   int n;
 };
 
-template <class ModelT>
-UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const GeneralRows& R, const float (&rt)[6], float (&tb)[6],
-                                       float (&tl)[3], float (&tr)[3], float (&lam_out)[10]) {
-  const int n = R.n;
+// What the general solve indexes dynamically. Private arrays of this kind live in scratch memory (one-lane kernels of very
+// large batches: limit_path_scratch); the eight-lane kernel keeps one per env of the wavefront in LDS (LimitWorkspace,
+// octet.hpp): private scratch of a path no env of a Pendulum batch ever takes is still allocated for every wavefront slot,
+// and at 135 KB per wavefront the runtime's scratch limit admitted one wavefront per SIMD, no more.
+struct GeneralWork {
   float A[10][10], Y[10][6], K[10][3], rhs[10], lam[10];
+  float L[55];  // Cholesky factor, lower triangle packed by rows
+  float yv[10];
+};
+UPKIE_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+template <class ModelT, class SystemT>
+UPKIE_HD void general_constraint_solve(const ModelT& M, const SystemT& S, const GeneralRows& R, const float (&rt)[6], float (&tb)[6],
+                                       float (&tl)[3], float (&tr)[3], float (&lam_out)[10], GeneralWork& W) {
+  const int n = R.n;
+  auto& A = W.A;
+  auto& Y = W.Y;
+  auto& K = W.K;
+  auto& rhs = W.rhs;
+  auto& lam = W.lam;
   for (int b = 0; b < n; ++b) {
     float y[6];
 #pragma unroll
@@ -990,33 +1005,33 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const System& S, const G
       A[a][b] = acc;
     }
   // Cholesky A = L L' in place of a copy, then two triangular solves
-  float L[10][10];
+  auto& L = W.L;
   bool spd = true;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j <= i; ++j) {
       float s = A[i][j];
-      for (int c = 0; c < j; ++c) s -= L[i][c] * L[j][c];
+      for (int c = 0; c < j; ++c) s -= L[tri(i, c)] * L[tri(j, c)];
       if (i == j) {
         if (!(s > 0.f)) spd = false;
-        L[i][i] = fast_sqrt(fmaxf(s, 1e-30f));
+        L[tri(i, i)] = fast_sqrt(fmaxf(s, 1e-30f));
       } else {
-        L[i][j] = s * fast_rcp(L[j][j]);
+        L[tri(i, j)] = s * fast_rcp(L[tri(j, j)]);
       }
     }
   const float mu = M.friction_mu;
   bool need_pgs = !spd;
   for (int i = 0; i < n; ++i) lam[i] = 0.f;
   if (spd) {
-    float yv[10];
+    auto& yv = W.yv;
     for (int i = 0; i < n; ++i) {
       float s = rhs[i];
-      for (int c = 0; c < i; ++c) s -= L[i][c] * yv[c];
-      yv[i] = s * fast_rcp(L[i][i]);
+      for (int c = 0; c < i; ++c) s -= L[tri(i, c)] * yv[c];
+      yv[i] = s * fast_rcp(L[tri(i, i)]);
     }
     for (int i = n - 1; i >= 0; --i) {
       float s = yv[i];
-      for (int c = i + 1; c < n; ++c) s -= L[c][i] * lam[c];
-      lam[i] = s * fast_rcp(L[i][i]);
+      for (int c = i + 1; c < n; ++c) s -= L[tri(c, i)] * lam[c];
+      lam[i] = s * fast_rcp(L[tri(i, i)]);
     }
     for (int r = 0; r < n; ++r)
       if (R.kind[r] != 1 && lam[r] < 0.f) {
@@ -1147,7 +1162,8 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
     }
   }
   float lam_rows[10];
-  general_constraint_solve(M, S, R, rt, tb, tl, tr, lam_rows);
+  GeneralWork W;
+  general_constraint_solve(M, S, R, rt, tb, tl, tr, lam_rows, W);
   {  // contact impulses back in the fixed (wheel, row) layout
     int i = 0;
 #pragma unroll

@@ -622,15 +622,44 @@ UPKIE_HD void octet_limit_path_registers(const ModelT& M, const DevLimits& Lm, c
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
-// The same path with the rows written straight into the general solver's scratch structures (no register arrays in
-// between: gathered into registers first, they cost the common path of a 256-register kernel spills).
+// The same path with the rows written straight into the general solver's structures (no register arrays in between:
+// gathered into registers first, they cost the common path of a 256-register kernel spills). Those structures are
+// indexed dynamically; they live in the env's LimitWorkspace, which the kernel keeps in LDS (one per env of the
+// wavefront, 2.2 KB each): as private arrays they were 2112 B of scratch memory per lane = 135 KB per wavefront for a
+// path no robot of a Pendulum batch takes, and the runtime sizes the scratch ring for every wavefront slot -- under its
+// default limit that left room for ONE wavefront per SIMD, so a second wavefront of this 256-register kernel never
+// became resident (16384 envs took as long as two launches of 8192). The eight lanes of an env write the same values to
+// the same words and read them back: every lane on identical data, as before.
+struct LimitLeg {
+  float Hinv[6];  // 00 11 22 01 02 12
+  float D[6][3];
+};
+struct LimitWorkspace {
+  LimitLeg leg[2];
+  GeneralRows R;
+  GeneralWork W;
+};
+struct LimitSystemRef {  // what system_solve / general_constraint_solve read of a System
+  Ldl6 A;                // registers (named fields)
+  LimitLeg* leg;         // the workspace's
+};
+// which of the wavefront's eight envs this lane belongs to (the workspace slot is worked out here, inside the rare
+// branch: computed in the kernel's prologue the address stayed live through the common path and cost it spills)
+UPKIE_HD int oct_env_slot() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)(((threadIdx.x >> 4) << 1) | ((threadIdx.x >> 2) & 1));
+#else
+  return 0;
+#endif
+}
 template <class ModelT>
 UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
                                V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active, bool active_partner, float qd,
                                float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_err,
-                               float (&xb)[6], float& xl) {
+                               float (&xb)[6], float& xl, LimitWorkspace& ws) {
   const bool left = L.leg == 0;
-  System S;
+  LimitSystemRef S;
+  S.leg = ws.leg;
   S.A.l10 = 0.f; S.A.l20 = fac.l20; S.A.l21 = 0.f; S.A.l30 = fac.l30; S.A.l31 = fac.l31; S.A.l32 = fac.l32;
   S.A.l40 = fac.l40; S.A.l41 = 0.f; S.A.l42 = fac.l42; S.A.l43 = fac.l43;
   S.A.l50 = fac.l50; S.A.l51 = fac.l51; S.A.l52 = fac.l52; S.A.l53 = fac.l53; S.A.l54 = fac.l54;
@@ -682,7 +711,7 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
     Jt[0] = acc[0]; Jt[1] = Jb[1]; Jt[2] = acc[1]; Jt[3] = acc[2]; Jt[4] = acc[3]; Jt[5] = acc[4];
   }
   const float dist_other = oct_swp(dist);
-  GeneralRows R;
+  GeneralRows& R = ws.R;
   R.n = 0;
   // rows of the touching tires in wheel order (left, right); each tire's rows come from its own quad
   auto tire = [&](int w) {
@@ -765,7 +794,7 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
     tb[c] = v;
   }
   float lam_rows[10];
-  general_constraint_solve(M, S, R, rt, tb, tl6[0], tl6[1], lam_rows);
+  general_constraint_solve(M, S, R, rt, tb, tl6[0], tl6[1], lam_rows, ws.W);
   system_solve<true, true>(S, tb, tl6[0], tl6[1]);
 #pragma unroll
   for (int c = 0; c < 6; ++c) xb[c] = tb[c];
@@ -776,6 +805,9 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
 
 // Substep outcomes (returned) and rare paths taken (reported through `census`).
 enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
+struct OctRare {  // which rare path the env took this substep, Gauss-Seidel sweeps it ran (two registers, never memory)
+  int path, sweeps;
+};
 
 // One physics substep, eight lanes per env. tau: commanded torque of the own
 // joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
@@ -783,7 +815,7 @@ enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
 template <bool LIMITS_IN_REGISTERS = false, class ModelT>
 UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const OctLane& L, OctPhys& s, float tau, float h,
-                                   const float* trunk_wrench, int* census = nullptr) {
+                                   const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
   if (Lm.enforce) {
@@ -948,14 +980,14 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
   float tlc = tl;  // own joint impulse incl. contacts
   float xl = 0.f;  // own joint velocity change
   if (__builtin_expect(at_a_stop, 0)) {
-    if (census) census[0] = OCT_NOT_MINE_LIMIT;
+    if (census) census->path = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
                                  erp, ih, xb, xl);
     } else {
       const bool low = L.bounded && s.q <= L.lower, high = L.bounded && !low && s.q >= L.upper;
       octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
-                               low ? 1.f : (high ? -1.f : 0.f), low ? L.lower - s.q : (high ? s.q - L.upper : 0.f), xb, xl);
+                               low ? 1.f : (high ? -1.f : 0.f), low ? L.lower - s.q : (high ? s.q - L.upper : 0.f), xb, xl, ws[oct_env_slot()]);
     }
   } else if (__builtin_expect(active || active_partner, 1)) {
     const float sa = oct_qb<3>(L.sg);
@@ -1039,7 +1071,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
       const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
       if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
-          if (census) census[0] = OCT_NOT_MINE_INFEASIBLE;
+          if (census) census->path = OCT_NOT_MINE_INFEASIBLE;
           // Both tires leaving the floor (neither normal row asks for an impulse, rhs_n <= 0): lam = 0 is the solution
           // -- what the sweeps return after one pass over the projected zeros; 38 % of the infeasible env-substeps of
           // the C5 workload, 95 % while robots land after a reset -- known without gathering the system.
@@ -1090,7 +1122,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const O
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
           const int sweeps = contact_pgs6(M, A6, rhs6, lam6, both);
-          if (census) census[1] = sweeps;
+          if (census) census->sweeps = sweeps;
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
           lam = left ? mine_l : mine_r;
@@ -1162,6 +1194,10 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
   float* st = state + e;
 #define SW(w) st[(size_t)(w) * B]
+  // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
+  // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
+  __shared__ LimitWorkspace limit_workspaces[8];
+  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS ? nullptr : limit_workspaces;
 
   // ---- load ----------------------------------------------------------
   OctPhys s;
@@ -1390,9 +1426,10 @@ next_step:
       }
       wrench[0] = Fs.x; wrench[1] = Fs.y; wrench[2] = Fs.z; wrench[3] = Ns.x; wrench[4] = Ns.y; wrench[5] = Ns.z;
     }
-    int rare_path[2] = {0, 0};  // which rare path the env took this substep, Gauss-Seidel sweeps it ran
-    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, census ? rare_path : nullptr);
-    const int rare = rare_path[0];
+    OctRare rare_path{0, 0};
+    // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, limit_ws, &rare_path);
+    const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)
       const unsigned long long limited = __builtin_amdgcn_ballot_w64(lead && rare == OCT_NOT_MINE_LIMIT);
@@ -1409,7 +1446,7 @@ next_step:
       if (swept) {  // the sweeps those envs ran, summed over the wavefront first (at most eight envs: a scalar loop over their lead lanes)
         unsigned total = 0, most = 0, capped = 0;
         for (unsigned long long left = swept; left; left &= left - 1) {
-          const unsigned count = (unsigned)__builtin_amdgcn_readlane(rare_path[1], __builtin_ctzll(left));
+          const unsigned count = (unsigned)__builtin_amdgcn_readlane(rare_path.sweeps, __builtin_ctzll(left));
           total += count;
           most = count > most ? count : most;
           capped += count >= (unsigned)M.pgs_iterations ? 1u : 0u;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2 };
+enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2, STREAM_PUSH = 3 };
 
 __device__ __forceinline__ void philox_uniform4(const DevConfig& C, unsigned env_local, unsigned episode, unsigned stream,
                                                 unsigned block, float (&u)[4]) {
@@ -822,8 +822,36 @@ __global__ __launch_bounds__(64) void body_inertials_kernel(DevConfig C, DevLink
   fuse_links(L, f, records + e, (size_t)B);
 }
 
+// Push domain randomisation (BASELINE.json configs[4]): a world-frame force on the trunk per env,
+// norm ~ U(0, max_norm), uniformly random horizontal direction; push number `push_index` of env e is one Philox block
+// keyed by (seed, global env id, push_index): the same whatever the sharding. force[3][B] is what
+// upkie_sim_set_external_forces reads (pybullet_backend.py:603-658 semantics: held until overwritten).
+__global__ __launch_bounds__(64) void push_kernel(DevConfig C, float* __restrict__ force, unsigned push_index, float max_norm) {
+  const int B = C.num_envs;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  float u[4];
+  philox_uniform4(C, (unsigned)e, push_index, STREAM_PUSH, 0u, u);
+  const float norm = max_norm * u[0];
+  float sn, cs;
+  sincosf(6.283185307179586f * u[1], &sn, &cs);
+  force[e] = norm * cs;
+  force[(size_t)B + e] = norm * sn;
+  force[(size_t)2 * B + e] = 0.f;
+}
+
 }  // namespace upkie
 
+#if defined(UPKIE_PROBE_OCTET_MODE)
+// Development builds (tools/isa_probe.sh): ONE eight-lane kernel and nothing else, for a look at its ISA in seconds
+// instead of the minutes all instantiations take. -DUPKIE_PROBE_OCTET_MODE=<Mode> [-DUPKIE_PROBE_RAND=true]
+#if !defined(UPKIE_PROBE_RAND)
+#define UPKIE_PROBE_RAND false
+#endif
+template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
+    const upkie::DevModel*, upkie::DevLimits, upkie::DevConfig, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
+    const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*);
+#else
 // =========================================================== C-ABI (host)
 using namespace upkie;
 
@@ -1189,6 +1217,14 @@ extern "C" int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inerti
   hipLaunchKernelGGL(body_inertials_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config,
                      sim->links, body_inertials, link_scale, (float)inertia_variation);
   return check_hip(sim, hipGetLastError(), "body_inertials_kernel");
+}
+
+extern "C" int upkie_sim_sample_pushes(UpkieSim* sim, float* force, uint32_t push_index, double max_norm, void* stream) {
+  if (!sim || !force) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
+  if (!(max_norm >= 0.0)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "max_norm must be non-negative");
+  hipLaunchKernelGGL(push_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config, force,
+                     (unsigned)push_index, (float)max_norm);
+  return check_hip(sim, hipGetLastError(), "push_kernel");
 }
 
 // 256 CUs x 4 SIMDs x 64 lanes x 2 waves
@@ -1743,3 +1779,4 @@ extern "C" int upkie_rollout_gae(int32_t num_steps, int32_t num_envs, const floa
   }
   return UPKIE_OK;
 }
+#endif  // UPKIE_PROBE_OCTET_MODE

@@ -176,6 +176,19 @@ class BatchedSim:
         self._ext_slots = slots
         self._push_randomization()
 
+    def sample_pushes(self, push_index: int, max_norm: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Push number `push_index` of every env (`upkie_sim_sample_pushes`): a
+        world-frame force ``[3, B]`` with norm ~ U(0, max_norm) in a uniformly
+        random horizontal direction, drawn on the device (Philox keyed by seed,
+        global env id, push number). Written into `out` (a new tensor if None);
+        hand it to `set_external_force` once -- the step kernels re-read the
+        buffer at every substep -- and `zero_()` it to end the push."""
+        if out is None:
+            out = torch.zeros((3, self.num_envs), dtype=torch.float32, device=self.device)
+        assert out.shape == (3, self.num_envs) and out.is_contiguous() and out.dtype == torch.float32
+        self._launch(self._lib.upkie_sim_sample_pushes, out.data_ptr(), int(push_index) & 0xFFFFFFFF, float(max_norm))
+        return out
+
     def _push_randomization(self):
         self._check(self._lib.upkie_sim_set_randomization(self._handle, _ptr(self.body_inertials), None, None))
         slots = getattr(self, "_ext_slots", None)
