@@ -138,6 +138,142 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     }
 
 
+STEADY_WARMUP, STEADY_STEPS = 200, 2000  # "measured over >= 2000 steps after 200 warm-up steps ... autoresets included"
+PUSH_PERIOD, PUSH_HOLD, PUSH_MAX_NORM = 400, 20, 20.0  # every 400 steps a force of norm ~ U(0, 20) N, held 20 steps
+TARGET_PERIOD = 400  # v* ~ U(-0.5, 0.5) per env resampled every 400 steps
+C3_BYTES_PER_ENV_STEP, C5_BYTES_PER_ENV_STEP = 554, 630  # SURVEY 8d, algorithmic bytes
+
+
+def _timed_loop(step, steps: int, warmup: int):
+    """`warmup` + `steps` calls of `step(k)` (k counts from 0 across both);
+    wall seconds and device milliseconds (HIP events on the launching stream)
+    of the timed ones."""
+    import torch
+
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    start.record()
+    for k in range(warmup, warmup + steps):
+        step(k)
+    stop.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, start.elapsed_time(stop)
+
+
+def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0) -> dict:
+    """BASELINE.json configs[2] as SURVEY.md section 8d writes it (C3):
+    UpkieBaseVelocity (the MPC balancer in front of UpkieGyropod,
+    upkie_base_velocity.py:164-202), horizon N = 16 (T = 0.02 s), leg length
+    0.58 m, a_max 10, v_max 3 (mpc_balancer.py:170-178), target
+    v* ~ U(-0.5, 0.5) per env RESAMPLED every 400 steps, yaw rate 0, 30 warm
+    started ADMM iterations on the fp32 MFMA, NEXT_STEP autoreset."""
+    import numpy as np
+    import torch
+
+    import upkie_amd.envs as envs_mod
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
+    env = envs_mod.make("Upkie-HIP-BaseVelocity-Vec", num_envs=envs, frequency=200.0, nb_timesteps=16, init_state=init, seed=seed)
+    env.reset(seed=seed)
+    gen = torch.Generator(device=env.device)
+    gen.manual_seed(seed)
+    act = torch.zeros(envs, 2, device=env.device)
+
+    def step(k):
+        if k % TARGET_PERIOD == 0:
+            act[:, 0].uniform_(-0.5, 0.5, generator=gen)
+        env.step(act)
+
+    wall, device_ms = _timed_loop(step, steps, warmup)
+    us = wall / steps * 1e6
+    out = {
+        "config": "C3: UpkieBaseVelocity + MPC balancer N = 16 (30 ADMM iterations, v_mfma_f32_16x16x4_f32), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
+                  "two launches per env.step() (upkie_mpc_step_env + upkie_sim_step_base_velocity), Python loop",
+        "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
+        "lanes_per_env": env.sim.lanes_per_env, "episodes": int(env.sim.state[40].sum().item()),
+        "algorithmic_bytes_per_env_step": C3_BYTES_PER_ENV_STEP,
+        "hbm_frac": C3_BYTES_PER_ENV_STEP * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+    }
+    env.close()
+    return out
+
+
+def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, census_steps: int = 400) -> dict:
+    """One GPU's share of BASELINE.json configs[4] as SURVEY.md section 8d
+    writes it (C5: 32768 envs over 8 GPUs): UpkieServos, inertia_variation 0.2
+    per env and link (pybullet_backend.py:571-601), wheel friction 0.1
+    (examples/pybullet/joint_friction.py:22), and the push schedule -- every
+    400 steps a world-frame force on the torso, norm ~ U(0, 20) N, uniformly
+    random horizontal direction, held 20 steps (set_external_forces,
+    pybullet_backend.py:603-658) -- drawn ON THE DEVICE (upkie_sim_sample_pushes,
+    Philox keyed by env and push number). Servo-level law evaluated by the
+    step's own lanes, fallen robots restart (NEXT_STEP): one launch per step.
+    `law`: "torque" = examples/pybullet/torque_balancing.py:15-37 (8d's law:
+    wheel torques +-10 x pitch, kd_scale 0), "velocity" = the README balancer
+    through the wheels' velocity loop."""
+    import numpy as np
+    import torch
+
+    import upkie_amd.envs as envs_mod
+    from upkie_amd import abi
+    from upkie_amd.model.joint_properties import JointProperties
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
+    env = envs_mod.make("Upkie-HIP-Servos-Vec", num_envs=envs, frequency=200.0, inertia_variation=0.2, init_state=init, autoreset_mode="next_step", seed=seed,
+                        joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
+    env.reset(seed=seed)
+    sim = env.sim
+    push = torch.zeros((3, envs), dtype=torch.float32, device=env.device)
+    sim.set_external_force(push)  # the kernels read this buffer at every substep from now on
+    m = env.model.struct
+    policy = (abi.torque_balancing_policy(10.0, 1.0, float(m.left_sign)) if law == "torque"
+              else abi.velocity_balancing_policy(float(m.wheel_radius), 1.0, float(m.left_sign)))
+
+    def step(k):
+        phase = k % PUSH_PERIOD
+        if phase == 0:
+            sim.sample_pushes(k // PUSH_PERIOD, PUSH_MAX_NORM, out=push)
+        elif phase == PUSH_HOLD:
+            push.zero_()
+        sim.step_servos_policy(policy)
+
+    wall, device_ms = _timed_loop(step, steps, warmup)
+    us = wall / steps * 1e6
+    out = {
+        "config": f"C5 share: UpkieServos, inertia_variation 0.2, wheel friction 0.1, torso push every {PUSH_PERIOD} steps (norm ~ U(0, {PUSH_MAX_NORM:g}) N, random heading, "
+                  f"held {PUSH_HOLD} steps, drawn on device), servo-level law = " + ("examples/pybullet/torque_balancing.py (wheel torque +-10 x pitch, kd_scale 0)" if law == "torque"
+                  else "README balancer through the wheel velocity loop") + ", evaluated inside the step's launch, NEXT_STEP autoreset of fallen robots; one launch per step, Python loop",
+        "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
+        "lanes_per_env": sim.lanes_per_env, "episodes": int(sim.state[40].sum().item()),
+        "algorithmic_bytes_per_env_step": C5_BYTES_PER_ENV_STEP,
+        "hbm_frac": C5_BYTES_PER_ENV_STEP * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+    }
+    if census_steps and sim.lanes_per_env == 8:
+        # rare-path census on its own steps afterwards (its atomics are not free), continuing the same schedule
+        sim.enable_census()
+        for k in range(warmup + steps, warmup + steps + census_steps):
+            step(k)
+        c = sim.census_counts()
+        sim.enable_census(False)
+        substeps = envs * 5 * census_steps
+        out["census"] = {
+            "env_substeps_in_gauss_seidel_sweeps": c["friction_cone"] / substeps,
+            "env_substeps_with_a_joint_at_its_stop": c["joint_limit"] / substeps,
+            "sweeps_per_infeasible_env_substep": c["sweeps_total"] / max(c["friction_cone"], 1),
+            "sweep_cap_hits": c["sweep_cap_hits"],
+            "sweeps_max": c["sweeps_max"],
+        }
+    env.close()
+    return out
+
+
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_step_b4096.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 
 
@@ -198,6 +334,9 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
                         help="strong scaling (SURVEY 8d): this many envs in total, split evenly over the ranks; default: --envs-per-gpu each (weak)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-fused", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
+    parser.add_argument("--no-steady-state", action="store_true",
+                        help="skip the steady_state block (SURVEY 8d's own window: 2000 steps after 200 warm-up, whatever --steps / --warmup say)")
+    parser.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-share blocks (rank 0, one GPU)")
     parser.add_argument("--gather-chunk", type=int, default=GATHER_CHUNK, help="steps per RCCL gather (N > 1)")
     parser.add_argument("--steps-per-launch", type=int, default=1,
                         help="env.step() per kernel launch in the TIMED region: 1 (the contract figure: one launch per env.step(), what "
@@ -263,6 +402,14 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
         device_ms = start_evt.elapsed_time(stop_evt) if on_gpu else wall * 1e3
         return elapsed, device_ms, launches, env.total_resets() - episodes_before
 
+    # SURVEY 8d's own definition of the metric, in the same run and on the same envs: >= 2000 steps after 200 warm-up
+    # steps, autoresets counted, one launch per env.step() -- regardless of --steps / --warmup. It runs FIRST: the
+    # contract's W + K steps below then continue this rollout (episodes spread over their whole life, the way a training
+    # run sees them, and a GPU that is already clocked up) instead of timing the landing transient right behind reset().
+    steady = None
+    if not args.no_steady_state:
+        advance(STEADY_WARMUP, 1)
+        steady = timed(STEADY_STEPS, 1)
     advance(args.warmup, args.steps_per_launch)
     elapsed, device_ms, launches, autoresets = timed(args.steps, args.steps_per_launch)
     # beside it: the same number of steps fused STEPS_PER_LAUNCH per launch (the on-device agent needs nothing from the host between steps)
@@ -322,6 +469,21 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
             "valu": valu_roofline(pmc, launch_us),
         },
     }
+    if steady is not None:
+        s_elapsed, s_ms, s_launches, s_resets = steady
+        s_launch_us = s_ms * 1e3 / s_launches
+        line["steady_state"] = {
+            "value": total_envs * STEADY_STEPS / s_elapsed,
+            "unit": "env-steps/s",
+            "steps": STEADY_STEPS,
+            "warmup": STEADY_WARMUP,
+            "ms_per_step": s_elapsed / STEADY_STEPS * 1e3,
+            "avg_launch_us": s_launch_us,
+            "autoresets_in_timed_region": s_resets,
+            "hbm_frac": ALGORITHMIC_BYTES_PER_ENV_STEP * B / (s_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "note": "SURVEY.md 8d's window (>= 2000 steps after 200 warm-up, autoresets included), one launch per env.step(); timed in this run BEFORE "
+                    "the --warmup / --steps region, which continues the same rollout",
+        }
     if fused is not None:
         f_elapsed, f_ms, f_launches, f_resets = fused
         line["fused_rollout"] = {
@@ -338,6 +500,14 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
     else:
         line["cpu_baseline"] = None
     env.shutdown()
+    if world == 1 and on_gpu and not args.no_secondary:
+        del env
+        torch.cuda.synchronize()
+        line["secondary"] = {
+            "c3": secondary_c3(),
+            "c5_share_torque_law": secondary_c5_share("torque"),
+            "c5_share_velocity_law": secondary_c5_share("velocity"),
+        }
     print(json.dumps(line), flush=True)
 
 

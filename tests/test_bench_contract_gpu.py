@@ -33,6 +33,22 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == "env-steps/s"
     assert out["value"] > 100 * cpu["value"] / cpu["cores"]  # sanity: a GPU is not slower than a CPU core
+    # SURVEY 8d's own window beside the contract figure, whatever --steps / --warmup were
+    steady = out["steady_state"]
+    assert steady["steps"] == 2000 and steady["warmup"] == 200 and steady["unit"] == "env-steps/s"
+    assert steady["value"] == pytest.approx(out["config"]["total_envs"] * 2000 / (steady["ms_per_step"] * 1e-3 * 2000), rel=1e-6)
+    assert steady["autoresets_in_timed_region"] > 0  # 2000 steps = 10 s per env: the README agent's robots fall about once per 11 s
+    assert steady["avg_launch_us"] <= steady["ms_per_step"] * 1e3 * 1.001
+    # the secondary BASELINE configs as SURVEY 8d writes them
+    sec = out["secondary"]
+    assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law"}
+    assert sec["c3"]["envs"] == 16384 and "resampled every 400 steps" in sec["c3"]["config"] and sec["c3"]["algorithmic_bytes_per_env_step"] == 554
+    for key in ("c5_share_torque_law", "c5_share_velocity_law"):
+        c5 = sec[key]
+        assert c5["envs"] == 4096 and c5["algorithmic_bytes_per_env_step"] == 630 and "drawn on device" in c5["config"]
+        assert c5["episodes"] > 4096  # pushed robots do fall and restart
+        assert 0 < c5["hbm_frac"] < 1 and c5["us_per_step"] >= c5["device_us_per_step"] * 0.999
+        assert c5["census"]["sweep_cap_hits"] >= 0
 
 
 def test_bench_under_torchrun_through_rccl_on_one_rank():

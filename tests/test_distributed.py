@@ -249,3 +249,6 @@ def test_bench_launch_line_on_cpu_doubles(world, flags, total, per_rank, ghosts)
     assert cfg["steps_per_launch"] == 1 and out["fused_rollout"]["value"] > 0  # (the double steps its rollouts one by one)
     assert out["cpu_baseline"] is None  # N = 1 on a GPU only
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0
+    steady = out["steady_state"]  # the window of SURVEY 8d, timed before the contract region (shrunk by the double)
+    assert steady["steps"] == 6 and steady["warmup"] == 2 and steady["value"] == pytest.approx(total * 6 / (steady["ms_per_step"] * 1e-3 * 6), rel=1e-6)
+    assert "secondary" not in out  # one GPU, rank 0 only
