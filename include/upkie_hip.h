@@ -294,6 +294,21 @@ int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inertials,
 int upkie_sim_sample_pushes(UpkieSim* sim, float* force, uint32_t push_index,
                             double max_norm, void* stream);
 
+/* Diagnostic: the projected Gauss-Seidel sweeps the step kernels run when the
+ * direct contact solution leaves its friction cone (what Bullet's
+ * btMultiBodyConstraintSolver iterates inside pybullet.stepSimulation(),
+ * pybullet_backend.py:306), on caller-provided 6 x 6 systems of the two tires
+ * (rows: normal, rolling, lateral of the left tire, then of the right one), one
+ * system per lane, with this handle's friction coefficient, tolerance and
+ * iteration cap: A[n][21] packed lower by rows with the CFM on the diagonal,
+ * rhs[n][6], lam[n][6] (in: warm start, out: impulses), both_tires[n] (0: one
+ * tire is off the floor, its rows are identity rows), sweeps[n] (may be NULL)
+ * receives the sweeps each system ran. Device pointers. */
+int upkie_sim_contact_sweeps(UpkieSim* sim, int32_t num_systems, const float* A,
+                             const float* rhs, float* lam,
+                             const uint8_t* both_tires, int32_t* sweeps,
+                             void* stream);
+
 /* Reset the envs whose mask byte is non-zero (all when mask is NULL):
  * sample the initial state in the reference's draw order (robot_state.py:
  * 182-187), zero joint velocities, run the one extra torque-free physics

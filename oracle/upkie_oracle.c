@@ -422,14 +422,22 @@ double oracle_energy(const UpkieModel* model, const double pos[3],
 }
 
 
-/* The two LATERAL friction rows (third row of each tire) nearly coincide in a
- * symmetric stance: coupling a25 = diagonals up to friction_cfm. Swept one at a
- * time they converge like (a / (a + cfm))^2 per sweep (hundreds of sweeps). In
- * sum / difference coordinates s = l2 + l5, d = l2 - l5 the block is almost
- * diagonal: the SUM (lateral force on the robot) is well posed and solved
- * exactly each sweep; the DIFFERENCE (how the two tires share it) is statically
- * indeterminate, only friction_cfm decides it: it relaxes slowly (as it did
- * under plain sweeps) and does not count in the convergence test. */
+/* The two LATERAL friction rows (third row of each tire): the tires share one
+ * axle direction, so their 2 x 2 block [[a22, a25], [a25, a55]] is nearly
+ * singular (only friction_cfm and the yaw lever arm of the wheel base separate
+ * the rows); swept one at a time they converge like (a / (a + cfm))^2 per
+ * sweep, hundreds of sweeps. They are therefore solved TOGETHER and exactly,
+ * given every other row: the minimiser of 1/2 x'Ax - r'x over the box
+ * |x_i| <= mu lam_n,i -- the free 2 x 2 solution when it lies inside the box,
+ * otherwise the best point of the four edges (one row on a bound, the other
+ * solved and clamped). Both rows count in the convergence test.
+ * (Until round 3 the pair was solved as a FREE pair in sum / difference
+ * coordinates and clamped afterwards, the weak coordinate left out of the
+ * convergence test: with a row on its bound -- a tire sliding sideways, or
+ * lifted -- the result violated the complementarity conditions of the
+ * problem, by up to O(1) of the velocity scale on robots tumbling under
+ * examples/pybullet/torque_balancing.py's law:
+ * tests/test_oracle_contact_kkt.py::test_torque_law_systems.) */
 static int lateral_pair_exists(int nrows, const int* kind, const int* normal_row) {
   int n = 0;
   for (int r = 0; r < nrows; ++r)
@@ -450,22 +458,40 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
     r5 -= W[i5 * ldw + b] * lam[b];
   }
   const double a22 = W[i2 * ldw + i2] + cfm[i2], a55 = W[i5 * ldw + i5] + cfm[i5], a25 = W[i5 * ldw + i2];
-  const double S11 = 0.5 * (a22 + 2.0 * a25 + a55), S12 = 0.5 * (a22 - a55), S22 = 0.5 * (a22 - 2.0 * a25 + a55);
-  double d = lam[i2] - lam[i5];
-  const double s_old = lam[i2] + lam[i5];
-  const double s_new = (r2 + r5 - S12 * d) / S11;
-  const double d_exact = (r2 - r5 - S12 * s_new) / S22;
-  double omega = 2.0 * S22 / S11; /* the pace of the plain sweeps */
-  if (omega > 1.0) omega = 1.0;
-  d += omega * (d_exact - d);
-  double x2 = 0.5 * (s_new + d), x5 = 0.5 * (s_new - d);
   const double lim2 = mu * lam[normal_row[i2]], lim5 = mu * lam[normal_row[i5]];
-  if (x2 < -lim2) x2 = -lim2;
-  if (x2 > lim2) x2 = lim2;
-  if (x5 < -lim5) x5 = -lim5;
-  if (x5 > lim5) x5 = lim5;
-  const double ds = fabs((x2 + x5) - s_old);
-  if (ds > *change) *change = ds;
+  const double det = a22 * a55 - a25 * a25;
+  double x2 = 0.0, x5 = 0.0;
+  int inside = 0;
+  if (det > 1e-12 * a22 * a55) {
+    x2 = (a55 * r2 - a25 * r5) / det;
+    x5 = (a22 * r5 - a25 * r2) / det;
+    inside = fabs(x2) <= lim2 && fabs(x5) <= lim5;
+  }
+  if (!inside) {
+    double best = 1e300;
+    for (int e = 0; e < 4; ++e) {
+      double c2, c5;
+      if (e < 2) {
+        c2 = e == 0 ? -lim2 : lim2;
+        c5 = (r5 - a25 * c2) / a55;
+        if (c5 < -lim5) c5 = -lim5;
+        if (c5 > lim5) c5 = lim5;
+      } else {
+        c5 = e == 2 ? -lim5 : lim5;
+        c2 = (r2 - a25 * c5) / a22;
+        if (c2 < -lim2) c2 = -lim2;
+        if (c2 > lim2) c2 = lim2;
+      }
+      const double value = 0.5 * (a22 * c2 * c2 + a55 * c5 * c5) + a25 * c2 * c5 - r2 * c2 - r5 * c5;
+      if (value < best) {
+        best = value;
+        x2 = c2;
+        x5 = c5;
+      }
+    }
+  }
+  if (fabs(x2 - lam[i2]) > *change) *change = fabs(x2 - lam[i2]);
+  if (fabs(x5 - lam[i5]) > *change) *change = fabs(x5 - lam[i5]);
   if (fabs(x2) > *scale) *scale = fabs(x2);
   if (fabs(x5) > *scale) *scale = fabs(x5);
   lam[i2] = x2;

@@ -38,6 +38,19 @@ extern "C" int harness_substep(const UpkieModel* model, float* st, const float* 
   return c ? 1 : 0;
 }
 
+// contact_pgs6() on the host (fp32, the arithmetic of the kernels): A [21] packed lower, rhs [6], lam [6] in / out
+extern "C" int harness_contact_pgs6(const UpkieModel* model, const float* A, const float* rhs, float* lam, int both_tires) {
+  DevModel M;
+  std::string why;
+  if (!convert_model(model, &M, &why)) return -1;
+  float a[21], r[6], l[6];
+  for (int k = 0; k < 21; ++k) a[k] = A[k];
+  for (int k = 0; k < 6; ++k) { r[k] = rhs[k]; l[k] = lam[k]; }
+  const int sweeps = contact_pgs6(M, a, r, l, both_tires != 0);
+  for (int k = 0; k < 6; ++k) lam[k] = l[k];
+  return sweeps;
+}
+
 // fuse_links() on the host: link factors [UPKIE_MAX_LINKS] -> records [70]
 extern "C" int harness_fuse_links(const UpkieModel* model, const float* factors, float* records) {
   DevLinks L;

@@ -514,3 +514,16 @@ def test_inertia_variation_scales_every_urdf_link():
     assert torch.isfinite(obs).all()
     env0 = envs.make("Upkie-HIP-Servos-Vec", num_envs=4, inertia_variation=0.0, **KW)
     assert env0.sim.body_inertials is None  # pybullet_backend.py:178-179: no call below 1e-10
+
+
+def test_constructor_seed_covers_an_unseeded_first_reset_of_single_envs():
+    """the single-robot envs draw their initial state on the host (gymnasium's generator, as the
+    reference does); without `reset(seed=...)` that generator starts from the constructor's `seed=`, not OS entropy."""
+    rand = lambda: RobotState(randomization=RobotStateRandomization(pitch=0.2, x=0.1))  # noqa: E731
+    a = envs.make("Upkie-HIP-Pendulum", frequency=200.0, seed=5, init_state=rand(), **KW)
+    b = envs.make("Upkie-HIP-Pendulum", frequency=200.0, seed=5, init_state=rand(), **KW)
+    c = envs.make("Upkie-HIP-Pendulum", frequency=200.0, seed=6, init_state=rand(), **KW)
+    oa, ob, oc = a.reset()[0], b.reset()[0], c.reset()[0]
+    assert np.array_equal(oa, ob) and not np.array_equal(oa, oc)
+    assert not np.array_equal(a.reset()[0], oa)  # the generator moves on: a second unseeded reset is another state
+    assert np.array_equal(a.reset(seed=5)[0], b.reset(seed=5)[0])

@@ -600,27 +600,50 @@ UPKIE_HD void system_solve(const SystemT& S, float (&bb)[6], float (&bl)[3], flo
   }
 }
 
-// Projected Gauss-Seidel sweep of the two LATERAL friction rows (row 2 of each
-// tire) together. In a symmetric stance the two rows nearly coincide (coupling
-// a25 = diagonals up to friction_cfm): swept one at a time they converge like
-// (a / (a + cfm))^2 per sweep, hundreds of sweeps. In sum / difference
-// coordinates s = l2 + l5, d = l2 - l5 the block is almost diagonal: the SUM
-// (the lateral force on the robot) is well posed and solved exactly; the
-// DIFFERENCE (how the tires share it) is statically indeterminate, only
-// friction_cfm decides it: it relaxes at the pace plain sweeps gave it and does
-// not count in the convergence test. r2, r5: right-hand sides minus the
-// contributions of every other row. Returns |change of the sum|.
+// The two LATERAL friction rows (row 2 of each tire) of a sweep, together. The tires share one axle direction, so the
+// two rows push the robot along the same line (with opposite signs on this model: a25 < 0): their 2 x 2 block
+// [[a22, a25], [a25, a55]] is nearly singular -- only friction_cfm and the yaw lever arm of the wheel base separate
+// the rows -- and swept one at a time they converge like (a / (a + cfm))^2 per sweep, hundreds of sweeps. Here the
+// pair is solved EXACTLY given every other row: the minimiser of 1/2 x'Ax - r'x over the box |x2| <= lim2,
+// |x5| <= lim5 -- the unconstrained 2 x 2 solution when it lies inside the box, otherwise the best point of the four
+// edges (one row on a bound, the other row solved and clamped; corners included). Round 2 solved the pair as a FREE
+// pair in sum / difference coordinates and clamped afterwards, and left the weak coordinate out of the convergence
+// test: with one row on its bound (a tire sliding sideways, or lifted: lim = 0) that is not the solution of the box
+// problem -- the converged impulses violated the complementarity conditions by up to O(1) of the velocity scale on
+// the systems of robots tumbling under examples/pybullet/torque_balancing.py's law, 1 % of them ran into the sweep
+// cap -- and the oracle did the same. r2, r5: right-hand sides minus the contributions of every other row.
+// Returns the largest change of the two impulses.
 UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, float r5, float lim2, float lim5, float& l2, float& l5) {
-  const float S11 = 0.5f * (a22 + 2.f * a25 + a55), S12 = 0.5f * (a22 - a55), S22 = 0.5f * (a22 - 2.f * a25 + a55);
-  float d = l2 - l5;
-  const float s_old = l2 + l5;
-  const float s_new = (r2 + r5 - S12 * d) * fast_rcp(S11);
-  const float d_exact = (r2 - r5 - S12 * s_new) * fast_rcp(S22);
-  const float omega = fminf(2.f * S22 * fast_rcp(S11), 1.f);
-  d = fmaf(omega, d_exact - d, d);
-  l2 = fminf(fmaxf(0.5f * (s_new + d), -lim2), lim2);
-  l5 = fminf(fmaxf(0.5f * (s_new - d), -lim5), lim5);
-  return fabsf((l2 + l5) - s_old);
+  const float det = a22 * a55 - a25 * a25;
+  const float idet = fast_rcp(det), i22 = fast_rcp(a22), i55 = fast_rcp(a55);
+  const float u2 = (a55 * r2 - a25 * r5) * idet, u5 = (a22 * r5 - a25 * r2) * idet;
+  // (friction_cfm keeps det / (a22 a55) at a few per cent; below fp32's resolution of the difference the free solution is not trusted)
+  const bool inside = det > 1e-5f * a22 * a55 && fabsf(u2) <= lim2 && fabsf(u5) <= lim5;
+  float best2 = u2, best5 = u5;
+  if (!inside) {
+    float best = 3.4e38f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x2, x5;
+      if (e < 2) {
+        x2 = e == 0 ? -lim2 : lim2;
+        x5 = fminf(fmaxf((r5 - a25 * x2) * i55, -lim5), lim5);
+      } else {
+        x5 = e == 2 ? -lim5 : lim5;
+        x2 = fminf(fmaxf((r2 - a25 * x5) * i22, -lim2), lim2);
+      }
+      const float value = 0.5f * (a22 * x2 * x2 + a55 * x5 * x5) + a25 * x2 * x5 - r2 * x2 - r5 * x5;
+      if (value < best) {
+        best = value;
+        best2 = x2;
+        best5 = x5;
+      }
+    }
+  }
+  const float change = fmaxf(fabsf(best2 - l2), fabsf(best5 - l5));
+  l2 = best2;
+  l5 = best5;
+  return change;
 }
 
 // Projected Gauss-Seidel on the 6 x 6 contact system of the two tires (rows 0-2

@@ -840,6 +840,28 @@ __global__ __launch_bounds__(64) void push_kernel(DevConfig C, float* __restrict
   force[(size_t)2 * B + e] = 0.f;
 }
 
+// The projected Gauss-Seidel sweeps of the step kernels (contact_pgs6: the code every lane mapping runs when a
+// contact solution leaves its friction cone) on caller-provided systems, one system per lane: A [n][21] (6 x 6, packed
+// lower by rows, CFM on the diagonal), rhs [n][6], lam [n][6] in: warm start, out: impulses; sweeps [n] out (may be null).
+__global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __restrict__ Mp, int n, const float* __restrict__ A,
+                                                           const float* __restrict__ rhs, float* __restrict__ lam,
+                                                           const uint8_t* __restrict__ pair, int* __restrict__ sweeps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[21], r[6], l[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) a[k] = A[(size_t)21 * i + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    r[k] = rhs[(size_t)6 * i + k];
+    l[k] = lam[(size_t)6 * i + k];
+  }
+  const int count = contact_pgs6(*Mp, a, r, l, pair[i] != 0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) lam[(size_t)6 * i + k] = l[k];
+  if (sweeps) sweeps[i] = count;
+}
+
 }  // namespace upkie
 
 #if defined(UPKIE_PROBE_OCTET_MODE)
@@ -1217,6 +1239,14 @@ extern "C" int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inerti
   hipLaunchKernelGGL(body_inertials_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->config,
                      sim->links, body_inertials, link_scale, (float)inertia_variation);
   return check_hip(sim, hipGetLastError(), "body_inertials_kernel");
+}
+
+extern "C" int upkie_sim_contact_sweeps(UpkieSim* sim, int32_t num_systems, const float* A, const float* rhs, float* lam,
+                                        const uint8_t* both_tires, int32_t* sweeps, void* stream) {
+  if (!sim || !A || !rhs || !lam || !both_tires || num_systems <= 0) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument or no system");
+  hipLaunchKernelGGL(contact_sweeps_kernel, grid_for(num_systems), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model, (int)num_systems, A,
+                     rhs, lam, both_tires, (int*)sweeps);
+  return check_hip(sim, hipGetLastError(), "contact_sweeps_kernel");
 }
 
 extern "C" int upkie_sim_sample_pushes(UpkieSim* sim, float* force, uint32_t push_index, double max_norm, void* stream) {

@@ -175,7 +175,15 @@ class UpkieVecEnv:
     def close(self) -> None:
         if self._observers is not None:
             self._observers.close()
+        self._disarm_same_step()
         self.sim.close()
+
+    def _disarm_same_step(self) -> None:
+        """Switch the in-step SAME_STEP autoreset off again (it is armed on `sim`, which other wrappers -- `HipSpine`,
+        a `Backend` around the same handle, direct `sim.step_*` calls -- may keep using after this env)."""
+        if self._final_obs is not None and hasattr(self.sim, "set_final_observation"):
+            self.sim.set_final_observation(None)
+        self._final_obs = None
 
     def __enter__(self):
         return self
@@ -213,6 +221,8 @@ class UpkieVecEnv:
                 self.sim.set_final_observation(self._final_obs)
                 self.sim.autoreset_done(self._same_step_layout, obs, self._final_obs)  # this first step's own resets
             info = dict(self._info())
+            # NOTE: one persistent buffer, rewritten by every step (the kernel stores into it): a rollout buffer that
+            # keeps final observations must copy the rows it needs (`info["final_obs"][info["_final_obs"]]` does)
             info["final_obs"] = self._final_obs
             info["_final_obs"] = done
             return obs, reward, terminated, truncated, info
@@ -271,8 +281,11 @@ class UpkieVecEnv:
                 self.sim.restart_random_streams()
         if self.host_sampling and mask is None:
             if seed is not None or self._np_random is None:
-                # gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))
-                self._np_random = np.random.default_rng(seed)
+                # gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed))). A first reset() without a
+                # seed falls back to the constructor's `seed=` (which already keys the device's noise streams), so that
+                # envs.make(..., seed=s) followed by reset() is reproducible as it was with the device-side sampler;
+                # gymnasium itself would draw OS entropy there.
+                self._np_random = np.random.default_rng(seed if seed is not None else int(self.config.seed))
             self.sampled_init_state = self.init_state.sample_state(self._np_random)
             self.sampled_init_state.write_exact_to_config(self.config)
             self.sim.push_config()
@@ -489,9 +502,10 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         obs6, info = super().reset(seed=seed, options=options, mask=mask)
         self._remember(obs6)
         self.mpc_balancer.reset(mask)  # upkie_base_velocity.py:158
-        if hasattr(self.sim, "step_base_velocity"):
-            # fused path: the dead-reckoned pose lives in the state words (the
-            # reset branch of the kernel has just zeroed them for the reset envs)
+        if hasattr(self.sim, "step_base_velocity") and hasattr(self.mpc_balancer, "step_env"):
+            # fused path (the condition step() takes it on): the dead-reckoned pose lives in the state words (the
+            # reset branch of the kernel has just zeroed them for the reset envs); the generic composition below
+            # dead-reckons in `_xy` and never touches those words
             self._xy.copy_(self.sim.state[abi.S_SE2_X : abi.S_SE2_Y + 1].t())
         elif mask is None:
             self._xy.zero_()

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_set_external_forces",
     "upkie_sim_sample_body_inertials",
     "upkie_sim_sample_pushes",
+    "upkie_sim_contact_sweeps",
     "upkie_sim_reset",
     "upkie_sim_step_pendulum",
     "upkie_sim_step_pendulum_agent",
@@ -169,6 +170,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_external_forces.argtypes = [vp, vp, C.POINTER(abi.UpkieExternalForces)]
     lib.upkie_sim_sample_body_inertials.restype = C.c_int
     lib.upkie_sim_sample_body_inertials.argtypes = [vp, vp, vp, C.c_double, vp]
+    lib.upkie_sim_contact_sweeps.restype = C.c_int
+    lib.upkie_sim_contact_sweeps.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.upkie_sim_sample_pushes.restype = C.c_int
     lib.upkie_sim_sample_pushes.argtypes = [vp, vp, C.c_uint32, C.c_double, vp]
     lib.upkie_sim_reset.restype = C.c_int

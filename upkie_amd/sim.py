@@ -176,6 +176,20 @@ class BatchedSim:
         self._ext_slots = slots
         self._push_randomization()
 
+    def contact_sweeps(self, A: torch.Tensor, rhs: torch.Tensor, lam: torch.Tensor, both_tires: torch.Tensor):
+        """The step kernels' projected Gauss-Seidel sweeps on given contact systems
+        (`upkie_sim_contact_sweeps`): ``A [n, 21]`` packed lower by rows, ``rhs
+        [n, 6]``, ``lam [n, 6]`` the warm start; returns (impulses, sweeps run)."""
+        n = int(A.shape[0])
+        A = A.to(self.device, torch.float32).contiguous()
+        rhs = rhs.to(self.device, torch.float32).contiguous()
+        lam = lam.to(self.device, torch.float32).contiguous().clone()
+        both = both_tires.to(self.device, torch.uint8).contiguous()
+        assert A.shape == (n, 21) and rhs.shape == (n, 6) and lam.shape == (n, 6) and both.shape == (n,)
+        sweeps = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._launch(self._lib.upkie_sim_contact_sweeps, n, A.data_ptr(), rhs.data_ptr(), lam.data_ptr(), both.data_ptr(), sweeps.data_ptr())
+        return lam, sweeps
+
     def sample_pushes(self, push_index: int, max_norm: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Push number `push_index` of every env (`upkie_sim_sample_pushes`): a
         world-frame force ``[3, B]`` with norm ~ U(0, max_norm) in a uniformly
