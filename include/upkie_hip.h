@@ -203,6 +203,13 @@ int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config);
 /* Size in bytes the caller must allocate for the state buffer. */
 int64_t upkie_sim_state_bytes(const UpkieSim* sim);
 
+/* The relative tolerance the Gauss-Seidel sweeps of this handle's kernels stop
+ * at: UpkieModel.pgs_tolerance, but never below 1e-5 -- the kernels sweep in
+ * fp32, where a six-term residual cannot be told from zero below that, and a
+ * tighter setting only ran systems into the iteration cap (the fp64 oracle
+ * honours the model's value). */
+double upkie_sim_pgs_tolerance(const UpkieSim* sim);
+
 /* Lanes of a wavefront that share one env in the step kernels of this handle:
  * chosen from the batch size at creation (small batches spread every env over
  * several lanes so that the chip's SIMDs all hold a wave; large ones keep one

@@ -1179,7 +1179,8 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                          const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
-                                                         float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census) {
+                                                         float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census,
+                                                         ServoPolicyArg<MODE> policy_arg) {
   warm_kernel_arguments();
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
@@ -1268,9 +1269,10 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   };
 
   // UpkieServos with the servo-level policy evaluated here instead of by a launch of its own in front of this one
-  // (upkie_sim_step_servos_policy: `packed` == 2, `act` is the device copy of the UpkieServoPolicy): what
+  // (upkie_sim_step_servos_policy: `packed` == 2, the policy is the kernel argument `policy_arg`): what
   // servo_policy_kernel computes from the state the step starts from, the own joint's row only.
-  const UpkieServoPolicy* policy = MODE == MODE_SERVOS && packed == 2 ? reinterpret_cast<const UpkieServoPolicy*>(act) : nullptr;
+  const UpkieServoPolicy* policy = nullptr;
+  if constexpr (MODE == MODE_SERVOS) policy = packed == 2 ? &policy_arg : nullptr;
   float policy_pitch = 0.f, policy_position = 0.f, policy_velocity = 0.f;
   if (MODE == MODE_SERVOS && policy) {
     policy_pitch = asinf(fminf(fmaxf(2.f * (s.qw * s.qy - s.qz * s.qx), -1.f), 1.f));

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "dynamics.hpp"
 #include "mpc.hpp"
@@ -580,6 +581,13 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
 #undef SW
 }
 
+// The servo-level policy of upkie_sim_step_servos_policy reaches the eight-lane Servos kernels BY VALUE, as a kernel
+// argument (268 bytes; the other modes carry an empty struct): no device copy to keep coherent with the host's, nothing
+// to upload under a hipGraph capture, no race between a policy change on one stream and a step still running on another.
+struct NoServoPolicy {};
+template <int MODE>
+using ServoPolicyArg = std::conditional_t<MODE == MODE_SERVOS, UpkieServoPolicy, NoServoPolicy>;
+
 #include "pair.hpp"
 #include "octet.hpp"
 
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
 #endif
 template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
     const upkie::DevModel*, upkie::DevLimits, upkie::DevConfig, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
-    const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*);
+    const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>);
 #else
 // =========================================================== C-ABI (host)
 using namespace upkie;
@@ -889,9 +897,6 @@ struct UpkieSim {
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
-  UpkieServoPolicy* d_policy = nullptr;  // device copy of the policy of upkie_sim_step_servos_policy, uploaded when it changes
-  UpkieServoPolicy policy_cache{};
-  bool policy_cached = false;
   std::string error;
 };
 
@@ -1183,7 +1188,6 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
-  if (sim && sim->d_policy) (void)hipFree(sim->d_policy);
   delete sim;
   return UPKIE_OK;
 }
@@ -1191,6 +1195,8 @@ extern "C" int upkie_sim_destroy(UpkieSim* sim) {
 extern "C" const char* upkie_sim_last_error(const UpkieSim* sim) {
   return sim ? sim->error.c_str() : g_create_error.c_str();
 }
+
+extern "C" double upkie_sim_pgs_tolerance(const UpkieSim* sim) { return sim ? (double)sim->model.pgs_tolerance : 0.0; }
 
 extern "C" int64_t upkie_sim_state_bytes(const UpkieSim* sim) {
   return sim ? (int64_t)UPKIE_STATE_WORDS * sim->config.num_envs * (int64_t)sizeof(float) : 0;
@@ -1304,7 +1310,7 @@ template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
                        BaseVelocityPtrs bv = BaseVelocityPtrs{}, bool done_pass = false,
-                       float* final_obs = nullptr, int n_steps = 1) {
+                       float* final_obs = nullptr, int n_steps = 1, const UpkieServoPolicy* policy = nullptr) {
   if (!sim || !state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (MODE != MODE_RESET && (!obs || (!packed && !done_pass && (!reward || !terminated || !truncated))))
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null output buffer");
@@ -1343,8 +1349,12 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
 #define UPKIE_LAUNCH_OCTET(R)                                                                                                \
   hipLaunchKernelGGL((step_kernel_octet<MODE, R>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
                      sim->d_model, sim->limits, config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, \
-                     final_obs, n_steps, sim->census)
+                     final_obs, n_steps, sim->census, policy_arg)
   const bool spine = sim->spine_state != nullptr;
+  ServoPolicyArg<MODE> policy_arg{};
+  if constexpr (MODE == MODE_SERVOS) {
+    if (policy) policy_arg = *policy;
+  }
   if (mapped_lanes(sim) == 8) {
     if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
   } else if (paired) {
@@ -1467,12 +1477,6 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
   return check_hip(sim, hipGetLastError(), "servo_policy_kernel");
 }
 
-__global__ void store_servo_policy_kernel(UpkieServoPolicy policy, UpkieServoPolicy* out) {
-  const float* from = reinterpret_cast<const float*>(&policy);
-  float* to = reinterpret_cast<float*>(out);
-  for (int i = threadIdx.x; i < (int)(sizeof(UpkieServoPolicy) / sizeof(float)); i += blockDim.x) to[i] = from[i];
-}
-
 extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
                                             uint8_t* terminated, uint8_t* truncated, void* stream) {
   if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
@@ -1481,18 +1485,8 @@ extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const U
     if (status != UPKIE_OK) return status;
     return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
   }
-  if (!sim->d_policy && hipMalloc((void**)&sim->d_policy, sizeof(UpkieServoPolicy)) != hipSuccess)
-    return fail(sim, UPKIE_ERR_HIP, "hipMalloc of the servo policy failed");
-  if (!sim->policy_cached || std::memcmp(&sim->policy_cache, policy, sizeof(UpkieServoPolicy)) != 0) {
-    sim->policy_cache = *policy;
-    sim->policy_cached = true;
-    // (as a kernel argument, not a host-to-device copy: capturable in a hipGraph, no host buffer to keep alive)
-    hipLaunchKernelGGL(store_servo_policy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sim->policy_cache, sim->d_policy);
-    const int stored = check_hip(sim, hipGetLastError(), "store_servo_policy_kernel");
-    if (stored != UPKIE_OK) return stored;
-  }
-  // (`packed` == 2 tells the eight-lane Servos kernel that `act` is the policy)
-  return launch_step<MODE_SERVOS>(sim, state, reinterpret_cast<const float*>(sim->d_policy), obs, reward, terminated, truncated, nullptr, stream, 2);
+  // (`packed` == 2 tells the eight-lane Servos kernel to take its actions from the policy argument; `act` is not read)
+  return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream, 2, BaseVelocityPtrs{}, false, nullptr, 1, policy);
 }
 
 extern "C" int upkie_sim_autoreset_done(UpkieSim* sim, int observation, float* state, float* obs, float* final_obs, void* stream) {

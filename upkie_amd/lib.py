@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_set_config",
     "upkie_sim_last_error",
     "upkie_sim_state_bytes",
+    "upkie_sim_pgs_tolerance",
     "upkie_sim_lanes_per_env",
     "upkie_sim_set_census",
     "upkie_sim_set_final_observation",
@@ -152,6 +153,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_destroy.argtypes = [vp]
     lib.upkie_sim_last_error.restype = C.c_char_p
     lib.upkie_sim_last_error.argtypes = [vp]
+    lib.upkie_sim_pgs_tolerance.restype = C.c_double
+    lib.upkie_sim_pgs_tolerance.argtypes = [vp]
     lib.upkie_sim_state_bytes.restype = C.c_int64
     lib.upkie_sim_state_bytes.argtypes = [vp]
     lib.upkie_sim_lanes_per_env.restype = C.c_int

@@ -341,6 +341,12 @@ class BatchedSim:
             )
         return records
 
+    def step_pendulum_records_raw(self, prev_records_ptr: int, records_ptr: int) -> None:
+        """`step_pendulum_records` on device addresses of two ``[B, 8]`` fp32 record
+        buffers the caller keeps alive (the rollout ring of `RolloutGather`): the
+        host side of one env.step() is then one ctypes call."""
+        self._launch(self._lib.upkie_sim_step_pendulum_agent_records, self.state.data_ptr(), prev_records_ptr, records_ptr)
+
     def rollout_pendulum_records(self, prev_records: torch.Tensor, records: torch.Tensor) -> torch.Tensor:
         """``records.shape[0]`` consecutive on-device-agent steps, records
         ``[K, B, 8]``: the same results as K `step_pendulum_records` calls
@@ -462,6 +468,12 @@ class BatchedSim:
         flagged here are re-initialised by their next step (used by the
         envs' time limit, which the kernel knows nothing about)."""
         self.state[abi.S_DONE] = done.to(self.device, torch.float32)
+
+    @property
+    def pgs_tolerance(self) -> float:
+        """Relative tolerance the kernels' Gauss-Seidel sweeps actually stop at
+        (`upkie_sim_pgs_tolerance`: the model's, floored at 1e-5 for fp32)."""
+        return float(self._lib.upkie_sim_pgs_tolerance(self._handle))
 
     @property
     def lanes_per_env(self) -> int:
