@@ -38,7 +38,11 @@ class Randomization(C.Structure):
         ("ext_slots", C.c_void_p),
         ("observer_config", C.c_void_p),
         ("observer_state", C.c_void_p),
+        ("bullet_manifold", C.c_void_p),
     ]
+
+
+BULLET_MANIFOLD_WORDS = 64
 
 
 class SpineObservation(C.Structure):
@@ -194,11 +198,12 @@ class Oracle:
         self.ext_slots = None  # abi.UpkieExternalForces
         self.observer_config = None  # abi.UpkieObserverConfig: spine observers inside the step ...
         self.observer_state = None  # ... and their memory [OBSERVER_STATE_WORDS, B]
+        self.bullet_manifold = None  # `use_bullet_like_contacts`: [BULLET_MANIFOLD_WORDS, B]
         self._lib = lib()
 
     # -- randomisation -----------------------------------------------------
     def _rnd(self):
-        if self.body_inertials is None and self.ext_force is None and self.observer_config is None:
+        if self.body_inertials is None and self.ext_force is None and self.observer_config is None and self.bullet_manifold is None:
             return None
         r = Randomization()
         r.body_inertials = _ptr(self.body_inertials)
@@ -208,8 +213,17 @@ class Oracle:
         if self.observer_config is not None:
             r.observer_config = C.cast(C.pointer(self.observer_config), C.c_void_p)
             r.observer_state = _ptr(self.observer_state)
+        r.bullet_manifold = _ptr(self.bullet_manifold)
         self._rnd_keepalive = r
         return C.byref(r)
+
+    def use_bullet_like_contacts(self, on: bool = True) -> None:
+        """Contacts by the Bullet-like specification of upkie_oracle.c (what
+        Bullet 3.25's multibody solver is published to do: persistent 4-point
+        manifolds, 50 fixed warm-started sweeps, cone friction, no friction
+        CFM) instead of the product's: the yardstick of
+        tools/bullet_like_deviation.py. Call before `reset()`."""
+        self.bullet_manifold = np.zeros((BULLET_MANIFOLD_WORDS, self.B)) if on else None
 
     def attach_observers(self, config: abi.UpkieObserverConfig):
         """Spine observers inside the step, one cycle per substep."""

@@ -498,6 +498,215 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
   lam[i5] = x5;
 }
 
+/* ------------------------------------------------- Bullet-like contact spec */
+/* A SECOND contact specification, for measuring how far the product's (one
+ * point per tire, exact solve + sweeps to convergence, box friction in the
+ * wheel's rolling / lateral directions, friction CFM 0.01) is from what Bullet
+ * 3.25's btMultiBodyConstraintSolver does inside pybullet.stepSimulation()
+ * (pybullet_backend.py:306) -- restated from the published sources as
+ * SURVEY.md Appendix B.1 / B.2 summarise them, [3P, unverified: Bullet is not
+ * available here]:
+ *   - a PERSISTENT manifold of up to 4 points per tire (btPersistentManifold):
+ *     every step the cached points are refreshed (removed beyond the contact
+ *     breaking threshold, along the normal or in the plane) and the deepest
+ *     point of the tire (btConvexPlaneCollisionAlgorithm's single support
+ *     point) replaces the cached point within the threshold of it in the
+ *     wheel's frame, or is added;
+ *   - one normal + two friction rows per cached point; friction directions
+ *     along / across the sliding velocity of the point (btPlaneSpace1 when it
+ *     does not slide); zero friction CFM; normal rows with the URDF contact
+ *     stiffness / damping as CFM / ERP, a separated point may close its gap;
+ *   - sequential impulses: a FIXED number of sweeps (numSolverIterations = 50),
+ *     joint limits first, then all normal rows, then the friction rows of each
+ *     point projected onto the cone |f| <= mu f_n (implicit cone friction),
+ *     normal impulses warm-started with 0.85 x last step's;
+ * everything else (articulated-body dynamics, torque law, integration, joint
+ * speed clamp, base damping) is shared with the product's specification.
+ * Enabled per call through OracleRandomization.bullet_manifold; used by
+ * tools/bullet_like_deviation.py and tests/test_oracle_bullet_like.py only. */
+#define BL_POINTS 4
+#define BL_POINT_WORDS 8 /* point in the wheel frame (3), on the plane (3), applied normal impulse, live */
+#define BL_ROWS (2 * BL_POINTS * 3 + 4)
+static _Thread_local double g_bullet_manifold[2 * BL_POINTS * BL_POINT_WORDS];
+static _Thread_local int g_bullet_active = 0;
+
+static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const double* L, const double* q, double h, double* nu) {
+  const double breaking = model->contact_breaking_threshold;
+  const double n[3] = {0, 0, 1};
+  double J[BL_ROWS][NV], MinvJt[BL_ROWS][NV], rhs[BL_ROWS], cfm[BL_ROWS], lam[BL_ROWS];
+  int kind[BL_ROWS], normal_row[BL_ROWS];
+  double* applied_slot[BL_ROWS];
+  int nrows = 0, any_contact = 0;
+  /* joint limits (btMultiBodyJointLimitConstraint, ERP 0.2): solved first in every sweep */
+  if (model->enforce_joint_limits) {
+    for (int j = 0; j < NJ; ++j) {
+      if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30)) continue;
+      double sign = 0.0, err = 0.0;
+      if (q[j] <= model->joint_lower[j]) { sign = 1.0; err = model->joint_lower[j] - q[j]; }
+      else if (q[j] >= model->joint_upper[j]) { sign = -1.0; err = q[j] - model->joint_upper[j]; }
+      else continue;
+      memset(J[nrows], 0, sizeof(double) * NV);
+      J[nrows][6 + j] = sign;
+      kind[nrows] = 2; normal_row[nrows] = nrows; cfm[nrows] = 0.0; lam[nrows] = 0.0; applied_slot[nrows] = NULL;
+      rhs[nrows] = -sign * nu[6 + j] + 0.2 * err / h;
+      ++nrows;
+    }
+  }
+  const double kpc = model->contact_stiffness, kdc = model->contact_damping, denom = h * kpc + kdc;
+  const double erp = denom > 0 ? h * kpc / denom : 0.2, cfm_n = denom > 0 ? 1.0 / (denom * h) : 0.0;
+  for (int wheel = 0; wheel < 2; ++wheel) {
+    const int body = 3 * wheel + 3, joint = 3 * wheel + 2;
+    double* pts = g_bullet_manifold + wheel * BL_POINTS * BL_POINT_WORDS;
+    /* btPersistentManifold::refreshContactPoints */
+    for (int p = 0; p < BL_POINTS; ++p) {
+      double* pt = pts + p * BL_POINT_WORDS;
+      if (pt[7] == 0.0) continue;
+      double r[3], A[3];
+      m3_mulv(k->R[body], pt, r);
+      for (int d = 0; d < 3; ++d) A[d] = k->o[body][d] + r[d];
+      const double dist = A[2];
+      const double dx = A[0] - pt[3], dy = A[1] - pt[4];
+      if (dist > breaking || dx * dx + dy * dy > breaking * breaking) pt[7] = 0.0;
+    }
+    /* the deepest point of the tire circle (the support point of the tire against the plane) */
+    {
+      double center[3], r[3];
+      m3_mulv(k->R[body], model->wheel_center[wheel], r);
+      for (int d = 0; d < 3; ++d) center[d] = k->o[body][d] + r[d];
+      const double* a = k->a[joint];
+      const double u[3] = {-a[2] * a[0], -a[2] * a[1], 1.0 - a[2] * a[2]};
+      const double un = sqrt(v3_dot(u, u));
+      if (un >= 1e-6) {
+        double P[3], rel[3], local[3];
+        for (int d = 0; d < 3; ++d) P[d] = center[d] - model->wheel_radius * u[d] / un;
+        if (P[2] <= breaking) {
+          for (int d = 0; d < 3; ++d) rel[d] = P[d] - k->o[body][d];
+          m3_tmulv(k->R[body], rel, local);
+          /* btPersistentManifold::getCacheEntry: the nearest cached point within the threshold is replaced */
+          int slot = -1;
+          double nearest = breaking * breaking;
+          for (int p = 0; p < BL_POINTS; ++p) {
+            const double* pt = pts + p * BL_POINT_WORDS;
+            if (pt[7] == 0.0) continue;
+            const double d0 = pt[0] - local[0], d1 = pt[1] - local[1], d2 = pt[2] - local[2];
+            const double dd = d0 * d0 + d1 * d1 + d2 * d2;
+            if (dd < nearest) { nearest = dd; slot = p; }
+          }
+          double keep = 0.0;
+          if (slot >= 0) {
+            keep = pts[slot * BL_POINT_WORDS + 6]; /* replaceContactPoint keeps the applied impulse */
+          } else {
+            for (int p = 0; p < BL_POINTS && slot < 0; ++p)
+              if (pts[p * BL_POINT_WORDS + 7] == 0.0) slot = p;
+            if (slot < 0) { /* full: the shallowest cached point makes room (sortCachedPoints keeps the deepest) */
+              double worst = -1e300;
+              for (int p = 0; p < BL_POINTS; ++p) {
+                double rr[3];
+                m3_mulv(k->R[body], pts + p * BL_POINT_WORDS, rr);
+                const double z = k->o[body][2] + rr[2];
+                if (z > worst) { worst = z; slot = p; }
+              }
+            }
+          }
+          double* pt = pts + slot * BL_POINT_WORDS;
+          for (int d = 0; d < 3; ++d) pt[d] = local[d];
+          pt[3] = P[0]; pt[4] = P[1]; pt[5] = 0.0;
+          pt[6] = keep;
+          pt[7] = 1.0;
+        }
+      }
+    }
+    /* rows of every cached point */
+    for (int p = 0; p < BL_POINTS; ++p) {
+      double* pt = pts + p * BL_POINT_WORDS;
+      if (pt[7] == 0.0) continue;
+      any_contact = 1;
+      double r[3], A[3], Jv[3][NV], Jw[3][NV], v[3];
+      m3_mulv(k->R[body], pt, r);
+      for (int d = 0; d < 3; ++d) A[d] = k->o[body][d] + r[d];
+      point_jacobian(k, body, A, Jv, Jw);
+      for (int d = 0; d < 3; ++d) {
+        v[d] = 0.0;
+        for (int c = 0; c < NV; ++c) v[d] += Jv[d][c] * nu[c];
+      }
+      const double vn = v3_dot(v, n), dist = A[2];
+      double vt[3] = {v[0] - vn * n[0], v[1] - vn * n[1], v[2] - vn * n[2]};
+      double t1[3], t2[3];
+      const double lat2 = v3_dot(vt, vt);
+      if (lat2 > 1.1920929e-07) { /* SIMD_EPSILON: friction along the sliding direction */
+        const double inv = 1.0 / sqrt(lat2);
+        for (int d = 0; d < 3; ++d) t1[d] = vt[d] * inv;
+        v3_cross(t1, n, t2);
+      } else { /* btPlaneSpace1(n) for n = z */
+        t1[0] = 0; t1[1] = -1; t1[2] = 0;
+        t2[0] = 1; t2[1] = 0; t2[2] = 0;
+      }
+      const double* dirs[3] = {n, t1, t2};
+      for (int r_ = 0; r_ < 3; ++r_) {
+        for (int c = 0; c < NV; ++c) J[nrows][c] = dirs[r_][0] * Jv[0][c] + dirs[r_][1] * Jv[1][c] + dirs[r_][2] * Jv[2][c];
+        double rel = 0.0;
+        for (int c = 0; c < NV; ++c) rel += J[nrows][c] * nu[c];
+        if (r_ == 0) {
+          kind[nrows] = 0; normal_row[nrows] = nrows; cfm[nrows] = cfm_n;
+          rhs[nrows] = dist <= 0.0 ? -rel + erp * (-dist) / h : -rel - dist / h;
+          lam[nrows] = 0.85 * pt[6]; /* m_warmstartingFactor */
+          applied_slot[nrows] = pt + 6;
+        } else {
+          kind[nrows] = 1; normal_row[nrows] = nrows - r_; cfm[nrows] = 0.0;
+          rhs[nrows] = -rel;
+          lam[nrows] = 0.0;
+          applied_slot[nrows] = NULL;
+        }
+        ++nrows;
+      }
+    }
+  }
+  if (nrows == 0) return 0;
+  static _Thread_local double W[BL_ROWS][BL_ROWS];
+  for (int r_ = 0; r_ < nrows; ++r_) cholesky_solve(NV, L, J[r_], MinvJt[r_]);
+  for (int a = 0; a < nrows; ++a)
+    for (int b = 0; b < nrows; ++b) {
+      double s_ = 0.0;
+      for (int c = 0; c < NV; ++c) s_ += J[a][c] * MinvJt[b][c];
+      W[a][b] = s_;
+    }
+  const double mu = model->friction_mu;
+  for (int it = 0; it < model->pgs_iterations; ++it) {
+    for (int pass = 0; pass < 2; ++pass) { /* joint limits, then normals */
+      for (int r_ = 0; r_ < nrows; ++r_) {
+        if (kind[r_] != (pass == 0 ? 2 : 0)) continue;
+        double wl = 0.0;
+        for (int b = 0; b < nrows; ++b) wl += W[r_][b] * lam[b];
+        double x = lam[r_] + (rhs[r_] - wl - cfm[r_] * lam[r_]) / (W[r_][r_] + cfm[r_]);
+        lam[r_] = x < 0.0 ? 0.0 : x;
+      }
+    }
+    for (int r_ = 0; r_ < nrows; ++r_) { /* the two friction rows of a point together, projected onto the cone */
+      if (kind[r_] != 1 || r_ != normal_row[r_] + 1) continue;
+      const int r1 = r_, r2 = r_ + 1;
+      double w1 = 0.0, w2 = 0.0;
+      for (int b = 0; b < nrows; ++b) {
+        w1 += W[r1][b] * lam[b];
+        w2 += W[r2][b] * lam[b];
+      }
+      double x1 = lam[r1] + (rhs[r1] - w1) / W[r1][r1], x2 = lam[r2] + (rhs[r2] - w2) / W[r2][r2];
+      const double lim = mu * lam[normal_row[r1]], norm = sqrt(x1 * x1 + x2 * x2);
+      if (norm > lim) {
+        const double sc = norm > 0.0 ? lim / norm : 0.0;
+        x1 *= sc;
+        x2 *= sc;
+      }
+      lam[r1] = x1;
+      lam[r2] = x2;
+    }
+  }
+  for (int r_ = 0; r_ < nrows; ++r_) {
+    if (applied_slot[r_]) *applied_slot[r_] = lam[r_];
+    for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
+  }
+  return any_contact;
+}
+
 /* Where oracle_substep_ext() leaves the contact points of the substep it
  * solved when asked (oracle_contact_points): [2][8] = per tire {exists,
  * position in world (3), force in world (3), 0}. */
@@ -575,6 +784,9 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   }
   for (int j = 0; j < NJ; ++j) nu[6 + j] = qd[j] + h * acc[6 + j];
 
+  int bullet_contact = -1;
+  if (g_bullet_active) bullet_contact = bullet_like_contacts(model, &k, L, q, h, nu);
+
   /* constraint rows: per wheel (normal, t1, t2), then joint limits */
   double J[MAXROWS][NV], MinvJt[MAXROWS][NV];
   double rhs_c[MAXROWS], cfm[MAXROWS];
@@ -587,7 +799,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   double denom = h * kpc + kdc;
   double erp = denom > 0 ? h * kpc / denom : 0.2;
   double cfm_n = denom > 0 ? 1.0 / (denom * h) : 0.0;
-  for (int wheel = 0; wheel < 2; ++wheel) {
+  for (int wheel = 0; wheel < 2 && bullet_contact < 0; ++wheel) {
     int body = 3 * wheel + 3, joint = 3 * wheel + 2;
     double center[3], r[3];
     m3_mulv(k.R[body], model->wheel_center[wheel], r);
@@ -641,7 +853,8 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       ++nrows;
     }
   }
-  if (model->enforce_joint_limits) {
+  if (bullet_contact >= 0) any_contact = bullet_contact; /* (contacts AND joint limits were solved there) */
+  if (model->enforce_joint_limits && bullet_contact < 0) {
     for (int j = 0; j < NJ; ++j) {
       if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30))
         continue;
@@ -813,17 +1026,25 @@ typedef struct {
 static _Thread_local SpineHook g_spine;
 
 static void spine_begin(const OracleRandomization* rnd, int B, int e) {
+  g_bullet_active = rnd && rnd->bullet_manifold;
+  if (g_bullet_active)
+    for (int w = 0; w < ORACLE_BULLET_MANIFOLD_WORDS; ++w) g_bullet_manifold[w] = rnd->bullet_manifold[(int64_t)w * B + e];
   g_spine.active = rnd && rnd->observer_config && rnd->observer_state;
   if (!g_spine.active) return;
   g_spine.config = rnd->observer_config;
   for (int w = 0; w < UPKIE_OBSERVER_STATE_WORDS; ++w) g_spine.st[w] = rnd->observer_state[(int64_t)w * B + e];
 }
 static void spine_end(const OracleRandomization* rnd, int B, int e) {
+  if (g_bullet_active) {
+    for (int w = 0; w < ORACLE_BULLET_MANIFOLD_WORDS; ++w) rnd->bullet_manifold[(int64_t)w * B + e] = g_bullet_manifold[w];
+    g_bullet_active = 0;
+  }
   if (!g_spine.active) return;
   for (int w = 0; w < UPKIE_OBSERVER_STATE_WORDS; ++w) rnd->observer_state[(int64_t)w * B + e] = g_spine.st[w];
   g_spine.active = 0;
 }
 static void spine_reset(void) {
+  if (g_bullet_active) memset(g_bullet_manifold, 0, sizeof(g_bullet_manifold)); /* resetBasePositionAndOrientation drops the contact cache */
   if (g_spine.active) memset(g_spine.st, 0, sizeof(g_spine.st));
 }
 static void spine_cycle(const double* s, const double tau[6], double h) {

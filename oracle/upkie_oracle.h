@@ -48,7 +48,13 @@ typedef struct OracleRandomization {
   /* spine observers run inside the step, one cycle per substep (or NULL) */
   const UpkieObserverConfig* observer_config;
   double* observer_state; /* [UPKIE_OBSERVER_STATE_WORDS][B] */
+  /* non-NULL: contacts follow the Bullet-like specification of upkie_oracle.c
+   * (persistent 4-point manifolds, 50 fixed warm-started sweeps, cone friction,
+   * no friction CFM) instead of the product's; this is its memory, zeroed by
+   * the caller before the first reset: [ORACLE_BULLET_MANIFOLD_WORDS][B] */
+  double* bullet_manifold;
 } OracleRandomization;
+#define ORACLE_BULLET_MANIFOLD_WORDS 64 /* 2 tires x 4 points x 8 words */
 
 /* Philox4x32-10 counter-based generator (Salmon et al., SC'11). */
 void oracle_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
