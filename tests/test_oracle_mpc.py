@@ -178,3 +178,63 @@ def test_condensed_qp_equals_the_cost_of_a_forward_simulation(N):
     factors = np.array(factors)
     assert np.abs(factors - factors[0]).max() < 1e-9 * abs(factors[0])
     assert min(abs(factors[0] - 1.0), abs(factors[0] - 2.0)) < 1e-9
+
+
+def proxqp_accepts(P, q, bound, u, z, eps=1e-3):
+    """ProxQP's stopping rule with the reference's settings (mpc_balancer.py:76-77:
+    eps_abs = 1e-3, eps_rel = 0) on min 1/2 u'Pu + q'u, -bound <= u <= bound with
+    multipliers z of the box: primal residual = violation of the box, dual
+    residual = |P u + q + z|, both in the infinity norm."""
+    primal = max(np.maximum(u - bound, 0.0).max(), np.maximum(-bound - u, 0.0).max())
+    dual = np.abs(P @ u + q + z).max()
+    return primal <= eps and dual <= eps
+
+
+@pytest.mark.parametrize("N", [16, 50])
+def test_what_a_solver_stopped_at_the_reference_tolerance_can_return(N):
+    """the product converges to the exact QP solution, the reference
+    stops ProxQP at eps_abs = 1e-3 (mpc_balancer.py:76-77); nobody had stated what
+    that allows. (1) The worst case over EVERY point the stopping rule accepts
+    while no bound is active: |dU0| <= eps ||P^-1 e0||_1. (2) What one concrete
+    solver that stops on that rule returns: the oracle's ADMM iterates (the
+    recurrences of the HIP kernel) stopped at the first one ProxQP would accept,
+    against the exact solution, over closed-loop-like states. The commanded
+    velocity integrates U0 dt / 2 per step (mpc_balancer.py:305-311)."""
+    cfg, P, Kx, kv = build(N)
+    eps, dt, bound, rho = 1e-3, 1.0 / 200.0, cfg.max_ground_accel, cfg.admm_rho
+    worst_u0 = eps * np.abs(np.linalg.solve(P, np.eye(N)[0])).sum()
+    worst_dv = worst_u0 * dt / 2.0
+    # N = 16: 1.88 m/s^2 of the +-10 m/s^2 input range, 4.7 mm/s of commanded velocity per step; N = 50 (the reference's
+    # default horizon): 2.43 m/s^2 and 6.1 mm/s -- the input weight w_u = 1e-3 is the smallest eigenvalue of P, so a
+    # gradient residual of 1e-3 is a large step along the flat directions of the cost
+    assert worst_u0 == pytest.approx(1.88 if N == 16 else 2.43, rel=0.01) and worst_dv < 6.2e-3, (worst_u0, worst_dv)
+    Minv = np.zeros((N, N))
+    O.lib().oracle_mpc_minv(N, p(P), C.c_double(rho), p(Minv))
+    rng = np.random.default_rng(3)
+    gaps, stops = [], []
+    for i in range(60):
+        scale = 1.0 if i < 40 else 4.0  # the last third saturates some inputs
+        x0 = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.1, 0.1) * scale, rng.uniform(-0.3, 0.3) * scale, rng.uniform(-0.3, 0.3) * scale])
+        q = Kx @ x0 + kv * rng.uniform(-0.5, 0.5)
+        exact = np.zeros(N)
+        assert O.lib().oracle_mpc_solve_exact(N, p(P), p(q), C.c_double(bound), p(exact)) >= 0
+        z, y, u = np.zeros(N), np.zeros(N), np.zeros(N)
+        for it in range(1, 2001):
+            O.lib().oracle_mpc_admm(N, p(Minv), p(q), C.c_double(rho), C.c_double(bound), 1, p(z), p(y), p(u))
+            if proxqp_accepts(P, q, bound, z, rho * y):  # ADMM's scaled dual y = multiplier / rho
+                break
+        gaps.append(abs(z[0] - exact[0]))
+        stops.append(it)
+    gaps = np.array(gaps)
+    print(f"N = {N}: ADMM stopped by ProxQP's rule after {int(np.median(stops))} iterations (median; at most {max(stops)}), |U0 - exact| median "
+          f"{np.median(gaps):.3f} max {gaps.max():.3f} m/s^2; worst case of the rule {worst_u0:.2f} m/s^2 = {worst_dv * 1e3:.1f} mm/s of commanded velocity per step")
+    assert gaps.max() < worst_u0 * 1.5 + 1e-9, (gaps.max(), np.median(gaps), max(stops))
+    # the HIP path runs 30 warm-started iterations: far inside the reference's tolerance
+    z, y, u = np.zeros(N), np.zeros(N), np.zeros(N)
+    x0 = np.array([0.1, 0.05, -0.2, 0.1])
+    q = Kx @ x0 + kv * 0.3
+    exact = np.zeros(N)
+    O.lib().oracle_mpc_solve_exact(N, p(P), p(q), C.c_double(bound), p(exact))
+    O.lib().oracle_mpc_admm(N, p(Minv), p(q), C.c_double(rho), C.c_double(bound), 30, p(z), p(y), p(u))
+    O.lib().oracle_mpc_admm(N, p(Minv), p(q), C.c_double(rho), C.c_double(bound), 30, p(z), p(y), p(u))  # the next step's warm start
+    assert abs(z[0] - exact[0]) < 1e-3 * bound
