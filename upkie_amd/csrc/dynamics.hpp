@@ -238,8 +238,25 @@ __device__ __forceinline__ void warm_kernel_arguments() {
       : "s"(args)
       : "memory");
 }
+// The same for a block of BYTES bytes of constants in device memory (the eight-lane kernels' DevParams): one load per
+// 64-byte line, all in flight together, one wait.
+template <int BYTES, class Ptr>
+__device__ __forceinline__ void warm_constant_block(Ptr block) {
+  constexpr int LINES = (BYTES + 63) / 64;
+  static_assert(LINES <= 24, "block larger than the unrolled touch sequence");
+  int sink;
+#define UPKIE_TOUCH(i) \
+  if (LINES > i) asm volatile("s_load_dword %0, %1, %2" : "=&s"(sink) : "s"(block), "n"(64 * i) : "memory");
+  UPKIE_TOUCH(0) UPKIE_TOUCH(1) UPKIE_TOUCH(2) UPKIE_TOUCH(3) UPKIE_TOUCH(4) UPKIE_TOUCH(5) UPKIE_TOUCH(6) UPKIE_TOUCH(7)
+  UPKIE_TOUCH(8) UPKIE_TOUCH(9) UPKIE_TOUCH(10) UPKIE_TOUCH(11) UPKIE_TOUCH(12) UPKIE_TOUCH(13) UPKIE_TOUCH(14) UPKIE_TOUCH(15)
+  UPKIE_TOUCH(16) UPKIE_TOUCH(17) UPKIE_TOUCH(18) UPKIE_TOUCH(19) UPKIE_TOUCH(20) UPKIE_TOUCH(21) UPKIE_TOUCH(22) UPKIE_TOUCH(23)
+#undef UPKIE_TOUCH
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 #else
 __device__ inline void warm_kernel_arguments() {}
+template <int BYTES, class Ptr>
+__device__ inline void warm_constant_block(Ptr) {}
 #endif
 
 // Base frame of a substep, shared by every lane mapping: rotation base -> world

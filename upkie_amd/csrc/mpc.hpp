@@ -60,12 +60,19 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   const bool live = env < B;
   const int N = P.n;
 
-  // A operands: a[t][s] = Minv_perm[16 t + col][4 s + g]
+  // A operands: a[t][s] = Minv_perm[16 t + col][4 s + g], stored lane by lane (mpc_host_setup): the 4 T^2 values of a lane
+  // are contiguous, T^2 16-byte loads (round 2 read them as 16 T^2 strided words: 43 % of the wave's cycles were memory waits)
   float a[T][4 * T];
+  {
+    const float4* mine = reinterpret_cast<const float4*>(P.minv) + (size_t)lane * T * T;
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int s = 0; s < 4 * T; ++s) a[t][s] = P.minv[(size_t)(16 * t + col) * NP + 4 * s + g];
+      for (int s4 = 0; s4 < T; ++s4) {
+        const float4 v = mine[t * T + s4];
+        a[t][4 * s4] = v.x; a[t][4 * s4 + 1] = v.y; a[t][4 * s4 + 2] = v.z; a[t][4 * s4 + 3] = v.w;
+      }
+  }
 
   float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
   float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
@@ -85,30 +92,39 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
       y[t][r] = in ? ws[(size_t)(N + n) * B + env] : 0.f;
     }
 
+  // The ADMM recurrences U <- Minv (rho (z - y) - q); z <- clip(U + y); y <- y + U - z with five VALU instructions per
+  // element and iteration between the MFMAs (round 2: eight): the accumulator starts from y, so the matrix product
+  // delivers w = U + y itself; z = med3(w, -b, b); y' = w - z; and the next right-hand side needs only
+  // z - y' = 2 z - w:  rb' = rho (2 z - w) - q. One dependent chain per wave: what is not MFMA latency is these.
+  const float rho = P.rho, bound = P.bound;
+  float rb[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[t][r] = fmaf(rho, z[t][r] - y[t][r], -q[t][r]);
   for (int it = 0; it < P.iterations; ++it) {
-    float rb[T][4];
+    floatx4 acc0[T], acc1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      // two independent accumulators per tile overlap the MFMA latencies; every tile's products are issued before any is read
+      acc0[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
+      acc1[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4 * T; s += 2) {
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], rb[s / 4][s % 4], acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s + 1], rb[(s + 1) / 4][(s + 1) % 4], acc1[t], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rb[t][r] = P.rho * (z[t][r] - y[t][r]) - q[t][r];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      // two independent accumulators per tile hide the MFMA latency
-      floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4 * T; s += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], rb[s / 4][s % 4], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s + 1], rb[(s + 1) / 4][(s + 1) % 4], acc1, 0, 0, 0);
-      }
-#pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float u = acc0[r] + acc1[r];
-        const float w = u + y[t][r];
-        const float zi = fminf(fmaxf(w, -P.bound), P.bound);
-        y[t][r] = y[t][r] + u - zi;
+        const float w = acc0[t][r] + acc1[t][r];  // U + y
+        const float zi = __builtin_amdgcn_fmed3f(w, -bound, bound);
+        y[t][r] = w - zi;
         z[t][r] = zi;
+        rb[t][r] = fmaf(rho, fmaf(2.f, zi, -w), -q[t][r]);
       }
-    }
   }
 
 #pragma unroll
@@ -240,6 +256,9 @@ inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* 
   minv_perm->assign((size_t)np * np, 0.f);
   kx->assign((size_t)np * 4, 0.f);
   kv->assign(np, 0.f);
+  // Row-permuted, then laid out LANE BY LANE as the kernel consumes it: lane (g, i) = 16 g + i of the wavefront holds
+  // A-operand element a[t][s] = Minv_perm[16 t + i][4 s + g] at [lane][t][s] (4 T^2 contiguous floats per lane)
+  const int tiles = np / 16;
   for (int p = 0; p < np; ++p) {
     const int t = p / 16, i = p % 16;
     const int row = 16 * t + 4 * (i % 4) + i / 4;  // logical row behind permuted row p
@@ -249,7 +268,8 @@ inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* 
         v = Minv[(size_t)row * N + col];
       else
         v = row == col ? 1.0 / (1.0 + c.admm_rho) : 0.0;
-      (*minv_perm)[(size_t)p * np + col] = (float)v;
+      const int s_ = col / 4, group = col % 4, lane = 16 * group + i;
+      (*minv_perm)[((size_t)lane * tiles + t) * 4 * tiles + s_] = (float)v;
     }
   }
   for (int n = 0; n < N; ++n) {

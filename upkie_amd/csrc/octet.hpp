@@ -354,8 +354,8 @@ struct OctLane {
   float total_mass;       // sum of the env's link masses: entry (1,1) of the base block
 };
 
-template <class ModelT>
-UPKIE_HD OctLane load_oct_lane(const ModelT& M, const DevLimits& Lm, const DevConfig& C, int l, int leg, const float* records, size_t stride) {
+template <class ModelT, class LimitsT, class ConfigT>
+UPKIE_HD OctLane load_oct_lane(const ModelT& M, const LimitsT& Lm, const ConfigT& C, int l, int leg, const float* records, size_t stride) {
   // the lane's row of DevModel::oct_table: eight 16-byte loads issued together (cached: eight rows for the whole grid)
   float t[OT_WORDS];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -531,12 +531,19 @@ UPKIE_HD void oct_gauss_jordan(const OctLane& L, float (&D)[3], float (&E)[NE]) 
 template <int K>
 UPKIE_HD float oct_from_joint(float x) { return oct_qb<K + 1>(x); }
 
-template <class ModelT>
-UPKIE_HD void octet_limit_path_registers(const ModelT& M, const DevLimits& Lm, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0,
+template <class ModelT, class LimitsT>
+UPKIE_HD void octet_limit_path_registers(const ModelT& M, const LimitsT& Lm_, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0,
                                float hv1, float hv2, V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active,
                                bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih,
                                float (&xb)[6], float& xl) {
   const bool left = L.leg == 0;
+  DevLimits Lm;  // (a register copy: the limits may sit in the constant address space, limit_path takes plain arrays)
+#pragma unroll
+  for (int j = 0; j < UPKIE_NJ; ++j) {
+    Lm.lower[j] = Lm_.lower[j];
+    Lm.upper[j] = Lm_.upper[j];
+    Lm.bounded[j] = Lm_.bounded[j];
+  }
   System S;
   S.A.l10 = 0.f; S.A.l20 = fac.l20; S.A.l21 = 0.f; S.A.l30 = fac.l30; S.A.l31 = fac.l31; S.A.l32 = fac.l32;
   S.A.l40 = fac.l40; S.A.l41 = 0.f; S.A.l42 = fac.l42; S.A.l43 = fac.l43;
@@ -813,8 +820,8 @@ struct OctRare {  // which rare path the env took this substep, Gauss-Seidel swe
 // joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
 // in the BASE frame and their moment about the base origin, or nullptr.
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
-template <bool LIMITS_IN_REGISTERS = false, class ModelT>
-UPKIE_HD int physics_substep_octet(const ModelT& M, const DevLimits& Lm, const OctLane& L, OctPhys& s, float tau, float h,
+template <bool LIMITS_IN_REGISTERS = false, class ModelT, class LimitsT>
+UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
                                    const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
@@ -1173,17 +1180,31 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
 template <int MODE, bool RAND>
-__global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
-                                                         float* __restrict__ state, const float* __restrict__ act,
+__global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
+                                                         int done_pass, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                          const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                          float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census,
                                                          ServoPolicyArg<MODE> policy_arg) {
-  warm_kernel_arguments();
+  // the handle's limits and config: a block in device memory (L2 hits), read through scalar loads; every line touched up front
+  typedef const __attribute__((address_space(4))) DevParams* ConstParamsPtr;
+  warm_constant_block<sizeof(DevParams)>((ConstParamsPtr)Pp);
+  const auto& Lm = ((ConstParamsPtr)Pp)->limits;
+  const auto& C = ((ConstParamsPtr)Pp)->config;
+  const int autoreset_mode = done_pass ? (int)AUTORESET_DONE_PASS : C.autoreset_mode;  // (the second launch of a SAME_STEP autoreset)
   typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
   const int B = C.num_envs;
+  // what the substep loop reads of the config, fetched once, here, where control flow is still uniform (left to the
+  // compiler the constant block is re-loaded -- and waited for -- in every iteration)
+  int nb_substeps = C.nb_substeps, any_control_noise = C.any_control_noise;
+  float kp_gain = C.kp, kd_gain = C.kd, substep_h = C.h;
+  UPKIE_KEEP_IN_SGPR(nb_substeps);
+  UPKIE_KEEP_IN_SGPR(any_control_noise);
+  UPKIE_KEEP_IN_SGPR(kp_gain);
+  UPKIE_KEEP_IN_SGPR(kd_gain);
+  UPKIE_KEEP_IN_SGPR(substep_h);
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   // row of 16 lanes = quads [env 2r left, env 2r+1 left, env 2r right, env 2r+1 right]
   const int l = tid & 3, quad = (tid >> 2) & 3, leg = quad >> 1;
@@ -1221,7 +1242,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   const auto& M = *(ConstModelPtr)Mp;
   // external forces: those on the trunk enter the substep as one wrench (launches with a force on a leg link use the
   // two-lane kernel: launch_step)
-  const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, &C.ext};
+  const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, nullptr};  // (the slots are read from C.ext below)
 
   float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
   asm volatile("" : "+v"(done_word));
@@ -1290,15 +1311,15 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   // last observation in `final_obs` and goes through the reset branch once more before the kernel returns -- its eight
   // lanes together, the other envs of the wavefront wait masked.
   constexpr bool CAN_RESET_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
-  const bool same_step = CAN_RESET_IN_PLACE && C.autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
+  const bool same_step = CAN_RESET_IN_PLACE && autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
   bool second_pass = false;
 next_step:
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
   } else {
-    do_reset = second_pass || ((C.autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || C.autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f);
-    if (C.autoreset_mode == AUTORESET_DONE_PASS) {
+    do_reset = second_pass || ((autoreset_mode == UPKIE_AUTORESET_NEXT_STEP || autoreset_mode == AUTORESET_DONE_PASS) && done_word != 0.f);
+    if (autoreset_mode == AUTORESET_DONE_PASS) {
       if (final_obs) {  // every env keeps its last observation (see step_kernel)
         constexpr int W = ObsWords<MODE>::value;
         if (MODE == MODE_SERVOS) {
@@ -1401,16 +1422,16 @@ next_step:
   // ---- substeps ------------------------------------------------------------
   float tau = 0.f;
   bool contact = false;
-  const int nsub = do_reset ? 1 : C.nb_substeps;
-  for (int sub = 0; sub < C.nb_substeps; ++sub) {
+  const int nsub = do_reset ? 1 : nb_substeps;
+  for (int sub = 0; sub < nb_substeps; ++sub) {
     if (sub >= nsub) break;
     float noise = 0.f;
-    if (C.any_control_noise && !do_reset) {
+    if (any_control_noise && !do_reset) {
       float zn[6];
       philox_normal6(C, (unsigned)e, step_count, (unsigned)sub, zn);
       noise = L.control_noise * pick6(joint, zn);
     }
-    tau = jointed ? joint_torque(s.q, s.qd, cmd, C.kp, C.kd, L.friction, noise) : 0.f;
+    tau = jointed ? joint_torque(s.q, s.qd, cmd, kp_gain, kd_gain, L.friction, noise) : 0.f;
     ConstModelPtr mp = (ConstModelPtr)Mp;
     asm volatile("" : "+s"(mp));
     const bool forces = RAND && ext.force && !do_reset;  // the reset substep runs without external forces
@@ -1430,7 +1451,7 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, C.h, forces ? wrench : nullptr, limit_ws, &rare_path);
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)
@@ -1581,7 +1602,7 @@ next_step:
       if (packed) {
         float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
         rec[0] = o4;
-        if (C.autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+        if (autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
         return;
       }
       reinterpret_cast<float4*>(obs)[e] = o4;
@@ -1614,7 +1635,7 @@ next_step:
         f2[2] = make_float2(obs6[4], obs6[5]);
       }
     }
-    if (C.autoreset_mode != AUTORESET_DONE_PASS && !second_pass) {  // (the flags are those of the step, not of the reset behind it)
+    if (autoreset_mode != AUTORESET_DONE_PASS && !second_pass) {  // (the flags are those of the step, not of the reset behind it)
       reward[e] = 0.f;
       terminated[e] = fallen ? 1 : 0;
       truncated[e] = timeout ? 1 : 0;

@@ -47,6 +47,15 @@ struct DevConfig {
   ObserverDev spine;  // in-step spine observers (one cycle per physics substep), used when attached
 };
 
+// What the eight-lane step kernels read of a handle's settings, in DEVICE memory (round 3): by value the two structures
+// were 1.2 KB of kernel arguments -- a segment the CPU writes over PCIe for every launch and that is not cached in L2
+// (a dependent scalar load from it costs ~460 cycles, an L2 hit ~160: profiles/r02_kernarg_latency.txt). The host
+// keeps the block current with a small store kernel on the launching stream whenever a setting changed (UpkieSim).
+struct DevParams {
+  DevLimits limits;
+  DevConfig config;
+};
+
 // DevConfig::autoreset_mode value of the second launch of a SAME_STEP autoreset
 // (upkie_sim_autoreset_done): only the envs whose DONE word is set run, down
 // the reset branch of the step that wrote their terminal observation.
@@ -100,7 +109,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 
 enum { STREAM_RESET = 0, STREAM_NOISE = 1, STREAM_INERTIA = 2, STREAM_PUSH = 3 };
 
-__device__ __forceinline__ void philox_uniform4(const DevConfig& C, unsigned env_local, unsigned episode, unsigned stream,
+template <class ConfigT>
+__device__ __forceinline__ void philox_uniform4(const ConfigT& C, unsigned env_local, unsigned episode, unsigned stream,
                                                 unsigned block, float (&u)[4]) {
   unsigned lo = C.env_lo + env_local;
   unsigned hi = C.env_hi + (lo < C.env_lo ? 1u : 0u);
@@ -113,7 +123,8 @@ __device__ __forceinline__ void philox_uniform4(const DevConfig& C, unsigned env
 // Six standard normals for (env, step, slot): Box-Muller on two Philox blocks.
 // slot = substep index (control noise) or NOISE_SLOT_MEASUREMENT.
 #define NOISE_SLOT_MEASUREMENT 0x7fffu
-__device__ __forceinline__ void philox_normal6(const DevConfig& C, unsigned env_local, unsigned step, unsigned slot, float (&z)[6]) {
+template <class ConfigT>
+__device__ __forceinline__ void philox_normal6(const ConfigT& C, unsigned env_local, unsigned step, unsigned slot, float (&z)[6]) {
   unsigned lo = C.env_lo + env_local;
   unsigned hi = C.env_hi + (lo < C.env_lo ? 1u : 0u);
   unsigned r[8];
@@ -168,7 +179,8 @@ __device__ __forceinline__ void quat_mul(const float (&a)[4], const float (&b)[4
 
 // Initial-state sampling: RobotState.sample_state draw order
 // (robot_state.py:182-187) and _reset_robot_state (pybullet_backend.py:234-267).
-__device__ __forceinline__ void sample_init_state(const DevConfig& C, unsigned env_local, unsigned episode, Phys& s) {
+template <class ConfigT>
+__device__ __forceinline__ void sample_init_state(const ConfigT& C, unsigned env_local, unsigned episode, Phys& s) {
   float u0[4], u1[4], u2[4];
   philox_uniform4(C, env_local, episode, STREAM_RESET, 0, u0);
   philox_uniform4(C, env_local, episode, STREAM_RESET, 1, u1);
@@ -879,7 +891,7 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
 #define UPKIE_PROBE_RAND false
 #endif
 template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
-    const upkie::DevModel*, upkie::DevLimits, upkie::DevConfig, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
+    const upkie::DevModel*, const upkie::DevParams*, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
     const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>);
 #else
 // =========================================================== C-ABI (host)
@@ -897,6 +909,13 @@ struct UpkieSim {
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
+  // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
+  // stream when a setting changed or the stream did (a launch still running on the other stream keeps its block:
+  // up to two streams may step one handle at a time)
+  DevParams* d_params[2] = {nullptr, nullptr};
+  int params_slot = 0;
+  bool params_dirty = true;
+  void* params_stream = nullptr;
   std::string error;
 };
 
@@ -1164,9 +1183,12 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
   if (const char* forced = std::getenv("UPKIE_LANES_PER_ENV")) sim->lanes_per_env = std::atoi(forced);
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
+  for (int i = 0; i < 2 && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
   if (err != hipSuccess) {
     std::string msg = std::string("hipMalloc/hipMemcpy(model): ") + hipGetErrorString(err);
     if (sim->d_model) (void)hipFree(sim->d_model);
+    for (int i = 0; i < 2; ++i)
+      if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
     delete sim;
     return fail(nullptr, UPKIE_ERR_HIP, msg);
   }
@@ -1183,11 +1205,14 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
   next.ext = sim->config.ext;
   next.spine = sim->config.spine;
   sim->config = next;
+  sim->params_dirty = true;
   return UPKIE_OK;
 }
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
+  for (int i = 0; sim && i < 2; ++i)
+    if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
   delete sim;
   return UPKIE_OK;
 }
@@ -1211,6 +1236,7 @@ extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* body_iner
   x = ExtSlots{};
   x.count = ext_force ? 1 : 0;
   for (int k = 0; k < 3; ++k) x.point[0][k] = ext_point ? (float)ext_point[k] : 0.f;
+  sim->params_dirty = true;
   return UPKIE_OK;
 }
 
@@ -1233,6 +1259,7 @@ extern "C" int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
     sim->ext_force = nullptr;
   }
   sim->config.ext = x;
+  sim->params_dirty = true;
   return UPKIE_OK;
 }
 
@@ -1306,6 +1333,27 @@ extern "C" int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs) 
   return UPKIE_OK;
 }
 
+__global__ void store_params_kernel(DevParams params, DevParams* out) {
+  const unsigned* from = reinterpret_cast<const unsigned*>(&params);
+  unsigned* to = reinterpret_cast<unsigned*>(out);
+  for (int i = threadIdx.x; i < (int)(sizeof(DevParams) / sizeof(unsigned)); i += blockDim.x) to[i] = from[i];
+}
+
+// The device block holding this handle's current {limits, config}, valid for launches on `stream` from here on.
+static const DevParams* current_params(UpkieSim* sim, void* stream) {
+  if (sim->params_dirty || stream != sim->params_stream) {
+    sim->params_slot ^= 1;
+    DevParams block;
+    block.limits = sim->limits;
+    block.config = sim->config;
+    // (as a kernel argument, not a host-to-device copy: ordered on the stream, capturable in a hipGraph, no host buffer to keep alive)
+    hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[sim->params_slot]);
+    sim->params_dirty = false;
+    sim->params_stream = stream;
+  }
+  return sim->d_params[sim->params_slot];
+}
+
 template <int MODE>
 static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, const uint8_t* mask, void* stream, int packed = 0,
@@ -1348,8 +1396,8 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
 #define UPKIE_LAUNCH_OCTET(R)                                                                                                \
   hipLaunchKernelGGL((step_kernel_octet<MODE, R>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
-                     sim->d_model, sim->limits, config, state, act, obs, reward, terminated, truncated, mask, scale, force, packed, bv, \
-                     final_obs, n_steps, sim->census, policy_arg)
+                     sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, state, act, obs, reward, terminated, truncated, mask, scale, \
+                     force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
   const bool spine = sim->spine_state != nullptr;
   ServoPolicyArg<MODE> policy_arg{};
   if constexpr (MODE == MODE_SERVOS) {
@@ -1744,6 +1792,7 @@ extern "C" int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConf
   dev.num_envs = sim->config.num_envs;
   sim->config.spine = dev;
   sim->spine_state = observer_state;
+  sim->params_dirty = true;
   return UPKIE_OK;
 }
 
