@@ -193,7 +193,9 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     us = wall / steps * 1e6
     out = {
         "config": "C3: UpkieBaseVelocity + MPC balancer N = 16 (30 ADMM iterations, v_mfma_f32_16x16x4_f32), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
-                  "two launches per env.step() (upkie_mpc_step_env + upkie_sim_step_base_velocity), Python loop",
+                  + ("ONE launch per env.step() (upkie_sim_step_base_velocity_mpc: the balancer's QPs solved by the step's own wavefronts)" if env.fuse_mpc
+                     else "two launches per env.step() (upkie_mpc_step_env + upkie_sim_step_base_velocity)") + ", Python loop",
+        "launches_per_step": 1 if env.fuse_mpc else 2,
         "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
         "lanes_per_env": env.sim.lanes_per_env, "episodes": int(env.sim.state[40].sum().item()),
         "algorithmic_bytes_per_env_step": C3_BYTES_PER_ENV_STEP,

@@ -46,7 +46,9 @@ __device__ __forceinline__ int mpc_index(int t, int g, int r) { return 16 * t + 
 // MPCBalancer.step of the 16 envs env0 .. env0 + 15 by one wavefront (all 64
 // lanes must be active). `handover`: 16 floats (LDS) that receive the commanded
 // velocities as well, for a step fused behind the solve in the same launch.
-template <int T>
+// COLUMNS: how many of the tile's 16 columns carry an env (16; 8 when the eight-lane step kernel solves the QPs of
+// its wavefront's eight envs in front of their step: the other columns compute on zeros).
+template <int T, int COLUMNS = 16>
 __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
                                          const float* __restrict__ v_target, int v_target_stride,
                                          const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
@@ -57,7 +59,7 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   const int col = lane & 15, g = lane >> 4;
   const int B = P.num_envs;
   const int env = env0 + col;
-  const bool live = env < B;
+  const bool live = col < COLUMNS && env < B;
   const int N = P.n;
 
   // A operands: a[t][s] = Minv_perm[16 t + col][4 s + g], stored lane by lane (mpc_host_setup): the 4 T^2 values of a lane

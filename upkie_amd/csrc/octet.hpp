@@ -436,6 +436,10 @@ struct OctPhys {
   float qw, qx, qy, qz;
   V3 linvel, angvel;
   float q, qd;  // own joint (trunk lane: 0)
+  // Gauss-Seidel warm start across the substeps of a launch (not part of the stored state): the impulse of the own
+  // contact row the sweeps of the PREVIOUS substep ended on, and whether they ran with both tires on the floor
+  float lam_prev = 0.f;
+  int swept_prev = 0;  // 0: the previous substep did not sweep; 1 / 2: it did, with one / both tires touching
 };
 
 // 6x6 LDL' of the base block of a robot whose legs move in the sagittal plane:
@@ -986,6 +990,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   float xb[6];   // base velocity change
   float tlc = tl;  // own joint impulse incl. contacts
   float xl = 0.f;  // own joint velocity change
+  int swept_now = 0;
+  float lam_now = 0.f;
   if (__builtin_expect(at_a_stop, 0)) {
     if (census) census->path = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
@@ -1114,7 +1120,13 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
             const float p1 = oct_swp(r1), p2 = oct_swp(r2), p3 = oct_swp(r3);
             rhs6[0] = left ? r1 : p1; rhs6[1] = left ? r2 : p2; rhs6[2] = left ? r3 : p3;
             rhs6[3] = left ? p1 : r1; rhs6[4] = left ? p2 : r2; rhs6[5] = left ? p3 : r3;
-            const float l1 = oct_qb<1>(lam), l2 = oct_qb<2>(lam), l3 = oct_qb<3>(lam);
+            // Warm start: the projected direct solution, or -- when the previous substep swept too, with the same tires
+            // on the floor -- the impulses it converged to: a robot that skids or tumbles does so for many substeps in
+            // a row and its contact state changes little from one millisecond to the next (same fixed point, fewer
+            // sweeps: the sweeps stop on their own convergence test either way)
+            const bool from_previous = s.swept_prev == (both ? 2 : 1);
+            const float start = from_previous ? s.lam_prev : lam;
+            const float l1 = oct_qb<1>(start), l2 = oct_qb<2>(start), l3 = oct_qb<3>(start);
             const float q1 = oct_swp(l1), q2 = oct_swp(l2), q3 = oct_swp(l3);
             lam6[0] = left ? l1 : q1; lam6[1] = left ? l2 : q2; lam6[2] = left ? l3 : q3;
             lam6[3] = left ? q1 : l1; lam6[4] = left ? q2 : l2; lam6[5] = left ? q3 : l3;
@@ -1133,10 +1145,12 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
           lam = left ? mine_l : mine_r;
+          swept_now = both ? 2 : 1;
           }
         }
       }
     }
+    lam_now = lam;
     // nu+ = A^-1 rt + sum_b lam_b Y_b: the trunk lane's Y is the free part (counted once)
     const float wgt = L.l == 0 ? L.w0_once : lam;  // (the trunk lane's own `lam` is the by-product of rows it does not have)
 #pragma unroll
@@ -1164,6 +1178,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     s.qd = L.wj * v;
     s.q = fmaf(h, s.qd, s.q);
   }
+  s.lam_prev = lam_now;
+  s.swept_prev = swept_now;
   const float n0 = vB.x + xb[0], n1 = vB.y + xb[1], n2 = vB.z + xb[2];
   const float n3 = wB.x + xb[3], n4 = wB.y + xb[4], n5 = wB.z + xb[5];
   integrate_base(bf, n0, n1, n2, n3, n4, n5, h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
@@ -1205,6 +1221,17 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   UPKIE_KEEP_IN_SGPR(kp_gain);
   UPKIE_KEEP_IN_SGPR(kd_gain);
   UPKIE_KEEP_IN_SGPR(substep_h);
+  // UpkieBaseVelocity with its MPC balancer in the same launch (upkie_sim_step_base_velocity_mpc): the wavefront first
+  // solves the condensed QPs of its eight envs on the matrix cores -- columns 0-7 of one 16-column MFMA tile, all 64
+  // lanes at work under the tile's own lane mapping (mpc_tile) -- and hands the commanded velocities to the lanes that
+  // step those envs through LDS. (One launch instead of two: no second dispatch, no second prologue; the solve is a
+  // 30-iteration dependent chain, so its half-empty tile costs the wavefront nothing.)
+  __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 16 : 1];
+  if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
+    const float* done_row = autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
+    mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)blockIdx.x, mpc_velocity);
+    __syncthreads();
+  }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   // row of 16 lanes = quads [env 2r left, env 2r+1 left, env 2r right, env 2r+1 right]
   const int l = tid & 3, quad = (tid >> 2) & 3, leg = quad >> 1;
@@ -1260,7 +1287,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
       act1 = a.y;
     }
   } else if (MODE == MODE_BASE_VELOCITY) {
-    act0 = bv.commanded[e];
+    act0 = bv.mpc_fused ? mpc_velocity[e & 7] : bv.commanded[e];
     act1 = act[2 * (size_t)e + 1];
   }
 
@@ -1314,6 +1341,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   const bool same_step = CAN_RESET_IN_PLACE && autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
   bool second_pass = false;
 next_step:
+  s.swept_prev = 0;  // the sweeps' warm start spans the substeps of ONE env.step(): several steps in a launch = as many launches, bit for bit
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;

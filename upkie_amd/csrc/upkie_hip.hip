@@ -893,6 +893,7 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
 template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
     const upkie::DevModel*, const upkie::DevParams*, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
     const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>);
+template __global__ void upkie::mpc_step_kernel<1>(upkie::MpcDev, float*, const float*, const float*, int, const uint8_t*, const float*, float, float*, float*);
 #else
 // =========================================================== C-ABI (host)
 using namespace upkie;
@@ -1295,10 +1296,15 @@ static const int kDenseBatch = 131072;
 // up to this many envs two lanes per env still fit one wave per SIMD (1024 SIMDs x 64 lanes / 2)
 static const int kPairBatch = 32768;
 
-// up to this many envs eight lanes per env (step_kernel_octet) are one wave per SIMD (1024 SIMDs x 64 lanes / 8). The kernel
-// fits 256 registers, but a second wave per SIMD buys little (the stream is issue bound): 26.1 us at 16384 envs against the
-// two-lane kernel's 25.7 (profiles/r02_batch_sweep_lanes.txt)
-static const int kOctetBatch = 8192;
+// up to this many envs the eight-lane kernel (step_kernel_octet) is at least as fast as the two-lane one: one wave per
+// SIMD up to 8192 envs (16.5 us), two from there to 16384, where both mappings take 25.3 us -- the two co-resident
+// waves do overlap, but the SIMD's issue port is then busy for the whole launch (profiles/r03_two_waves_per_simd_pmc.json)
+// -- and the eight-lane kernel is the one that can carry the MPC balancer (upkie_sim_step_base_velocity_mpc) and the
+// SAME_STEP autoreset inside its launch
+static const int kOctetBatch = 16384;
+// ... except the Servos kernels, which take the whole 512-entry register file (joint stops solved in registers): one
+// wave per SIMD, 8192 envs
+static const int kOctetBatchServos = 8192;
 
 // Lanes per env of a step launch: eight (one quad per leg, one lane per body:
 // octet.hpp) while that leaves the chip under-subscribed, two (one lane per
@@ -1370,7 +1376,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
   constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
   const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
-  const bool same_step_in_kernel = same_step && mapped_lanes(sim) == 8;
+  const bool same_step_in_kernel = same_step && mapped_lanes(sim) == 8 && !(MODE == MODE_SERVOS && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos);
   if (same_step_in_kernel) final_obs = sim->final_obs;
   const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
@@ -1399,11 +1405,13 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
                      sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
   const bool spine = sim->spine_state != nullptr;
+  int lanes = mapped_lanes(sim);
+  if (MODE == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
   ServoPolicyArg<MODE> policy_arg{};
   if constexpr (MODE == MODE_SERVOS) {
     if (policy) policy_arg = *policy;
   }
-  if (mapped_lanes(sim) == 8) {
+  if (lanes == 8) {
     if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
   } else if (paired) {
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
@@ -1528,7 +1536,7 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
 extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
                                             uint8_t* terminated, uint8_t* truncated, void* stream) {
   if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  if (mapped_lanes(sim) != 8) {  // the other mappings: the policy's own launch into `act`, then the step
+  if (mapped_lanes(sim) != 8 || (sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos)) {  // the other mappings: the policy's own launch into `act`, then the step
     const int status = upkie_sim_servo_policy(sim, state, policy, act, stream);
     if (status != UPKIE_OK) return status;
     return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);
@@ -1698,7 +1706,7 @@ extern "C" int upkie_sim_step_base_velocity_mpc(UpkieSim* sim, UpkieMpc* mpc, fl
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
   if (mpc->dev.num_envs != sim->config.num_envs) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "balancer and simulation differ in num_envs");
   if (!(sim->config.dt / 0.1 < 0.5)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
-  if (mapped_lanes(sim) == 2 && mpc->tiles == 1) {
+  if ((mapped_lanes(sim) == 2 || mapped_lanes(sim) == 8) && mpc->tiles == 1) {
     BaseVelocityPtrs bv{commanded_velocity, mpc_x0, mpc_contact};
     bv.mpc_fused = 1;
     bv.mpc = mpc->dev;

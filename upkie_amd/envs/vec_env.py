@@ -487,10 +487,12 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
         self._x0 = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
         self._contact = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._xy = torch.zeros((B, 2), dtype=torch.float32, device=self.device)
-        # balancer and step in ONE launch (upkie_sim_step_base_velocity_mpc) instead of two: same bits, but measured SLOWER at
-        # 16384 envs (37.9 vs 35.6 us: the wavefront that steps 32 envs solves their two MPC tiles one after the other, the
-        # separate kernel spreads them over twice as many wavefronts; profiles/r02_secondary_configs_c.jsonl): off by default
-        self.fuse_mpc = False
+        # balancer and step in ONE launch (upkie_sim_step_base_velocity_mpc) instead of two, same bits: on by default where
+        # the eight-lane kernel steps the batch (up to 16384 envs: a wavefront solves the QPs of its eight envs as one
+        # half-filled MFMA tile in front of their step); off on the two-lane mapping, where it measured SLOWER (37.9 vs
+        # 35.6 us at 16384 envs: a wavefront that steps 32 envs solves two tiles one after the other, the separate kernel
+        # spreads them over twice as many wavefronts; profiles/r02_secondary_configs_c.jsonl)
+        self.fuse_mpc = getattr(self.sim, "lanes_per_env", 0) == 8
 
     def _remember(self, obs6: torch.Tensor) -> None:
         # MPC state [ground position, pitch, ground velocity, pitch rate] of the
