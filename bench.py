@@ -471,6 +471,13 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
             "valu": valu_roofline(pmc, launch_us),
         },
     }
+    if env.gather.collectives:
+        # DESIGN.md section 7's model, printed beside the measurement so that a multi-GPU run can be judged against it:
+        # ranks share nothing but one asynchronous gather per chunk of K steps, which costs ~27 us of queue time whatever
+        # its size (profiles/r01_gather_chunk_sweep.txt, one-rank RCCL group) => N-GPU weak-scaling efficiency
+        # ~ K t_step / (K t_step + 27 us), independent of N (0.983 measured at K = 64 on one rank)
+        k_steps, t_step = env.gather.chunk, launch_us * 1e-6 * (launches / args.steps)
+        line["config"]["predicted_weak_scaling_efficiency"] = k_steps * t_step / (k_steps * t_step + 27e-6)
     if steady is not None:
         s_elapsed, s_ms, s_launches, s_resets = steady
         s_launch_us = s_ms * 1e3 / s_launches

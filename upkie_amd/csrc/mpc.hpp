@@ -108,15 +108,22 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
     floatx4 acc0[T], acc1[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      // two independent accumulators per tile overlap the MFMA latencies; every tile's products are issued before any is read
+      // Two accumulator chains per tile overlap the MFMA latencies. Accumulators in VGPRs (gfx950's register file is
+      // unified; hipcc keeps MFMA results in AGPRs and pays twelve v_accvgpr moves per iteration, and its
+      // -amdgpu-mfma-vgpr-form option allocates a destination that PARTLY overlaps the C operand, which the hardware
+      // does not allow): written as inline asm with the destination tied to C. The wait states the hazard recogniser
+      // would insert are written out: VALU write -> MFMA read of rb (s_nop 1), MFMA write -> VALU read (s_nop 12).
       acc0[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
-      acc1[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][0]), "v"(rb[0][0]));
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rb[0][1]));
 #pragma unroll
-      for (int s = 0; s < 4 * T; s += 2) {
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], rb[s / 4][s % 4], acc0[t], 0, 0, 0);
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s + 1], rb[(s + 1) / 4][(s + 1) % 4], acc1[t], 0, 0, 0);
+      for (int s = 2; s < 4 * T; s += 2) {
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rb[s / 4][s % 4]));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rb[(s + 1) / 4][(s + 1) % 4]));
       }
     }
+#pragma unroll
+    for (int t = 0; t < T; ++t) asm volatile("s_nop 12" : "+v"(acc0[t]), "+v"(acc1[t]));
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll

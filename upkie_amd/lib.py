@@ -104,10 +104,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # SLP-packing scalar fp32 chains into v_pk_* costs ~1700 v_mov and
             # 180 extra registers in the step kernel (tools/isa_stats.sh)
             "-fno-slp-vectorize",
-            # MFMA accumulators in VGPRs (gfx950's register file is unified): the MPC kernel's ADMM loop loses twelve
-            # v_accvgpr_read / _write per iteration (41 -> 29 instructions)
-            "-mllvm",
-            "-amdgpu-mfma-vgpr-form=1",
             "-shared",
             "-fPIC",
             SOURCES[0],
