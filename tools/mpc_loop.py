@@ -12,6 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
 env = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=B, frequency=200.0, nb_timesteps=16, init_state=init)
 env.reset(seed=0)
+env.fuse_mpc = "--fused" in sys.argv  # default: the balancer as its own launch (mpc_step_kernel), what tools/pmc_mpc.sh profiles
 act = torch.zeros(B, 2, device="cuda:0")
 act[:, 0] = torch.empty(B, device="cuda:0").uniform_(-0.5, 0.5)
 for _ in range(50):

@@ -20,6 +20,6 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- \
-    python $R/bench.py --steps 128 --warmup 64 --no-cpu-baseline --no-fused "$@" > $OUT/pass$i.log 2>&1
+    python $R/bench.py --steps 128 --warmup 64 --no-cpu-baseline --no-fused --no-steady-state --no-secondary "$@" > $OUT/pass$i.log 2>&1
 done
 ls -R $OUT | head -40

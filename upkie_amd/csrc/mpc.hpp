@@ -81,6 +81,10 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   // envs that the coming env.step() will reset: MPCBalancer.reset() instead of
   // a solve (upkie_base_velocity.py:158): zero warm start, zero velocity
   const bool resetting = live && done != nullptr && done[env] != 0.f;
+  // (fetched with everything else: read after the loop, each of the two would be a memory round trip of its own at the end)
+  float v_before = live ? commanded[env] : 0.f;
+  unsigned touching = live ? contact[env] : 0u;
+  asm volatile("" : "+v"(v_before), "+v"(touching));  // pins the loads here
   float q[T][4], z[T][4], y[T][4];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -150,10 +154,10 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
     const float u0 = z[0][0];  // plan.first_input, mpc_balancer.py:307
     if (first_input) first_input[env] = u0;
     const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
-    float v = commanded[env];
+    float v = v_before;
     if (resetting) {
       v = 0.f;  // mpc_balancer.py:232
-    } else if (fallen || !contact[env]) {
+    } else if (fallen || !touching) {
       v = v + (dt / 0.1f) * (0.f - v);  // :295-301
     } else {
       v = v + u0 * dt / 2.0f;  // :305-311
@@ -170,7 +174,10 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
                                                        const uint8_t* __restrict__ contact,
                                                        const float* __restrict__ done, float dt,
                                                        float* __restrict__ commanded, float* __restrict__ first_input) {
-  mpc_tile<T>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, blockIdx.x * 16, nullptr);
+  // (XCD-aware: the two wavefronts that share a 128-byte line of a workspace row run on one XCD, see step_kernel_octet)
+  unsigned block = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
+  mpc_tile<T>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16, nullptr);
 }
 
 

@@ -1226,13 +1226,20 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   // lanes at work under the tile's own lane mapping (mpc_tile) -- and hands the commanded velocities to the lanes that
   // step those envs through LDS. (One launch instead of two: no second dispatch, no second prologue; the solve is a
   // 30-iteration dependent chain, so its half-empty tile costs the wavefront nothing.)
+  // Which eight envs this wavefront steps. Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md) and
+  // every XCD has its own L2: with envs handed out in launch order the four wavefronts that share a 128-byte line of a
+  // state row (32 envs) sit on four different XCDs and each L2 fetches -- and writes back -- the whole line for its
+  // 32 bytes. Swizzled, XCD x owns one contiguous eighth of the batch: a line lives in one L2. (A speed matter only:
+  // any placement gives the same results.)
+  unsigned block = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
   __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 16 : 1];
   if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
     const float* done_row = autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
-    mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)blockIdx.x, mpc_velocity);
+    mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)block, mpc_velocity);
     __syncthreads();
   }
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tid = block * blockDim.x + threadIdx.x;
   // row of 16 lanes = quads [env 2r left, env 2r+1 left, env 2r right, env 2r+1 right]
   const int l = tid & 3, quad = (tid >> 2) & 3, leg = quad >> 1;
   const int e = (tid >> 4) * 2 + (quad & 1);
