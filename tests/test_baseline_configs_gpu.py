@@ -198,11 +198,11 @@ def test_c5_servos_share_4096_envs_matches_oracle():
     # loosely and the typical one tightly (measured on 24576 joint values: 2 beyond 1e-3 rad, worst 2.5e-3)
     dq = np.abs(sh[:, :, 0] - so[:, :, 0])
     assert dq[:, [0, 1, 3, 4]].max() <= 1e-3, dq.max(axis=0)  # hips and knees (position controlled)
-    assert dq[:, [2, 5]].max() <= 2e-2 and np.quantile(dq[:, [2, 5]], 0.999) <= 1e-3 and np.quantile(dq, 0.5) <= 1e-5, (dq.max(axis=0), np.quantile(dq, [0.5, 0.99, 0.999]))
+    assert dq[:, [2, 5]].max() <= 1e-2 and np.quantile(dq[:, [2, 5]], 0.999) <= 1e-3 and np.quantile(dq, 0.5) <= 1e-5, (dq.max(axis=0), np.quantile(dq, [0.5, 0.99, 0.999]))
     dv = np.abs(sh[:, [0, 1, 3, 4], 1] - so[:, [0, 1, 3, 4], 1])  # hip / knee velocities (measured: 1 of 16384 beyond 2e-2, at 3.3e-2)
-    assert dv.max() <= 0.1 and np.quantile(dv, 0.999) <= 2e-2 and np.quantile(dv, 0.5) <= 1e-4, (dv.max(), np.quantile(dv, [0.5, 0.99, 0.999]))
+    assert dv.max() <= 0.1 and np.quantile(dv, 0.999) <= 2e-3 and np.quantile(dv, 0.5) <= 1e-4, (dv.max(), np.quantile(dv, [0.5, 0.99, 0.999]))  # round 3: p99.9 1.5e-4
     dw = np.abs(sh[:, [2, 5], 1] - so[:, [2, 5], 1])
-    assert dw.max() <= 2.0 and np.quantile(dw, 0.999) <= 0.2, (dw.max(), np.quantile(dw, [0.5, 0.99, 0.999]))  # wheel velocities: rim speed / 0.05 m
+    assert dw.max() <= 0.5 and np.quantile(dw, 0.999) <= 0.05, (dw.max(), np.quantile(dw, [0.5, 0.99, 0.999]))  # wheel velocities: rim speed / 0.05 m (round 3: worst 0.11 rad/s, p99.9 1e-2)
     dt = np.abs(sh[:, [2, 5], 2] - so[:, [2, 5], 2])  # wheel torques = clipped feedforward -+ 0.1 N.m of friction, whose sign switches on at |qd| = 1e-3 rad/s
     assert dt.max() <= 0.2 + 1e-3 and (dt > 1e-3).sum() <= 4, (dt.max(), (dt > 1e-3).sum())
     assert np.abs(sh[:, [2, 5], 2]).max() <= 1.7 + 1e-6 and int(term.max()) == 0

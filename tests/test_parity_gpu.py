@@ -106,10 +106,11 @@ def test_closed_loop_200_steps_matches_oracle():
         obs_o, _, term_o, _ = oracle.step_pendulum_agent(obs_o)
         obs_h, _, term_h, _ = sim.step_pendulum_agent()
     obs_h = obs_h.cpu().numpy()
-    assert np.max(np.abs(obs_h[:, 0] - obs_o[:, 0])) <= 1e-3  # pitch, rad
-    assert np.max(np.abs(obs_h[:, 1] - obs_o[:, 1])) <= 1e-3  # position, m
-    assert np.max(np.abs(obs_h[:, 2] - obs_o[:, 2])) <= 2e-2  # pitch rate
-    assert np.max(np.abs(obs_h[:, 3] - obs_o[:, 3])) <= 1e-2  # velocity
+    # measured in round 3 (tools/parity_margins.py, profiles/r03_parity_margins.txt): 9e-7 rad, 6e-6 m, 1.1e-5 rad/s, 8e-6 m/s
+    assert np.max(np.abs(obs_h[:, 0] - obs_o[:, 0])) <= 1e-5  # pitch, rad
+    assert np.max(np.abs(obs_h[:, 1] - obs_o[:, 1])) <= 3e-5  # position, m
+    assert np.max(np.abs(obs_h[:, 2] - obs_o[:, 2])) <= 1e-4  # pitch rate
+    assert np.max(np.abs(obs_h[:, 3] - obs_o[:, 3])) <= 1e-4  # velocity
     assert np.array_equal(term_h.cpu().numpy(), term_o)
 
 
@@ -124,7 +125,8 @@ def test_gyropod_step_matches_oracle():
         obs_h, _, term_h, _ = sim.step_gyropod(torch.from_numpy(act))
     # random +-1.5 m/s commands saturate the wheel torque: see the saturated
     # actions test for why a few envs can only agree loosely
-    assert_mostly_close(obs_h.cpu().numpy(), obs_o, atol=2e-3, fraction=0.97, hard_atol=0.1)
+    # (measured in round 3: median 1.2e-5, p97 3e-4, worst env 9.9e-4 -- profiles/r03_parity_margins.txt)
+    assert_mostly_close(obs_h.cpu().numpy(), obs_o, atol=1e-3, fraction=0.99, hard_atol=4e-3)
     err = state_errors(oracle.state, sim.state_numpy())
     assert err["yaw"] < 1e-6 and err["pos"] < 1e-3, err
 
@@ -150,8 +152,9 @@ def test_servos_step_matches_oracle():
         obs_h, _, term_h, _ = sim.step_servos(torch.from_numpy(act))
     obs_h = obs_h.cpu().numpy()
     np.testing.assert_allclose(obs_h[:, :, 0], obs_o[:, :, 0], atol=2e-5)  # position
-    assert_mostly_close(obs_h[:, :, 1], obs_o[:, :, 1], atol=1e-2, fraction=0.99, hard_atol=0.1)  # velocity
-    assert_mostly_close(obs_h[:, :, 2], obs_o[:, :, 2], atol=1e-2, fraction=0.99, hard_atol=0.1)  # torque
+    # measured in round 3: velocity median 2e-5, p99 2.1e-3, worst 9e-3 rad/s; torque median 4e-6, p99 4.3e-3, worst 2.7e-2 N m
+    assert_mostly_close(obs_h[:, :, 1], obs_o[:, :, 1], atol=5e-3, fraction=0.99, hard_atol=3e-2)  # velocity
+    assert_mostly_close(obs_h[:, :, 2], obs_o[:, :, 2], atol=1e-2, fraction=0.99, hard_atol=6e-2)  # torque
     assert np.all(obs_h[:, :, 3] == 42.0) and np.all(obs_h[:, :, 4] == 18.0)
     assert int(term_h.max()) == 0
 
@@ -227,7 +230,7 @@ def test_autoreset_next_step():
         resets += int(term_o.sum())
     assert resets > 64  # every env fell and was reset at least once
     # a fall threshold crossed within rounding can shift one env by a step
-    assert in_sync.mean() >= 0.9
+    assert in_sync.mean() >= 0.96  # (measured in round 3: every env in step with the oracle)
     episodes_o = oracle.state[abi.S_EPISODE]
     episodes_h = sim.state_numpy()[abi.S_EPISODE]
     assert np.array_equal(episodes_o[in_sync], episodes_h[in_sync])

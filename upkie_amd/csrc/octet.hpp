@@ -814,6 +814,24 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
+// The model scalars the COMMON path of a substep reads, fetched once per launch and kept in scalar registers: read
+// from the model where they are used, each costs the lone wavefront a scalar-cache round trip per substep
+// (five to six waits of 100-200 cycles per substep: a seventh of the launch).
+struct OctScalars {
+  float gravity, wheel_radius, contact_breaking_threshold, friction_cfm, friction_mu, max_joint_velocity;
+};
+template <class ModelT>
+UPKIE_HD OctScalars load_oct_scalars(const ModelT& M) {
+  OctScalars H{M.gravity, M.wheel_radius, M.contact_breaking_threshold, M.friction_cfm, M.friction_mu, M.max_joint_velocity};
+  UPKIE_KEEP_IN_SGPR(H.gravity);
+  UPKIE_KEEP_IN_SGPR(H.wheel_radius);
+  UPKIE_KEEP_IN_SGPR(H.contact_breaking_threshold);
+  UPKIE_KEEP_IN_SGPR(H.friction_cfm);
+  UPKIE_KEEP_IN_SGPR(H.friction_mu);
+  UPKIE_KEEP_IN_SGPR(H.max_joint_velocity);
+  return H;
+}
+
 // Substep outcomes (returned) and rare paths taken (reported through `census`).
 enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
 struct OctRare {  // which rare path the env took this substep, Gauss-Seidel sweeps it ran (two registers, never memory)
@@ -825,7 +843,7 @@ struct OctRare {  // which rare path the env took this substep, Gauss-Seidel swe
 // in the BASE frame and their moment about the base origin, or nullptr.
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
 template <bool LIMITS_IN_REGISTERS = false, class ModelT, class LimitsT>
-UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
+UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
                                    const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
@@ -837,7 +855,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   // ---- base frame ----------------------------------------------------------
   const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
-  const V3 gn = M.gravity * nB;
+  const V3 gn = H.gravity * nB;
 
   // ---- kinematics along the chain (prefix sums over the quad) -----------------
   const float psi = L.keep_psi * oct_chain(L.sg * s.q);
@@ -981,9 +999,9 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   const float ih = L.inv_h, erp = L.erp, cfm = L.cfm;  // of this launch's h (load_oct_lane)
   const V3 ow = v3(oct_qb<3>(o.x), oct_qb<3>(o.y), oct_qb<3>(o.z));
   const V3 center = ow + v3(L.wheel_center[0], L.wheel_center[1], L.wheel_center[2]);
-  const V3 Pc = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
+  const V3 Pc = center + H.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
   const float dist = s.pos.z + dot(nB, Pc);
-  const bool active = un >= 1e-6f && dist <= M.contact_breaking_threshold;
+  const bool active = un >= 1e-6f && dist <= H.contact_breaking_threshold;
   const bool active_partner = oct_swp(active ? 1.f : 0.f) != 0.f;
   const bool both = active && active_partner;
 
@@ -1049,8 +1067,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
       oct_rows9(Dg, Jt, Y, Jl, Kv);
     }
     Dg[0] = active ? fmaf(L.e[0], cfm, Dg[0]) : L.e[0];
-    Dg[1] = active ? fmaf(L.e[1], M.friction_cfm, Dg[1]) : L.e[1];
-    Dg[2] = active ? fmaf(L.e[2], M.friction_cfm, Dg[2]) : L.e[2];
+    Dg[1] = active ? fmaf(L.e[1], H.friction_cfm, Dg[1]) : L.e[1];
+    Dg[2] = active ? fmaf(L.e[2], H.friction_cfm, Dg[2]) : L.e[2];
     float JtP[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) JtP[i] = oct_swp(Jt[i]);
@@ -1081,7 +1099,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     // on it (contact_pgs6: same rows, same order), every lane of the env in lockstep on identical data
     {
       const float lam_n = oct_qb<1>(lam);
-      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
+      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > H.friction_mu * lam_n);
       if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
           if (census) census->path = OCT_NOT_MINE_INFEASIBLE;
@@ -1174,7 +1192,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 
   // ---- integrate --------------------------------------------------------------------
   {
-    const float v = fminf(fmaxf(s.qd + xl, -M.max_joint_velocity), M.max_joint_velocity);
+    const float v = fminf(fmaxf(s.qd + xl, -H.max_joint_velocity), H.max_joint_velocity);
     s.qd = L.wj * v;
     s.q = fmaf(h, s.qd, s.q);
   }
@@ -1274,6 +1292,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B);
   const auto& M = *(ConstModelPtr)Mp;
+  const OctScalars H = load_oct_scalars(M);
   // external forces: those on the trunk enter the substep as one wrench (launches with a force on a leg link use the
   // two-lane kernel: launch_step)
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, nullptr};  // (the slots are read from C.ext below)
@@ -1486,7 +1505,7 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, H, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)

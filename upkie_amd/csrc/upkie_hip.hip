@@ -913,10 +913,11 @@ struct UpkieSim {
   // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
   // stream when a setting changed or the stream did (a launch still running on the other stream keeps its block:
   // up to two streams may step one handle at a time)
-  DevParams* d_params[2] = {nullptr, nullptr};
+  DevParams* d_params[3] = {nullptr, nullptr, nullptr};  // [2]: the block of launches recorded into a hipGraph
   int params_slot = 0;
-  bool params_dirty = true;
+  unsigned long long params_version = 1, eager_version = 0, capture_version = 0;  // settings changed / last uploaded
   void* params_stream = nullptr;
+  unsigned long long capture_id = ~0ull;  // the hipGraph capture whose launches read d_params[2]
   std::string error;
 };
 
@@ -1184,11 +1185,11 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
   if (const char* forced = std::getenv("UPKIE_LANES_PER_ENV")) sim->lanes_per_env = std::atoi(forced);
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
-  for (int i = 0; i < 2 && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
+  for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
   if (err != hipSuccess) {
     std::string msg = std::string("hipMalloc/hipMemcpy(model): ") + hipGetErrorString(err);
     if (sim->d_model) (void)hipFree(sim->d_model);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
       if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
     delete sim;
     return fail(nullptr, UPKIE_ERR_HIP, msg);
@@ -1206,13 +1207,13 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
   next.ext = sim->config.ext;
   next.spine = sim->config.spine;
   sim->config = next;
-  sim->params_dirty = true;
+  sim->params_version += 1;
   return UPKIE_OK;
 }
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
-  for (int i = 0; sim && i < 2; ++i)
+  for (int i = 0; sim && i < 3; ++i)
     if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
   delete sim;
   return UPKIE_OK;
@@ -1237,7 +1238,7 @@ extern "C" int upkie_sim_set_randomization(UpkieSim* sim, const float* body_iner
   x = ExtSlots{};
   x.count = ext_force ? 1 : 0;
   for (int k = 0; k < 3; ++k) x.point[0][k] = ext_point ? (float)ext_point[k] : 0.f;
-  sim->params_dirty = true;
+  sim->params_version += 1;
   return UPKIE_OK;
 }
 
@@ -1260,7 +1261,7 @@ extern "C" int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
     sim->ext_force = nullptr;
   }
   sim->config.ext = x;
-  sim->params_dirty = true;
+  sim->params_version += 1;
   return UPKIE_OK;
 }
 
@@ -1347,14 +1348,30 @@ __global__ void store_params_kernel(DevParams params, DevParams* out) {
 
 // The device block holding this handle's current {limits, config}, valid for launches on `stream` from here on.
 static const DevParams* current_params(UpkieSim* sim, void* stream) {
-  if (sim->params_dirty || stream != sim->params_stream) {
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  unsigned long long capture_id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &capturing, &capture_id) == hipSuccess && capturing == hipStreamCaptureStatusActive) {
+    // a launch recorded into a hipGraph: the graph carries its own store of the settings as they are now into a block
+    // no eager launch uses (a replay must neither see later settings nor leave stale ones behind for eager launches);
+    // one store per capture, again when a setting changes while capturing
+    if (sim->capture_version != sim->params_version || sim->capture_id != capture_id) {
+      DevParams block;
+      block.limits = sim->limits;
+      block.config = sim->config;
+      hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[2]);
+      sim->capture_id = capture_id;
+      sim->capture_version = sim->params_version;
+    }
+    return sim->d_params[2];
+  }
+  if (sim->eager_version != sim->params_version || stream != sim->params_stream) {
     sim->params_slot ^= 1;
     DevParams block;
     block.limits = sim->limits;
     block.config = sim->config;
     // (as a kernel argument, not a host-to-device copy: ordered on the stream, capturable in a hipGraph, no host buffer to keep alive)
     hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[sim->params_slot]);
-    sim->params_dirty = false;
+    sim->eager_version = sim->params_version;
     sim->params_stream = stream;
   }
   return sim->d_params[sim->params_slot];
@@ -1800,7 +1817,7 @@ extern "C" int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConf
   dev.num_envs = sim->config.num_envs;
   sim->config.spine = dev;
   sim->spine_state = observer_state;
-  sim->params_dirty = true;
+  sim->params_version += 1;
   return UPKIE_OK;
 }
 
