@@ -124,10 +124,9 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
       s.qd = l > 0 ? st[UPKIE_S_QD + joint] : 0.f;
       const float own_tau = l > 0 ? tau[joint] : 0.f;
       LimitWorkspace workspace;  // (the kernel keeps one per env in LDS; here every lane's thread has its own)
-      const OctScalars H = load_oct_scalars(M);
       for (int i = 0; i < substeps; ++i) {
-        const int r = limits_in_registers ? physics_substep_octet<true>(M, H, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
-                                          : physics_substep_octet<false>(M, H, Lm, L, s, own_tau, h, trunk_wrench, &workspace);
+        const int r = limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
+                                          : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace);
         lane_status[t][i] = r;
       }
       result[t] = s;

@@ -814,24 +814,6 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
-// The model scalars the COMMON path of a substep reads, fetched once per launch and kept in scalar registers: read
-// from the model where they are used, each costs the lone wavefront a scalar-cache round trip per substep
-// (five to six waits of 100-200 cycles per substep: a seventh of the launch).
-struct OctScalars {
-  float gravity, wheel_radius, contact_breaking_threshold, friction_cfm, friction_mu, max_joint_velocity;
-};
-template <class ModelT>
-UPKIE_HD OctScalars load_oct_scalars(const ModelT& M) {
-  OctScalars H{M.gravity, M.wheel_radius, M.contact_breaking_threshold, M.friction_cfm, M.friction_mu, M.max_joint_velocity};
-  UPKIE_KEEP_IN_SGPR(H.gravity);
-  UPKIE_KEEP_IN_SGPR(H.wheel_radius);
-  UPKIE_KEEP_IN_SGPR(H.contact_breaking_threshold);
-  UPKIE_KEEP_IN_SGPR(H.friction_cfm);
-  UPKIE_KEEP_IN_SGPR(H.friction_mu);
-  UPKIE_KEEP_IN_SGPR(H.max_joint_velocity);
-  return H;
-}
-
 // Substep outcomes (returned) and rare paths taken (reported through `census`).
 enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
 struct OctRare {  // which rare path the env took this substep, Gauss-Seidel sweeps it ran (two registers, never memory)
@@ -843,7 +825,7 @@ struct OctRare {  // which rare path the env took this substep, Gauss-Seidel swe
 // in the BASE frame and their moment about the base origin, or nullptr.
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
 template <bool LIMITS_IN_REGISTERS = false, class ModelT, class LimitsT>
-UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
+UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
                                    const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
@@ -855,7 +837,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const L
   // ---- base frame ----------------------------------------------------------
   const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
-  const V3 gn = H.gravity * nB;
+  const V3 gn = M.gravity * nB;
 
   // ---- kinematics along the chain (prefix sums over the quad) -----------------
   const float psi = L.keep_psi * oct_chain(L.sg * s.q);
@@ -999,9 +981,9 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const L
   const float ih = L.inv_h, erp = L.erp, cfm = L.cfm;  // of this launch's h (load_oct_lane)
   const V3 ow = v3(oct_qb<3>(o.x), oct_qb<3>(o.y), oct_qb<3>(o.z));
   const V3 center = ow + v3(L.wheel_center[0], L.wheel_center[1], L.wheel_center[2]);
-  const V3 Pc = center + H.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
+  const V3 Pc = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
   const float dist = s.pos.z + dot(nB, Pc);
-  const bool active = un >= 1e-6f && dist <= H.contact_breaking_threshold;
+  const bool active = un >= 1e-6f && dist <= M.contact_breaking_threshold;
   const bool active_partner = oct_swp(active ? 1.f : 0.f) != 0.f;
   const bool both = active && active_partner;
 
@@ -1067,8 +1049,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const L
       oct_rows9(Dg, Jt, Y, Jl, Kv);
     }
     Dg[0] = active ? fmaf(L.e[0], cfm, Dg[0]) : L.e[0];
-    Dg[1] = active ? fmaf(L.e[1], H.friction_cfm, Dg[1]) : L.e[1];
-    Dg[2] = active ? fmaf(L.e[2], H.friction_cfm, Dg[2]) : L.e[2];
+    Dg[1] = active ? fmaf(L.e[1], M.friction_cfm, Dg[1]) : L.e[1];
+    Dg[2] = active ? fmaf(L.e[2], M.friction_cfm, Dg[2]) : L.e[2];
     float JtP[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) JtP[i] = oct_swp(Jt[i]);
@@ -1099,7 +1081,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const L
     // on it (contact_pgs6: same rows, same order), every lane of the env in lockstep on identical data
     {
       const float lam_n = oct_qb<1>(lam);
-      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > H.friction_mu * lam_n);
+      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
       if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
           if (census) census->path = OCT_NOT_MINE_INFEASIBLE;
@@ -1192,7 +1174,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const OctScalars& H, const L
 
   // ---- integrate --------------------------------------------------------------------
   {
-    const float v = fminf(fmaxf(s.qd + xl, -H.max_joint_velocity), H.max_joint_velocity);
+    const float v = fminf(fmaxf(s.qd + xl, -M.max_joint_velocity), M.max_joint_velocity);
     s.qd = L.wj * v;
     s.q = fmaf(h, s.qd, s.q);
   }
@@ -1215,65 +1197,34 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // with observers attached use the two-lane kernel).
 template <int MODE, bool RAND>
 __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
-                                                         int done_pass, float* __restrict__ state, const float* __restrict__ act,
+                                                         int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                          const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                          float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census,
                                                          ServoPolicyArg<MODE> policy_arg) {
-  // the handle's limits and config: a block in device memory (L2 hits), read through scalar loads; every line touched up front
-  typedef const __attribute__((address_space(4))) DevParams* ConstParamsPtr;
-  warm_constant_block<sizeof(DevParams)>((ConstParamsPtr)Pp);
-  const auto& Lm = ((ConstParamsPtr)Pp)->limits;
-  const auto& C = ((ConstParamsPtr)Pp)->config;
-  const int autoreset_mode = done_pass ? (int)AUTORESET_DONE_PASS : C.autoreset_mode;  // (the second launch of a SAME_STEP autoreset)
-  typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
-  const int B = C.num_envs;
-  // what the substep loop reads of the config, fetched once, here, where control flow is still uniform (left to the
-  // compiler the constant block is re-loaded -- and waited for -- in every iteration)
-  int nb_substeps = C.nb_substeps, any_control_noise = C.any_control_noise;
-  float kp_gain = C.kp, kd_gain = C.kd, substep_h = C.h;
-  UPKIE_KEEP_IN_SGPR(nb_substeps);
-  UPKIE_KEEP_IN_SGPR(any_control_noise);
-  UPKIE_KEEP_IN_SGPR(kp_gain);
-  UPKIE_KEEP_IN_SGPR(kd_gain);
-  UPKIE_KEEP_IN_SGPR(substep_h);
-  // UpkieBaseVelocity with its MPC balancer in the same launch (upkie_sim_step_base_velocity_mpc): the wavefront first
-  // solves the condensed QPs of its eight envs on the matrix cores -- columns 0-7 of one 16-column MFMA tile, all 64
-  // lanes at work under the tile's own lane mapping (mpc_tile) -- and hands the commanded velocities to the lanes that
-  // step those envs through LDS. (One launch instead of two: no second dispatch, no second prologue; the solve is a
-  // 30-iteration dependent chain, so its half-empty tile costs the wavefront nothing.)
   // Which eight envs this wavefront steps. Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md) and
   // every XCD has its own L2: with envs handed out in launch order the four wavefronts that share a 128-byte line of a
   // state row (32 envs) sit on four different XCDs and each L2 fetches -- and writes back -- the whole line for its
   // 32 bytes. Swizzled, XCD x owns one contiguous eighth of the batch: a line lives in one L2. (A speed matter only:
   // any placement gives the same results.)
+  const int B = num_envs;  // (a kernel argument of its own: the state loads below wait for nothing but the argument segment)
   unsigned block = blockIdx.x;
   if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
-  __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 16 : 1];
-  if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
-    const float* done_row = autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
-    mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)block, mpc_velocity);
-    __syncthreads();
-  }
   const int tid = block * blockDim.x + threadIdx.x;
   // row of 16 lanes = quads [env 2r left, env 2r+1 left, env 2r right, env 2r+1 right]
   const int l = tid & 3, quad = (tid >> 2) & 3, leg = quad >> 1;
   const int e = (tid >> 4) * 2 + (quad & 1);
-  if (e >= B) return;  // the eight lanes of an env leave together
+  const bool in_batch = e < B;  // the eight lanes of an env leave together (below, once the whole wavefront has solved its MPC tile)
   const bool lead = l == 0 && leg == 0;  // the lane that writes per-env words
   const bool jointed = l != 0;
   const int k = jointed ? l - 1 : 0;
   const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
-  float* st = state + e;
+  float* st = state + (in_batch ? e : 0);
 #define SW(w) st[(size_t)(w) * B]
-  // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
-  // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
-  __shared__ LimitWorkspace limit_workspaces[8];
-  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS ? nullptr : limit_workspaces;
 
-  // ---- load ----------------------------------------------------------
+  // ---- load: issued first, in flight while the settings below arrive ------------------
   OctPhys s;
   s.pos = v3(SW(UPKIE_S_POS), SW(UPKIE_S_POS + 1), SW(UPKIE_S_POS + 2));
   s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
@@ -1289,16 +1240,48 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
     yaw = SW(UPKIE_S_YAW);
     yawvel = SW(UPKIE_S_YAWVEL);
   }
+  float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
+  asm volatile("" : "+v"(done_word), "+v"(s.pos.x), "+v"(s.qw), "+v"(s.q));  // pins the loads here
+
+  // the handle's limits and config: a block in device memory (L2 hits), read through scalar loads; every line touched up front
+  typedef const __attribute__((address_space(4))) DevParams* ConstParamsPtr;
+  warm_constant_block<sizeof(DevParams)>((ConstParamsPtr)Pp);
+  const auto& Lm = ((ConstParamsPtr)Pp)->limits;
+  const auto& C = ((ConstParamsPtr)Pp)->config;
+  const int autoreset_mode = done_pass ? (int)AUTORESET_DONE_PASS : C.autoreset_mode;  // (the second launch of a SAME_STEP autoreset)
+  typedef const __attribute__((address_space(4))) DevModel* ConstModelPtr;
+  // what the substep loop reads of the config, fetched once, here, where control flow is still uniform (left to the
+  // compiler the constant block is re-loaded -- and waited for -- in every iteration)
+  int nb_substeps = C.nb_substeps, any_control_noise = C.any_control_noise;
+  float kp_gain = C.kp, kd_gain = C.kd, substep_h = C.h;
+  UPKIE_KEEP_IN_SGPR(nb_substeps);
+  UPKIE_KEEP_IN_SGPR(any_control_noise);
+  UPKIE_KEEP_IN_SGPR(kp_gain);
+  UPKIE_KEEP_IN_SGPR(kd_gain);
+  UPKIE_KEEP_IN_SGPR(substep_h);
+  // UpkieBaseVelocity with its MPC balancer in the same launch (upkie_sim_step_base_velocity_mpc): the wavefront first
+  // solves the condensed QPs of its eight envs on the matrix cores -- columns 0-7 of one 16-column MFMA tile, all 64
+  // lanes at work under the tile's own lane mapping (mpc_tile) -- and hands the commanded velocities to the lanes that
+  // step those envs through LDS. (One launch instead of two: no second dispatch, no second prologue; the solve is a
+  // 30-iteration dependent chain, so its half-empty tile costs the wavefront nothing.)
+  __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 16 : 1];
+  if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
+    const float* done_row = autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
+    mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)block, mpc_velocity);
+    __syncthreads();
+  }
+  if (!in_batch) return;
+  // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
+  // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
+  __shared__ LimitWorkspace limit_workspaces[8];
+  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS ? nullptr : limit_workspaces;
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B);
   const auto& M = *(ConstModelPtr)Mp;
-  const OctScalars H = load_oct_scalars(M);
   // external forces: those on the trunk enter the substep as one wrench (launches with a force on a leg link use the
   // two-lane kernel: launch_step)
   const ExtForces ext{RAND && ext_force ? ext_force + e : nullptr, (size_t)B, nullptr};  // (the slots are read from C.ext below)
 
-  float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
-  asm volatile("" : "+v"(done_word));
   float act0 = 0.f, act1 = 0.f;
   float4 prev_obs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == MODE_PENDULUM) {
@@ -1505,7 +1488,7 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, H, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
+    const int status = physics_substep_octet<MODE == MODE_SERVOS>(*mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)

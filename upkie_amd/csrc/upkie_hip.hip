@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
 #define UPKIE_PROBE_RAND false
 #endif
 template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
-    const upkie::DevModel*, const upkie::DevParams*, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
+    const upkie::DevModel*, const upkie::DevParams*, int, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
     const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>);
 template __global__ void upkie::mpc_step_kernel<1>(upkie::MpcDev, float*, const float*, const float*, int, const uint8_t*, const float*, float, float*, float*);
 #else
@@ -1419,7 +1419,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
 #define UPKIE_LAUNCH_OCTET(R)                                                                                                \
   hipLaunchKernelGGL((step_kernel_octet<MODE, R>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
-                     sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, state, act, obs, reward, terminated, truncated, mask, scale, \
+                     sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
   const bool spine = sim->spine_state != nullptr;
   int lanes = mapped_lanes(sim);
