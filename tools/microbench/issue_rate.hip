@@ -65,6 +65,14 @@
 #define BR_TAKEN_FAR(i) "s_cbranch_execnz .Ltf%=_" #i "\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\n.Ltf%=_" #i ":\n"
 #define BR_NT_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execz .Lnv%=_" #i "\n.Lnv%=_" #i ":\n"
 #define BR_TK_VALU(i) "v_fmac_f32_e32 %" #i ", %16, %17\ns_cbranch_execnz .Ltv%=_" #i "\n.Ltv%=_" #i ":\n"
+// selects as the compiler writes them: one compare, then one or three v_cndmask on its mask -- through VCC (e32) or through an SGPR pair (e64)
+#define CMP64_CND64(i) "v_cmp_lt_f32_e64 s[20:21], %16, %" #i "\nv_cndmask_b32_e64 %" #i ", %16, %17, s[20:21]\n"
+#define CMP32_3CND32(i) "v_cmp_lt_f32_e32 vcc, %16, %" #i "\nv_cndmask_b32_e32 %" #i ", %16, %17, vcc\nv_cndmask_b32_e32 %" #i ", %17, %16, vcc\nv_cndmask_b32_e32 %" #i ", %16, %17, vcc\n"
+#define CMP64_3CND64(i) "v_cmp_lt_f32_e64 s[20:21], %16, %" #i "\nv_cndmask_b32_e64 %" #i ", %16, %17, s[20:21]\nv_cndmask_b32_e64 %" #i ", %17, %16, s[20:21]\nv_cndmask_b32_e64 %" #i ", %16, %17, s[20:21]\n"
+#define CMP32_FMA_CND32(i) "v_cmp_lt_f32_e32 vcc, %16, %" #i "\nv_fmac_f32_e32 %" #i ", %16, %17\nv_fmac_f32_e32 %" #i ", %16, %17\nv_cndmask_b32_e32 %" #i ", %16, %17, vcc\n"
+#define CND32_FMA3(i) "v_cndmask_b32_e32 %" #i ", %16, %17, vcc\nv_fmac_f32_e32 %" #i ", %16, %17\nv_fmac_f32_e32 %" #i ", %16, %17\nv_fmac_f32_e32 %" #i ", %16, %17\n"
+#define CND64_FMA3(i) "v_cndmask_b32_e64 %" #i ", %16, %17, s[20:21]\nv_fmac_f32_e32 %" #i ", %16, %17\nv_fmac_f32_e32 %" #i ", %16, %17\nv_fmac_f32_e32 %" #i ", %16, %17\n"
+#define CND_VCC_E64(i) "v_cndmask_b32_e64 %" #i ", %16, %17, vcc\n"
 #define KERNEL(NAME, STR)                                                          \
   __global__ void NAME(float* out, long long* cyc, int iters, float b, float c) { \
     float a[16];                                                                   \
@@ -134,6 +142,14 @@ KERNEL(k_br_tf, BR_TAKEN_FAR)
 KERNEL(k_br_nt_valu, BR_NT_VALU)
 KERNEL(k_br_tk_valu, BR_TK_VALU)
 
+KERNEL(k_cmp64_cnd64, CMP64_CND64)
+KERNEL(k_cmp32_3cnd32, CMP32_3CND32)
+KERNEL(k_cmp64_3cnd64, CMP64_3CND64)
+KERNEL(k_cmp32_fma_cnd32, CMP32_FMA_CND32)
+KERNEL(k_cnd32_fma3, CND32_FMA3)
+KERNEL(k_cnd64_fma3, CND64_FMA3)
+KERNEL(k_cnd_vcc_e64, CND_VCC_E64)
+
 typedef void (*kern_t)(float*, long long*, int, float, float);
 
 int main() {
@@ -181,7 +197,14 @@ int main() {
       {"s_cbranch_execnz taken (to the next instruction)", k_br_tk},
       {"s_cbranch_execnz taken over 8 skipped instructions", k_br_tf},
       {"v_fmac + s_cbranch_execz not taken (per pair)", k_br_nt_valu},
-      {"v_fmac + s_cbranch_execnz taken (per pair)", k_br_tk_valu}};
+      {"v_fmac + s_cbranch_execnz taken (per pair)", k_br_tk_valu},
+      {"v_cmp_e64 + v_cndmask_e64 sgpr pair (per pair)", k_cmp64_cnd64},
+      {"v_cmp_e32 + 3 v_cndmask_e32 vcc (per 4)", k_cmp32_3cnd32},
+      {"v_cmp_e64 + 3 v_cndmask_e64 sgpr pair (per 4)", k_cmp64_3cnd64},
+      {"v_cmp_e32, 2 v_fmac, v_cndmask_e32 vcc (per 4)", k_cmp32_fma_cnd32},
+      {"v_cndmask_e32 vcc + 3 v_fmac (per 4)", k_cnd32_fma3},
+      {"v_cndmask_e64 sgpr pair + 3 v_fmac (per 4)", k_cnd64_fma3},
+      {"v_cndmask_b32_e64 with vcc as the mask", k_cnd_vcc_e64}};
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_fma_vop3, dim3(256), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
   (void)hipDeviceSynchronize();
   for (int wps : {1}) {

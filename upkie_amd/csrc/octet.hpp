@@ -814,6 +814,11 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
+#if defined(UPKIE_PROBE_HOT_CONST)
+#define OCT_HOT(field, value) (value)
+#else
+#define OCT_HOT(field, value) (M.field)
+#endif
 // Substep outcomes (returned) and rare paths taken (reported through `census`).
 enum { OCT_NOT_MINE_INFEASIBLE = -3, OCT_NOT_MINE_LIMIT = -1, OCT_NO_CONTACT = 0, OCT_CONTACT = 1 };
 struct OctRare {  // which rare path the env took this substep, Gauss-Seidel sweeps it ran (two registers, never memory)
@@ -837,7 +842,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   // ---- base frame ----------------------------------------------------------
   const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   const V3 vB = bf.vB, wB = bf.wB, nB = bf.nB;
-  const V3 gn = M.gravity * nB;
+  const V3 gn = OCT_HOT(gravity, 9.81f) * nB;
 
   // ---- kinematics along the chain (prefix sums over the quad) -----------------
   const float psi = L.keep_psi * oct_chain(L.sg * s.q);
@@ -981,9 +986,9 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   const float ih = L.inv_h, erp = L.erp, cfm = L.cfm;  // of this launch's h (load_oct_lane)
   const V3 ow = v3(oct_qb<3>(o.x), oct_qb<3>(o.y), oct_qb<3>(o.z));
   const V3 center = ow + v3(L.wheel_center[0], L.wheel_center[1], L.wheel_center[2]);
-  const V3 Pc = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
+  const V3 Pc = center + OCT_HOT(wheel_radius, 0.05f) * v3(-nB.x * iun, 0.f, -nB.z * iun);
   const float dist = s.pos.z + dot(nB, Pc);
-  const bool active = un >= 1e-6f && dist <= M.contact_breaking_threshold;
+  const bool active = un >= 1e-6f && dist <= OCT_HOT(contact_breaking_threshold, 0.02f);
   const bool active_partner = oct_swp(active ? 1.f : 0.f) != 0.f;
   const bool both = active && active_partner;
 
@@ -1049,8 +1054,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
       oct_rows9(Dg, Jt, Y, Jl, Kv);
     }
     Dg[0] = active ? fmaf(L.e[0], cfm, Dg[0]) : L.e[0];
-    Dg[1] = active ? fmaf(L.e[1], M.friction_cfm, Dg[1]) : L.e[1];
-    Dg[2] = active ? fmaf(L.e[2], M.friction_cfm, Dg[2]) : L.e[2];
+    Dg[1] = active ? fmaf(L.e[1], OCT_HOT(friction_cfm, 0.01f), Dg[1]) : L.e[1];
+    Dg[2] = active ? fmaf(L.e[2], OCT_HOT(friction_cfm, 0.01f), Dg[2]) : L.e[2];
     float JtP[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) JtP[i] = oct_swp(Jt[i]);
@@ -1081,7 +1086,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     // on it (contact_pgs6: same rows, same order), every lane of the env in lockstep on identical data
     {
       const float lam_n = oct_qb<1>(lam);
-      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > M.friction_mu * lam_n);
+      const bool bad = L.l == 1 ? lam < 0.f : (L.l != 0 && fabsf(lam) > OCT_HOT(friction_mu, 1.0f) * lam_n);
       if (__builtin_expect(oct_wave_any(bad), 0)) {
         if (oct_env_any(bad)) {
           if (census) census->path = OCT_NOT_MINE_INFEASIBLE;
@@ -1137,7 +1142,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
             if ((r % 3) == 0) continue;
-            const float lim = M.friction_mu * lam6[3 * (r / 3)];
+            const float lim = OCT_HOT(friction_mu, 1.0f) * lam6[3 * (r / 3)];
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
           const int sweeps = contact_pgs6(M, A6, rhs6, lam6, both);
@@ -1174,7 +1179,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 
   // ---- integrate --------------------------------------------------------------------
   {
-    const float v = fminf(fmaxf(s.qd + xl, -M.max_joint_velocity), M.max_joint_velocity);
+    const float v = fminf(fmaxf(s.qd + xl, -OCT_HOT(max_joint_velocity, 100.0f)), OCT_HOT(max_joint_velocity, 100.0f));
     s.qd = L.wj * v;
     s.q = fmaf(h, s.qd, s.q);
   }
