@@ -271,8 +271,23 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
             "sweeps_per_infeasible_env_substep": c["sweeps_total"] / max(c["friction_cone"], 1),
             "sweep_cap_hits": c["sweep_cap_hits"],
             "sweeps_max": c["sweeps_max"],
+            # per wavefront-substep that swept: the most sweeps among its eight envs (what the launch waits for); quantiles
+            "wavefront_sweeps_quantiles": _histogram_quantiles(c["wavefront_max_sweeps_histogram"], (0.5, 0.9, 0.99, 0.999)),
         }
     env.close()
+    return out
+
+
+def _histogram_quantiles(hist, qs):
+    total = sum(hist)
+    out = {}
+    for q in qs:
+        acc = 0
+        for value, count in enumerate(hist):
+            acc += count
+            if total and acc >= q * total:
+                out[f"p{q * 100:g}"] = value
+                break
     return out
 
 

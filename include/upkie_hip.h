@@ -242,10 +242,13 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * wavefront-substeps (what the paths cost) that took, for at least one of their
  * eight envs, [4] the joint-stop path, [5] the sweeps. Sweeps run by the
  * env-substeps of [2]: [6] their sum, [7] the largest count, [1] how many
- * stopped at the iteration cap. Word [3] is unused. Diagnostics only: no entry
+ * stopped at the iteration cap. Word [3] is unused. Words [8 .. 71]: histogram
+ * over the wavefront-substeps of [5] of the LARGEST sweep count among the
+ * wavefront's envs (bin 63: 63 or more) -- what a launch waits for, since a
+ * wavefront leaves the sweeps with its slowest env. Diagnostics only: no entry
  * point of the reference corresponds to it, and its atomics (up to five per
  * wavefront and substep on a rare path) are not free: time without it. */
-#define UPKIE_CENSUS_WORDS 8
+#define UPKIE_CENSUS_WORDS 72
 int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters);
 
 /* Optional per-env domain randomisation buffers (device pointers, may be

@@ -71,7 +71,7 @@ def test_struct_layouts_match_header():
     assert [int(x) for x in out[3].split()] == [p.sampling_period.offset, p.admm_rho.offset]
     assert [int(x) for x in out[4].split()] == [abi.STATE_WORDS, abi.S_TORQUE, abi.S_DONE, abi.S_CONTACT]
     sp = abi.UpkieServoPolicy
-    assert [int(x) for x in out[5].split()] == [C.sizeof(sp), sp.velocity_feedback_clip.offset, sp.fall_pitch.offset, 8]
+    assert [int(x) for x in out[5].split()] == [C.sizeof(sp), sp.velocity_feedback_clip.offset, sp.fall_pitch.offset, abi.CENSUS_WORDS]
     o = abi.UpkieObserverConfig
     assert [int(x) for x in out[6].split()] == [
         o.dt.offset,

@@ -73,3 +73,80 @@ def test_device_sweeps_reach_the_oracle_solution():
     sim = BatchedSim(randomized_config(64), Model().struct)
     lam, sweeps = sim.contact_sweeps(torch.from_numpy(packed), torch.from_numpy(rhs), torch.from_numpy(warm), torch.ones(len(A), dtype=torch.uint8))
     check(A, rhs, want, lam.cpu().numpy().astype(np.float64), sweeps.cpu().numpy())
+
+
+# ---- the systems that DID end at the cap on the device -----------------------------------------------------------
+# tests/golden/device_sweep_cap_systems.npz: the 224 contact systems (fp32, as gathered by the eight-lane kernel:
+# A packed, rhs, the warm start) that ran into the 50-sweep cap in 1700 steps x 4096 envs of the C5 share under
+# torque_balancing.py's law on an MI355X, written out by a development build of the kernel. Each of them has its
+# solution within ~1e-4 of a lateral bound; the exact solve of the lateral pair compared its four edge candidates
+# by the VALUE of the objective, which fp32 cannot tell apart there, and flipped between the bound and the interior
+# point for ever. With the candidates chosen by the sign of the gradient they converge.
+import os
+
+CAP_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "device_sweep_cap_systems.npz")
+
+
+def unpack_lower(packed):
+    A = np.zeros((len(packed), 6, 6))
+    k = 0
+    for r in range(6):
+        for c in range(r + 1):
+            A[:, r, c] = A[:, c, r] = packed[:, k]
+            k += 1
+    return A
+
+
+def check_fixed_point(A, rhs, lam, mu, sweeps):
+    """Complementarity of the box-friction problem (tests/test_oracle_contact_kkt.py), to the tolerance fp32 sweeps
+    stopped at 1e-5 can hold: in units of the largest impulse, through each row's own diagonal."""
+    assert sweeps.max() < 50, int((sweeps >= 50).sum())
+    w = np.einsum("nij,nj->ni", A, lam) - rhs
+    move = w / np.diagonal(A, axis1=1, axis2=2)  # what a sweep would still move a free row by
+    scale = np.maximum(np.abs(lam).max(axis=1), 1e-12)[:, None]
+    tol = 3e-4
+    for tire in (0, 3):
+        n = lam[:, tire]
+        assert (n >= 0).all()
+        loaded = n > 0
+        assert (np.abs(move[:, tire])[loaded] <= tol * scale[loaded, 0]).all()
+        assert (move[:, tire][~loaded] >= -tol * scale[~loaded, 0]).all()
+        for t in (tire + 1, tire + 2):
+            bound = mu * n
+            assert (np.abs(lam[:, t]) <= bound * (1 + 1e-6) + 1e-30).all()
+            inside = np.abs(lam[:, t]) < bound * (1 - 1e-6)
+            assert (np.abs(move[:, t])[inside] <= tol * scale[inside, 0]).all()
+            upper = ~inside & (lam[:, t] > 0)
+            lower = ~inside & (lam[:, t] < 0)
+            assert (move[:, t][upper] <= tol * scale[upper, 0]).all() and (move[:, t][lower] >= -tol * scale[lower, 0]).all()
+
+
+def test_host_sweeps_converge_on_the_systems_that_hit_the_cap_on_the_device(harness):  # noqa: F811
+    f = np.load(CAP_FIXTURE)
+    model = Model().struct
+    harness.harness_contact_pgs6.restype = C.c_int
+    got = np.zeros((len(f["A"]), 6))
+    sweeps = np.zeros(len(got), dtype=np.int64)
+    for i in range(len(got)):
+        a32, r32, l32 = (np.ascontiguousarray(f[k][i], dtype=np.float32) for k in ("A", "rhs", "start"))
+        sweeps[i] = harness.harness_contact_pgs6(C.byref(model), a32.ctypes.data_as(C.c_void_p), r32.ctypes.data_as(C.c_void_p),
+                                                l32.ctypes.data_as(C.c_void_p), int(f["both"][i]))
+        got[i] = l32
+    assert len(got) > 200 and sweeps.max() <= 12, sweeps.max()
+    check_fixed_point(unpack_lower(f["A"].astype(np.float64)), f["rhs"].astype(np.float64), got, float(model.friction_mu), sweeps)
+
+
+@pytest.mark.gpu
+def test_device_sweeps_converge_on_the_systems_that_hit_the_cap_on_the_device():
+    import torch
+
+    from tests.helpers import randomized_config
+    from upkie_amd.sim import BatchedSim
+
+    f = np.load(CAP_FIXTURE)
+    model = Model().struct
+    sim = BatchedSim(randomized_config(64), model)
+    lam, sweeps = sim.contact_sweeps(torch.from_numpy(f["A"]), torch.from_numpy(f["rhs"]), torch.from_numpy(f["start"]), torch.from_numpy(f["both"]))
+    sweeps = sweeps.cpu().numpy()
+    assert sweeps.max() <= 12, sweeps.max()
+    check_fixed_point(unpack_lower(f["A"].astype(np.float64)), f["rhs"].astype(np.float64), lam.cpu().numpy().astype(np.float64), float(model.friction_mu), sweeps)

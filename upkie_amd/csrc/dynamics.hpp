@@ -638,20 +638,30 @@ UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, flo
   const bool inside = det > 1e-5f * a22 * a55 && fabsf(u2) <= lim2 && fabsf(u5) <= lim5;
   float best2 = u2, best5 = u5;
   if (!inside) {
+    // The solution sits on an edge: one row on a bound, the other row solved for it and clamped. It is the candidate
+    // whose bounded row pushes OUTWARD (gradient of 1/2 x'Ax - r'x against the bound): chosen by that sign, the
+    // smallest violation winning. (The four candidates used to be compared by the value of the objective: with the
+    // solution within 1e-4 of a bound the values differ by 1e-8 of themselves, fp32 cannot tell them apart, and the
+    // pair flipped between the bound and the interior point from one sweep to the next, 1.6e-4 apart, for ever --
+    // every system that ended at the sweep cap on the device did that: profiles/r03_sweep_cap_systems.txt.)
     float best = 3.4e38f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float x2, x5;
+      float x2, x5, outward;
       if (e < 2) {
         x2 = e == 0 ? -lim2 : lim2;
         x5 = fminf(fmaxf((r5 - a25 * x2) * i55, -lim5), lim5);
+        const float g = (a22 * x2 + a25 * x5 - r2) * i22;  // in impulse: how far a free row 2 would move from here
+        outward = e == 0 ? g : -g;                         // (on the lower bound the gradient must not be negative)
       } else {
         x5 = e == 2 ? -lim5 : lim5;
         x2 = fminf(fmaxf((r2 - a25 * x5) * i22, -lim2), lim2);
+        const float g = (a55 * x5 + a25 * x2 - r5) * i55;
+        outward = e == 2 ? g : -g;
       }
-      const float value = 0.5f * (a22 * x2 * x2 + a55 * x5 * x5) + a25 * x2 * x5 - r2 * x2 - r5 * x5;
-      if (value < best) {
-        best = value;
+      const float violation = fmaxf(-outward, 0.f);
+      if (violation < best) {
+        best = violation;
         best2 = x2;
         best5 = x5;
       }

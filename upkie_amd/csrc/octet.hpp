@@ -1520,6 +1520,7 @@ next_step:
           atomicAdd(&census[6], total);
           atomicMax(&census[7], most);
           if (capped) atomicAdd(&census[1], capped);
+          atomicAdd(&census[8 + (most < 63u ? most : 63u)], 1u);  // what the wavefront waited for in this substep
         }
       }
     }

@@ -485,7 +485,7 @@ class BatchedSim:
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
         """Rare-path census of the eight-lane step kernel (`upkie_sim_set_census`):
         a zeroed device buffer the kernels count into, or None when switched off."""
-        self.census = torch.zeros(8, dtype=torch.int32, device=self.device) if on else None
+        self.census = torch.zeros(abi.CENSUS_WORDS, dtype=torch.int32, device=self.device) if on else None
         self._check(self._lib.upkie_sim_set_census(self._handle, _ptr(self.census)))
         return self.census
 
@@ -493,7 +493,9 @@ class BatchedSim:
         """Counters of `enable_census` so far: env-substeps on the eight-lane
         kernel's rare paths, and wavefront-substeps that ran them."""
         values = self.census.cpu().tolist()
-        return dict(zip(self.CENSUS_FIELDS, values))
+        counts = dict(zip(self.CENSUS_FIELDS, values))
+        counts["wavefront_max_sweeps_histogram"] = values[8:abi.CENSUS_WORDS]
+        return counts
 
     def restart_random_streams(self) -> None:
         """Zero the per-env episode and noise-step counters that key the Philox
