@@ -26,6 +26,7 @@
 namespace upkie {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 struct MpcDev {
   const float* minv;  // [Np][Np] row-permuted
@@ -103,11 +104,28 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   // delivers w = U + y itself; z = med3(w, -b, b); y' = w - z; and the next right-hand side needs only
   // z - y' = 2 z - w:  rb' = rho (2 z - w) - q. One dependent chain per wave: what is not MFMA latency is these.
   const float rho = P.rho, bound = P.bound;
-  float rb[T][4];
+  // Per tile the four elements of a lane as two register pairs: the element-wise part of an iteration is packed fp32
+  // arithmetic (v_pk_add_f32 / v_pk_fma_f32: two elements per instruction, same rounding as the scalar forms); only the
+  // clip is per element (v_med3_f32 has no packed form). y stays a register quadruple: it IS the C operand of the
+  // iteration's first MFMA (destination and C are different registers there, which the hardware allows as long as
+  // they do not overlap partially), so nothing is copied into the accumulator.
+  floatx2 rbp[T][2], qp[T][2];
+  floatx4 yv[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    yv[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      qp[t][h] = floatx2{q[t][2 * h], q[t][2 * h + 1]};
+      rbp[t][h] = floatx2{fmaf(rho, z[t][2 * h] - y[t][2 * h], -q[t][2 * h]), fmaf(rho, z[t][2 * h + 1] - y[t][2 * h + 1], -q[t][2 * h + 1])};
+    }
+  }
+  floatx2 zp[T][2];
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rb[t][r] = fmaf(rho, z[t][r] - y[t][r], -q[t][r]);
+    for (int h = 0; h < 2; ++h) zp[t][h] = floatx2{z[t][2 * h], z[t][2 * h + 1]};
+  const floatx2 rho2 = floatx2{rho, rho}, two = floatx2{2.f, 2.f};
   for (int it = 0; it < P.iterations; ++it) {
     floatx4 acc0[T], acc1[T];
 #pragma unroll
@@ -115,30 +133,41 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
       // Two accumulator chains per tile overlap the MFMA latencies. Accumulators in VGPRs (gfx950's register file is
       // unified; hipcc keeps MFMA results in AGPRs and pays twelve v_accvgpr moves per iteration, and its
       // -amdgpu-mfma-vgpr-form option allocates a destination that PARTLY overlaps the C operand, which the hardware
-      // does not allow): written as inline asm with the destination tied to C. The wait states the hazard recogniser
-      // would insert are written out: VALU write -> MFMA read of rb (s_nop 1), MFMA write -> VALU read (s_nop 12).
-      acc0[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
-      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][0]), "v"(rb[0][0]));
-      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rb[0][1]));
+      // does not allow): written as inline asm, destination either tied to C or early-clobber. The wait states the
+      // hazard recogniser would insert are written out: VALU write -> MFMA read of rb (s_nop 1), MFMA write -> VALU
+      // read (s_nop 12).
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(acc0[t]) : "v"(a[t][0]), "v"(rbp[0][0].x), "v"(yv[t]));
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rbp[0][0].y));
 #pragma unroll
       for (int s = 2; s < 4 * T; s += 2) {
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rb[s / 4][s % 4]));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rb[(s + 1) / 4][(s + 1) % 4]));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rbp[s / 4][(s % 4) / 2].x));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rbp[(s + 1) / 4][((s + 1) % 4) / 2].y));
       }
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) asm volatile("s_nop 12" : "+v"(acc0[t]), "+v"(acc1[t]));
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t) {
+      floatx2 yn[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float w = acc0[t][r] + acc1[t][r];  // U + y
-        const float zi = __builtin_amdgcn_fmed3f(w, -bound, bound);
-        y[t][r] = w - zi;
-        z[t][r] = zi;
-        rb[t][r] = fmaf(rho, fmaf(2.f, zi, -w), -q[t][r]);
+      for (int h = 0; h < 2; ++h) {
+        const floatx2 w = (h == 0 ? floatx2{acc0[t][0], acc0[t][1]} : floatx2{acc0[t][2], acc0[t][3]}) +
+                          (h == 0 ? floatx2{acc1[t][0], acc1[t][1]} : floatx2{acc1[t][2], acc1[t][3]});  // U + y
+        const floatx2 zi = floatx2{__builtin_amdgcn_fmed3f(w.x, -bound, bound), __builtin_amdgcn_fmed3f(w.y, -bound, bound)};
+        yn[h] = w - zi;
+        zp[t][h] = zi;
+        rbp[t][h] = __builtin_elementwise_fma(rho2, __builtin_elementwise_fma(two, zi, -w), -qp[t][h]);
       }
+      yv[t] = floatx4{yn[0].x, yn[0].y, yn[1].x, yn[1].y};
+    }
   }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      y[t][r] = yv[t][r];
+      z[t][r] = r < 2 ? zp[t][0][r] : zp[t][1][r - 2];
+    }
 
 #pragma unroll
   for (int t = 0; t < T; ++t)
