@@ -5,7 +5,7 @@ set -e
 MODE=${1:-2}; RAND=${2:-false}; shift || true; shift || true
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${OUT:-/tmp/isa_probe}; mkdir -p $OUT; cd $OUT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -S --cuda-device-only -Rpass-analysis=kernel-resource-usage \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage \
   -DUPKIE_PROBE_OCTET_MODE=$MODE -DUPKIE_PROBE_RAND=$RAND "$@" $R/upkie_amd/csrc/upkie_hip.hip -o k.s 2> remarks.txt || { tail -30 remarks.txt; exit 1; }
 python3 - <<'PY'
 import re

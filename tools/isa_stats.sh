@@ -9,7 +9,7 @@ D=$(mktemp -d)
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $D
 # the library's flags (upkie_amd/lib.py): SLP-packing scalar fp32 chains into v_pk_* costs registers and moves
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -S --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" \
   $R/upkie_amd/csrc/upkie_hip.hip -o k.s 2> remarks.txt || { tail -20 remarks.txt; exit 1; }
 python3 - "$K" <<'PY'
 import collections, re, sys

@@ -104,6 +104,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # SLP-packing scalar fp32 chains into v_pk_* costs ~1700 v_mov and
             # 180 extra registers in the step kernel (tools/isa_stats.sh)
             "-fno-slp-vectorize",
+            # the scheduler's AMDGPU-specific register-pressure trackers: another schedule of the same code, 1.4 % faster
+            # step kernel A/B (profiles/r03_ab_scheduler_flags.txt; max-ilp, max-memory-clause, no post-RA: slower)
+            "-mllvm",
+            "-amdgpu-use-amdgpu-trackers=1",
             "-shared",
             "-fPIC",
             SOURCES[0],
