@@ -554,6 +554,12 @@ def test_c5_share_sweeps_converge_in_fp32():
     c = env.sim.census_counts()
     infeasible = c["friction_cone"]
     assert infeasible > 0.003 * B * 5 * steps  # pushed robots do skid, tip over and land: the rare path is exercised
-    assert c["sweep_cap_hits"] <= 0.002 * infeasible, c  # (2.5 % of them before the tolerance floor)
+    # none at the cap (2.5 % of them before the tolerance floor of round 2; a handful per million until the lateral
+    # pair's edge was chosen by gradient sign, round 3: tests/test_contact_sweeps_replay.py)
+    assert c["sweep_cap_hits"] == 0 and c["sweeps_max"] < 40, c
     assert c["sweeps_total"] <= 3.5 * infeasible, c  # 2.3 sweeps on average (6.9 before)
-    assert c["sweeps_max"] <= 50 and torch.isfinite(env.sim.state).all()
+    assert torch.isfinite(env.sim.state).all()
+    # the histogram of what a wavefront waits for (words 8..71): one entry per wavefront-substep that swept
+    hist = c["wavefront_max_sweeps_histogram"]
+    assert len(hist) == abi.CENSUS_WORDS - 8 and sum(hist) == c["wavefront_substeps_sweeps"]
+    assert max(k for k, n in enumerate(hist) if n) == c["sweeps_max"]
