@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
 
 #define BODY16(STR)                                                                                                   \
   asm volatile(STR(0) STR(1) STR(2) STR(3) STR(4) STR(5) STR(6) STR(7) STR(8) STR(9) STR(10) STR(11) STR(12) STR(13) \
@@ -207,6 +208,33 @@ int main() {
       {"v_cndmask_b32_e64 with vcc as the mask", k_cnd_vcc_e64}};
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_fma_vop3, dim3(256), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
   (void)hipDeviceSynchronize();
+  // two and four waves per SIMD for the instruction classes of the step kernel: what the vector ALU sustains when it is shared
+  for (int wps : {2, 4}) {
+    const char* shared[] = {"v_fma_f32 (VOP3, 8 B) independent", "v_fmac_f32_e32 (4 B) independent", "v_mul_f32_e32 independent", "v_sub_f32_e32",
+                            "v_fmac_f32_dpp quad_perm broadcast", "v_add_f32_dpp row_ror:8", "v_mov_b32_dpp quad_perm", "v_cndmask_b32_e64 sgpr-pair mask",
+                            "v_mov_b32", "v_max_f32_e32", "v_rcp_f32", "v_fmac_f32_e32 dependent chain", "s_mov_b32"};
+    for (auto& k : ks) {
+      bool wanted = false;
+      for (const char* name : shared) wanted = wanted || std::string(name) == k.name;
+      if (!wanted) continue;
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k.k, dim3(256), dim3(256 * wps), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
+      (void)hipEventRecord(e1, 0);
+      (void)hipDeviceSynchronize();
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      std::vector<long long> h(256);
+      (void)hipMemcpy(h.data(), cyc, sizeof(long long) * 256, hipMemcpyDeviceToHost);
+      long long longest = 0;
+      for (long long v : h) longest = v > longest ? v : longest;
+      // (wall clock beside the wave's own counter: the counter is a constant-rate timer, the wall clock is what a launch costs)
+      printf("%d wave(s)/SIMD  %-40s %.2f ticks per instruction per wave (slowest block %.2f), kernel %.3f ms = %.2f ns per instruction per wave\n", wps, k.name,
+             h[0] / (64.0 * iters), longest / (64.0 * iters), ms, ms * 1e6 / (64.0 * iters));
+    }
+  }
   for (int wps : {1}) {
     for (auto& k : ks) {
       hipLaunchKernelGGL(k.k, dim3(256), dim3(256 * wps), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
