@@ -622,8 +622,8 @@ UPKIE_HD void system_solve(const SystemT& S, float (&bb)[6], float (&bl)[3], flo
 // [[a22, a25], [a25, a55]] is nearly singular -- only friction_cfm and the yaw lever arm of the wheel base separate
 // the rows -- and swept one at a time they converge like (a / (a + cfm))^2 per sweep, hundreds of sweeps. Here the
 // pair is solved EXACTLY given every other row: the minimiser of 1/2 x'Ax - r'x over the box |x2| <= lim2,
-// |x5| <= lim5 -- the unconstrained 2 x 2 solution when it lies inside the box, otherwise the best point of the four
-// edges (one row on a bound, the other row solved and clamped; corners included). Round 2 solved the pair as a FREE
+// |x5| <= lim5 -- the unconstrained 2 x 2 solution when it lies inside the box, otherwise the optimal point of the
+// four edges (one row on a bound, the other row solved and clamped; corners included). Round 2 solved the pair as a FREE
 // pair in sum / difference coordinates and clamped afterwards, and left the weak coordinate out of the convergence
 // test: with one row on its bound (a tire sliding sideways, or lifted: lim = 0) that is not the solution of the box
 // problem -- the converged impulses violated the complementarity conditions by up to O(1) of the velocity scale on
