@@ -354,24 +354,34 @@ struct OctLane {
   float total_mass;       // sum of the env's link masses: entry (1,1) of the base block
 };
 
-template <class ModelT, class LimitsT, class ConfigT>
-UPKIE_HD OctLane load_oct_lane(const ModelT& M, const LimitsT& Lm, const ConfigT& C, int l, int leg, const float* records, size_t stride) {
-  // the lane's row of DevModel::oct_table: eight 16-byte loads issued together (cached: eight rows for the whole grid)
-  float t[OT_WORDS];
+// the lane's row of DevModel::oct_table: eight 16-byte loads issued together (cached: eight rows for the whole grid).
+// Its own function so that a kernel can issue them with its first loads, before the settings they are combined with arrive.
+template <class ModelT>
+UPKIE_HD void load_oct_table_row(const ModelT& M, int l, int leg, float (&t)[OT_WORDS]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  {
-    typedef float Vec4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) Vec4* GlobalVec;
-    GlobalVec row = (GlobalVec)(const void*)&M.oct_table[4 * leg + l][0];
+  typedef float Vec4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) Vec4* GlobalVec;
+  GlobalVec row = (GlobalVec)(const void*)&M.oct_table[4 * leg + l][0];
 #pragma unroll
-    for (int i = 0; i < OT_WORDS / 4; ++i) {
-      const Vec4 v = row[i];
-      t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
-    }
+  for (int i = 0; i < OT_WORDS / 4; ++i) {
+    const Vec4 v = row[i];
+    t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
   }
 #else
   for (int i = 0; i < OT_WORDS; ++i) t[i] = M.oct_table[4 * leg + l][i];
 #endif
+}
+
+template <class ModelT, class LimitsT, class ConfigT>
+UPKIE_HD OctLane load_oct_lane(const ModelT& M, const LimitsT& Lm, const ConfigT& C, int l, int leg, const float* records, size_t stride,
+                               const float (*preloaded_row)[OT_WORDS] = nullptr) {
+  float t[OT_WORDS];
+  if (preloaded_row) {
+#pragma unroll
+    for (int i = 0; i < OT_WORDS; ++i) t[i] = (*preloaded_row)[i];
+  } else {
+    load_oct_table_row(M, l, leg, t);
+  }
   OctLane L;
   L.l = l;
   L.leg = leg;
@@ -1246,7 +1256,13 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
     yawvel = SW(UPKIE_S_YAWVEL);
   }
   float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
-  asm volatile("" : "+v"(done_word), "+v"(s.pos.x), "+v"(s.qw), "+v"(s.q));  // pins the loads here
+  // (and the lane's row of constants: eight more loads that wait for nothing but the model pointer)
+  // (not in front of the balancer's tile, which wants the registers and has its own loads to wait for: measured, C3)
+  constexpr bool ROW_UP_FRONT = MODE != MODE_BASE_VELOCITY;
+  float lane_row[OT_WORDS];
+  if (ROW_UP_FRONT) load_oct_table_row(*(const __attribute__((address_space(4))) DevModel*)Mp, l, leg, lane_row);
+  // (they stay in front of the settings block: its touch sequence is a memory barrier to the compiler -- and nothing
+  // here makes the wave WAIT for them before that sequence is issued)
 
   // the handle's limits and config: a block in device memory (L2 hits), read through scalar loads; every line touched up front
   typedef const __attribute__((address_space(4))) DevParams* ConstParamsPtr;
@@ -1281,7 +1297,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   __shared__ LimitWorkspace limit_workspaces[8];
   LimitWorkspace* const limit_ws = MODE == MODE_SERVOS ? nullptr : limit_workspaces;
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
-  const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B);
+  const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B, ROW_UP_FRONT ? &lane_row : nullptr);
   const auto& M = *(ConstModelPtr)Mp;
   // external forces: those on the trunk enter the substep as one wrench (launches with a force on a leg link use the
   // two-lane kernel: launch_step)
