@@ -397,6 +397,7 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
         return launches
 
     def timed(total: int, per_launch: int):
+        env.flush()  # (what earlier steps left in the current chunk travels outside the timed region)
         env.barrier()
         sync()
         episodes_before = env.total_resets()
@@ -491,8 +492,12 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
         # ranks share nothing but one asynchronous gather per chunk of K steps, which costs ~27 us of queue time whatever
         # its size (profiles/r01_gather_chunk_sweep.txt, one-rank RCCL group) => N-GPU weak-scaling efficiency
         # ~ K t_step / (K t_step + 27 us), independent of N (0.983 measured at K = 64 on one rank)
+        # -- for THIS run's window: a window shorter than a chunk (the driver's --steps 20) ends on one gather of its own
+        # steps with nothing left to overlap it with, so its efficiency is lower than the steady one beside it
         k_steps, t_step = env.gather.chunk, launch_us * 1e-6 * (launches / args.steps)
-        line["config"]["predicted_weak_scaling_efficiency"] = k_steps * t_step / (k_steps * t_step + 27e-6)
+        gathers = -(-args.steps // k_steps)
+        line["config"]["predicted_weak_scaling_efficiency"] = args.steps * t_step / (args.steps * t_step + gathers * 27e-6)
+        line["config"]["predicted_weak_scaling_efficiency_steady_state"] = k_steps * t_step / (k_steps * t_step + 27e-6)
     if steady is not None:
         s_elapsed, s_ms, s_launches, s_resets = steady
         s_launch_us = s_ms * 1e3 / s_launches

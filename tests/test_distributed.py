@@ -252,3 +252,42 @@ def test_bench_launch_line_on_cpu_doubles(world, flags, total, per_rank, ghosts)
     steady = out["steady_state"]  # the window of SURVEY 8d, timed before the contract region (shrunk by the double)
     assert steady["steps"] == 6 and steady["warmup"] == 2 and steady["value"] == pytest.approx(total * 6 / (steady["ms_per_step"] * 1e-3 * 6), rel=1e-6)
     assert "secondary" not in out  # one GPU, rank 0 only
+
+
+def test_a_flush_ships_only_the_steps_it_has_not_shipped(monkeypatch):
+    """A flush in the middle of a chunk (the end of bench.py's timed region: the driver times 20 steps against a
+    64-step chunk) sends the steps produced since the last flush, not the whole chunk buffer, and the completed
+    chunk only what no flush has sent."""
+    from upkie_amd import distributed as D
+
+    sent = []
+
+    class Done:
+        def wait(self):
+            return None
+
+    def fake_gather(tensor, gather_list=None, dst=0, async_op=False):
+        sent.append(tuple(tensor.shape))
+        assert gather_list is not None and all(tuple(g.shape) == tuple(tensor.shape) and g.is_contiguous() for g in gather_list)
+        gather_list[0].copy_(tensor)
+        return Done()
+
+    monkeypatch.setattr(D.dist, "gather", fake_gather)
+    g = RolloutGather(5, 0, 1, device="cpu", horizon=16, chunk=8, collectives=True)
+
+    def advance(first, last):
+        for step in range(first, last):
+            g.begin_step().copy_(record_pattern(step, 0, 5))
+            g.end_step()
+
+    advance(0, 3)
+    g.flush()
+    g.flush()  # nothing new: nothing sent
+    advance(3, 5)
+    g.flush()
+    advance(5, 8)  # the chunk completes: its remaining steps are sent
+    advance(8, 9)
+    g.flush()
+    assert sent == [(3, 5, RECORD_WORDS), (2, 5, RECORD_WORDS), (3, 5, RECORD_WORDS), (1, 5, RECORD_WORDS)], sent
+    for step in range(9):
+        assert torch.equal(g.records(step)[0], record_pattern(step, 0, 5))

@@ -99,6 +99,7 @@ class RolloutGather:
         self.staging = torch.zeros((2, K, local_envs, words), **f32) if self.collectives else None
         self._work = [None, None]
         self._step = 0  # index of the step being produced
+        self._flushed_to = 0  # steps of the current chunk that a flush has already shipped
         self.rollout: Optional[torch.Tensor] = None
         if rank == 0:
             # [chunks, world, K, B, words]: step t of rank r at [t // K % chunks, r, t % K]
@@ -160,27 +161,36 @@ class RolloutGather:
         self._step += n - 1
         self.end_step()
 
-    def _gather_chunk(self, chunk_index: int) -> None:
+    def _gather_chunk(self, chunk_index: int, first: int = 0, stop: Optional[int] = None) -> None:
+        """Steps ``first .. stop - 1`` of a chunk (default: all of it) in one collective: the step axis is the
+        slowest one of a chunk on both sides, so a range of steps is one contiguous block per rank."""
         c = chunk_index % 2
+        stop = self.chunk if stop is None else stop
         gather_list: Optional[List[torch.Tensor]] = None
         if self.rank == 0:
-            gather_list = list(self.rollout[chunk_index % self.num_chunks].unbind(0))
+            gather_list = [block[first:stop] for block in self.rollout[chunk_index % self.num_chunks].unbind(0)]
         if self._work[c] is not None:
             self._work[c].wait()
-        self._work[c] = dist.gather(self.staging[c], gather_list, dst=0, async_op=True)
+        self._work[c] = dist.gather(self.staging[c, first:stop], gather_list, dst=0, async_op=True)
 
     def end_step(self) -> None:
         step = self._step
         self._step += 1
         if self.collectives and step % self.chunk == self.chunk - 1:
-            self._gather_chunk(step // self.chunk)
+            self._gather_chunk(step // self.chunk, self._flushed_to)  # (what a flush has shipped is on rank 0 already)
+            self._flushed_to = 0
 
     def flush(self) -> None:
         """Ship a partially filled chunk and wait for every gather in flight
         (end of a rollout / of the bench). Every rank must call it at the same
         step."""
-        if self.collectives and self._step % self.chunk != 0:
-            self._gather_chunk(self._step // self.chunk)  # re-sent in full when the chunk completes
+        filled = self._step % self.chunk
+        if self.collectives and filled > self._flushed_to:
+            # only the steps produced since the last flush (a flush in the middle of a 64-step chunk used to ship all 64
+            # steps' worth, 8 MB per rank at 4096 envs, with nothing left to overlap it with -- and the chunk again, in
+            # full, when it completed)
+            self._gather_chunk(self._step // self.chunk, self._flushed_to, filled)
+            self._flushed_to = filled
         for i, work in enumerate(self._work):
             if work is not None:
                 work.wait()
