@@ -337,7 +337,7 @@ def valu_roofline(pmc, launch_us: float):
     return out
 
 
-def main(argv=None, sim_factory=None, backend=None) -> None:
+def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     """`sim_factory` / `backend` exist for tests/ only (a CPU double of the
     simulation handle over gloo, so that the N > 1 launch line, the shard
     arithmetic and the JSON contract are covered where there is no GPU); the
@@ -537,8 +537,14 @@ def main(argv=None, sim_factory=None, backend=None) -> None:
             "c5_share_torque_law": secondary_c5_share("torque"),
             "c5_share_velocity_law": secondary_c5_share("velocity"),
         }
-    print(json.dumps(line), flush=True)
+    print(json.dumps(line), file=json_out or sys.stdout, flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    # Native libraries write to file descriptor 1 too (RCCL prints a five-line version banner there when its first
+    # communicator comes up, on every rank): the contract's ONE JSON line goes to the real stdout, everything else
+    # -- of this process, whatever its rank -- to stderr.
+    sys.stdout.flush()
+    json_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    main(json_out=json_stream)
