@@ -112,14 +112,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
             "-fPIC",
             SOURCES[0],
             "-o",
-            LIB_PATH,
         ]
-        result = subprocess.run(cmd, capture_output=True, text=True)
+        partial = f"{LIB_PATH}.{os.getpid()}.partial"  # (a library is never loadable half-written: built beside it, renamed into place)
+        result = subprocess.run(cmd + [partial], capture_output=True, text=True)
         if verbose or result.returncode != 0:
             print(result.stdout)
             print(result.stderr)
         if result.returncode != 0:
+            if os.path.exists(partial):
+                os.remove(partial)
             raise UpkieRuntimeError("hipcc failed to build libupkie_hip.so")
+        os.replace(partial, LIB_PATH)
     return LIB_PATH
 
 
