@@ -1,20 +1,107 @@
-"""Long runs of the three BASELINE workloads on one GPU (bench.py's own functions): every state word stays finite, episodes
-keep ending and restarting, no contact system ends at the sweep cap. Usage: python tools/soak.py [steps]"""
-import json, os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import torch
-import bench
-from upkie_amd.sim import BatchedSim
+"""Soak run: long randomised rollouts in every mode and lane mapping, checking
+that no state ever becomes non-finite and that invariants hold (unit
+quaternions, joints within their stops, bounded speeds).
+Usage: python tools/soak.py [steps] [B]"""
+import os
+import sys
+import time
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-sim = BatchedSim(bench.make_config(4096)); sim.reset(); sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
-for _ in range(steps):
-    sim.step_pendulum_agent()
-torch.cuda.synchronize()
-print(json.dumps({"workload": "C2 Pendulum 4096 envs", "steps": steps, "env_steps": steps * 4096, "finite": bool(torch.isfinite(sim.state).all()),
-                  "episodes": int(sim.state[40].sum().item())}), flush=True)
-out = bench.secondary_c3(steps=steps // 4, warmup=200)
-print(json.dumps({"workload": "C3 16384 envs", "steps": steps // 4, "us_per_step": out["us_per_step"], "episodes": out["episodes"]}), flush=True)
-for law in ("torque", "velocity"):
-    out = bench.secondary_c5_share(law, steps=steps // 2, warmup=200, census_steps=2000)
-    print(json.dumps({"workload": f"C5 share, {law} law", "steps": steps // 2, "us_per_step": out["us_per_step"], "episodes": out["episodes"], "census": out["census"]}), flush=True)
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from upkie_amd import abi  # noqa: E402
+from upkie_amd.model.model import Model  # noqa: E402
+from upkie_amd.sim import BatchedSim  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+
+
+def check(sim, tag, k):
+    st = sim.state
+    bad = ~torch.isfinite(st[:41]).all(dim=0)
+    assert not bad.any(), f"{tag}: {int(bad.sum())} non-finite envs at step {k}"
+    qn = (st[abi.S_QUAT : abi.S_QUAT + 4] ** 2).sum(0).sqrt()
+    assert (qn - 1).abs().max() < 1e-3, f"{tag}: quaternion norm {float(qn.min())}..{float(qn.max())} at step {k}"
+    lo = torch.tensor(list(sim.model.joint_lower), device=st.device)
+    hi = torch.tensor(list(sim.model.joint_upper), device=st.device)
+    q = st[abi.S_Q : abi.S_Q + 6]
+    for j in (0, 1, 3, 4):
+        assert q[j].min() > lo[j] - 0.1 and q[j].max() < hi[j] + 0.1, f"{tag}: joint {j} outside its stops at step {k}"
+    assert st[abi.S_QD : abi.S_QD + 6].abs().max() <= 100.0 + 1e-3
+    assert st[abi.S_LINVEL : abi.S_LINVEL + 3].abs().max() < 100.0, f"{tag}: base speed {float(st[abi.S_LINVEL:abi.S_LINVEL+3].abs().max())}"
+
+
+def config(seed):
+    cfg = abi.default_sim_config(B, seed=seed)
+    cfg.rand_pitch, cfg.rand_roll, cfg.rand_x, cfg.rand_omega_y = 0.2, 0.05, 0.05, 0.3
+    cfg.rand_linvel[0] = 0.1
+    cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+    cfg.max_episode_steps = 1500  # time limit kept by the kernel
+    for j in range(6):
+        cfg.torque_control_noise[j] = 0.05
+        cfg.joint_friction[j] = 0.05
+    return cfg
+
+
+for lanes in ("8", "2", "1"):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
+    t0 = time.time()
+    # Pendulum with the README agent, randomised inertias, random pushes renewed every 500 steps
+    sim = BatchedSim(config(1), Model().struct)  # URDF model: 13 links behind the 7 bodies, randomised one by one
+    sim.randomize_inertias(0.3)
+    sim.reset()
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    for k in range(steps):
+        if k % 500 == 0:
+            f = (torch.rand((3, B), device=sim.device) * 2 - 1) * torch.tensor([[15.0], [8.0], [5.0]], device=sim.device)
+            sim.set_external_force(f, point=(0.0, 0.0, 0.1))
+        sim.step_pendulum_agent()
+        if k % 1000 == 999:
+            check(sim, f"pendulum lanes={lanes}", k)
+    resets = int(sim.state[abi.S_EPISODE].sum()) - B
+    print(f"lanes={lanes} pendulum agent + inertia 0.3 + pushes + noise: {steps} steps ok, {resets} episode resets, {time.time() - t0:.1f} s")
+    # the same agent in fused 32-step launches (state carried in registers from step to step)
+    sim = BatchedSim(config(3), Model().struct)
+    sim.randomize_inertias(0.3)
+    o6 = sim.reset()
+    prev = torch.zeros((B, 8), device=sim.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    window = torch.zeros((32, B, 8), device=sim.device)
+    for k in range(0, steps, 32):
+        sim.rollout_pendulum_records(prev, window)
+        prev.copy_(window[31])
+        assert torch.isfinite(window).all(), f"rollout lanes={lanes}: non-finite records at step {k}"
+        if k % 1024 == 992:
+            check(sim, f"rollout lanes={lanes}", k)
+    print(f"lanes={lanes} fused rollouts (32 steps per launch): {steps} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} episode resets")
+    # Gyropod with random commands
+    sim = BatchedSim(config(2))
+    sim.reset()
+    for k in range(steps // 2):
+        act = (torch.rand((B, 2), device=sim.device) * 2 - 1) * torch.tensor([2.0, 1.5], device=sim.device)
+        sim.step_gyropod(act)
+        if k % 1000 == 999:
+            check(sim, f"gyropod lanes={lanes}", k)
+    print(f"lanes={lanes} gyropod random commands: {steps // 2} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} resets")
+    # Servos: random torques and position targets, no termination: robots flail, fall, fold
+    cfg = config(3)
+    cfg.autoreset_mode = abi.AUTORESET_DISABLED
+    sim = BatchedSim(cfg)
+    sim.reset()
+    scale = torch.tensor([16.0, 16.0, 1.7, 16.0, 16.0, 1.7], device=sim.device)
+    act = torch.zeros((B, 6, 6), device=sim.device)
+    for k in range(steps // 2):
+        if k % 20 == 0:
+            act[:, :, 0] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 3.0
+            act[:, :, 0] = torch.where(torch.rand((B, 6), device=sim.device) < 0.3, torch.full_like(act[:, :, 0], float("nan")), act[:, :, 0])
+            act[:, :, 1] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 10.0
+            act[:, :, 2] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * scale
+            act[:, :, 3] = torch.rand((B, 6), device=sim.device) * 2.0
+            act[:, :, 4] = torch.rand((B, 6), device=sim.device) * 2.0
+            act[:, :, 5] = torch.rand((B, 6), device=sim.device) * scale
+        sim.step_servos(act)
+        if k % 1000 == 999:
+            check(sim, f"servos lanes={lanes}", k)
+    print(f"lanes={lanes} servos random commands, no resets: {steps // 2} steps ok")
+print("soak passed")
