@@ -890,7 +890,10 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
 #if !defined(UPKIE_PROBE_RAND)
 #define UPKIE_PROBE_RAND false
 #endif
-template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND>(
+#if !defined(UPKIE_PROBE_DEFAULT_SCALARS)
+#define UPKIE_PROBE_DEFAULT_SCALARS false
+#endif
+template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_PROBE_RAND, UPKIE_PROBE_DEFAULT_SCALARS>(
     const upkie::DevModel*, const upkie::DevParams*, int, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*,
     const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>);
 template __global__ void upkie::mpc_step_kernel<1>(upkie::MpcDev, float*, const float*, const float*, int, const uint8_t*, const float*, float, float*, float*);
@@ -908,6 +911,7 @@ struct UpkieSim {
   DevLinks links;
   const float* ext_force = nullptr;
   float* spine_state = nullptr;  // observer memory [16][B] when the spine observers run inside the step
+  bool default_scalars = false;  // the model's wheel / floor scalars are the default model's: eight-lane agent steps run the instantiations that hold them as constants (octet.hpp, OctDefaultScalars)
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
   // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
@@ -1183,6 +1187,9 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
     return fail(nullptr, UPKIE_ERR_UNSUPPORTED_MODEL, why);
   }
   if (const char* forced = std::getenv("UPKIE_LANES_PER_ENV")) sim->lanes_per_env = std::atoi(forced);
+  // (UPKIE_GENERIC_SCALARS=1: the generic instantiations whatever the model, for the test that holds both to the same bits)
+  const char* generic = getenv("UPKIE_GENERIC_SCALARS");
+  sim->default_scalars = oct_model_has_default_scalars(sim->model) && !(generic && generic[0] == '1');
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
   for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
@@ -1417,10 +1424,19 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
                      n_steps)
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
-#define UPKIE_LAUNCH_OCTET(R)                                                                                                \
-  hipLaunchKernelGGL((step_kernel_octet<MODE, R>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+#define UPKIE_LAUNCH_OCTET_D(R, D)                                                                                              \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, D>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
                      sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
+  // the agent-in-the-launch steps (the rollout workloads) also exist with the default model's scalars as constants
+#define UPKIE_LAUNCH_OCTET(R)                                                                  \
+  do {                                                                                         \
+    if constexpr (fused_agent(MODE)) {                                                         \
+      if (sim->default_scalars) UPKIE_LAUNCH_OCTET_D(R, true); else UPKIE_LAUNCH_OCTET_D(R, false); \
+    } else {                                                                                   \
+      UPKIE_LAUNCH_OCTET_D(R, false);                                                          \
+    }                                                                                          \
+  } while (0)
   const bool spine = sim->spine_state != nullptr;
   int lanes = mapped_lanes(sim);
   if (MODE == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
@@ -1440,6 +1456,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
 #undef UPKIE_LAUNCH_OCTET
+#undef UPKIE_LAUNCH_OCTET_D
 #undef UPKIE_LAUNCH_PAIR_S
 #undef UPKIE_LAUNCH_S
 #undef UPKIE_LAUNCH_PAIR
