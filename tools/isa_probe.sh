@@ -1,12 +1,12 @@
 #!/bin/bash
 # ISA of ONE eight-lane step kernel in ~15 s (tools/isa_stats.sh compiles all instantiations: minutes).
-# Usage: tools/isa_probe.sh <mode 0..6> [true|false (RAND)] [extra hipcc flags]; leaves k.s / remarks.txt in $OUT (default /tmp/isa_probe)
+# Usage: tools/isa_probe.sh <mode 0..6> [true|false (RAND)] [extra hipcc flags, e.g. -DUPKIE_PROBE_DEFAULT_SCALARS=true -DUPKIE_PROBE_IN_PLACE=true]; leaves k.s / remarks.txt in $OUT (default /tmp/isa_probe)
 set -e
 MODE=${1:-2}; RAND=${2:-false}; shift || true; shift || true
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${OUT:-/tmp/isa_probe}; mkdir -p $OUT; cd $OUT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage \
-  -DUPKIE_PROBE_OCTET_MODE=$MODE -DUPKIE_PROBE_RAND=$RAND "$@" $R/upkie_amd/csrc/upkie_hip.hip -o k.s 2> remarks.txt || { tail -30 remarks.txt; exit 1; }
+  -DUPKIE_PROBE_OCTET_MODE=$MODE -DUPKIE_PROBE_RAND=$RAND "$@" $R/upkie_amd/csrc/step_instances.hip -o k.s 2> remarks.txt || { tail -30 remarks.txt; exit 1; }
 python3 - <<'PY'
 import re
 remarks = open('remarks.txt').read()

@@ -1,16 +1,23 @@
 #!/bin/bash
 # Static ISA statistics of the step kernels: registers, scratch, spills per kernel, and the instruction
-# histogram of one of them (default: the bench's eight-lane kernel, step_kernel_octet<MODE_PENDULUM_AGENT, false>).
+# histogram of one of them (default: the bench's eight-lane kernel, step_kernel_octet<MODE_PENDULUM_AGENT, false, true, false>).
 # Usage: tools/isa_stats.sh [mangled-kernel-prefix] [extra hipcc flags]
 set -e
-K=${1:-_ZN5upkie17step_kernel_octetILi2ELb0EEE}
+K=${1:-_ZN5upkie17step_kernel_octetILi2ELb0ELb1ELb0EEE}
 shift || true
 D=$(mktemp -d)
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $D
-# the library's flags (upkie_amd/lib.py): SLP-packing scalar fp32 chains into v_pk_* costs registers and moves
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" \
-  $R/upkie_amd/csrc/upkie_hip.hip -o k.s 2> remarks.txt || { tail -20 remarks.txt; exit 1; }
+# the library's flags (upkie_amd/lib.py): SLP-packing scalar fp32 chains into v_pk_* costs registers and moves; the step
+# kernels are compiled by groups (csrc/step_instances.hpp), side by side
+for g in 0 1 2 3 4 5 6 7; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" \
+    -DUPKIE_INSTANCE_GROUP=$g $R/upkie_amd/csrc/step_instances.hip -o k$g.s 2> remarks$g.txt &
+done
+wait
+cat remarks?.txt > remarks.txt
+cat k?.s > k.s
+grep -q "error:" remarks.txt && { grep -A5 "error:" remarks.txt | head -40; exit 1; }
 python3 - "$K" <<'PY'
 import collections, re, sys
 remarks = open('remarks.txt').read()

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
 }
 
 
+#if !defined(UPKIE_STEP_INSTANCES_ONLY)  // (step_instances.hip: the non-template kernels live in the C-ABI's translation unit alone)
 __global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __restrict__ ws, float* __restrict__ commanded,
                                                         const uint8_t* __restrict__ mask) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __re
   for (int n = 0; n < 2 * N; ++n) ws[(size_t)n * B + e] = 0.f;
   commanded[e] = 0.f;  // mpc_balancer.py:232
 }
+#endif
 
 // ------------------------------------------------------------ host setup
 // Exact zero-order-hold discretisation of the wheeled inverted pendulum and

@@ -52,6 +52,7 @@ __device__ __forceinline__ void wheel_contact_observe(const ObserverDev& P, floa
   }
 }
 
+#if !defined(UPKIE_STEP_INSTANCES_ONLY)  // (step_instances.hip: the non-template kernels live in the C-ABI's translation unit alone)
 __global__ __launch_bounds__(64) void observers_reset_kernel(int B, float* __restrict__ st, const uint8_t* __restrict__ mask) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
@@ -184,5 +185,6 @@ __global__ __launch_bounds__(64) void observers_step_kernel(ObserverDev P, float
   if (out.wheel_odometry) reinterpret_cast<float2*>(out.wheel_odometry)[e] = make_float2(position, velocity);
 #undef OW
 }
+#endif  // UPKIE_STEP_INSTANCES_ONLY
 
 }  // namespace upkie

@@ -1221,7 +1221,7 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // One env.step() of B envs on 8 B lanes. Same contract as step_kernel /
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
-template <int MODE, bool RAND, bool DEFAULT_SCALARS = false>
+template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false>
 __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
@@ -1377,8 +1377,10 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   }
   // gymnasium's SAME_STEP autoreset inside the launch (upkie_sim_set_final_observation): an env that finishes keeps its
   // last observation in `final_obs` and goes through the reset branch once more before the kernel returns -- its eight
-  // lanes together, the other envs of the wavefront wait masked.
-  constexpr bool CAN_RESET_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
+  // lanes together, the other envs of the wavefront wait masked. Its own instantiations (IN_PLACE, round 4): the jump back
+  // to `next_step` makes the whole step a loop body, and with it in every kernel the NEXT_STEP / disabled launches -- what
+  // `VecEnv.step(actions)` runs by default -- carried 19-21 spilled VGPRs and 80-112 B of scratch for a pass they never take.
+  constexpr bool CAN_RESET_IN_PLACE = IN_PLACE && (MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS);
   const bool same_step = CAN_RESET_IN_PLACE && autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
   bool second_pass = false;
 next_step:

@@ -1,0 +1,99 @@
+// step_instances.hpp -- every instantiation of the three step kernels that launch_step (upkie_hip.hip) can launch, as
+// one list read twice: upkie_hip.hip includes it with UPKIE_INSTANCE_KW = `extern` (declarations: the C-ABI's
+// translation unit compiles no step kernel), step_instances.hip with UPKIE_INSTANCE_KW empty and UPKIE_INSTANCE_GROUP = g
+// (definitions of group g). ~100 kernels of 5-20 k instructions each: in one translation unit the library took two
+// minutes to build; by groups, on eight cores, about forty seconds (upkie_amd/lib.py).
+//
+// The kernels of different groups share no device symbol (every device function is inlined), so no relocatable device
+// code is needed: each object carries its own code object, the host-side launch stubs are ordinary weak symbols.
+#pragma once
+#include "step_kernels.hpp"
+
+#if !defined(UPKIE_INSTANCE_KW)
+#define UPKIE_INSTANCE_KW extern
+#define UPKIE_INSTANCE_GROUP (-1) /* declarations: every group */
+#endif
+#define UPKIE_INSTANCE_GROUPS 8
+
+namespace upkie {
+
+#define UPKIE_ONE_LANE_ARGS                                                                                                             \
+  const DevModel*, DevLimits, DevConfig, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*, const float*, \
+      const float*, int, BaseVelocityPtrs, float*, float*
+#define UPKIE_PAIR_ARGS UPKIE_ONE_LANE_ARGS, int
+#define UPKIE_OCTET_ARGS(MODE)                                                                                                          \
+  const DevModel*, const DevParams*, int, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*, const float*, \
+      const float*, int, BaseVelocityPtrs, float*, int, unsigned*, ServoPolicyArg<MODE>
+
+// one env per lane: <MODE, RAND, waves per SIMD, in-step spine observers>
+#define UPKIE_ONE_LANE(MODE)                                                                        \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, false>(UPKIE_ONE_LANE_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, true>(UPKIE_ONE_LANE_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, false>(UPKIE_ONE_LANE_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, true>(UPKIE_ONE_LANE_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, false>(UPKIE_ONE_LANE_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, true>(UPKIE_ONE_LANE_ARGS);   \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, false>(UPKIE_ONE_LANE_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, true>(UPKIE_ONE_LANE_ARGS);
+// two lanes per env: <MODE, RAND, in-step spine observers>
+#define UPKIE_PAIR(MODE)                                                                          \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, false, false>(UPKIE_PAIR_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, false, true>(UPKIE_PAIR_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, true, false>(UPKIE_PAIR_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, true, true>(UPKIE_PAIR_ARGS);
+// eight lanes per env: <MODE, RAND, default model's scalars as constants, SAME_STEP autoreset inside the launch>
+#define UPKIE_OCTET(MODE, D, IP)                                                                                \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, D, IP>(UPKIE_OCTET_ARGS(MODE)); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, D, IP>(UPKIE_OCTET_ARGS(MODE));
+
+// which octet instantiations exist (launch_step dispatches on exactly these)
+constexpr bool octet_has_default_scalars(int mode) { return mode == MODE_PENDULUM || fused_agent(mode) || mode == MODE_GYROPOD; }
+constexpr bool octet_resets_in_place(int mode) { return mode == MODE_PENDULUM || mode == MODE_GYROPOD || mode == MODE_SERVOS; }
+
+#define UPKIE_IN_GROUP(g) (UPKIE_INSTANCE_GROUP < 0 || UPKIE_INSTANCE_GROUP == (g))
+
+#if UPKIE_IN_GROUP(0)
+UPKIE_ONE_LANE(MODE_RESET)
+UPKIE_ONE_LANE(MODE_PENDULUM)
+UPKIE_ONE_LANE(MODE_PENDULUM_AGENT)
+#endif
+#if UPKIE_IN_GROUP(1)
+UPKIE_ONE_LANE(MODE_GYROPOD)
+UPKIE_ONE_LANE(MODE_BASE_VELOCITY)
+#endif
+#if UPKIE_IN_GROUP(2)
+UPKIE_ONE_LANE(MODE_SERVOS)
+UPKIE_PAIR(MODE_RESET)
+UPKIE_PAIR(MODE_PENDULUM)
+#endif
+#if UPKIE_IN_GROUP(3)
+UPKIE_PAIR(MODE_PENDULUM_AGENT)
+UPKIE_PAIR(MODE_PENDULUM_ROLLOUT)
+UPKIE_PAIR(MODE_GYROPOD)
+#endif
+#if UPKIE_IN_GROUP(4)
+UPKIE_PAIR(MODE_SERVOS)
+UPKIE_PAIR(MODE_BASE_VELOCITY)
+UPKIE_OCTET(MODE_RESET, false, false)
+#endif
+#if UPKIE_IN_GROUP(5)
+UPKIE_OCTET(MODE_PENDULUM, false, false)
+UPKIE_OCTET(MODE_PENDULUM, true, false)
+UPKIE_OCTET(MODE_PENDULUM, false, true)
+UPKIE_OCTET(MODE_PENDULUM_AGENT, false, false)
+UPKIE_OCTET(MODE_PENDULUM_AGENT, true, false)
+#endif
+#if UPKIE_IN_GROUP(6)
+UPKIE_OCTET(MODE_PENDULUM_ROLLOUT, false, false)
+UPKIE_OCTET(MODE_PENDULUM_ROLLOUT, true, false)
+UPKIE_OCTET(MODE_GYROPOD, false, false)
+UPKIE_OCTET(MODE_GYROPOD, true, false)
+UPKIE_OCTET(MODE_GYROPOD, false, true)
+#endif
+#if UPKIE_IN_GROUP(7)
+UPKIE_OCTET(MODE_SERVOS, false, false)
+UPKIE_OCTET(MODE_SERVOS, false, true)
+UPKIE_OCTET(MODE_BASE_VELOCITY, false, false)
+#endif
+
+}  // namespace upkie

@@ -17,6 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPKIE_HIP_LIBRARY") or os.path.join(_HERE, "_lib", "libupkie_hip.so")
 SOURCES = [
     os.path.join(_HERE, "csrc", "upkie_hip.hip"),
+    os.path.join(_HERE, "csrc", "step_instances.hip"),
+    os.path.join(_HERE, "csrc", "step_instances.hpp"),
+    os.path.join(_HERE, "csrc", "step_kernels.hpp"),
     os.path.join(_HERE, "csrc", "dynamics.hpp"),
     os.path.join(_HERE, "csrc", "mpc.hpp"),
     os.path.join(_HERE, "csrc", "pair.hpp"),
@@ -26,6 +29,8 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "wave_io.hpp"),
     os.path.join(_HERE, "..", "include", "upkie_hip.h"),
 ]
+
+INSTANCES_SOURCE = SOURCES[1]
 
 ## Every symbol `include/upkie_hip.h` declares.
 EXPORTED_SYMBOLS = (
@@ -86,8 +91,29 @@ class UpkieHipError(UpkieRuntimeError):
         self.status = status
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library for gfx950 with hipcc (in-tree)."""
+INSTANCE_GROUPS = 8  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    # SLP-packing scalar fp32 chains into v_pk_* costs ~1700 v_mov and
+    # 180 extra registers in the step kernel (tools/isa_stats.sh)
+    "-fno-slp-vectorize",
+    # the scheduler's AMDGPU-specific register-pressure trackers: another schedule of the same code, 1.4 % faster
+    # step kernel A/B (profiles/r03_ab_scheduler_flags.txt; max-ilp, max-memory-clause, no post-RA: slower)
+    "-mllvm",
+    "-amdgpu-use-amdgpu-trackers=1",
+    "-fPIC",
+]
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """Compile the HIP library for gfx950 with hipcc (in-tree): the C-ABI's
+    translation unit (`upkie_hip.hip`: host code and the small kernels) and the
+    ~100 step-kernel instantiations in `INSTANCE_GROUPS` groups
+    (`step_instances.hip -DUPKIE_INSTANCE_GROUP=g`), compiled side by side on
+    `jobs` cores (default: all this process may use), then linked."""
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:
         mtime = os.path.getmtime(LIB_PATH)
@@ -96,33 +122,42 @@ def build(force: bool = False, verbose: bool = False) -> str:
         )
     if stale:
         os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-        cmd = [
-            "hipcc",
-            "--offload-arch=gfx950",
-            "-O3",
-            "-std=c++17",
-            # SLP-packing scalar fp32 chains into v_pk_* costs ~1700 v_mov and
-            # 180 extra registers in the step kernel (tools/isa_stats.sh)
-            "-fno-slp-vectorize",
-            # the scheduler's AMDGPU-specific register-pressure trackers: another schedule of the same code, 1.4 % faster
-            # step kernel A/B (profiles/r03_ab_scheduler_flags.txt; max-ilp, max-memory-clause, no post-RA: slower)
-            "-mllvm",
-            "-amdgpu-use-amdgpu-trackers=1",
-            "-shared",
-            "-fPIC",
-            SOURCES[0],
-            "-o",
-        ]
-        partial = f"{LIB_PATH}.{os.getpid()}.partial"  # (a library is never loadable half-written: built beside it, renamed into place)
-        result = subprocess.run(cmd + [partial], capture_output=True, text=True)
-        if verbose or result.returncode != 0:
-            print(result.stdout)
-            print(result.stderr)
-        if result.returncode != 0:
-            if os.path.exists(partial):
-                os.remove(partial)
-            raise UpkieRuntimeError("hipcc failed to build libupkie_hip.so")
-        os.replace(partial, LIB_PATH)
+        tag = f"{LIB_PATH}.{os.getpid()}"
+        units = [(SOURCES[0], [], f"{tag}.abi.o")]
+        units += [(INSTANCES_SOURCE, [f"-DUPKIE_INSTANCE_GROUP={g}"], f"{tag}.g{g}.o") for g in range(INSTANCE_GROUPS)]
+        jobs = jobs or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        partial = f"{tag}.partial"  # (a library is never loadable half-written: built beside it, renamed into place)
+        objects = [obj for _, _, obj in units]
+        try:
+            pending, running, failed = list(units), [], None
+            while (pending or running) and failed is None:
+                while pending and len(running) < jobs:
+                    src, defines, obj = pending.pop(0)
+                    cmd = ["hipcc"] + HIPCC_FLAGS + defines + ["-c", src, "-o", obj]
+                    running.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), cmd))
+                proc, cmd = running.pop(0)
+                out, _ = proc.communicate()
+                if verbose or proc.returncode != 0:
+                    print(" ".join(cmd))
+                    print(out)
+                if proc.returncode != 0:
+                    failed = cmd
+            for proc, _ in running:
+                proc.kill()
+                proc.communicate()
+            if failed is not None:
+                raise UpkieRuntimeError("hipcc failed to build libupkie_hip.so: " + " ".join(failed))
+            result = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", partial], capture_output=True, text=True)
+            if verbose or result.returncode != 0:
+                print(result.stdout)
+                print(result.stderr)
+            if result.returncode != 0:
+                raise UpkieRuntimeError("hipcc failed to link libupkie_hip.so")
+            os.replace(partial, LIB_PATH)
+        finally:
+            for path in objects + [partial]:
+                if os.path.exists(path):
+                    os.remove(path)
     return LIB_PATH
 
 
