@@ -205,6 +205,55 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     return out
 
 
+def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0) -> dict:
+    """SURVEY.md 8d words the metric as the wall time of `VecEnv.step`: the
+    PUBLIC path, `obs, reward, terminated, truncated, info = env.step(policy(obs))`
+    on `Upkie-HIP-Pendulum-Vec`, the README balancer written as a three-op
+    PyTorch policy on the device (matmul, clamp, unsqueeze) -- from a plain
+    Python loop, and as one hipGraph launch per step
+    (`upkie_amd.graphs.GraphedEnvStep`: policy kernels + step kernel recorded
+    once). Same workload as the headline (C2), NEXT_STEP and SAME_STEP
+    autoreset; the step kernel is `step_kernel_octet<MODE_PENDULUM>` (its own
+    launch per step, action read from HBM), not the agent-in-the-launch one."""
+    import numpy as np
+    import torch
+
+    import upkie_amd.envs as envs_mod
+    from upkie_amd.graphs import GraphedEnvStep
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    out = {"policy": "act = (obs @ gains).clamp(-0.99, 0.99).unsqueeze(1), gains = [10, 1, 0, 0.1] (README.md:60-67), torch ops on the device",
+           "envs": envs, "steps": steps, "warmup": warmup}
+    for mode in ("next_step", "same_step"):
+        init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
+        env = envs_mod.make("Upkie-HIP-Pendulum-Vec", num_envs=envs, frequency=200.0, autoreset_mode=mode, init_state=init, seed=seed)
+        obs, _ = env.reset(seed=seed)
+        gains = torch.tensor([10.0, 1.0, 0.0, 0.1], device=env.device)
+        policy = lambda o: (o @ gains).clamp(-0.99, 0.99).unsqueeze(1)
+        state = {"obs": obs}
+
+        def eager(k):
+            state["obs"] = env.step(policy(state["obs"]))[0]
+
+        wall, device_ms = _timed_loop(eager, steps, warmup)
+        # the step call alone (action buffer reused): what the env's own host path and kernel cost
+        act = policy(obs).contiguous()
+        wall_step, device_ms_step = _timed_loop(lambda k: env.step(act), steps, warmup)
+        graphed = GraphedEnvStep(env, policy)
+        wall_graph, device_ms_graph = _timed_loop(lambda k: graphed(), steps, warmup)
+        episodes = int(env.sim.state[40].sum().item())
+        out[mode] = {
+            "python_loop_us_per_env_step": wall / steps * 1e6, "python_loop_device_us": device_ms * 1e3 / steps,
+            "env_step_alone_us": wall_step / steps * 1e6, "env_step_alone_device_us": device_ms_step * 1e3 / steps,
+            "graphed_us_per_env_step": wall_graph / steps * 1e6, "graphed_device_us": device_ms_graph * 1e3 / steps,
+            "env_steps_per_s_python_loop": envs * steps / wall, "env_steps_per_s_graphed": envs * steps / wall_graph,
+            "episodes": episodes, "lanes_per_env": env.sim.lanes_per_env,
+        }
+        env.close()
+    return out
+
+
 def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, census_steps: int = 400) -> dict:
     """One GPU's share of BASELINE.json configs[4] as SURVEY.md section 8d
     writes it (C5: 32768 envs over 8 GPUs): UpkieServos, inertia_variation 0.2
@@ -532,6 +581,7 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     if world == 1 and on_gpu and not args.no_secondary:
         del env
         torch.cuda.synchronize()
+        line["vec_env_api"] = vec_env_api(B)
         line["secondary"] = {
             "c3": secondary_c3(),
             "c5_share_torque_law": secondary_c5_share("torque"),

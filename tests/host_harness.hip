@@ -1,6 +1,9 @@
 // Test-only: runs the product's device functions on the HOST so that a single
 // physics substep can be compared with the oracle without a GPU.
-#include "../upkie_amd/csrc/upkie_hip.hip"
+// (step_kernels.hpp + host_setup.hpp, not upkie_hip.hip: no launch, so no kernel is instantiated and this builds in seconds)
+#include <string>
+
+#include "../upkie_amd/csrc/host_setup.hpp"
 
 extern "C" int harness_substep(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
                                const float* ext_forces, const UpkieExternalForces* ext_slots) {

@@ -46,9 +46,6 @@ namespace upkie {
   UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, D, IP>(UPKIE_OCTET_ARGS(MODE)); \
   UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, D, IP>(UPKIE_OCTET_ARGS(MODE));
 
-// which octet instantiations exist (launch_step dispatches on exactly these)
-constexpr bool octet_has_default_scalars(int mode) { return mode == MODE_PENDULUM || fused_agent(mode) || mode == MODE_GYROPOD; }
-constexpr bool octet_resets_in_place(int mode) { return mode == MODE_PENDULUM || mode == MODE_GYROPOD || mode == MODE_SERVOS; }
 
 #define UPKIE_IN_GROUP(g) (UPKIE_INSTANCE_GROUP < 0 || UPKIE_INSTANCE_GROUP == (g))
 

@@ -594,4 +594,9 @@ using ServoPolicyArg = std::conditional_t<MODE == MODE_SERVOS, UpkieServoPolicy,
 #include "pair.hpp"
 #include "octet.hpp"
 
+// which eight-lane instantiations exist beside <MODE, RAND, false, false> (step_instances.hpp lists them, launch_step
+// dispatches on exactly these)
+constexpr bool octet_has_default_scalars(int mode) { return mode == MODE_PENDULUM || fused_agent(mode) || mode == MODE_GYROPOD; }
+constexpr bool octet_resets_in_place(int mode) { return mode == MODE_PENDULUM || mode == MODE_GYROPOD || mode == MODE_SERVOS; }
+
 }  // namespace upkie

@@ -53,6 +53,34 @@ class _SpineObserverBlocks(dict):
         return blocks.items()
 
 
+class _SameStepInfo(dict):
+    """`info` of a SAME_STEP env whose step call completes the autoreset
+    itself: one persistent dictionary (``spine_observation``, ``final_obs``);
+    ``_final_obs`` = terminated | truncated is computed when it is read (a
+    device op per step that most steps of a rollout never look at)."""
+
+    def __init__(self, terminated, truncated, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._flags = (terminated, truncated)
+
+    def __missing__(self, key):
+        if key == "_final_obs":
+            return self._flags[0] | self._flags[1]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "_final_obs" or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(super().keys()) + ["_final_obs"]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
 class UpkieVecEnv:
     """Common part of the batched envs: owns the simulation handle, the model
     and the configuration (the role of UpkieEnv + PyBulletBackend,
@@ -172,6 +200,16 @@ class UpkieVecEnv:
     def unwrapped(self):
         return self
 
+    @property
+    def observation(self) -> torch.Tensor:
+        """The persistent device buffer `reset()` and `step()` return as `obs`
+        (rewritten in place by every step): what a graph-captured policy reads
+        (`upkie_amd.graphs.GraphedEnvStep`)."""
+        sim = self.sim
+        if self._stepper_kind == "servos" and sim.obs_servos is None:
+            sim.obs_servos = torch.zeros((self.num_envs, 6, 5), dtype=torch.float32, device=self.device)
+        return {"pendulum": sim.obs4, "gyropod": sim.obs6, "servos": sim.obs_servos}.get(self._stepper_kind, getattr(sim, "obs3", None))
+
     def close(self) -> None:
         if self._observers is not None:
             self._observers.close()
@@ -184,6 +222,7 @@ class UpkieVecEnv:
         if self._final_obs is not None and hasattr(self.sim, "set_final_observation"):
             self.sim.set_final_observation(None)
         self._final_obs = None
+        self._step_out = None
 
     def __enter__(self):
         return self
@@ -204,6 +243,43 @@ class UpkieVecEnv:
         if self.eager_spine_observation:
             self._spine.materialize()
         return {"spine_observation": self._spine}
+
+    #: kind of `BatchedSim.stepper` behind `step()` (None: the wrapper composes its step from several calls)
+    _stepper_kind = None
+    _stepper = None
+    _step_out = None
+
+    def _fast_step(self, action, shape):
+        """`step()` of the fused env kinds: one ctypes call on cached addresses
+        (`BatchedSim.stepper`), the outputs returned as ONE cached tuple of the
+        handle's persistent buffers -- `obs`, `reward`, `terminated`, `truncated`
+        are rewritten in place by every step, `info` is one dictionary whose
+        ``spine_observation`` materialises on first access (a rollout buffer
+        copies what it keeps, as with any vector env that reuses its buffers)."""
+        step = self._stepper
+        if step is None:
+            if not hasattr(self.sim, "stepper"):  # (test doubles)
+                return None
+            step = self._stepper = self.sim.stepper(self._stepper_kind)
+        if not (type(action) is torch.Tensor and action.dtype is torch.float32 and action.device == self.device and action.is_contiguous()
+                and action.numel() == self.num_envs * self._action_words):
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(shape).contiguous()
+        step(action.data_ptr())
+        out = self._step_out
+        if out is None or self._observers is not None or self.eager_spine_observation or (self.autoreset_mode == "same_step" and self._final_obs is None):
+            sim = self.sim
+            obs = {"pendulum": sim.obs4, "gyropod": sim.obs6, "servos": sim.obs_servos}[self._stepper_kind]
+            out = self._finish_step(obs, sim.reward, sim.terminated, sim.truncated)
+            if self._observers is None and not self.eager_spine_observation and (self.autoreset_mode != "same_step" or self._final_obs is not None):
+                if self.autoreset_mode == "same_step":
+                    if self._same_step_layout is None or not hasattr(self.sim, "set_final_observation"):
+                        return out  # (composed through reset(mask): nothing to cache)
+                    info = _SameStepInfo(out[2], out[3], spine_observation=self._spine, final_obs=self._final_obs)
+                    out = (out[0], out[1], out[2], out[3], info)
+                self._step_out = out
+            return out
+        self._spine._fresh = False
+        return out
 
     def _finish_step(self, obs, reward, terminated, truncated):
         # the kernels write 0/1 bytes: reinterpreting them as bool launches nothing
@@ -323,11 +399,15 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
         obs6 = self._reset_sim(seed, mask)
-        obs = obs6.index_select(1, self._pendulum_obs_indices)  # upkie_pendulum.py:17,122
-        self.sim.obs4.copy_(obs)
-        return obs, self._info()
+        torch.index_select(obs6, 1, self._pendulum_obs_indices, out=self.sim.obs4)  # upkie_pendulum.py:17,122
+        return self.sim.obs4, self._info()  # (the buffer step() rewrites: `obs = env.step(policy(obs))[0]` stays on one tensor)
+
+    _stepper_kind, _action_words = "pendulum", 1
 
     def step(self, action):
+        out = self._fast_step(action, (self.num_envs,))
+        if out is not None:
+            return out
         obs, reward, terminated, truncated = self.sim.step_pendulum(action)  # (converted / reshaped to [B] there)
         return self._finish_step(obs, reward, terminated, truncated)
 
@@ -386,7 +466,12 @@ class UpkieGyropodVecEnv(UpkieVecEnv):
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 2)
         return self.sim.step_gyropod(act)
 
+    _stepper_kind, _action_words = "gyropod", 2
+
     def step(self, action):
+        out = self._fast_step(action, (self.num_envs, 2)) if self._stepper_kind is not None else None
+        if out is not None:
+            return out
         return self._finish_step(*self._gyropod_step(action))
 
 
@@ -436,9 +521,18 @@ class UpkieServosVecEnv(UpkieVecEnv):
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
         self._reset_sim(seed, mask)
-        return self._servo_obs(), self._info()
+        obs = self._servo_obs()
+        if getattr(self.sim, "obs_servos", None) is not None and self.sim.obs_servos.shape == obs.shape:
+            self.sim.obs_servos.copy_(obs)
+            obs = self.sim.obs_servos  # (the buffer step() rewrites)
+        return obs, self._info()
+
+    _stepper_kind, _action_words = "servos", 36
 
     def step(self, action):
+        out = self._fast_step(action, (self.num_envs, 6, 6))
+        if out is not None:
+            return out
         act = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs, 6, 6)
         obs, reward, terminated, truncated = self.sim.step_servos(act)
         return self._finish_step(obs, reward, terminated, truncated)
@@ -450,6 +544,7 @@ class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
     [x, y, yaw] (upkie_base_velocity.py:21-202)."""
 
     _same_step_layout = None  # the MPC workspace and the dead-reckoned pose restart with the env: through reset(mask)
+    _stepper_kind = None  # (its step is the balancer + the Gyropod step: composed below)
 
     def __init__(
         self,

@@ -40,3 +40,41 @@ class GraphedLoop:
     def replay(self) -> None:
         """`unroll` iterations of `body`, one graph launch."""
         self.graph.replay()
+
+
+class GraphedEnvStep:
+    """``env.step(policy(obs))`` of a batched env as ONE hipGraph launch.
+
+    A Python RL loop around a 14 us step is host bound as soon as the policy
+    is a few PyTorch ops (each costs 4-6 us of interpreter and dispatch time);
+    recorded once, policy kernels + step kernel replay with a single launch::
+
+        env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=4096)
+        obs, _ = env.reset(seed=0)                   # the env's persistent observation buffer
+        step = GraphedEnvStep(env, lambda o: (o @ gain).clamp(-0.99, 0.99).unsqueeze(1))
+        for _ in range(n):
+            obs, reward, terminated, truncated, info = step()
+
+    `policy` maps the env's observation buffer (`env.observation`: rewritten in
+    place by every step) to an action tensor with PyTorch ops only (no
+    synchronisation, no data-dependent shapes: the rules of graph capture).
+    The outputs are the env's persistent buffers, as with `env.step`."""
+
+    def __init__(self, env, policy: Callable, unroll: int = 1, warmup: int = 3):
+        self.env = env
+        obs = env.observation
+        holder = {}
+
+        def body():
+            holder["out"] = env.step(policy(obs))
+
+        self._loop = GraphedLoop(body, unroll=unroll, warmup=warmup, device=env.device)
+        self.out = holder["out"]
+        self.steps_per_call = self._loop.unroll
+
+    def __call__(self):
+        self._loop.replay()
+        spine = self.out[4].get("spine_observation") if isinstance(self.out[4], dict) else None
+        if spine is not None and hasattr(spine, "invalidate"):
+            spine.invalidate()
+        return self.out

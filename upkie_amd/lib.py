@@ -20,6 +20,7 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "step_instances.hip"),
     os.path.join(_HERE, "csrc", "step_instances.hpp"),
     os.path.join(_HERE, "csrc", "step_kernels.hpp"),
+    os.path.join(_HERE, "csrc", "host_setup.hpp"),
     os.path.join(_HERE, "csrc", "dynamics.hpp"),
     os.path.join(_HERE, "csrc", "mpc.hpp"),
     os.path.join(_HERE, "csrc", "pair.hpp"),
