@@ -386,6 +386,125 @@ def valu_roofline(pmc, launch_us: float):
     return out
 
 
+def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
+    """`python bench.py --config c5 --gpus N`: BASELINE.json configs[4] (SURVEY
+    8d "C5"): UpkieServos, 4096 envs per GPU (32768 on 8), per-link inertia
+    randomisation 0.2, wheel friction 0.1, the device-drawn push schedule,
+    `examples/pybullet/torque_balancing.py`'s law (`--law velocity`: the
+    README balancer through the wheel loop) evaluated inside the step's launch,
+    NEXT_STEP autoreset of fallen robots; every step's outputs (servo
+    observations ``[B, 6, 5]``, reward, flags: 126 B per env) staged and gathered
+    to rank 0's ring, one asynchronous RCCL gather per `--gather-chunk` steps
+    (`upkie_amd.distributed.ShardedVecEnv`). Same timing contract as the
+    headline: W warm-up steps, K timed steps between barriers, max over ranks."""
+    import numpy as np
+    import torch
+
+    import upkie_amd.envs as envs_mod
+    from upkie_amd import abi
+    from upkie_amd.distributed import ShardedVecEnv, init_distributed
+    from upkie_amd.model.joint_properties import JointProperties
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    rank, world, local_rank = init_distributed(args.gpus, backend=backend)
+    on_gpu = sim_factory is None
+    B = -(-args.total_envs // world) if args.total_envs > 0 else args.envs_per_gpu
+    counted_envs = args.total_envs if args.total_envs > 0 else B * world
+    device = f"cuda:{local_rank}" if on_gpu else "cpu"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    forced = True if os.environ.get("UPKIE_FORCE_PROCESS_GROUP") == "1" else None
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
+    base = envs_mod.make("Upkie-HIP-Servos-Vec", num_envs=B, device=device, frequency=200.0, inertia_variation=0.2, init_state=init, autoreset_mode="next_step", seed=0,
+                         env_id_offset=rank * B, joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")},
+                         **({"sim_factory": sim_factory} if sim_factory is not None else {}))
+    m = base.model.struct
+    policy = (abi.torque_balancing_policy(10.0, 1.0, float(m.left_sign)) if args.law == "torque"
+              else abi.velocity_balancing_policy(float(m.wheel_radius), 1.0, float(m.left_sign)))
+    env = ShardedVecEnv("servos", None, device, rank=rank, world_size=world, chunk=args.gather_chunk, collectives=forced, servo_policy=policy, sim=base.sim)
+    sim = base.sim
+    env.reset()
+    push = torch.zeros((3, B), dtype=torch.float32, device=sim.device)
+    sim.set_external_force(push)
+    counter = {"k": 0}
+
+    def advance(n):
+        for _ in range(n):
+            k = counter["k"]
+            phase = k % PUSH_PERIOD
+            if phase == 0:
+                sim.sample_pushes(k // PUSH_PERIOD, PUSH_MAX_NORM, out=push)
+            elif phase == PUSH_HOLD:
+                push.zero_()
+            env.step(None)
+            counter["k"] = k + 1
+
+    def timed(n):
+        env.flush()
+        env.barrier()
+        sync()
+        before = env.total_resets()
+        env.barrier()
+        sync()
+        if on_gpu:
+            start_evt, stop_evt = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start_evt.record()
+        t0 = time.perf_counter()
+        advance(n)
+        env.flush()
+        if on_gpu:
+            stop_evt.record()
+        env.barrier()
+        sync()
+        wall = time.perf_counter() - t0
+        return env.max_over_ranks(wall), (start_evt.elapsed_time(stop_evt) if on_gpu else wall * 1e3), env.total_resets() - before
+
+    steady = None
+    if not args.no_steady_state:
+        advance(STEADY_WARMUP)
+        steady = timed(STEADY_STEPS)
+    advance(args.warmup)
+    elapsed, device_ms, resets = timed(args.steps)
+    if rank != 0:
+        env.shutdown()
+        return
+    step_us = device_ms * 1e3 / args.steps
+    achieved = C5_BYTES_PER_ENV_STEP * B / (step_us * 1e-6) / 1e9
+    blob = env.blob.nbytes
+    line = {
+        "metric": "env-steps/sec (batched UpkieServos, BASELINE configs[4] \"C5\", 200 Hz)",
+        "value": counted_envs * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs > 0 else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"UpkieServos batched env.step() (C5): inertia_variation 0.2, wheel friction 0.1, torso push every {PUSH_PERIOD} steps (norm ~ U(0, {PUSH_MAX_NORM:g}) N, held {PUSH_HOLD}, "
+                        f"drawn on device), servo-level law '{args.law}' inside the launch, NEXT_STEP autoreset",
+            "envs_per_gpu": B, "total_envs": counted_envs, "ghost_envs": B * world - counted_envs,
+            "gather": (f"RCCL gather of every step's outputs (servo observations [B, 6, 5], reward, flags: {blob} B per rank and step) into rank 0's ring, one asynchronous "
+                       f"collective per {env.gather.chunk}-step chunk ({blob * env.gather.chunk / 1e6:.1f} MB per rank), overlapped with the next chunk's kernels") if env.gather.collectives
+                      else "none (single GPU): outputs written straight into the rollout ring",
+            "autoresets_in_timed_region": resets, "lanes_per_env": env.lanes_per_env,
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "step_kernel_octet<MODE_SERVOS> (policy in the launch)", "avg_launch_us": step_us, "algorithmic_bytes_per_env_step": C5_BYTES_PER_ENV_STEP},
+        "cpu_baseline": None,
+    }
+    if env.gather.collectives:
+        # DESIGN.md section 7: a gather costs ~27 us of queue time plus its wire time; rank 0 receives (N - 1) x chunk x blob
+        # bytes per chunk over its xGMI links (one link per peer, ~50 GB/s achievable each): overlapped unless it outlasts the chunk
+        t_chunk = env.gather.chunk * step_us * 1e-6
+        wire = blob * env.gather.chunk / 50e9
+        line["config"]["predicted_weak_scaling_efficiency_steady_state"] = t_chunk / (max(t_chunk, wire) + 27e-6)
+    if steady is not None:
+        s_elapsed, s_ms, s_resets = steady
+        line["steady_state"] = {"value": counted_envs * STEADY_STEPS / s_elapsed, "unit": "env-steps/s", "steps": STEADY_STEPS, "warmup": STEADY_WARMUP,
+                                "ms_per_step": s_elapsed / STEADY_STEPS * 1e3, "avg_launch_us": s_ms * 1e3 / STEADY_STEPS, "autoresets_in_timed_region": s_resets}
+    env.shutdown()
+    print(json.dumps(line), file=json_out or sys.stdout, flush=True)
+
+
 def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     """`sim_factory` / `backend` exist for tests/ only (a CPU double of the
     simulation handle over gloo, so that the N > 1 launch line, the shard
@@ -407,7 +526,13 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     parser.add_argument("--steps-per-launch", type=int, default=1,
                         help="env.step() per kernel launch in the TIMED region: 1 (the contract figure: one launch per env.step(), what "
                              "VecEnv.step gives a policy on the host side of the boundary); > 1 times the fused rollout instead (profiling runs)")
+    parser.add_argument("--config", choices=("c2", "c5"), default="c2",
+                        help="c2 (default): the headline, Upkie-Pendulum with the PD agent on device (BASELINE configs[1], [3] with --envs-per-gpu 8192); "
+                             "c5: UpkieServos with push / inertia randomisation, every env kind's sharded runner (BASELINE configs[4])")
+    parser.add_argument("--law", choices=("torque", "velocity"), default="torque", help="--config c5: the servo-level law evaluated inside the launch")
     args = parser.parse_args(argv)
+    if args.config == "c5":
+        return main_c5(args, sim_factory=sim_factory, backend=backend, json_out=json_out)
 
     import torch
 

@@ -184,6 +184,82 @@ class OracleSim:
         return {k: torch.from_numpy(v if v.dtype == np.uint8 else v.astype(np.float32)) for k, v in out.items()}
 
 
+def servo_policy_action(policy, state, radius_signed):
+    """`servo_policy_kernel` / the in-launch policy of the eight-lane Servos
+    kernel in numpy on an oracle state: action [B, 6, 6] and who fell."""
+    q = state[abi.S_QUAT:abi.S_QUAT + 4]
+    pitch = np.arcsin(np.clip(2.0 * (q[0] * q[2] - q[3] * q[1]), -1.0, 1.0))
+    p = 0.5 * (state[abi.S_Q + 2] - state[abi.S_Q + 5]) * radius_signed
+    pd = 0.5 * (state[abi.S_QD + 2] - state[abi.S_QD + 5]) * radius_signed
+    B = state.shape[1]
+    act = np.zeros((B, 6, 6))
+    for j in range(6):
+        for i in range(6):
+            act[:, j, i] = policy.action[j][i]
+        fb = policy.pitch_to_velocity[j] * pitch + policy.position_to_velocity[j] * p + policy.velocity_to_velocity[j] * pd
+        clip = policy.velocity_feedback_clip[j]
+        if clip > 0.0:
+            fb = np.clip(fb, -clip, clip)
+        act[:, j, 1] += fb
+        act[:, j, 2] += policy.pitch_to_torque[j] * pitch
+    fallen = np.abs(pitch) > policy.fall_pitch if policy.fall_pitch > 0.0 else np.zeros(B, dtype=bool)
+    return act, fallen
+
+
+def _from_address(address, count, ctype, dtype):
+    return np.frombuffer((ctype * count).from_address(address), dtype=dtype)
+
+
+def _step_into_fn(self, kind, policy=None, mpc=None, mpc_x0=None, mpc_contact=None):
+    """`BatchedSim.step_into_fn` on the oracle: the same raw-address contract
+    (CPU tensors have addresses too), so `ShardedVecEnv` runs unchanged."""
+    B = self.num_envs
+    obs_words = {"pendulum": 4, "gyropod": 6, "servos": 30, "servos_policy": 30, "base_velocity": 3}[kind]
+    act_words = {"pendulum": 1, "gyropod": 2, "servos": 36, "servos_policy": 0, "base_velocity": 2}[kind]
+    xy = np.zeros((B, 2))
+
+    def step(act, obs, rew, term, trunc):
+        o = self._o
+        a = _from_address(act, B * act_words, C.c_float, np.float32).astype(np.float64) if act_words else None
+        if kind == "pendulum":
+            out = o.step_pendulum(a)
+        elif kind == "gyropod":
+            out = o.step_gyropod(a.reshape(B, 2))
+        elif kind == "servos":
+            out = o.step_servos(a.reshape(B, 6, 6))
+        elif kind == "servos_policy":
+            action, fallen = servo_policy_action(policy, o.state, float(self.model.left_sign) * float(self.model.wheel_radius))
+            o.state[abi.S_DONE] = np.where(fallen, 1.0, o.state[abi.S_DONE])
+            if self.ext_force is not None:
+                o.ext_force = np.ascontiguousarray(self.ext_force.double().numpy())
+            out = o.step_servos(action.astype(np.float32).astype(np.float64))
+        else:  # UpkieBaseVelocity.step, upkie_base_velocity.py:164-202 (the generic composition of UpkieBaseVelocityVecEnv)
+            a = a.reshape(B, 2)
+            autoreset = (o.state[abi.S_DONE] != 0) if self.config.autoreset_mode else np.zeros(B, dtype=bool)
+            v, _ = mpc.step(mpc_x0, torch.from_numpy(a[:, 0].copy()), mpc_contact, float(self.config.dt))
+            obs6, r, t, tr = o.step_gyropod(np.stack([v.double().numpy(), a[:, 1]], axis=1))
+            mpc_x0.copy_(torch.from_numpy(obs6[:, [0, 1, 3, 4]].astype(np.float32)))
+            mpc_contact.copy_(torch.from_numpy((o.state[abi.S_CONTACT] != 0).astype(np.uint8)))
+            if autoreset.any():
+                mpc.reset(torch.from_numpy(autoreset.astype(np.uint8)))
+                xy[autoreset] = 0.0
+            live = ~autoreset
+            dt = float(self.config.dt)
+            xy[live, 0] += (a[:, 0] * np.cos(obs6[:, 2]) * dt)[live]
+            xy[live, 1] += (a[:, 0] * np.sin(obs6[:, 2]) * dt)[live]
+            out = (np.concatenate([xy, obs6[:, 2:3]], axis=1), r, t, tr)
+        o_, r_, t_, tr_ = out
+        _from_address(obs, B * obs_words, C.c_float, np.float32)[:] = np.asarray(o_, dtype=np.float32).reshape(-1)
+        _from_address(rew, B, C.c_float, np.float32)[:] = r_.astype(np.float32)
+        _from_address(term, B, C.c_uint8, np.uint8)[:] = t_
+        _from_address(trunc, B, C.c_uint8, np.uint8)[:] = tr_
+
+    return step
+
+
+OracleSim.step_into_fn = _step_into_fn
+
+
 def oracle_sim_factory(config, model_struct, device):
     return OracleSim(config, model_struct, device)
 

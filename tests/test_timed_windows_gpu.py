@@ -27,7 +27,7 @@ from upkie_amd import abi
 from upkie_amd.model.default_model import default_model
 from upkie_amd.sim import BatchedSim
 
-from .fake_sim import OracleMpc, oracle_sim_factory
+from .fake_sim import OracleMpc, oracle_sim_factory, servo_policy_action as _policy_action
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -256,28 +256,6 @@ def _c5_env(B, seed):
     init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
     return envs.make("Upkie-HIP-Servos-Vec", num_envs=B, frequency=200.0, inertia_variation=0.2, init_state=init, autoreset_mode="next_step", seed=seed,
                      joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
-
-
-def _policy_action(policy, state, radius_signed):
-    """`servo_policy_kernel` / the in-launch policy of the eight-lane Servos
-    kernel in numpy on an oracle state: action [B, 6, 6] and who fell."""
-    q = state[abi.S_QUAT:abi.S_QUAT + 4]
-    pitch = np.arcsin(np.clip(2.0 * (q[0] * q[2] - q[3] * q[1]), -1.0, 1.0))
-    p = 0.5 * (state[abi.S_Q + 2] - state[abi.S_Q + 5]) * radius_signed
-    pd = 0.5 * (state[abi.S_QD + 2] - state[abi.S_QD + 5]) * radius_signed
-    B = state.shape[1]
-    act = np.zeros((B, 6, 6))
-    for j in range(6):
-        for i in range(6):
-            act[:, j, i] = policy.action[j][i]
-        fb = policy.pitch_to_velocity[j] * pitch + policy.position_to_velocity[j] * p + policy.velocity_to_velocity[j] * pd
-        clip = policy.velocity_feedback_clip[j]
-        if clip > 0.0:
-            fb = np.clip(fb, -clip, clip)
-        act[:, j, 1] += fb
-        act[:, j, 2] += policy.pitch_to_torque[j] * pitch
-    fallen = np.abs(pitch) > policy.fall_pitch if policy.fall_pitch > 0.0 else np.zeros(B, dtype=bool)
-    return act, fallen
 
 
 @pytest.mark.parametrize("law", ["velocity", "torque"])

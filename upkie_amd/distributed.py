@@ -304,3 +304,269 @@ class ShardedPendulum:
         self.sim.close()
         if self._collectives and dist.is_initialized():
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Every env kind, sharded (BASELINE.json configs[4]: UpkieServos on 8 GPUs)
+
+ENV_KINDS = {
+    # kind: (observation shape, action shape) per env -- the layouts of upkie_amd.envs.vec_env
+    "pendulum": ((4,), (1,)),
+    "gyropod": ((6,), (2,)),
+    "servos": ((6, 5), (6, 6)),
+    "base_velocity": ((3,), (2,)),
+}
+
+
+def _prod(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+class StepBlob:
+    """Layout of ONE step's outputs of a rank as one contiguous message: the
+    four buffers a step call writes -- ``obs [B, *obs_shape]`` f32, ``reward
+    [B]`` f32, ``terminated [B]`` u8, ``truncated [B]`` u8 -- back to back,
+    each region 16-byte aligned, the whole rounded up to 16 bytes. The step
+    kernel is handed the four region addresses of a slot of the staging buffer
+    and stores straight into the message the collective ships: no packing
+    kernel, no copy, whatever the env kind (the Pendulum's 8-word records of
+    `ShardedPendulum` are the special case where a record fits two stores)."""
+
+    def __init__(self, num_envs: int, obs_shape):
+        B, d = int(num_envs), _prod(obs_shape)
+        up = lambda n: (n + 15) // 16 * 16  # noqa: E731
+        self.num_envs, self.obs_shape = B, tuple(int(x) for x in obs_shape)
+        self.obs_offset = 0
+        self.reward_offset = up(4 * B * d)
+        self.terminated_offset = self.reward_offset + up(4 * B)
+        self.truncated_offset = self.terminated_offset + up(B)
+        self.nbytes = self.truncated_offset + up(B)
+        self.words = self.nbytes // 4
+
+    def views(self, blob: torch.Tensor):
+        """``(obs, reward, terminated, truncated)`` views of a blob ``[..., words]`` f32
+        (leading dimensions kept: a rank-0 ring slice ``[world, words]`` decodes to ``[world, B, ...]``)."""
+        B, lead = self.num_envs, tuple(blob.shape[:-1])
+        raw = blob.view(torch.uint8)
+        obs = blob[..., : B * _prod(self.obs_shape)].view(*lead, B, *self.obs_shape)
+        reward = blob[..., self.reward_offset // 4 : self.reward_offset // 4 + B]
+        terminated = raw[..., self.terminated_offset : self.terminated_offset + B]
+        truncated = raw[..., self.truncated_offset : self.truncated_offset + B]
+        return obs, reward, terminated, truncated
+
+    def addresses(self, blob: torch.Tensor):
+        base = blob.data_ptr()
+        return base + self.obs_offset, base + self.reward_offset, base + self.terminated_offset, base + self.truncated_offset
+
+
+class ShardedVecEnv:
+    """This rank's shard of a batch of envs of ANY kind ("pendulum" |
+    "gyropod" | "servos" | "base_velocity") with the same pipelined gather of
+    per-step outputs into rank 0's rollout ring as `ShardedPendulum`, and the
+    reverse path for a policy that lives on rank 0.
+
+    Envs are sharded by index (``config.env_id_offset`` = first global env id
+    of the shard: random streams are keyed by the global id, so results do not
+    depend on the number of ranks); a step has no data-path collective.
+
+    * Per-rank policies (every rank holds a policy replica -- data-parallel
+      learners -- or the servo-level law runs inside the launch,
+      `servo_policy=`): ``obs, reward, terminated, truncated = env.step(actions)``
+      with this rank's actions; outputs are staged in chunks of `chunk` steps
+      and ONE asynchronous gather per chunk ships them to rank 0's ring
+      ``[chunks, world, chunk, blob]`` (`records(step)` decodes a step).
+    * A policy on rank 0: ``env.step_from_root(policy)`` = gather of the
+      latest observations to rank 0 -> ``policy(obs [world * B, ...])`` there
+      -> scatter of the actions -> step. Both collectives are issued
+      asynchronously into double-buffered tensors and waited for on the
+      stream (RCCL) right where the data is consumed, so the host runs one
+      step ahead of the device; they ARE on the step's critical path (two
+      latency-bound collectives per step, tens of microseconds each over
+      xGMI): the price of a central policy, stated in DESIGN.md section 7.
+    """
+
+    def __init__(self, kind: str, config, device: str, rank: int = 0, world_size: int = 1, model=None, horizon: int = 128, chunk: int = 8,
+                 sim_factory=None, collectives: Optional[bool] = None, servo_policy=None, mpc_config=None, mpc_factory=None, sim=None):
+        from . import abi
+        from .sim import BatchedSim
+
+        if kind not in ENV_KINDS:
+            raise ValueError(f"unknown env kind '{kind}' (one of {sorted(ENV_KINDS)})")
+        self.kind, self.rank, self.world_size = kind, rank, world_size
+        self.obs_shape, self.act_shape = ENV_KINDS[kind]
+        # `sim`: an existing handle (e.g. the `.sim` of a vector env built with this rank's `env_id_offset`, its
+        # inertia randomisation and joint properties already applied) instead of a new one from `config`
+        # (sim_factory / mpc_factory: test doubles only; the product always builds a BatchedSim / BatchedMpc)
+        if sim is not None:
+            self.sim = sim
+        else:
+            self.sim = sim_factory(config, model, device) if sim_factory is not None else BatchedSim(config, model, device=device)
+        B = self.num_envs = self.sim.num_envs
+        self._device = self.sim.device
+        self.blob = StepBlob(B, self.obs_shape)
+        self.gather = RolloutGather(1, rank, world_size, self._device, horizon=horizon, words=self.blob.words, chunk=chunk, collectives=collectives)
+        self._collectives = self.gather.collectives
+        f32 = dict(dtype=torch.float32, device=self._device)
+        self.actions = torch.zeros((2, B) + self.act_shape, **f32)  # double-buffered: scatter target of step t + 1 while step t reads the other
+        self._action_slot = 0
+        self._root_obs = torch.zeros((2, world_size, B) + self.obs_shape, **f32) if rank == 0 else None
+        self._works = []
+        extra = {}
+        step_kind = kind
+        if kind == "servos" and servo_policy is not None:
+            step_kind, extra = "servos_policy", {"policy": servo_policy}
+        self.mpc = None
+        if kind == "base_velocity":
+            if mpc_config is None:
+                mpc_config = abi.default_mpc_config(B, 16)
+            if mpc_factory is None:
+                from .mpc import BatchedMpc
+
+                mpc_factory = BatchedMpc
+            self.mpc = mpc_factory(mpc_config, device=str(self._device))
+            self._mpc_x0 = torch.zeros((B, 4), **f32)
+            self._mpc_contact = torch.zeros(B, dtype=torch.uint8, device=self._device)
+            extra = {"mpc": self.mpc, "mpc_x0": self._mpc_x0, "mpc_contact": self._mpc_contact}
+        self._servo_policy = servo_policy
+        self._step_fn = self.sim.step_into_fn(step_kind, **extra)
+        self._slot_cache = {}
+        self.last = None  # (obs, reward, terminated, truncated) views of the latest step, this rank
+
+    # ------------------------------------------------------------------ steps
+    def _slot(self):
+        """Views and addresses of the slot the step being produced writes into."""
+        g = self.gather
+        blob = g.begin_step()[0]
+        key = blob.data_ptr()
+        hit = self._slot_cache.get(key)
+        if hit is None:
+            hit = self._slot_cache[key] = (self.blob.views(blob), self.blob.addresses(blob))
+        return hit
+
+    def reset(self) -> torch.Tensor:
+        """Reset every local env; returns this rank's first observation ``[B, *obs_shape]``."""
+        from . import abi
+
+        obs6 = self.sim.reset()
+        self.gather.flush()
+        if self.kind == "pendulum":
+            obs = obs6[:, [1, 0, 4, 3]].contiguous()  # upkie_pendulum.py:17
+        elif self.kind == "gyropod":
+            obs = obs6.clone()
+        elif self.kind == "servos":
+            st = self.sim.state
+            obs = torch.empty((self.num_envs, 6, 5), dtype=torch.float32, device=self._device)
+            obs[:, :, 0] = st[abi.S_Q : abi.S_Q + 6].t()
+            obs[:, :, 1] = st[abi.S_QD : abi.S_QD + 6].t()
+            obs[:, :, 2] = st[abi.S_TORQUE : abi.S_TORQUE + 6].t()
+            obs[:, :, 3] = 42.0
+            obs[:, :, 4] = 18.0
+        else:  # base_velocity: the dead-reckoned pose restarts at the origin (upkie_base_velocity.py:160-162)
+            self._mpc_x0.copy_(obs6[:, [0, 1, 3, 4]])
+            self._mpc_contact.copy_((self.sim.state[abi.S_CONTACT] != 0).to(torch.uint8))
+            self.mpc.reset(None)
+            obs = torch.cat([torch.zeros((self.num_envs, 2), dtype=torch.float32, device=self._device), obs6[:, 2:3]], dim=1)
+        self._reset_obs = obs
+        self.last = (obs, None, None, None)
+        return obs
+
+    def step(self, actions: Optional[torch.Tensor] = None):
+        """One env.step() of every local env. `actions`: this rank's actions
+        ``[B, *act_shape]`` (fp32, contiguous, on the device); None = the buffer
+        the last `scatter_actions` filled (or nothing at all when the
+        servo-level policy runs inside the launch). Returns views of this step's
+        slot of the staging buffer: valid until the ring wraps
+        (``2 * chunk`` steps with collectives, `horizon` steps without)."""
+        if actions is None:
+            actions = self.actions[self._action_slot]
+        elif not (actions.dtype is torch.float32 and actions.is_contiguous() and actions.numel() == self.num_envs * _prod(self.act_shape)):
+            actions = actions.to(self._device, torch.float32).reshape((self.num_envs,) + self.act_shape).contiguous()
+        views, addresses = self._slot()
+        self._step_fn(actions.data_ptr(), *addresses)
+        self.gather.end_step()
+        self.last = views
+        return views
+
+    # -------------------------------------------------- a policy on rank 0
+    def gather_observations(self) -> Optional[torch.Tensor]:
+        """Collective: the latest observation of every rank to rank 0,
+        ``[world * B, *obs_shape]`` there (a persistent double buffer), None elsewhere."""
+        obs = self.last[0]
+        if not self._collectives:
+            return obs.reshape((self.num_envs,) + self.obs_shape)
+        slot = self._action_slot
+        out = None
+        if self.rank == 0:
+            out = list(self._root_obs[slot].unbind(0))
+        work = dist.gather(obs.contiguous(), out, dst=0, async_op=True)
+        work.wait()  # (RCCL: a stream dependency, the host does not block)
+        return self._root_obs[slot].reshape((self.world_size * self.num_envs,) + self.obs_shape) if self.rank == 0 else None
+
+    def scatter_actions(self, actions: Optional[torch.Tensor]) -> torch.Tensor:
+        """Collective: rank 0 hands over the actions of ALL envs ``[world * B, *act_shape]``
+        (None elsewhere); every rank receives its block into the action buffer the next `step()` reads."""
+        self._action_slot ^= 1
+        mine = self.actions[self._action_slot]
+        if not self._collectives:
+            mine.copy_(actions.reshape(mine.shape))
+            return mine
+        chunks = None
+        if self.rank == 0:
+            chunks = list(actions.to(torch.float32).reshape((self.world_size, self.num_envs) + self.act_shape).contiguous().unbind(0))
+        work = dist.scatter(mine, chunks, src=0, async_op=True)
+        work.wait()
+        return mine
+
+    def step_from_root(self, policy):
+        """``obs -> policy (rank 0) -> actions -> step`` with the policy on rank 0
+        only: `policy` maps ``[world * B, *obs_shape]`` to ``[world * B, *act_shape]``
+        there and is not called on the other ranks."""
+        obs_all = self.gather_observations()
+        self.scatter_actions(policy(obs_all) if self.rank == 0 else None)
+        return self.step(None)
+
+    # ------------------------------------------------------------ rank 0 reads
+    def records(self, step: int):
+        """Rank 0: ``(obs [world, B, ...], reward [world, B], terminated, truncated)`` of absolute
+        step `step` (one of the last `horizon` steps, after `flush`); None elsewhere."""
+        blob = self.gather.records(step)
+        if blob is None:
+            return None
+        return self.blob.views(blob[:, 0])
+
+    def flush(self) -> None:
+        self.gather.flush()
+
+    def barrier(self) -> None:
+        if self._collectives:
+            dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if not self._collectives:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self._device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def total_resets(self) -> int:
+        from . import abi
+
+        n = self.sim.state[abi.S_EPISODE].sum().to(torch.float64).reshape(1)
+        if self._collectives:
+            dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        return int(n.item())
+
+    @property
+    def lanes_per_env(self) -> int:
+        return int(getattr(self.sim, "lanes_per_env", 1))
+
+    def shutdown(self) -> None:
+        self.gather.flush()
+        if self.mpc is not None:
+            self.mpc.close()
+        self.sim.close()
+        if self._collectives and dist.is_initialized():
+            dist.destroy_process_group()

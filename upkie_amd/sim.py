@@ -266,6 +266,49 @@ class BatchedSim:
 
         return step
 
+    def step_into_fn(self, kind: str, policy: Optional["abi.UpkieServoPolicy"] = None, mpc=None, mpc_x0: Optional[torch.Tensor] = None,
+                     mpc_contact: Optional[torch.Tensor] = None):
+        """`stepper` with caller-chosen OUTPUT buffers: returns
+        ``step(action_address, obs_address, reward_address, terminated_address, truncated_address)``
+        for env kind "pendulum" | "gyropod" | "servos" | "servos_policy" (the
+        servo-level `policy` evaluated inside the launch; `action_address` is
+        ignored) | "base_velocity" (the balancer `mpc` -- a `BatchedMpc` -- in
+        front of the step, one launch where the mapping allows; `mpc_x0`
+        ``[B, 4]`` / `mpc_contact` ``[B]`` u8 carry the balancer's inputs from
+        step to step). The step writes straight into the addresses it is given
+        -- e.g. a slot of the staging buffer a collective ships
+        (`upkie_amd.distributed.ShardedVecEnv`) -- no copy, no packing launch."""
+        lib_, handle, index, raw_stream = self._lib, self._handle, self._device_index, _raw_stream
+        state = self.state.data_ptr()
+        current_device = torch.cuda.current_device
+        device = self.device
+
+        def launch(call):
+            if raw_stream is not None and current_device() == index:
+                status = call(raw_stream(index))
+            else:
+                with torch.cuda.device(device):
+                    status = call(self._stream())
+            if status < 0:
+                lib.check(status, handle)
+
+        if kind in ("pendulum", "gyropod", "servos"):
+            fn = {"pendulum": lib_.upkie_sim_step_pendulum, "gyropod": lib_.upkie_sim_step_gyropod, "servos": lib_.upkie_sim_step_servos}[kind]
+            return lambda act, obs, rew, term, trunc: launch(lambda st: fn(handle, state, act, obs, rew, term, trunc, st))
+        if kind == "servos_policy":
+            assert policy is not None
+            if getattr(self, "_policy_act", None) is None:
+                self._policy_act = torch.zeros((self.num_envs, 6, 6), dtype=torch.float32, device=self.device)
+            policy_act, policy_ref = self._policy_act.data_ptr(), C.byref(policy)
+            fn = lib_.upkie_sim_step_servos_policy
+            return lambda act, obs, rew, term, trunc: launch(lambda st: fn(handle, state, policy_ref, policy_act, obs, rew, term, trunc, st))
+        if kind == "base_velocity":
+            assert mpc is not None and mpc_x0 is not None and mpc_contact is not None
+            ws, commanded, x0, contact = mpc.workspace.data_ptr(), mpc.commanded_velocity.data_ptr(), mpc_x0.data_ptr(), mpc_contact.data_ptr()
+            fn, mpc_handle = lib_.upkie_sim_step_base_velocity_mpc, mpc._handle
+            return lambda act, obs, rew, term, trunc: launch(lambda st: fn(handle, mpc_handle, state, ws, act, commanded, obs, x0, contact, rew, term, trunc, st))
+        raise ValueError(f"unknown env kind '{kind}'")
+
     def step_pendulum(self, act):
         act = self._as_action(act, (self.num_envs,))
         return self._step(self._lib.upkie_sim_step_pendulum, act, self.obs4)
