@@ -232,6 +232,30 @@ int upkie_sim_lanes_per_env(const UpkieSim* sim);
  * (the reference's envs are single robots: no counterpart there). */
 int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
 
+/* Contact model. Default (`manifold` NULL): the product's specification -- one
+ * contact point per tire, exact solve with Gauss-Seidel sweeps to convergence
+ * when the solution leaves the friction box, friction CFM 0.01 (DESIGN.md
+ * section 3). With `manifold` set -- the caller's device buffer
+ * [UPKIE_CONTACT_MANIFOLD_WORDS][B] fp32, zeroed by the caller, kept between
+ * steps -- every step of this handle solves contacts and joint limits the way
+ * Bullet's multibody solver is published to inside pybullet.stepSimulation()
+ * (call sites pybullet_backend.py:228,306; third
+ * party, absent here: restated, unverified): a persistent manifold of up to
+ * four points per tire (refresh against the breaking threshold, nearest cached
+ * point replaced), one normal + two friction rows per point along / across
+ * its sliding velocity, no friction CFM, a FIXED number of sequential-impulse
+ * sweeps (UpkieModel.pgs_iterations = 50; joint limits, normals, then each
+ * point's friction pair projected onto the cone), normal impulses warm-started
+ * with 0.85 x the last applied ones. Per env and tire four records of 8 words:
+ * point in the wheel frame (3), on the plane in world coordinates (3), applied
+ * normal impulse, live flag. A reset clears an env's manifold. This model
+ * exists in the one-env-per-lane kernels only (upkie_sim_lanes_per_env
+ * reports 1 while it is set) and is several times slower than the default:
+ * it is there to answer "what would PyBullet's contact pipeline do", e.g. as
+ * the first thing tools/compare_with_pybullet.py should be pointed at. */
+#define UPKIE_CONTACT_MANIFOLD_WORDS 64
+int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold);
+
 /* Rare-path census of the eight-lanes-per-env step kernel (octet.hpp): `counters`
  * is the caller's device buffer of UPKIE_CENSUS_WORDS uint32 (zeroed by the
  * caller) or NULL to switch the census off (the default). Env-substeps:

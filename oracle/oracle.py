@@ -152,6 +152,7 @@ def _load(path):
     _lib.oracle_energy.restype = C.c_double
     _lib.oracle_substep.restype = C.c_int
     _lib.oracle_substep_ext.restype = C.c_int
+    _lib.oracle_substep_bullet_like.restype = C.c_int
     _lib.oracle_mpc_solve_exact.restype = C.c_int
     _lib.oracle_observers_check.restype = C.c_int
     _lib.oracle_pitch_frame_in_parent.restype = C.c_double

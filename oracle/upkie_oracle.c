@@ -1718,6 +1718,18 @@ void oracle_gyropod_observation(const UpkieModel* model, const double* state, do
 }
 
 /* One world-frame force at a trunk point (the original entry point). */
+/* One substep under the Bullet-like contact specification on a caller-held
+ * manifold [ORACLE_BULLET_MANIFOLD_WORDS] (tests of the device's twin,
+ * upkie_amd/csrc/bullet_like.hpp, substep by substep). */
+int oracle_substep_bullet_like(const UpkieModel* model, double* s, const double tau[6], double h, double* manifold) {
+  memcpy(g_bullet_manifold, manifold, sizeof(g_bullet_manifold));
+  g_bullet_active = 1;
+  const int contact = oracle_substep_ext(model, s, tau, h, NULL, NULL, NULL);
+  memcpy(manifold, g_bullet_manifold, sizeof(g_bullet_manifold));
+  g_bullet_active = 0;
+  return contact;
+}
+
 int oracle_substep(const UpkieModel* model, double* s, const double tau[6],
                    double h, const double* body_inertials,
                    const double* ext_force, const double* ext_point) {

@@ -100,6 +100,7 @@ int oracle_substep(const UpkieModel* model, double* state, const double tau[6],
                    double h, const double* body_inertials /* [70] of this env or NULL */,
                    const double* ext_force, const double* ext_point);
 /* Same with forces on any link: ext_forces[count][3], pybullet_backend.py:603-658. */
+int oracle_substep_bullet_like(const UpkieModel* model, double* state, const double tau[6], double h, double* manifold);
 int oracle_substep_ext(const UpkieModel* model, double* state, const double tau[6],
                        double h, const double* body_inertials /* [70] of this env or NULL */,
                        const double* ext_forces, const UpkieExternalForces* ext_slots);

@@ -38,6 +38,9 @@ class OracleSim:
     def close(self):
         pass
 
+    def use_bullet_like_contacts(self, on=True):
+        self._o.use_bullet_like_contacts(on)
+
     def restart_random_streams(self):
         self._o.state[abi.S_EPISODE] = 0.0
         self._o.state[abi.S_STEP] = 0.0

@@ -41,6 +41,35 @@ extern "C" int harness_substep(const UpkieModel* model, float* st, const float* 
   return c ? 1 : 0;
 }
 
+// One substep under the Bullet-like contact specification (bullet_like.hpp) on the host: manifold [64] in / out.
+extern "C" int harness_substep_bullet_like(const UpkieModel* model, float* st, const float* tau, float h, float* manifold) {
+  DevModel M;
+  std::string why;
+  if (!convert_model(model, &M, &why)) return -1;
+  Phys s;
+  s.pos = v3(st[UPKIE_S_POS], st[UPKIE_S_POS + 1], st[UPKIE_S_POS + 2]);
+  s.qw = st[UPKIE_S_QUAT]; s.qx = st[UPKIE_S_QUAT + 1]; s.qy = st[UPKIE_S_QUAT + 2]; s.qz = st[UPKIE_S_QUAT + 3];
+  s.linvel = v3(st[UPKIE_S_LINVEL], st[UPKIE_S_LINVEL + 1], st[UPKIE_S_LINVEL + 2]);
+  s.angvel = v3(st[UPKIE_S_ANGVEL], st[UPKIE_S_ANGVEL + 1], st[UPKIE_S_ANGVEL + 2]);
+  for (int j = 0; j < 6; ++j) { s.q[j] = st[UPKIE_S_Q + j]; s.qd[j] = st[UPKIE_S_QD + j]; }
+  float t[6];
+  for (int j = 0; j < 6; ++j) t[j] = tau[j];
+  ExtSlots x{};
+  const ExtForces ext{nullptr, 1, &x};
+  DevLimits Lm;
+  model_limits(M, &Lm);
+  float mf[BL_MANIFOLD_WORDS];
+  for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) mf[w] = manifold[w];
+  const bool c = physics_substep<false, true>(M, Lm, s, t, h, nullptr, ext, nullptr, &mf);
+  for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) manifold[w] = mf[w];
+  st[UPKIE_S_POS] = s.pos.x; st[UPKIE_S_POS + 1] = s.pos.y; st[UPKIE_S_POS + 2] = s.pos.z;
+  st[UPKIE_S_QUAT] = s.qw; st[UPKIE_S_QUAT + 1] = s.qx; st[UPKIE_S_QUAT + 2] = s.qy; st[UPKIE_S_QUAT + 3] = s.qz;
+  st[UPKIE_S_LINVEL] = s.linvel.x; st[UPKIE_S_LINVEL + 1] = s.linvel.y; st[UPKIE_S_LINVEL + 2] = s.linvel.z;
+  st[UPKIE_S_ANGVEL] = s.angvel.x; st[UPKIE_S_ANGVEL + 1] = s.angvel.y; st[UPKIE_S_ANGVEL + 2] = s.angvel.z;
+  for (int j = 0; j < 6; ++j) { st[UPKIE_S_Q + j] = s.q[j]; st[UPKIE_S_QD + j] = s.qd[j]; }
+  return c ? 1 : 0;
+}
+
 // contact_pgs6() on the host (fp32, the arithmetic of the kernels): A [21] packed lower, rhs [6], lam [6] in / out
 extern "C" int harness_contact_pgs6(const UpkieModel* model, const float* A, const float* rhs, float* lam, int both_tires) {
   DevModel M;

@@ -1,0 +1,155 @@
+"""The Bullet-like contact model ON THE DEVICE (`upkie_sim_set_contact_manifold`,
+upkie_amd/csrc/bullet_like.hpp) against the oracle's `bullet_like` mode
+(oracle/upkie_oracle.c::bullet_like_contacts) over whole env.step() rollouts of
+BASELINE's C2 and C5-share workloads, at the fp32 tolerances the default
+contact model is held to. (Substep by substep, manifold bookkeeping included:
+tests/test_bullet_like_on_host.py, no GPU.)"""
+
+import numpy as np
+import pytest
+import torch
+
+from upkie_amd import abi
+from upkie_amd.model.default_model import default_model
+from upkie_amd.model.model import Model
+from upkie_amd.sim import BatchedSim
+
+from .helpers import randomized_config, state_errors
+
+pytestmark = pytest.mark.gpu
+
+
+def manifolds(sim, ref):
+    mh = sim.contact_manifold.cpu().numpy().astype(np.float64).reshape(2, 4, 8, -1)
+    mo = ref.bullet_manifold.reshape(2, 4, 8, -1)
+    return mh, mo
+
+
+def test_c2_rollout_under_the_bullet_like_model_matches_the_oracle():
+    """Upkie-Pendulum, README agent, 2048 envs x 60 steps: observations within
+    the closed-loop tolerances of the default model, the same points cached,
+    applied normal impulses within 1e-4 N.s."""
+    from oracle import oracle as O
+
+    B = 2048
+    cfg = randomized_config(B, seed=3)
+    sim = BatchedSim(cfg)
+    assert sim.lanes_per_env == 8
+    sim.use_bullet_like_contacts()
+    assert sim.lanes_per_env == 1  # (the model lives in the one-lane kernels)
+    ref = O.Oracle(default_model(), cfg)
+    ref.use_bullet_like_contacts()
+    sim.reset()
+    obs_ref = ref.reset()[:, [1, 0, 4, 3]]
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    worst = np.zeros((B, 4))
+    for k in range(60):
+        obs_ref, _, term_ref, _ = ref.step_pendulum_agent(obs_ref)
+        obs, _, term, _ = sim.step_pendulum_agent()
+        worst = np.maximum(worst, np.abs(obs.cpu().numpy() - obs_ref))
+        assert np.array_equal(term.cpu().numpy(), term_ref)
+    q = {p: np.quantile(worst, p, axis=0) for p in (0.5, 0.99, 1.0)}
+    print("bullet-like C2: |obs - oracle| quantiles", {k: v.round(7).tolist() for k, v in q.items()})
+    assert q[1.0][0] <= 1e-3 and q[1.0][1] <= 1e-3, q  # SURVEY A.9 closed-loop tolerance, every env
+    assert q[0.5][0] <= 2e-6 and q[0.5][1] <= 5e-6 and q[0.99][0] <= 1e-4 and q[0.99][1] <= 1e-4, q
+    mh, mo = manifolds(sim, ref)
+    assert np.array_equal(mh[:, :, 7] != 0, mo[:, :, 7] != 0)
+    assert (mo[:, :, 7].sum(axis=1) == 1).all()  # rolling wheels: one cached point per tire
+    live = mo[:, :, 7] != 0
+    assert np.abs(mh[:, :, 6] - mo[:, :, 6])[live].max() < 1e-4 and mo[:, :, 6][live].min() > 0.01  # ~0.026 N.s per tire and substep
+    assert np.abs(mh[:, :, :3] - mo[:, :, :3]).transpose(0, 1, 3, 2)[live].max() < 2e-5  # the cached points, wheel frame
+    err = state_errors(ref.state, sim.state_numpy())
+    assert err["pos"] < 1e-3 and err["quat"] < 1e-3 and err["contact"] == 0, err
+
+
+def test_autoreset_clears_the_manifold_and_falls_match_the_oracle():
+    """NEXT_STEP autoreset with a small fall pitch: envs fall and restart inside
+    the 80 steps; a reset drops the env's contact cache on both sides."""
+    from oracle import oracle as O
+
+    B = 512
+    cfg = randomized_config(B, seed=5, autoreset=True)
+    cfg.fall_pitch = 0.12
+    sim = BatchedSim(cfg)
+    sim.use_bullet_like_contacts()
+    ref = O.Oracle(default_model(), cfg)
+    ref.use_bullet_like_contacts()
+    sim.reset()
+    ref.reset()
+    act = torch.zeros(B, device=sim.device)  # no balancing: every robot falls
+    ends = 0
+    for _ in range(80):
+        oh, _, th, _ = sim.step_pendulum(act)
+        oo, _, to, _ = ref.step_pendulum(np.zeros(B))
+        assert np.array_equal(th.cpu().numpy(), to)
+        ends += int(to.sum())
+        assert np.abs(oh.cpu().numpy() - oo)[:, :2].max() < 2e-4
+    assert ends >= B  # every env ended an episode at least once
+    mh, mo = manifolds(sim, ref)
+    assert np.array_equal(mh[:, :, 7] != 0, mo[:, :, 7] != 0)
+    assert np.array_equal(sim.state_numpy()[abi.S_EPISODE], ref.state[abi.S_EPISODE])
+
+
+def test_c5_share_under_the_bullet_like_model_matches_the_oracle():
+    """Servos env, per-link inertia randomisation, a push on the torso, wheel
+    friction, the torque-balancing action: 1024 envs x 10 steps (the RAND
+    instantiations of the Bullet-like kernels)."""
+    from oracle import oracle as O
+
+    B = 1024
+    cfg = randomized_config(B, seed=2)
+    cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
+    model = Model().struct
+    sim = BatchedSim(cfg, model)
+    sim.use_bullet_like_contacts()
+    ref = O.Oracle(model, cfg)
+    ref.use_bullet_like_contacts()
+    sim.randomize_inertias(0.2)
+    ref.body_inertials = ref.sample_body_inertials(0.2)
+    rng = np.random.default_rng(5)
+    angle, norm = rng.uniform(0, 2 * np.pi, B), rng.uniform(0.0, 20.0, B)
+    force = np.stack([norm * np.cos(angle), norm * np.sin(angle), np.zeros(B)])
+    ref.ext_force = force
+    ref.ext_point = np.array([0.0, 0.0, -0.1])
+    sim.set_external_force(torch.from_numpy(force).float(), point=(0.0, 0.0, -0.1))
+    obs_o = ref.reset()
+    sim.reset()
+    act = np.zeros((B, 6, 6))
+    act[:, :, 3] = 1.0
+    act[:, :, 4] = 1.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = np.nan
+    act[:, [2, 5], 4] = 0.0
+    pitch = obs_o[:, 1]
+    for _ in range(10):
+        act[:, 2, 2] = 10.0 * pitch
+        act[:, 5, 2] = -10.0 * pitch
+        so, _, _, _ = ref.step_servos(act)
+        sh, _, term, _ = sim.step_servos(torch.from_numpy(act).float())
+        st = ref.state
+        pitch = np.arcsin(np.clip(2.0 * (st[abi.S_QUAT] * st[abi.S_QUAT + 2] - st[abi.S_QUAT + 3] * st[abi.S_QUAT + 1]), -1, 1))
+    err = state_errors(ref.state, sim.state_numpy())
+    print("bullet-like C5 share, state errors after 10 steps", err)
+    assert err["pos"] < 2e-4 and err["quat"] < 2e-4, err
+    assert err["linvel"] < 5e-3 and err["angvel"] < 2e-2, err
+    sh = sh.cpu().numpy()
+    dq = np.abs(sh[:, :, 0] - so[:, :, 0])
+    assert dq[:, [0, 1, 3, 4]].max() <= 1e-3 and np.quantile(dq, 0.5) <= 1e-5, (dq.max(axis=0), np.quantile(dq, [0.5, 0.99]))
+    assert np.quantile(dq[:, [2, 5]], 0.99) <= 1e-3, np.quantile(dq[:, [2, 5]], [0.5, 0.99, 1.0])
+
+
+def test_switching_the_model_off_restores_the_default_kernels():
+    B = 256
+    cfg = randomized_config(B, seed=1)
+    a, b = BatchedSim(cfg), BatchedSim(cfg)
+    b.use_bullet_like_contacts()
+    b.use_bullet_like_contacts(False)
+    assert b.lanes_per_env == a.lanes_per_env == 8
+    a.reset()
+    b.reset()
+    a.obs4.copy_(a.obs6[:, [1, 0, 4, 3]])
+    b.obs4.copy_(b.obs6[:, [1, 0, 4, 3]])
+    for _ in range(5):
+        oa = a.step_pendulum_agent()[0]
+        ob = b.step_pendulum_agent()[0]
+    assert torch.equal(oa, ob)

@@ -56,6 +56,7 @@ S_CONTACT = 45
 S_STEP = 46
 S_ELAPSED = 47  # steps of the current episode (time limit)
 STATE_WORDS = 48
+CONTACT_MANIFOLD_WORDS = 64  # UPKIE_CONTACT_MANIFOLD_WORDS (upkie_sim_set_contact_manifold)
 CENSUS_WORDS = 72  # UPKIE_CENSUS_WORDS: eight counters + a 64-bin histogram (upkie_sim_set_census)
 PENDULUM_STATE_WORDS = 29
 

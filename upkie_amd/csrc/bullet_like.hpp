@@ -1,0 +1,299 @@
+// bullet_like.hpp -- the Bullet-like contact specification on the device, selectable per handle next to the product's
+// default one (upkie_sim_set_contact_manifold, include/upkie_hip.h; `contact_model="bullet_like"` of the vector envs).
+//
+// What pybullet.stepSimulation() (call site pybullet_backend.py:306; reset: :228) is published to do between the free
+// acceleration and the position update, as SURVEY.md Appendix B.1 / B.2 summarise Bullet 3.25's btPersistentManifold
+// and btMultiBodyConstraintSolver [third party, absent from /root/reference: restated, unverified]:
+//   - a PERSISTENT manifold of up to four points per tire: every step the cached points are refreshed (dropped beyond
+//     the contact breaking threshold, along the normal or in the plane), and the deepest point of the tire replaces
+//     the cached point nearest to it in the wheel's frame within the threshold, or is added (a full manifold gives up
+//     its shallowest point);
+//   - one normal and two friction rows per cached point; friction directions along / across the sliding velocity of
+//     the point (btPlaneSpace1 of the normal when it does not slide); zero friction CFM; the normal rows carry the
+//     URDF contact stiffness / damping as CFM / ERP and may only close a gap within the step;
+//   - sequential impulses, a FIXED number of sweeps (numSolverIterations = 50, DevModel::pgs_iterations): joint-limit
+//     rows, then the normal rows, then the two friction rows of each point together, projected onto the cone
+//     |f| <= mu f_n; normal impulses warm-started with 0.85 x the impulse applied in the previous step.
+// The same algorithm as the test-side fp64 checker's `bullet_like_contacts` (world frame, dense Delassus matrix),
+// stated here the way Bullet itself iterates: on VELOCITIES (each row keeps M^-1 J' and adds its
+// impulse change to the running velocity change), in the base frame, on top of the factored system the default
+// specification builds (System: 6 x 6 base block + the two 3 x 3 leg blocks). In exact arithmetic the two produce the
+// same impulses after every sweep.
+//
+// One env per lane (the one-lane step kernels only: launch_step sends handles with a contact manifold there whatever
+// the batch size). Rows live in private memory (up to 28 rows x 29 words, indexed dynamically: scratch); the manifold
+// (64 words per env) is loaded from / stored to the caller's buffer [BL_MANIFOLD_WORDS][B] once per env.step().
+#pragma once
+#include "dynamics.hpp"
+
+namespace upkie {
+
+enum {
+  BL_POINTS = 4,
+  BL_POINT_WORDS = 8,  // point in the wheel frame (3), on the plane in world coordinates (3), applied normal impulse, live
+  BL_MANIFOLD_WORDS = 2 * BL_POINTS * BL_POINT_WORDS,  // == UPKIE_CONTACT_MANIFOLD_WORDS
+  BL_ROWS = 2 * BL_POINTS * 3 + 4
+};
+
+struct BlRow {
+  float Jb[6];   // base part of the row (base frame: linear 0-2, angular 3-5)
+  float Jl[3];   // joint part: the three joints of leg `leg` (the other leg's entries are zero)
+  float Mb[6], Ml[3], Mr[3];  // M^-1 J'
+  float rhs, cfm, inv_diag, lam;
+  int leg, kind, normal_row, slot;  // kind: 0 normal, 1 friction, 2 joint limit; slot: manifold word of the applied impulse or -1
+};
+
+// Contacts and joint limits of one substep under the Bullet-like specification.
+//   S: the factored system of this substep; bf: its base frame; tb / tl / tr: on entry the generalised impulse
+//   h (applied - bias) (base, left leg, right leg), on return the velocity change of the substep, contacts included;
+//   mf: the env's contact manifold (updated). Returns the floor-contact flag (a cached point exists).
+template <class ModelT>
+UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const System& S, const BaseFrame& bf, const Phys& s, float h,
+                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[BL_MANIFOLD_WORDS]) {
+  // free velocity: nu + M^-1 h (applied - bias)
+  system_solve<true, true>(S, tb, tl, tr);
+  const V3 vF = bf.vB + v3(tb[0], tb[1], tb[2]), wF = bf.wB + v3(tb[3], tb[4], tb[5]);
+  float qdF[UPKIE_NJ];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    qdF[j] = s.qd[j] + tl[j];
+    qdF[3 + j] = s.qd[3 + j] + tr[j];
+  }
+  const V3 nB = bf.nB;
+  const float breaking = M.contact_breaking_threshold, ih = fast_rcp(h);
+  const float denom = h * M.contact_stiffness + M.contact_damping;
+  const float erp = denom > 0.f ? h * M.contact_stiffness * fast_rcp(denom) : 0.2f;
+  const float cfm_n = denom > 0.f ? fast_rcp(denom * h) : 0.f;
+
+  BlRow rows[BL_ROWS];
+  int nrows = 0;
+  bool any_contact = false;
+  auto finish_row = [&](BlRow& R) {  // M^-1 J' and the diagonal of the Delassus matrix
+#pragma unroll
+    for (int c = 0; c < 6; ++c) R.Mb[c] = R.Jb[c];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      R.Ml[j] = R.leg == 0 ? R.Jl[j] : 0.f;
+      R.Mr[j] = R.leg == 0 ? 0.f : R.Jl[j];
+    }
+    system_solve<true, true>(S, R.Mb, R.Ml, R.Mr);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) d = fmaf(R.Jb[c], R.Mb[c], d);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) d = fmaf(R.Jl[j], R.leg == 0 ? R.Ml[j] : R.Mr[j], d);
+    R.inv_diag = 1.f / (d + R.cfm);
+  };
+
+  // ---- joint limits (btMultiBodyJointLimitConstraint, ERP 0.2): first in every sweep
+  if (Lm.enforce) {
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      if (!Lm.bounded[j]) continue;
+      float sign = 0.f, err = 0.f;
+      if (s.q[j] <= Lm.lower[j]) { sign = 1.f; err = Lm.lower[j] - s.q[j]; }
+      else if (s.q[j] >= Lm.upper[j]) { sign = -1.f; err = s.q[j] - Lm.upper[j]; }
+      else continue;
+      BlRow& R = rows[nrows];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) R.Jb[c] = 0.f;
+      R.leg = j / 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R.Jl[k] = (j % 3) == k ? sign : 0.f;
+      R.kind = 2; R.normal_row = nrows; R.cfm = 0.f; R.lam = 0.f; R.slot = -1;
+      R.rhs = -sign * qdF[j] + 0.2f * err * ih;
+      finish_row(R);
+      ++nrows;
+    }
+  }
+
+  // ---- the tires
+  for (int wheel = 0; wheel < 2; ++wheel) {
+    const Leg& G = S.leg[wheel];
+    float* pts = mf + wheel * BL_POINTS * BL_POINT_WORDS;
+    const V3 ow = G.o[2];
+    // orientation of the wheel body in the base frame: one rotation about y by the leg's summed joint angles
+    float sn, cs;
+    joint_sincos(G.sgn[0] * s.q[3 * wheel] + G.sgn[1] * s.q[3 * wheel + 1] + G.sgn[2] * s.q[3 * wheel + 2], &sn, &cs);
+    auto in_base = [&](const float* pt) { return ow + rot_y(cs, sn, v3(pt[0], pt[1], pt[2])); };
+    auto world_xy = [&](V3 A, float& x, float& y) {
+      x = s.pos.x + bf.r00 * A.x + bf.r01 * A.y + bf.r02 * A.z;
+      y = s.pos.y + bf.r10 * A.x + bf.r11 * A.y + bf.r12 * A.z;
+    };
+    // btPersistentManifold::refreshContactPoints
+    for (int p = 0; p < BL_POINTS; ++p) {
+      float* pt = pts + p * BL_POINT_WORDS;
+      if (pt[7] == 0.f) continue;
+      const V3 A = in_base(pt);
+      const float dist = s.pos.z + dot(nB, A);
+      float x, y;
+      world_xy(A, x, y);
+      const float dx = x - pt[3], dy = y - pt[4];
+      if (dist > breaking || dx * dx + dy * dy > breaking * breaking) pt[7] = 0.f;
+    }
+    // the deepest point of the tire circle (btConvexPlaneCollisionAlgorithm's support point)
+    {
+      const float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
+      if (un >= 1e-6f) {
+        const float iun = fast_rcp(un);
+        const V3 center = ow + v3(M.wheel_center[wheel][0], M.wheel_center[wheel][1], M.wheel_center[wheel][2]);
+        const V3 P = center + M.wheel_radius * v3(-nB.x * iun, 0.f, -nB.z * iun);
+        const float Pz = s.pos.z + dot(nB, P);
+        if (Pz <= breaking) {
+          const V3 local = rot_y(cs, -sn, P - ow);
+          // btPersistentManifold::getCacheEntry: the nearest cached point within the threshold is replaced
+          int slot = -1;
+          float nearest = breaking * breaking;
+          for (int p = 0; p < BL_POINTS; ++p) {
+            const float* pt = pts + p * BL_POINT_WORDS;
+            if (pt[7] == 0.f) continue;
+            const float d0 = pt[0] - local.x, d1 = pt[1] - local.y, d2 = pt[2] - local.z;
+            const float dd = d0 * d0 + d1 * d1 + d2 * d2;
+            if (dd < nearest) { nearest = dd; slot = p; }
+          }
+          float keep = 0.f;
+          if (slot >= 0) {
+            keep = pts[slot * BL_POINT_WORDS + 6];  // replaceContactPoint keeps the applied impulse
+          } else {
+            for (int p = 0; p < BL_POINTS && slot < 0; ++p)
+              if (pts[p * BL_POINT_WORDS + 7] == 0.f) slot = p;
+            if (slot < 0) {  // full: the shallowest cached point makes room
+              float worst = -3.0e38f;
+              for (int p = 0; p < BL_POINTS; ++p) {
+                const float z = s.pos.z + dot(nB, in_base(pts + p * BL_POINT_WORDS));
+                if (z > worst) { worst = z; slot = p; }
+              }
+            }
+          }
+          float* pt = pts + slot * BL_POINT_WORDS;
+          pt[0] = local.x; pt[1] = local.y; pt[2] = local.z;
+          world_xy(P, pt[3], pt[4]);
+          pt[5] = 0.f;
+          pt[6] = keep;
+          pt[7] = 1.f;
+        }
+      }
+    }
+    // rows of every cached point
+    for (int p = 0; p < BL_POINTS; ++p) {
+      float* pt = pts + p * BL_POINT_WORDS;
+      if (pt[7] == 0.f) continue;
+      any_contact = true;
+      const V3 A = in_base(pt);
+      const float dist = s.pos.z + dot(nB, A);
+      // velocity of the point at the free velocity
+      V3 v = vF + cross(wF, A);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const V3 rr = A - G.o[j];
+        const float sq = G.sgn[j] * qdF[3 * wheel + j];
+        v = v + sq * v3(rr.z, 0.f, -rr.x);  // (sgn y) x rr
+      }
+      const float vn = dot(v, nB);
+      const V3 vt = v - vn * nB;
+      const float lat2 = dot(vt, vt);
+      V3 t1, t2;
+      if (lat2 > 1.1920929e-07f) {  // SIMD_EPSILON: friction along the sliding direction
+        t1 = (1.f / sqrtf(lat2)) * vt;
+        t2 = cross(t1, nB);
+      } else {  // btPlaneSpace1(n) for n = world z: (0, -1, 0) and (1, 0, 0), in base coordinates
+        t1 = v3(-bf.r10, -bf.r11, -bf.r12);
+        t2 = v3(bf.r00, bf.r01, bf.r02);
+      }
+      const V3 dirs[3] = {nB, t1, t2};
+      for (int k = 0; k < 3; ++k) {
+        BlRow& R = rows[nrows];
+        const V3 d = dirs[k];
+        const V3 Axd = cross(A, d);
+        R.Jb[0] = d.x; R.Jb[1] = d.y; R.Jb[2] = d.z; R.Jb[3] = Axd.x; R.Jb[4] = Axd.y; R.Jb[5] = Axd.z;
+        R.leg = wheel;
+        float rel = d.x * vF.x + d.y * vF.y + d.z * vF.z + Axd.x * wF.x + Axd.y * wF.y + Axd.z * wF.z;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const V3 rr = A - G.o[j];
+          R.Jl[j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
+          rel = fmaf(R.Jl[j], qdF[3 * wheel + j], rel);
+        }
+        if (k == 0) {
+          R.kind = 0; R.normal_row = nrows; R.cfm = cfm_n;
+          R.rhs = dist <= 0.f ? -rel + erp * (-dist) * ih : -rel - dist * ih;
+          R.lam = 0.85f * pt[6];  // m_warmstartingFactor
+          R.slot = (wheel * BL_POINTS + p) * BL_POINT_WORDS + 6;
+        } else {
+          R.kind = 1; R.normal_row = nrows - k; R.cfm = 0.f;
+          R.rhs = -rel;
+          R.lam = 0.f;
+          R.slot = -1;
+        }
+        finish_row(R);
+        ++nrows;
+      }
+    }
+  }
+  if (nrows == 0) return false;  // (tb, tl, tr hold the free velocity change)
+
+  // ---- sequential impulses on the velocity change dv = M^-1 J' lam
+  float dvb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dvl[3] = {0.f, 0.f, 0.f}, dvr[3] = {0.f, 0.f, 0.f};
+  auto apply = [&](const BlRow& R, float delta) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dvb[c] = fmaf(R.Mb[c], delta, dvb[c]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dvl[j] = fmaf(R.Ml[j], delta, dvl[j]);
+      dvr[j] = fmaf(R.Mr[j], delta, dvr[j]);
+    }
+  };
+  auto along = [&](const BlRow& R) {  // J dv
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a = fmaf(R.Jb[c], dvb[c], a);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a = fmaf(R.Jl[j], R.leg == 0 ? dvl[j] : dvr[j], a);
+    return a;
+  };
+  for (int r = 0; r < nrows; ++r)
+    if (rows[r].lam != 0.f) apply(rows[r], rows[r].lam);  // the warm start
+  const float mu = M.friction_mu;
+  for (int it = 0; it < M.pgs_iterations; ++it) {
+    for (int pass = 0; pass < 2; ++pass) {  // joint limits, then normals
+      for (int r = 0; r < nrows; ++r) {
+        BlRow& R = rows[r];
+        if (R.kind != (pass == 0 ? 2 : 0)) continue;
+        float x = R.lam + (R.rhs - along(R) - R.cfm * R.lam) * R.inv_diag;
+        x = x < 0.f ? 0.f : x;
+        const float delta = x - R.lam;
+        R.lam = x;
+        apply(R, delta);
+      }
+    }
+    for (int r = 0; r + 1 < nrows; ++r) {  // the two friction rows of a point together, projected onto the cone
+      BlRow& R1 = rows[r];
+      if (R1.kind != 1 || r != R1.normal_row + 1) continue;
+      BlRow& R2 = rows[r + 1];
+      const float w1 = along(R1), w2 = along(R2);
+      float x1 = R1.lam + (R1.rhs - w1) * R1.inv_diag, x2 = R2.lam + (R2.rhs - w2) * R2.inv_diag;
+      const float lim = mu * rows[R1.normal_row].lam, norm = sqrtf(x1 * x1 + x2 * x2);
+      if (norm > lim) {
+        const float sc = norm > 0.f ? lim / norm : 0.f;
+        x1 *= sc;
+        x2 *= sc;
+      }
+      const float d1 = x1 - R1.lam, d2 = x2 - R2.lam;
+      R1.lam = x1;
+      R2.lam = x2;
+      apply(R1, d1);
+      apply(R2, d2);
+    }
+  }
+  for (int r = 0; r < nrows; ++r)
+    if (rows[r].slot >= 0) mf[rows[r].slot] = rows[r].lam;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) tb[c] += dvb[c];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    tl[j] += dvl[j];
+    tr[j] += dvr[j];
+  }
+  return any_contact;
+}
+
+}  // namespace upkie

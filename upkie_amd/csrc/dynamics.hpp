@@ -1279,9 +1279,16 @@ struct ContactReport {
 // One physics substep of duration h. tau: commanded joint torques.
 // bi: inertial records of this env's bodies or nullptr (the model's). ext: external forces.
 // Returns the floor-contact flag.
-template <bool SCRATCH_LIMITS = false, class ModelT>
+// BULLET_LIKE: contacts and joint limits by the Bullet-like specification of bullet_like.hpp on the env's contact
+// manifold `manifold` (upkie_sim_set_contact_manifold) instead of the default one.
+template <class ModelT>
+UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const System& S, const BaseFrame& bf, const Phys& s, float h,
+                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[64]);
+
+template <bool SCRATCH_LIMITS = false, bool BULLET_LIKE = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
-                                                const BodyInertials* bi, const ExtForces& ext, ContactReport* report = nullptr) {
+                                                const BodyInertials* bi, const ExtForces& ext, ContactReport* report = nullptr,
+                                                float (*manifold)[64] = nullptr) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
   // unilateral rows with ERP 0.2): rare, handled by the general solver
   bool any_limit = false;
@@ -1406,6 +1413,10 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     rt[c] = tb[c] - (S.leg[0].D[c][0] * tl[0] + S.leg[0].D[c][1] * tl[1] + S.leg[0].D[c][2] * tl[2]) -
             (S.leg[1].D[c][0] * tr[0] + S.leg[1].D[c][1] * tr[1] + S.leg[1].D[c][2] * tr[2]);
 
+  bool any_contact = false;
+  if constexpr (BULLET_LIKE) {
+    any_contact = bullet_like_contacts(M, Lm, S, bf, s, h, tb, tl, tr, *manifold);  // (leaves the velocity change in tb, tl, tr)
+  } else {
   // ---- tire / floor contacts -------------------------------------------
   // Rows 3w+0..2 = (normal, t1, t2) of wheel w. Row r of wheel w only touches
   // the base and leg w: J = [d ; P x d ; leg part (3)].
@@ -1413,7 +1424,6 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   float Jt[6][6];            // rows reduced onto the base
   float rhs[6], vnow[6], dists[2];
   bool active[2];
-  bool any_contact = false;
   float un = fast_sqrt(nB.x * nB.x + nB.z * nB.z);
   float iun = fast_rcp(fmaxf(un, 1e-12f));
   float denom = h * M.contact_stiffness + M.contact_damping;
@@ -1554,6 +1564,12 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   }
   // nu+ = nu + M^-1 t
   system_solve<true, true>(S, tb, tl, tr);
+  if (report) {
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      report->force[w] = ih * (lam[3 * w] * report->dir[w][0] + lam[3 * w + 1] * report->dir[w][1] + lam[3 * w + 2] * report->dir[w][2]);
+  }
+  }
   float nu[12];
   nu[0] = vB.x + tb[0]; nu[1] = vB.y + tb[1]; nu[2] = vB.z + tb[2];
   nu[3] = wB.x + tb[3]; nu[4] = wB.y + tb[4]; nu[5] = wB.z + tb[5];
@@ -1571,11 +1587,6 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     s.q[j] = fmaf(h, v, s.q[j]);
   }
   integrate_base(bf, nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
-  if (report) {
-#pragma unroll
-    for (int w = 0; w < 2; ++w)
-      report->force[w] = ih * (lam[3 * w] * report->dir[w][0] + lam[3 * w + 1] * report->dir[w][1] + lam[3 * w + 2] * report->dir[w][2]);
-  }
   return any_contact;
 }
 

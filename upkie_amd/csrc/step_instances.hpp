@@ -1,7 +1,7 @@
 // step_instances.hpp -- every instantiation of the three step kernels that launch_step (upkie_hip.hip) can launch, as
 // one list read twice: upkie_hip.hip includes it with UPKIE_INSTANCE_KW = `extern` (declarations: the C-ABI's
 // translation unit compiles no step kernel), step_instances.hip with UPKIE_INSTANCE_KW empty and UPKIE_INSTANCE_GROUP = g
-// (definitions of group g). ~100 kernels of 5-20 k instructions each: in one translation unit the library took two
+// (definitions of group g). ~115 kernels of 5-20 k instructions each: in one translation unit the library took two
 // minutes to build; by groups, on eight cores, about forty seconds (upkie_amd/lib.py).
 //
 // The kernels of different groups share no device symbol (every device function is inlined), so no relocatable device
@@ -13,7 +13,7 @@
 #define UPKIE_INSTANCE_KW extern
 #define UPKIE_INSTANCE_GROUP (-1) /* declarations: every group */
 #endif
-#define UPKIE_INSTANCE_GROUPS 8
+#define UPKIE_INSTANCE_GROUPS 9
 
 namespace upkie {
 
@@ -21,20 +21,25 @@ namespace upkie {
   const DevModel*, DevLimits, DevConfig, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*, const float*, \
       const float*, int, BaseVelocityPtrs, float*, float*
 #define UPKIE_PAIR_ARGS UPKIE_ONE_LANE_ARGS, int
+#define UPKIE_ONE_LANE_KERNEL_ARGS UPKIE_ONE_LANE_ARGS, float*
 #define UPKIE_OCTET_ARGS(MODE)                                                                                                          \
   const DevModel*, const DevParams*, int, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*, const float*, \
       const float*, int, BaseVelocityPtrs, float*, int, unsigned*, ServoPolicyArg<MODE>
 
 // one env per lane: <MODE, RAND, waves per SIMD, in-step spine observers>
-#define UPKIE_ONE_LANE(MODE)                                                                        \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, false>(UPKIE_ONE_LANE_ARGS); \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, true>(UPKIE_ONE_LANE_ARGS);  \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, false>(UPKIE_ONE_LANE_ARGS); \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, true>(UPKIE_ONE_LANE_ARGS);  \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, false>(UPKIE_ONE_LANE_ARGS);  \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, true>(UPKIE_ONE_LANE_ARGS);   \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, false>(UPKIE_ONE_LANE_ARGS);  \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, true>(UPKIE_ONE_LANE_ARGS);
+#define UPKIE_ONE_LANE(MODE)                                                                                      \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, false, false>(UPKIE_ONE_LANE_KERNEL_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, true, false>(UPKIE_ONE_LANE_KERNEL_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, false, false>(UPKIE_ONE_LANE_KERNEL_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 2, true, false>(UPKIE_ONE_LANE_KERNEL_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, false, false>(UPKIE_ONE_LANE_KERNEL_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, true, false>(UPKIE_ONE_LANE_KERNEL_ARGS);   \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, false, false>(UPKIE_ONE_LANE_KERNEL_ARGS);  \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 2, true, false>(UPKIE_ONE_LANE_KERNEL_ARGS);
+// one env per lane under the Bullet-like contact model (upkie_sim_set_contact_manifold): <MODE, RAND, 1, false, true>
+#define UPKIE_ONE_LANE_BULLET(MODE)                                                                                \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, false, 1, false, true>(UPKIE_ONE_LANE_KERNEL_ARGS); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel<MODE, true, 1, false, true>(UPKIE_ONE_LANE_KERNEL_ARGS);
 // two lanes per env: <MODE, RAND, in-step spine observers>
 #define UPKIE_PAIR(MODE)                                                                          \
   UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, false, false>(UPKIE_PAIR_ARGS); \
@@ -91,6 +96,14 @@ UPKIE_OCTET(MODE_GYROPOD, false, true)
 UPKIE_OCTET(MODE_SERVOS, false, false)
 UPKIE_OCTET(MODE_SERVOS, false, true)
 UPKIE_OCTET(MODE_BASE_VELOCITY, false, false)
+#endif
+#if UPKIE_IN_GROUP(8)
+UPKIE_ONE_LANE_BULLET(MODE_RESET)
+UPKIE_ONE_LANE_BULLET(MODE_PENDULUM)
+UPKIE_ONE_LANE_BULLET(MODE_PENDULUM_AGENT)
+UPKIE_ONE_LANE_BULLET(MODE_GYROPOD)
+UPKIE_ONE_LANE_BULLET(MODE_SERVOS)
+UPKIE_ONE_LANE_BULLET(MODE_BASE_VELOCITY)
 #endif
 
 }  // namespace upkie

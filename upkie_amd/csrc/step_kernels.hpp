@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "dynamics.hpp"
+#include "bullet_like.hpp"
 #include "mpc.hpp"
 #include "observers.hpp"
 #include "wave_io.hpp"
@@ -229,14 +230,17 @@ __device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phy
 // WPS = waves per SIMD the register allocation is capped for: 1 (up to 512
 // registers, no spills: lowest latency, small batches) or 2 (256 registers,
 // ~90 spilled: +25 % throughput once the batch oversubscribes the chip).
-template <int MODE, bool RAND, int WPS, bool SPINE>
+// BULLET_LIKE: contacts by the Bullet-like specification (bullet_like.hpp) on the env's persistent contact manifold
+// `manifold` [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) instead of the default one; its own instantiations.
+template <int MODE, bool RAND, int WPS, bool SPINE, bool BULLET_LIKE = false>
 __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C, float* __restrict__ state,
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ body_inertials,
                                                    const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
-                                                   float* __restrict__ spine_state, float* __restrict__ final_obs) {
+                                                   float* __restrict__ spine_state, float* __restrict__ final_obs,
+                                                   float* __restrict__ manifold) {
   warm_kernel_arguments();
   const DevModel& M = *Mp;
   const int B = C.num_envs;
@@ -394,6 +398,13 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
     }
   }
 
+  // the env's persistent contact manifold (Bullet-like contact model): held privately for the step's substeps; a
+  // reset drops the contact cache (Bullet: resetBasePositionAndOrientation) before its one torque-free substep
+  float contact_manifold[BULLET_LIKE ? BL_MANIFOLD_WORDS : 1];
+  if constexpr (BULLET_LIKE) {
+    for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) contact_manifold[w] = do_reset ? 0.f : manifold[(size_t)w * B + e];
+  }
+
   // ---- PyBulletBackend.step: substeps of {torques; stepSimulation} -------
   float tau[UPKIE_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool contact = false;
@@ -418,7 +429,11 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       asm volatile("" : "+s"(mp));
       // PyBulletBackend.reset steps once WITHOUT __apply_external_forces (pybullet_backend.py:220-232 vs :303)
       const ExtForces ext_now{do_reset ? nullptr : ext.force, ext.stride, ext.slots};
-      contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now);
+      if constexpr (BULLET_LIKE) {
+        contact = physics_substep<(WPS > 1), true>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now, nullptr, &contact_manifold);
+      } else {
+        contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now);
+      }
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline (spines/common/observers.h:22-42): it sees the
@@ -505,6 +520,9 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   }
 
   // ---- store -------------------------------------------------------------
+  if constexpr (BULLET_LIKE) {
+    for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) manifold[(size_t)w * B + e] = contact_manifold[w];
+  }
   SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
   SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
   SW(UPKIE_S_LINVEL) = s.linvel.x; SW(UPKIE_S_LINVEL + 1) = s.linvel.y; SW(UPKIE_S_LINVEL + 2) = s.linvel.z;

@@ -279,6 +279,7 @@ struct UpkieSim {
   bool default_scalars = false;  // the model's wheel / floor scalars are the default model's: eight-lane agent steps run the instantiations that hold them as constants (octet.hpp, OctDefaultScalars)
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
+  float* manifold = nullptr;     // upkie_sim_set_contact_manifold: Bullet-like contact model on this persistent manifold (one-lane kernels)
   // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
   // stream when a setting changed or the stream did (a launch still running on the other stream keeps its block:
   // up to two streams may step one handle at a time)
@@ -466,6 +467,7 @@ static const int kOctetBatchServos = 8192;
 // leg: pair.hpp) up to one wave per SIMD, one beyond. The in-step spine
 // observers exist in the one- and two-lane kernels only.
 static int mapped_lanes(const UpkieSim* sim) {
+  if (sim->manifold) return 1;  // the Bullet-like contact model exists in the one-lane kernels only (bullet_like.hpp)
   // the eight-lane kernel restates neither the in-step spine observers nor forces on leg links
   bool eight = !sim->spine_state;
   if (sim->ext_force)
@@ -485,6 +487,13 @@ extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : 
 extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   sim->census = counters;
+  return UPKIE_OK;
+}
+
+extern "C" int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (manifold && sim->spine_state) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "the Bullet-like contact model does not run the in-step spine observers");
+  sim->manifold = manifold;
   return UPKIE_OK;
 }
 
@@ -560,9 +569,12 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const bool paired = uses_lane_pairs(sim);
   // SPINE: the spine observers run inside the step (a separate instantiation:
   // compiled in but switched off they would still cost the common path 2 %)
-#define UPKIE_LAUNCH_S(R, W, S)                                                                                            \
-  hipLaunchKernelGGL((step_kernel<MODE, R, W, S>), grid, block, 0, st, sim->d_model, sim->limits, config, state, act, obs, \
-                     reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs)
+#define UPKIE_LAUNCH_S(R, W, S)                                                                                                   \
+  hipLaunchKernelGGL((step_kernel<MODE, R, W, S, false>), grid, block, 0, st, sim->d_model, sim->limits, config, state, act, obs, \
+                     reward, terminated, truncated, mask, scale, force, packed, bv, sim->spine_state, final_obs, (float*)nullptr)
+#define UPKIE_LAUNCH_BULLET(R)                                                                                                          \
+  hipLaunchKernelGGL((step_kernel<MODE, R, 1, false, true>), grid, block, 0, st, sim->d_model, sim->limits, config, state, act, obs, \
+                     reward, terminated, truncated, mask, scale, force, packed, bv, (float*)nullptr, final_obs, sim->manifold)
 #define UPKIE_LAUNCH(R, W) \
   do { if (spine) UPKIE_LAUNCH_S(R, W, true); else UPKIE_LAUNCH_S(R, W, false); } while (0)
 #define UPKIE_LAUNCH_PAIR_S(R, S)                                                                                                 \
@@ -602,12 +614,15 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
   } else if constexpr (MODE == MODE_PENDULUM_ROLLOUT) {
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "several steps per launch need the two-lane mapping");
+  } else if (sim->manifold) {  // the Bullet-like contact model (upkie_sim_set_contact_manifold)
+    if (rnd) UPKIE_LAUNCH_BULLET(true); else UPKIE_LAUNCH_BULLET(false);
   } else if (rnd) {
     if (dense) UPKIE_LAUNCH(true, 2); else UPKIE_LAUNCH(true, 1);
   } else {
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
 #undef UPKIE_LAUNCH_OCTET
+#undef UPKIE_LAUNCH_BULLET
 #undef UPKIE_LAUNCH_OCTET_D
 #undef UPKIE_LAUNCH_PAIR_S
 #undef UPKIE_LAUNCH_S

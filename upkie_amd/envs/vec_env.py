@@ -108,6 +108,7 @@ class UpkieVecEnv:
         max_episode_steps: Optional[int] = None,
         env_id_offset: int = 0,
         eager_spine_observation: bool = False,
+        contact_model: str = "default",
         spine_observers=None,
         sim_factory=None,
         observers_factory=None,
@@ -162,6 +163,15 @@ class UpkieVecEnv:
         factory = sim_factory if sim_factory is not None else _default_sim_factory
         self.sim = factory(cfg, self.model.struct, device)
         self.device = self.sim.device
+        # "default": the product's contact specification; "bullet_like": what pybullet.stepSimulation() is published to
+        # do (persistent 4-point manifolds, 50 fixed sweeps, cone friction: `BatchedSim.use_bullet_like_contacts`), slower
+        if contact_model not in ("default", "bullet_like"):
+            raise UpkieException(f"unknown contact_model '{contact_model}'")
+        self.contact_model = contact_model
+        if contact_model == "bullet_like":
+            if spine_observers:
+                raise UpkieException("the Bullet-like contact model does not run the in-step spine observers")
+            self.sim.use_bullet_like_contacts()
         if abs(self.inertia_variation) > 1e-10:  # pybullet_backend.py:178-179
             self.sim.randomize_inertias(self.inertia_variation)
         self._spine = LazySpineObservation(self.sim)

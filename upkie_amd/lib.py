@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_lanes_per_env",
     "upkie_sim_set_census",
     "upkie_sim_set_final_observation",
+    "upkie_sim_set_contact_manifold",
     "upkie_sim_set_randomization",
     "upkie_sim_set_external_forces",
     "upkie_sim_sample_body_inertials",
@@ -92,7 +93,7 @@ class UpkieHipError(UpkieRuntimeError):
         self.status = status
 
 
-INSTANCE_GROUPS = 8  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
+INSTANCE_GROUPS = 9  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -206,6 +207,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_census.argtypes = [vp, vp]
     lib.upkie_sim_set_final_observation.restype = C.c_int
     lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
+    lib.upkie_sim_set_contact_manifold.restype = C.c_int
+    lib.upkie_sim_set_contact_manifold.argtypes = [vp, vp]
     lib.upkie_sim_servo_policy.restype = C.c_int
     lib.upkie_sim_servo_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp]
     lib.upkie_sim_step_servos_policy.restype = C.c_int

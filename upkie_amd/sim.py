@@ -484,6 +484,19 @@ class BatchedSim:
             )
         return out
 
+    def use_bullet_like_contacts(self, on: bool = True) -> Optional[torch.Tensor]:
+        """Contact model of this handle's steps (`upkie_sim_set_contact_manifold`):
+        True = the Bullet-like specification (persistent 4-point manifolds per
+        tire, 50 fixed warm-started sequential-impulse sweeps, cone friction
+        along the sliding direction, no friction CFM: what
+        `pybullet.stepSimulation()` is published to do, pybullet_backend.py:306)
+        on a zeroed per-env manifold this handle keeps ``[64, B]``; False = the
+        product's default specification. One env per lane, several times slower
+        than the default: a fidelity option, not the fast path."""
+        self.contact_manifold = torch.zeros((abi.CONTACT_MANIFOLD_WORDS, self.num_envs), dtype=torch.float32, device=self.device) if on else None
+        self._check(self._lib.upkie_sim_set_contact_manifold(self._handle, _ptr(self.contact_manifold)))
+        return self.contact_manifold
+
     def set_final_observation(self, final_obs: Optional[torch.Tensor]) -> None:
         """SAME_STEP autoreset completed by the step calls themselves
         (`upkie_sim_set_final_observation`): `final_obs`, shaped like the step's
