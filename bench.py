@@ -302,11 +302,11 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
                   f"held {PUSH_HOLD} steps, drawn on device), servo-level law = " + ("examples/pybullet/torque_balancing.py (wheel torque +-10 x pitch, kd_scale 0)" if law == "torque"
                   else "README balancer through the wheel velocity loop") + ", evaluated inside the step's launch, NEXT_STEP autoreset of fallen robots; one launch per step, Python loop",
         "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
-        "lanes_per_env": sim.lanes_per_env, "episodes": int(sim.state[40].sum().item()),
+        "lanes_per_env": sim.lanes_per_env_of(abi.OBSERVATION_SERVOS), "episodes": int(sim.state[40].sum().item()),
         "algorithmic_bytes_per_env_step": C5_BYTES_PER_ENV_STEP,
         "hbm_frac": C5_BYTES_PER_ENV_STEP * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
     }
-    if census_steps and sim.lanes_per_env == 8:
+    if census_steps and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8:  # (the census is counted by the eight-lane kernels)
         # rare-path census on its own steps afterwards (its atomics are not free), continuing the same schedule
         sim.enable_census()
         for k in range(warmup + steps, warmup + steps + census_steps):
@@ -324,6 +324,37 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
             "wavefront_sweeps_quantiles": _histogram_quantiles(c["wavefront_max_sweeps_histogram"], (0.5, 0.9, 0.99, 0.999)),
         }
     env.close()
+    return out
+
+
+def secondary_bullet_like(envs: int = ENVS_PER_GPU, steps: int = 400, warmup: int = 100, seed: int = 0) -> dict:
+    """The headline workload (C2: Upkie-Pendulum, PD agent on device, NEXT_STEP
+    autoreset) under the Bullet-like contact model
+    (`upkie_sim_set_contact_manifold`: persistent 4-point manifolds, 50 fixed
+    sequential-impulse sweeps, cone friction) and, on the same handle class and
+    lane mapping (one env per lane), under the default model: what the fidelity
+    option costs."""
+    from upkie_amd.sim import BatchedSim
+
+    out = {"config": "C2 workload, one env per lane (UPKIE_LANES_PER_ENV=1 for the default model's row), one launch per env.step()", "envs": envs, "steps": steps, "warmup": warmup}
+    for name in ("bullet_like", "default_one_lane"):
+        saved = os.environ.get("UPKIE_LANES_PER_ENV")
+        os.environ["UPKIE_LANES_PER_ENV"] = "1"
+        try:
+            sim = BatchedSim(make_config(envs, seed=seed))
+        finally:
+            if saved is None:
+                os.environ.pop("UPKIE_LANES_PER_ENV", None)
+            else:
+                os.environ["UPKIE_LANES_PER_ENV"] = saved
+        if name == "bullet_like":
+            sim.use_bullet_like_contacts()
+        o6 = sim.reset()
+        sim.obs4.copy_(o6[:, [1, 0, 4, 3]])
+        wall, device_ms = _timed_loop(lambda k: sim.step_pendulum_agent(), steps, warmup)
+        out[name] = {"us_per_step": wall / steps * 1e6, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs * steps / wall,
+                     "lanes_per_env": sim.lanes_per_env, "episodes": int(sim.state[40].sum().item())}
+        sim.close()
     return out
 
 
@@ -711,6 +742,7 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
             "c3": secondary_c3(),
             "c5_share_torque_law": secondary_c5_share("torque"),
             "c5_share_velocity_law": secondary_c5_share("velocity"),
+            "c2_bullet_like_contact_model": secondary_bullet_like(B),
         }
     print(json.dumps(line), file=json_out or sys.stdout, flush=True)
 

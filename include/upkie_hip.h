@@ -217,6 +217,13 @@ double upkie_sim_pgs_tolerance(const UpkieSim* sim);
  * (tests, sweeps). Results agree across mappings to fp32 rounding and bit for
  * bit within one. */
 int upkie_sim_lanes_per_env(const UpkieSim* sim);
+/* ... of the step kernel a given entry point launches, named by the layout of
+ * its observation output (UpkieObservationLayout): the Servos kernels, which
+ * take the whole register file, leave the eight-lane mapping at 8192 envs, the
+ * others at 16384 -- a caller that keys on the mapping (the census below is
+ * counted by the eight-lane kernels only; the SAME_STEP autoreset runs inside
+ * the launch there) asks for the entry point it uses. */
+int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout);
 
 /* gymnasium's SAME_STEP autoreset completed by the step calls themselves: with
  * `final_obs` set (a device buffer shaped like the step's observation output:

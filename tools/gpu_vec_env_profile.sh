@@ -1,7 +1,12 @@
+#!/bin/bash
+# On the GPU box: per-kernel times of the PUBLIC loop `env.step(policy(obs))` (tools/bench_vec_env.py, NEXT_STEP, no graphs)
+# from rocprofv3's kernel trace -> gpurun_out/prof_vec_env/. Every step under `timeout`: a profiler that does not exit
+# must not eat the call's limit (round 4 lost 15 GPU-minutes to one that was run without --output-format csv).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
-python tools/bench_vec_env.py 4096 2000 next_step,same_step > gpurun_out/r04_vec_env_b.txt 2>&1
-cat gpurun_out/r04_vec_env_b.txt
-cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_vec_env -o vec -- python $R/tools/bench_vec_env.py 4096 2000 next_step --no-graph > $R/gpurun_out/r04_vec_env_prof.log 2>&1
-cd $R; ls gpurun_out/prof_vec_env | head; f=$(ls gpurun_out/prof_vec_env/*kernel_stats.csv | head -1); head -12 $f
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_vec_env
+rm -rf $OUT; mkdir -p $OUT
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vec -- python $R/tools/bench_vec_env.py 4096 1500 next_step --no-graph > $OUT/run.log 2>&1
+echo "rocprofv3 rc $?"
+f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -8 "$f" | cut -c1-220

@@ -106,19 +106,77 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
     }
   }
 
-  // ---- the tires
+  // ---- the tires: orientation of each wheel body in the base frame (one rotation about y by the leg's summed joint
+  // angles), then the manifold bookkeeping
+  float wsn[2], wcs[2];
+#pragma unroll
+  for (int wheel = 0; wheel < 2; ++wheel) {
+    const Leg& G = S.leg[wheel];
+    joint_sincos(G.sgn[0] * s.q[3 * wheel] + G.sgn[1] * s.q[3 * wheel + 1] + G.sgn[2] * s.q[3 * wheel + 2], &wsn[wheel], &wcs[wheel]);
+  }
+  auto world_xy = [&](V3 A, float& x, float& y) {
+    x = s.pos.x + bf.r00 * A.x + bf.r01 * A.y + bf.r02 * A.z;
+    y = s.pos.y + bf.r10 * A.x + bf.r11 * A.y + bf.r12 * A.z;
+  };
+  // the three rows (normal, two friction directions) of one cached point `pt` of `wheel`
+  auto point_rows = [&](int wheel, const float* pt, int applied_slot, BlRow& Rn, BlRow& R1, BlRow& R2, int first_row) {
+    const Leg& G = S.leg[wheel];
+    const V3 A = G.o[2] + rot_y(wcs[wheel], wsn[wheel], v3(pt[0], pt[1], pt[2]));
+    const float dist = s.pos.z + dot(nB, A);
+    // velocity of the point at the free velocity
+    V3 v = vF + cross(wF, A);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const V3 rr = A - G.o[j];
+      const float sq = G.sgn[j] * (wheel == 0 ? qdF[j] : qdF[3 + j]);
+      v = v + sq * v3(rr.z, 0.f, -rr.x);  // (sgn y) x rr
+    }
+    const float vn = dot(v, nB);
+    const V3 vt = v - vn * nB;
+    const float lat2 = dot(vt, vt);
+    V3 t1, t2;
+    if (lat2 > 1.1920929e-07f) {  // SIMD_EPSILON: friction along the sliding direction
+      t1 = (1.f / sqrtf(lat2)) * vt;
+      t2 = cross(t1, nB);
+    } else {  // btPlaneSpace1(n) for n = world z: (0, -1, 0) and (1, 0, 0), in base coordinates
+      t1 = v3(-bf.r10, -bf.r11, -bf.r12);
+      t2 = v3(bf.r00, bf.r01, bf.r02);
+    }
+    auto one = [&](BlRow& R, V3 d, int k) {
+      const V3 Axd = cross(A, d);
+      R.Jb[0] = d.x; R.Jb[1] = d.y; R.Jb[2] = d.z; R.Jb[3] = Axd.x; R.Jb[4] = Axd.y; R.Jb[5] = Axd.z;
+      R.leg = wheel;
+      float rel = d.x * vF.x + d.y * vF.y + d.z * vF.z + Axd.x * wF.x + Axd.y * wF.y + Axd.z * wF.z;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const V3 rr = A - G.o[j];
+        R.Jl[j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
+        rel = fmaf(R.Jl[j], wheel == 0 ? qdF[j] : qdF[3 + j], rel);
+      }
+      if (k == 0) {
+        R.kind = 0; R.normal_row = first_row; R.cfm = cfm_n;
+        R.rhs = dist <= 0.f ? -rel + erp * (-dist) * ih : -rel - dist * ih;
+        R.lam = 0.85f * pt[6];  // m_warmstartingFactor
+        R.slot = applied_slot;
+      } else {
+        R.kind = 1; R.normal_row = first_row; R.cfm = 0.f;
+        R.rhs = -rel;
+        R.lam = 0.f;
+        R.slot = -1;
+      }
+      finish_row(R);
+    };
+    one(Rn, nB, 0);
+    one(R1, t1, 1);
+    one(R2, t2, 2);
+  };
+  int live_points[2] = {0, 0}, live_slot[2] = {0, 0};
   for (int wheel = 0; wheel < 2; ++wheel) {
     const Leg& G = S.leg[wheel];
     float* pts = mf + wheel * BL_POINTS * BL_POINT_WORDS;
     const V3 ow = G.o[2];
-    // orientation of the wheel body in the base frame: one rotation about y by the leg's summed joint angles
-    float sn, cs;
-    joint_sincos(G.sgn[0] * s.q[3 * wheel] + G.sgn[1] * s.q[3 * wheel + 1] + G.sgn[2] * s.q[3 * wheel + 2], &sn, &cs);
+    const float sn = wsn[wheel], cs = wcs[wheel];
     auto in_base = [&](const float* pt) { return ow + rot_y(cs, sn, v3(pt[0], pt[1], pt[2])); };
-    auto world_xy = [&](V3 A, float& x, float& y) {
-      x = s.pos.x + bf.r00 * A.x + bf.r01 * A.y + bf.r02 * A.z;
-      y = s.pos.y + bf.r10 * A.x + bf.r11 * A.y + bf.r12 * A.z;
-    };
     // btPersistentManifold::refreshContactPoints
     for (int p = 0; p < BL_POINTS; ++p) {
       float* pt = pts + p * BL_POINT_WORDS;
@@ -173,59 +231,101 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
         }
       }
     }
-    // rows of every cached point
-    for (int p = 0; p < BL_POINTS; ++p) {
-      float* pt = pts + p * BL_POINT_WORDS;
-      if (pt[7] == 0.f) continue;
-      any_contact = true;
-      const V3 A = in_base(pt);
-      const float dist = s.pos.z + dot(nB, A);
-      // velocity of the point at the free velocity
-      V3 v = vF + cross(wF, A);
+    for (int p = 0; p < BL_POINTS; ++p)
+      if (pts[p * BL_POINT_WORDS + 7] != 0.f) {
+        live_points[wheel] += 1;
+        live_slot[wheel] = p;
+        any_contact = true;
+      }
+  }
+  // The common case -- at most ONE cached point per tire (a wheel that rolls: its deepest point replaces the cached
+  // one) and no joint at its stop -- has a fixed layout of six rows: rows, Delassus matrix and impulses stay in
+  // registers and the sweeps are the dense Gauss-Seidel of the published algorithm, row for row. Anything else (several
+  // points on a tire, limit rows) goes through the general row list below, in private memory.
+  const bool fast = nrows == 0 && live_points[0] <= 1 && live_points[1] <= 1;
+  if (fast) {
+    if (!any_contact) return false;  // (tb, tl, tr hold the free velocity change)
+    BlRow F[6];
+    bool on[2];
+#pragma unroll
+    for (int wheel = 0; wheel < 2; ++wheel) {
+      on[wheel] = live_points[wheel] == 1;
+      const int word = (wheel * BL_POINTS + live_slot[wheel]) * BL_POINT_WORDS;
+      float pt[BL_POINT_WORDS];
+#pragma unroll
+      for (int i = 0; i < BL_POINT_WORDS; ++i) pt[i] = on[wheel] ? mf[word + i] : 0.f;
+      point_rows(wheel, pt, word + 6, F[3 * wheel], F[3 * wheel + 1], F[3 * wheel + 2], 3 * wheel);
+    }
+    float W[6][6], lam[6], rhs[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        float w = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) w = fmaf(F[a].Jb[c], F[b].Mb[c], w);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w = fmaf(F[a].Jl[j], a < 3 ? F[b].Ml[j] : F[b].Mr[j], w);
+        W[a][b] = on[a / 3] && on[b / 3] ? w : 0.f;
+      }
+      lam[a] = on[a / 3] ? F[a].lam : 0.f;
+      rhs[a] = F[a].rhs;
+    }
+    const float mu = M.friction_mu;
+    for (int it = 0; it < M.pgs_iterations; ++it) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {  // the normal rows
+        const int r = 3 * w;
+        float wl = 0.f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
+        const float x = lam[r] + (rhs[r] - wl - F[r].cfm * lam[r]) * F[r].inv_diag;
+        lam[r] = on[w] ? (x < 0.f ? 0.f : x) : 0.f;
+      }
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {  // each point's friction pair, projected onto the cone
+        const int r1 = 3 * w + 1, r2 = 3 * w + 2;
+        float w1 = 0.f, w2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          w1 = fmaf(W[r1][b], lam[b], w1);
+          w2 = fmaf(W[r2][b], lam[b], w2);
+        }
+        float x1 = lam[r1] + (rhs[r1] - w1) * F[r1].inv_diag, x2 = lam[r2] + (rhs[r2] - w2) * F[r2].inv_diag;
+        const float lim = mu * lam[3 * w], norm = sqrtf(x1 * x1 + x2 * x2);
+        if (norm > lim) {
+          const float sc = norm > 0.f ? lim / norm : 0.f;
+          x1 *= sc;
+          x2 *= sc;
+        }
+        lam[r1] = on[w] ? x1 : 0.f;
+        lam[r2] = on[w] ? x2 : 0.f;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      if (on[w]) mf[(w * BL_POINTS + live_slot[w]) * BL_POINT_WORDS + 6] = lam[3 * w];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) tb[c] = fmaf(F[a].Mb[c], lam[a], tb[c]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const V3 rr = A - G.o[j];
-        const float sq = G.sgn[j] * qdF[3 * wheel + j];
-        v = v + sq * v3(rr.z, 0.f, -rr.x);  // (sgn y) x rr
+        tl[j] = fmaf(F[a].Ml[j], lam[a], tl[j]);
+        tr[j] = fmaf(F[a].Mr[j], lam[a], tr[j]);
       }
-      const float vn = dot(v, nB);
-      const V3 vt = v - vn * nB;
-      const float lat2 = dot(vt, vt);
-      V3 t1, t2;
-      if (lat2 > 1.1920929e-07f) {  // SIMD_EPSILON: friction along the sliding direction
-        t1 = (1.f / sqrtf(lat2)) * vt;
-        t2 = cross(t1, nB);
-      } else {  // btPlaneSpace1(n) for n = world z: (0, -1, 0) and (1, 0, 0), in base coordinates
-        t1 = v3(-bf.r10, -bf.r11, -bf.r12);
-        t2 = v3(bf.r00, bf.r01, bf.r02);
-      }
-      const V3 dirs[3] = {nB, t1, t2};
-      for (int k = 0; k < 3; ++k) {
-        BlRow& R = rows[nrows];
-        const V3 d = dirs[k];
-        const V3 Axd = cross(A, d);
-        R.Jb[0] = d.x; R.Jb[1] = d.y; R.Jb[2] = d.z; R.Jb[3] = Axd.x; R.Jb[4] = Axd.y; R.Jb[5] = Axd.z;
-        R.leg = wheel;
-        float rel = d.x * vF.x + d.y * vF.y + d.z * vF.z + Axd.x * wF.x + Axd.y * wF.y + Axd.z * wF.z;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const V3 rr = A - G.o[j];
-          R.Jl[j] = G.sgn[j] * (rr.z * d.x - rr.x * d.z);
-          rel = fmaf(R.Jl[j], qdF[3 * wheel + j], rel);
-        }
-        if (k == 0) {
-          R.kind = 0; R.normal_row = nrows; R.cfm = cfm_n;
-          R.rhs = dist <= 0.f ? -rel + erp * (-dist) * ih : -rel - dist * ih;
-          R.lam = 0.85f * pt[6];  // m_warmstartingFactor
-          R.slot = (wheel * BL_POINTS + p) * BL_POINT_WORDS + 6;
-        } else {
-          R.kind = 1; R.normal_row = nrows - k; R.cfm = 0.f;
-          R.rhs = -rel;
-          R.lam = 0.f;
-          R.slot = -1;
-        }
-        finish_row(R);
-        ++nrows;
+    }
+    return true;
+  }
+  for (int wheel = 0; wheel < 2; ++wheel) {
+    float* pts = mf + wheel * BL_POINTS * BL_POINT_WORDS;
+    // rows of every cached point
+    {
+      for (int p = 0; p < BL_POINTS; ++p) {
+        float* pt = pts + p * BL_POINT_WORDS;
+        if (pt[7] == 0.f) continue;
+        point_rows(wheel, pt, (wheel * BL_POINTS + p) * BL_POINT_WORDS + 6, rows[nrows], rows[nrows + 1], rows[nrows + 2], nrows);
+        nrows += 3;
       }
     }
   }

@@ -244,14 +244,25 @@ template <int BYTES, class Ptr>
 __device__ __forceinline__ void warm_constant_block(Ptr block) {
   constexpr int LINES = (BYTES + 63) / 64;
   static_assert(LINES <= 24, "block larger than the unrolled touch sequence");
+  // ONE asm statement: the loads and the wait for them together, the sink an early-clobber output of the whole block --
+  // as separate statements the compiler saw the sink dead after each touch and could hand the register to a live value
+  // that a load still in flight would then overwrite. Offsets past the block's last line touch that line again.
+#define UPKIE_LINE(i) "n"(64 * ((i) < LINES ? (i) : LINES - 1))
   int sink;
-#define UPKIE_TOUCH(i) \
-  if (LINES > i) asm volatile("s_load_dword %0, %1, %2" : "=&s"(sink) : "s"(block), "n"(64 * i) : "memory");
-  UPKIE_TOUCH(0) UPKIE_TOUCH(1) UPKIE_TOUCH(2) UPKIE_TOUCH(3) UPKIE_TOUCH(4) UPKIE_TOUCH(5) UPKIE_TOUCH(6) UPKIE_TOUCH(7)
-  UPKIE_TOUCH(8) UPKIE_TOUCH(9) UPKIE_TOUCH(10) UPKIE_TOUCH(11) UPKIE_TOUCH(12) UPKIE_TOUCH(13) UPKIE_TOUCH(14) UPKIE_TOUCH(15)
-  UPKIE_TOUCH(16) UPKIE_TOUCH(17) UPKIE_TOUCH(18) UPKIE_TOUCH(19) UPKIE_TOUCH(20) UPKIE_TOUCH(21) UPKIE_TOUCH(22) UPKIE_TOUCH(23)
-#undef UPKIE_TOUCH
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile(
+      "s_load_dword %0, %1, %2\n s_load_dword %0, %1, %3\n s_load_dword %0, %1, %4\n s_load_dword %0, %1, %5\n"
+      "s_load_dword %0, %1, %6\n s_load_dword %0, %1, %7\n s_load_dword %0, %1, %8\n s_load_dword %0, %1, %9\n"
+      "s_load_dword %0, %1, %10\n s_load_dword %0, %1, %11\n s_load_dword %0, %1, %12\n s_load_dword %0, %1, %13\n"
+      "s_load_dword %0, %1, %14\n s_load_dword %0, %1, %15\n s_load_dword %0, %1, %16\n s_load_dword %0, %1, %17\n"
+      "s_load_dword %0, %1, %18\n s_load_dword %0, %1, %19\n s_load_dword %0, %1, %20\n s_load_dword %0, %1, %21\n"
+      "s_load_dword %0, %1, %22\n s_load_dword %0, %1, %23\n s_load_dword %0, %1, %24\n s_load_dword %0, %1, %25\n"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(sink)
+      : "s"(block), UPKIE_LINE(0), UPKIE_LINE(1), UPKIE_LINE(2), UPKIE_LINE(3), UPKIE_LINE(4), UPKIE_LINE(5), UPKIE_LINE(6), UPKIE_LINE(7),
+        UPKIE_LINE(8), UPKIE_LINE(9), UPKIE_LINE(10), UPKIE_LINE(11), UPKIE_LINE(12), UPKIE_LINE(13), UPKIE_LINE(14), UPKIE_LINE(15),
+        UPKIE_LINE(16), UPKIE_LINE(17), UPKIE_LINE(18), UPKIE_LINE(19), UPKIE_LINE(20), UPKIE_LINE(21), UPKIE_LINE(22), UPKIE_LINE(23)
+      : "memory");
+#undef UPKIE_LINE
 }
 #else
 __device__ inline void warm_kernel_arguments() {}

@@ -828,7 +828,7 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
 // default_model.py; what the reference's wheel / floor settings come to). A handle whose model carries exactly these
 // values runs instantiations in which they are compile-time constants (DEFAULT_SCALARS): no scalar load in the common
 // path of the substep loop, multiplications by mu = 1 folded away -- the same arithmetic on the same values, bit for
-// bit the same results (tests/test_mapping_gpu.py), 1.6 % less time per launch (profiles/r03_ab_model_scalars_as_constants.txt).
+// bit the same results (tests/test_default_scalars_gpu.py), 1.6 % less time per launch (profiles/r03_ab_model_scalars_as_constants.txt).
 struct OctDefaultScalars {
   static constexpr float gravity = 9.81f, wheel_radius = 0.05f, contact_breaking_threshold = 0.02f, friction_cfm = 0.01f, friction_mu = 1.0f,
                          max_joint_velocity = 100.0f;

@@ -484,6 +484,17 @@ static bool uses_lane_pairs(const UpkieSim* sim) { return mapped_lanes(sim) >= 2
 
 extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : mapped_lanes(sim); }
 
+// ... of the step kernel a given entry point launches: the Servos kernels leave the eight-lane mapping earlier
+static int mapped_lanes_of_mode(const UpkieSim* sim, int mode) {
+  int lanes = mapped_lanes(sim);
+  if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
+  return lanes;
+}
+extern "C" int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout) {
+  if (!sim) return 0;
+  return mapped_lanes_of_mode(sim, observation_layout == UPKIE_OBSERVATION_SERVOS ? MODE_SERVOS : MODE_PENDULUM);
+}
+
 extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   sim->census = counters;
@@ -522,6 +533,7 @@ static const DevParams* current_params(UpkieSim* sim, void* stream) {
       block.limits = sim->limits;
       block.config = sim->config;
       hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[2]);
+      if (hipGetLastError() != hipSuccess) return nullptr;  // (nothing recorded: the step launch behind it is refused too)
       sim->capture_id = capture_id;
       sim->capture_version = sim->params_version;
     }
@@ -534,6 +546,10 @@ static const DevParams* current_params(UpkieSim* sim, void* stream) {
     block.config = sim->config;
     // (as a kernel argument, not a host-to-device copy: ordered on the stream, capturable in a hipGraph, no host buffer to keep alive)
     hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[sim->params_slot]);
+    if (hipGetLastError() != hipSuccess) {  // the block was not refreshed: no step kernel may read it as if it were
+      sim->params_slot ^= 1;
+      return nullptr;
+    }
     sim->eager_version = sim->params_version;
     sim->params_stream = stream;
   }
@@ -556,7 +572,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
   constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
   const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
-  const bool same_step_in_kernel = same_step && mapped_lanes(sim) == 8 && !(MODE == MODE_SERVOS && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos);
+  const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8;
   if (same_step_in_kernel) final_obs = sim->final_obs;
   const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
@@ -585,7 +601,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
 #define UPKIE_LAUNCH_OCTET_D(R, D, IP)                                                                                          \
   hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
-                     sim->d_model, current_params(sim, stream), done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
+                     sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
   // which instantiation (step_instances.hpp lists them): the SAME_STEP autoreset inside the launch has its own (the second
   // pass makes the whole step a loop body: spills); the Pendulum / Gyropod steps also exist with the default model's
@@ -602,12 +618,14 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     if (!launched) UPKIE_LAUNCH_OCTET_D(R, false, false);                                        \
   } while (0)
   const bool spine = sim->spine_state != nullptr;
-  int lanes = mapped_lanes(sim);
-  if (MODE == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
+  const int lanes = mapped_lanes_of_mode(sim, MODE);
   ServoPolicyArg<MODE> policy_arg{};
   if constexpr (MODE == MODE_SERVOS) {
     if (policy) policy_arg = *policy;
   }
+  // the eight-lane kernels read limits and config from this handle's device block
+  const DevParams* params = lanes == 8 ? current_params(sim, stream) : nullptr;
+  if (lanes == 8 && !params) return fail(sim, UPKIE_ERR_HIP, "could not refresh the device block of the handle's settings");
   if (lanes == 8) {
     if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
   } else if (paired) {
@@ -737,7 +755,7 @@ extern "C" int upkie_sim_servo_policy(UpkieSim* sim, float* state, const UpkieSe
 extern "C" int upkie_sim_step_servos_policy(UpkieSim* sim, float* state, const UpkieServoPolicy* policy, float* act, float* obs, float* reward,
                                             uint8_t* terminated, uint8_t* truncated, void* stream) {
   if (!sim || !state || !policy || !act) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  if (mapped_lanes(sim) != 8 || (sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos)) {  // the other mappings: the policy's own launch into `act`, then the step
+  if (mapped_lanes_of_mode(sim, MODE_SERVOS) != 8) {  // the other mappings: the policy's own launch into `act`, then the step
     const int status = upkie_sim_servo_policy(sim, state, policy, act, stream);
     if (status != UPKIE_OK) return status;
     return launch_step<MODE_SERVOS>(sim, state, act, obs, reward, terminated, truncated, nullptr, stream);

@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_state_bytes",
     "upkie_sim_pgs_tolerance",
     "upkie_sim_lanes_per_env",
+    "upkie_sim_lanes_per_env_of",
     "upkie_sim_set_census",
     "upkie_sim_set_final_observation",
     "upkie_sim_set_contact_manifold",
@@ -207,6 +208,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_census.argtypes = [vp, vp]
     lib.upkie_sim_set_final_observation.restype = C.c_int
     lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
+    lib.upkie_sim_lanes_per_env_of.restype = C.c_int
+    lib.upkie_sim_lanes_per_env_of.argtypes = [vp, C.c_int]
     lib.upkie_sim_set_contact_manifold.restype = C.c_int
     lib.upkie_sim_set_contact_manifold.argtypes = [vp, vp]
     lib.upkie_sim_servo_policy.restype = C.c_int

@@ -564,6 +564,12 @@ class BatchedSim:
         """Lanes of a wavefront sharing one env in this handle's step kernels."""
         return int(self._lib.upkie_sim_lanes_per_env(self._handle))
 
+    def lanes_per_env_of(self, observation_layout: int) -> int:
+        """... in the step kernel of one entry point, named by its observation
+        layout (`abi.OBSERVATION_*`): the Servos kernels leave the eight-lane
+        mapping at 8192 envs, the others at 16384."""
+        return int(self._lib.upkie_sim_lanes_per_env_of(self._handle, int(observation_layout)))
+
     CENSUS_FIELDS = ("joint_limit", "sweep_cap_hits", "friction_cone", "unused_3", "wavefront_substeps_limit", "wavefront_substeps_sweeps", "sweeps_total", "sweeps_max")
 
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
