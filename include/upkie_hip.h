@@ -548,6 +548,10 @@ typedef struct UpkieMpcConfig {
   double stage_state_cost_weight; /* 1e-3 */
   double terminal_cost_weight;    /* 1.0  */
   double admm_rho;
+  double admm_relaxation; /* over-relaxation alpha of the ADMM iteration (Boyd et al. 2011, section 3.4.3; OSQP's
+                             default is 1.6): x^ = alpha x + (1 - alpha) z replaces x in the z- and y-updates.
+                             1.0 (or 0: unset) = the plain iteration; 1.5 by default: same fixed point, and at the
+                             reference's N = 50 an order of magnitude closer to it after the same 30 iterations */
 } UpkieMpcConfig;
 
 typedef struct UpkieMpc UpkieMpc;

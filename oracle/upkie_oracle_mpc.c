@@ -277,9 +277,19 @@ void oracle_mpc_minv(int n, const double* P, double rho, double* Minv) {
 
 /* Same recurrences as the HIP kernel:
  *   U <- Minv (rho (z - y) - q);  z <- clip(U + y);  y <- y + U - z */
+void oracle_mpc_admm_relaxed(int n, const double* Minv, const double* q, double rho, double alpha,
+                             double bound, int iterations, double* z, double* y, double* u);
 void oracle_mpc_admm(int n, const double* Minv, const double* q, double rho,
                      double bound, int iterations, double* z, double* y,
                      double* u) {
+  oracle_mpc_admm_relaxed(n, Minv, q, rho, 1.0, bound, iterations, z, y, u);
+}
+
+/* ... with over-relaxation (UpkieMpcConfig.admm_relaxation; Boyd et al. 2011,
+ * section 3.4.3): x^ = alpha U + (1 - alpha) z takes U's place in the z- and
+ * y-updates; alpha = 1 is the plain iteration. */
+void oracle_mpc_admm_relaxed(int n, const double* Minv, const double* q, double rho, double alpha,
+                             double bound, int iterations, double* z, double* y, double* u) {
   double* r = (double*)malloc(sizeof(double) * n);
   for (int it = 0; it < iterations; ++it) {
     for (int i = 0; i < n; ++i) r[i] = rho * (z[i] - y[i]) - q[i];
@@ -289,9 +299,10 @@ void oracle_mpc_admm(int n, const double* Minv, const double* q, double rho,
       u[i] = s;
     }
     for (int i = 0; i < n; ++i) {
-      double x = u[i] + y[i];
+      const double relaxed = alpha * u[i] + (1.0 - alpha) * z[i];
+      double x = relaxed + y[i];
       double zi = x > bound ? bound : (x < -bound ? -bound : x);
-      y[i] = y[i] + u[i] - zi;
+      y[i] = y[i] + relaxed - zi;
       z[i] = zi;
     }
   }
@@ -320,8 +331,8 @@ void oracle_mpc_step(const UpkieMpcConfig* cfg, double* workspace,
       z[i] = workspace[(size_t)i * B + e];
       y[i] = workspace[(size_t)(N + i) * B + e];
     }
-    oracle_mpc_admm(N, Minv, q, cfg->admm_rho, cfg->max_ground_accel,
-                    cfg->admm_iterations, z, y, u);
+    oracle_mpc_admm_relaxed(N, Minv, q, cfg->admm_rho, cfg->admm_relaxation > 0.0 ? cfg->admm_relaxation : 1.0, cfg->max_ground_accel,
+                            cfg->admm_iterations, z, y, u);
     for (int i = 0; i < N; ++i) {
       workspace[(size_t)i * B + e] = z[i];
       workspace[(size_t)(N + i) * B + e] = y[i];

@@ -85,11 +85,16 @@ def test_exact_solver_satisfies_kkt_and_admm_converges_to_it(N):
         assert np.all(np.abs(u) <= bound + 1e-12)
         assert np.abs(g[free]).max(initial=0.0) < 1e-9  # stationarity
         assert np.all(g[lo] >= -1e-9) and np.all(g[hi] <= 1e-9)  # multiplier signs
+        # the handle's defaults (over-relaxed, 15 iterations at N = 16, 30 at N = 50), cold start: plan.first_input (the
+        # only entry the balancer uses, mpc_balancer.py:307) within the contract 2e-3 a_max of the exact one
         z, y, uu = np.zeros(N), np.zeros(N), np.zeros(N)
-        O.lib().oracle_mpc_admm(N, p(Minv), p(q), C.c_double(cfg.admm_rho), C.c_double(bound), cfg.admm_iterations, p(z), p(y), p(uu))
-        # cold start, default rho / iterations: plan.first_input (the only
-        # entry the balancer uses, mpc_balancer.py:307) is far below ProxQP's
-        # eps_abs = 1e-3; the tail of the horizon is a nearly flat direction
+        O.lib().oracle_mpc_admm_relaxed(N, p(Minv), p(q), C.c_double(cfg.admm_rho), C.c_double(cfg.admm_relaxation), C.c_double(bound), cfg.admm_iterations,
+                                        p(z), p(y), p(uu))
+        assert abs(z[0] - u[0]) < 2e-3 * bound and cfg.admm_relaxation == 1.5 and cfg.admm_iterations == (15 if N <= 16 else 30)
+        z, y, uu = np.zeros(N), np.zeros(N), np.zeros(N)
+        O.lib().oracle_mpc_admm(N, p(Minv), p(q), C.c_double(cfg.admm_rho), C.c_double(bound), 30, p(z), p(y), p(uu))
+        # cold start, default rho, 30 plain iterations (selectable: admm_iterations = 30, admm_relaxation = 1): far below
+        # ProxQP's eps_abs = 1e-3; the tail of the horizon is a nearly flat direction
         # of the cost and is only required to reach the same objective value
         assert abs(z[0] - u[0]) < 1e-5
         f = lambda w: 0.5 * w @ P @ w + q @ w

@@ -36,6 +36,7 @@ struct MpcDev {
   int n;       // horizon length N
   int iterations;
   float rho;
+  float alpha;  // over-relaxation (1: the plain iteration)
   float bound;  // max_ground_accel
   float max_ground_velocity;
   float fall_pitch;
@@ -126,6 +127,15 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
 #pragma unroll
     for (int h = 0; h < 2; ++h) zp[t][h] = floatx2{z[t][2 * h], z[t][2 * h + 1]};
   const floatx2 rho2 = floatx2{rho, rho}, two = floatx2{2.f, 2.f};
+  // Over-relaxation (UpkieMpcConfig.admm_relaxation): x^ = alpha U + (1 - alpha) z takes U's place in the z- and
+  // y-updates, i.e. w = U + y becomes alpha w + (1 - alpha)(z + y), and z + y of the previous iterate is its own
+  // relaxed w (y' = w - z): one packed multiply and one packed fma per register pair and iteration.
+  const floatx2 alpha2 = floatx2{P.alpha, P.alpha}, beta2 = floatx2{1.f - P.alpha, 1.f - P.alpha};
+  floatx2 carry[T][2];  // (1 - alpha) x the previous relaxed w
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) carry[t][h] = beta2 * (zp[t][h] + floatx2{y[t][2 * h], y[t][2 * h + 1]});
   for (int it = 0; it < P.iterations; ++it) {
     floatx4 acc0[T], acc1[T];
 #pragma unroll
@@ -151,8 +161,10 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
       floatx2 yn[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const floatx2 w = (h == 0 ? floatx2{acc0[t][0], acc0[t][1]} : floatx2{acc0[t][2], acc0[t][3]}) +
-                          (h == 0 ? floatx2{acc1[t][0], acc1[t][1]} : floatx2{acc1[t][2], acc1[t][3]});  // U + y
+        const floatx2 plain = (h == 0 ? floatx2{acc0[t][0], acc0[t][1]} : floatx2{acc0[t][2], acc0[t][3]}) +
+                              (h == 0 ? floatx2{acc1[t][0], acc1[t][1]} : floatx2{acc1[t][2], acc1[t][3]});  // U + y
+        const floatx2 w = __builtin_elementwise_fma(alpha2, plain, carry[t][h]);
+        carry[t][h] = beta2 * w;
         const floatx2 zi = floatx2{__builtin_amdgcn_fmed3f(w.x, -bound, bound), __builtin_amdgcn_fmed3f(w.y, -bound, bound)};
         yn[h] = w - zi;
         zp[t][h] = zi;

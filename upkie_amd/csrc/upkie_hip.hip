@@ -827,6 +827,8 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   *out = nullptr;
   if (config->num_envs <= 0 || config->nb_timesteps <= 0 || config->admm_iterations <= 0 || !(config->admm_rho > 0.0))
     return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "num_envs, nb_timesteps, admm_iterations, admm_rho must be positive");
+  if (!(config->admm_relaxation >= 0.0 && config->admm_relaxation < 2.0))
+    return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "admm_relaxation must lie in (0, 2) (0: unset, the plain iteration)");
   if (config->nb_timesteps > 64)
     return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, "nb_timesteps > 64 is not supported by the HIP path");
   if (upkie_hip_device_count() <= 0) return mpc_fail(nullptr, UPKIE_ERR_NO_DEVICE, "no HIP device visible");
@@ -858,6 +860,7 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   mpc->dev.n = config->nb_timesteps;
   mpc->dev.iterations = config->admm_iterations;
   mpc->dev.rho = (float)config->admm_rho;
+  mpc->dev.alpha = config->admm_relaxation > 0.0 ? (float)config->admm_relaxation : 1.f;
   mpc->dev.bound = (float)config->max_ground_accel;
   mpc->dev.max_ground_velocity = (float)config->max_ground_velocity;
   mpc->dev.fall_pitch = (float)config->fall_pitch;
