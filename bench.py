@@ -224,7 +224,10 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
     from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 
     out = {"policy": "act = (obs @ gains).clamp(-0.99, 0.99).unsqueeze(1), gains = [10, 1, 0, 0.1] (README.md:60-67), torch ops on the device",
-           "envs": envs, "steps": steps, "warmup": warmup}
+           "envs": envs, "steps": steps, "warmup": warmup,
+           "note": "the loop is GPU bound: step kernel (step_kernel_octet<MODE_PENDULUM>, ~14.5 us) + the policy's two kernels (rocblas gemv ~4.5 us, clamp ~2 us) "
+                   "+ three dependent-launch gaps; rocprofv3 per-kernel times under profiles/ (r04_vec_env_kernel_stats.csv). A hipGraph of the same "
+                   "three kernels replays SLOWER than the eager loop on ROCm 7.2 (per-node latency), see graphed_us_per_env_step"}
     for mode in ("next_step", "same_step"):
         init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
         env = envs_mod.make("Upkie-HIP-Pendulum-Vec", num_envs=envs, frequency=200.0, autoreset_mode=mode, init_state=init, seed=seed)
@@ -237,16 +240,21 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
             state["obs"] = env.step(policy(state["obs"]))[0]
 
         wall, device_ms = _timed_loop(eager, steps, warmup)
-        # the step call alone (action buffer reused): what the env's own host path and kernel cost
-        act = policy(obs).contiguous()
-        wall_step, device_ms_step = _timed_loop(lambda k: env.step(act), steps, warmup)
+        # where a loop iteration goes: the policy's own kernels (rocBLAS gemv + clamp: the same three ops, result dropped),
+        # and what the interpreter needs to ISSUE one iteration (no synchronisation inside the loop)
+        wall_policy, _ = _timed_loop(lambda k: policy(state["obs"]), steps, 10)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            eager(k)
+        host_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
         graphed = GraphedEnvStep(env, policy)
         wall_graph, device_ms_graph = _timed_loop(lambda k: graphed(), steps, warmup)
         episodes = int(env.sim.state[40].sum().item())
         out[mode] = {
             "python_loop_us_per_env_step": wall / steps * 1e6, "python_loop_device_us": device_ms * 1e3 / steps,
-            "env_step_alone_us": wall_step / steps * 1e6, "env_step_alone_device_us": device_ms_step * 1e3 / steps,
-            "graphed_us_per_env_step": wall_graph / steps * 1e6, "graphed_device_us": device_ms_graph * 1e3 / steps,
+            "policy_ops_alone_us": wall_policy / steps * 1e6, "host_time_to_issue_one_iteration_us": host_issue / steps * 1e6,
+            "graphed_us_per_env_step": wall_graph / steps * 1e6,
             "env_steps_per_s_python_loop": envs * steps / wall, "env_steps_per_s_graphed": envs * steps / wall_graph,
             "episodes": episodes, "lanes_per_env": env.sim.lanes_per_env,
         }

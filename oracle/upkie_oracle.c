@@ -707,6 +707,14 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
   return any_contact;
 }
 
+/* The sweeps' warm start across the substeps of ONE env.step() (the product's
+ * rule, upkie_amd/csrc/dynamics.hpp SweepWarmStart): the impulses the previous
+ * substep's sweeps ended on, per tire row (wheel w: entries 3w .. 3w + 2), and
+ * with how many tires touching (0: it did not sweep). Armed by backend_step()
+ * for the substeps of a step; single-substep calls start cold. */
+static _Thread_local double g_sweep_warm_lam[6];
+static _Thread_local int g_sweep_warm_swept = 0, g_sweep_warm_armed = 0;
+
 /* Where oracle_substep_ext() leaves the contact points of the substep it
  * solved when asked (oracle_contact_points): [2][8] = per tire {exists,
  * position in world (3), force in world (3), 0}. */
@@ -917,6 +925,36 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       }
     }
     int sweeps_here = 0;
+    /* the product's start of the sweeps (contact_sweeps_warm, dynamics.hpp), for the contact-only systems it applies
+     * to there (no joint at its stop): both tires leaving the floor is lam = 0 without a sweep; a substep that follows
+     * a swept one with the same tires on the floor starts from the impulses that one ended on */
+    const int contact_only = nrows == 3 * ((contact_row[0] >= 0) + (contact_row[1] >= 0)) && nrows > 0;
+    const int touching = (contact_row[0] >= 0) + (contact_row[1] >= 0);
+    int swept_state = 0;
+    if (need_pgs && contact_only) {
+      int leaving = 1;
+      for (int wheel = 0; wheel < 2; ++wheel)
+        if (contact_row[wheel] >= 0 && rhs_c[contact_row[wheel]] > 0.0) leaving = 0;
+      if (leaving) {
+        memset(lam, 0, sizeof(lam));
+        need_pgs = 0;
+      } else {
+        swept_state = touching;
+        if (g_sweep_warm_armed && g_sweep_warm_swept == touching) {
+          for (int wheel = 0; wheel < 2; ++wheel)
+            if (contact_row[wheel] >= 0)
+              for (int r_ = 0; r_ < 3; ++r_) lam[contact_row[wheel] + r_] = g_sweep_warm_lam[3 * wheel + r_];
+          for (int r_ = 0; r_ < nrows; ++r_)
+            if (kind[r_] == 0 && lam[r_] < 0.0) lam[r_] = 0.0;
+          for (int r_ = 0; r_ < nrows; ++r_)
+            if (kind[r_] == 1) {
+              double lim = mu * lam[normal_row[r_]];
+              if (lam[r_] < -lim) lam[r_] = -lim;
+              if (lam[r_] > lim) lam[r_] = lim;
+            }
+        }
+      }
+    }
     double warm_start[MAXROWS];
     memcpy(warm_start, lam, sizeof(warm_start));
     for (int it = 0; need_pgs && it < model->pgs_iterations; ++it) {
@@ -967,10 +1005,15 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
       oracle_debug_fallbacks += 1;
       oracle_debug_sweep_hist[sweeps_here < 63 ? sweeps_here : 63] += 1;
     }
+    g_sweep_warm_swept = need_pgs ? swept_state : 0;
+    if (g_sweep_warm_swept)
+      for (int wheel = 0; wheel < 2; ++wheel)
+        for (int r_ = 0; r_ < 3; ++r_) g_sweep_warm_lam[3 * wheel + r_] = contact_row[wheel] >= 0 ? lam[contact_row[wheel] + r_] : 0.0;
     for (int r_ = 0; r_ < nrows; ++r_)
       for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
   }
 
+  if (nrows == 0) g_sweep_warm_swept = 0;
   if (g_contact_sink) {
     /* getContactPoints: normalForce and lateralFriction1/2 are the applied
      * impulses over the time step (pybullet_backend.py:697-708 sums them) */
@@ -1318,6 +1361,8 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
   double h = cfg->dt / cfg->nb_substeps;
   int noisy = has_noise(cfg->torque_control_noise);
   uint32_t step = (uint32_t)s[UPKIE_S_STEP];
+  g_sweep_warm_armed = 1; /* the sweeps' warm start spans the substeps of this step */
+  g_sweep_warm_swept = 0;
   for (int sub = 0; sub < cfg->nb_substeps; ++sub) {
     double tau[NJ], z[6] = {0, 0, 0, 0, 0, 0};
     /* control noise: one draw per joint per substep, :545-550 */
@@ -1332,6 +1377,7 @@ static void backend_step(const UpkieModel* model, const UpkieSimConfig* cfg,
     oracle_substep_ext(model, s, tau, h, scale, force, point);
     spine_cycle(s, tau, h);
   }
+  g_sweep_warm_armed = 0;
   s[UPKIE_S_STEP] = (double)((step + 1u) & UPKIE_COUNTER_MASK);
 }
 

@@ -41,7 +41,14 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert steady["avg_launch_us"] <= steady["ms_per_step"] * 1e3 * 1.001
     # the secondary BASELINE configs as SURVEY 8d writes them
     sec = out["secondary"]
-    assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law"}
+    assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law", "c2_bullet_like_contact_model"}
+    bl = sec["c2_bullet_like_contact_model"]  # the fidelity option beside the default model on the same mapping
+    assert bl["bullet_like"]["lanes_per_env"] == 1 and bl["default_one_lane"]["lanes_per_env"] == 1
+    assert bl["bullet_like"]["us_per_step"] > bl["default_one_lane"]["us_per_step"] > 0
+    # the public path: env.step(policy(obs)) of the vector env, NEXT_STEP and SAME_STEP
+    api = out["vec_env_api"]
+    for mode in ("next_step", "same_step"):
+        assert api[mode]["python_loop_us_per_env_step"] > 0 and api[mode]["lanes_per_env"] == 8 and api[mode]["episodes"] > 0
     assert sec["c3"]["envs"] == 16384 and "resampled every 400 steps" in sec["c3"]["config"] and sec["c3"]["algorithmic_bytes_per_env_step"] == 554
     for key in ("c5_share_torque_law", "c5_share_velocity_law"):
         c5 = sec[key]

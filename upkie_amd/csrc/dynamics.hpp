@@ -795,6 +795,51 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
 // Gauss-Seidel sweeps (normals, then frictions, then limits). Row data come
 // reduced onto the base: Jt (6) and the leg part (3). On return
 // (tb, tl, tr) += J' lam.
+// What the Gauss-Seidel sweeps of one substep hand to the next substep of the SAME env.step(): the impulses they ended on
+// and with which tires on the floor (0: that substep did not sweep, 1 / 2: it did, with one / both tires touching). A
+// robot that skids or tumbles does so for many substeps in a row and its contact state changes little from one
+// millisecond to the next: started from there the sweeps reach the same fixed point in fewer passes (they stop on their
+// own convergence test either way). Every lane mapping and the fp64 checker follow this rule (round 4; round 3: the
+// eight-lane kernel only).
+struct SweepWarmStart {
+  float lam[6];
+  int swept;
+};
+
+// The contact impulses of a substep whose direct solution `lam` left the friction box / pulls: projected Gauss-Seidel
+// sweeps (contact_pgs6) from the projected direct solution, or from the previous substep's impulses (`warm`); both tires
+// leaving the floor (neither normal row asks for an impulse) is lam = 0 without a sweep. Returns the sweeps run.
+template <class ModelT>
+UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool both, SweepWarmStart* warm) {
+  if (rhs[0] <= 0.f && rhs[3] <= 0.f) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) lam[r] = 0.f;
+    if (warm) warm->swept = 0;
+    return 0;
+  }
+  const int state = both ? 2 : 1;
+  if (warm && warm->swept == state) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) lam[r] = warm->lam[r];
+  }
+  const float mu = M.friction_mu;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) lam[3 * w] = fmaxf(lam[3 * w], 0.f);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    if ((r % 3) == 0) continue;
+    const float lim = mu * lam[3 * (r / 3)];
+    lam[r] = fminf(fmaxf(lam[r], -lim), lim);
+  }
+  const int sweeps = contact_pgs6(M, A, rhs, lam, both);
+  if (warm) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) warm->lam[r] = lam[r];
+    warm->swept = state;
+  }
+  return sweeps;
+}
+
 constexpr int kRows = 10;
 UPKIE_HD constexpr int row_leg(int r) { return r < 3 ? 0 : (r < 6 ? 1 : (r < 8 ? 0 : 1)); }
 UPKIE_HD constexpr int row_kind(int r) { return r >= 6 ? 2 : (r % 3 == 0 ? 0 : 1); }  // 0 normal, 1 friction, 2 limit
@@ -1299,7 +1344,7 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
 template <bool SCRATCH_LIMITS = false, bool BULLET_LIKE = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
                                                 const BodyInertials* bi, const ExtForces& ext, ContactReport* report = nullptr,
-                                                float (*manifold)[64] = nullptr) {
+                                                float (*manifold)[64] = nullptr, SweepWarmStart* warm = nullptr) {
   // hip / knee position limits (URDF revolute limits, enforced by Bullet as
   // unilateral rows with ERP 0.2): rare, handled by the general solver
   bool any_limit = false;
@@ -1486,6 +1531,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
     }
   }
   float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (warm && (any_limit || !(active[0] || active[1]))) warm->swept = 0;
   if (any_limit) {
     if (SCRATCH_LIMITS)
       limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr, lam);
@@ -1558,7 +1604,11 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
         if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
       }
     }
-    if (need_pgs) contact_pgs6(M, A, rhs, lam, active[0] && active[1]);
+    if (need_pgs) {
+      contact_sweeps_warm(M, A, rhs, lam, active[0] && active[1], warm);
+    } else if (warm) {
+      warm->swept = 0;
+    }
     // t += J' lam
 #pragma unroll
     for (int c = 0; c < 6; ++c) {

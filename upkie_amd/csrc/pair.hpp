@@ -122,7 +122,8 @@ struct PhysPair {
 // owns. Returns the floor-contact flag (identical in both lanes).
 template <class XL = AdjacentLanes, class ModelT>
 __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
-                                                     const float (&tau)[3], float h, const TrunkInertial* trunk, const ExtForces& ext) {
+                                                     const float (&tau)[3], float h, const TrunkInertial* trunk, const ExtForces& ext,
+                                                     SweepWarmStart* warm = nullptr) {
   bool own_limit = false;
   if (Lm.enforce) {
 #pragma unroll
@@ -274,6 +275,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   const bool active_l = pick(leg, active_own, active_partner), active_r = pick(leg, active_partner, active_own);
   const bool any_contact = active_own || active_partner;
 
+  if (warm && (any_limit || !any_contact)) warm->swept = 0;
   if (any_limit) {
     // rare: rebuild both legs' data in both lanes and run the shared path
     System S2;
@@ -413,7 +415,11 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
         if (lam[r] > lim) { lam[r] = lim; need_pgs = true; }
       }
     }
-    if (need_pgs) contact_pgs6(M, A, rhs, lam, active_l && active_r);  // identical data in both lanes: they iterate in lockstep
+    if (need_pgs) {
+      contact_sweeps_warm(M, A, rhs, lam, active_l && active_r, warm);  // identical data in both lanes: they iterate in lockstep
+    } else if (warm) {
+      warm->swept = 0;
+    }
     // t += J' lam: own rows locally, base part as own + partner
     float lo_[3];
 #pragma unroll
@@ -557,7 +563,9 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   const bool any_noise = C.any_control_noise || C.any_measurement_noise;
   unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
 
+  SweepWarmStart sweep_warm_start;  // spans the substeps of ONE env.step() (dynamics.hpp): several steps in a launch = as many launches
 next_step:
+  sweep_warm_start.swept = 0;
   bool do_reset;
   if (MODE == MODE_RESET) {
     do_reset = mask ? mask[e] != 0 : true;
@@ -687,7 +695,7 @@ next_step:
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
       const ExtForces ext_now{do_reset ? nullptr : ext.force, ext.stride, ext.slots};  // reset steps once without external forces
-      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext_now);
+      contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext_now, &sweep_warm_start);
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline: each lane runs the WheelContact estimator of its

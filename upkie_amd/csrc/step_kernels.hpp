@@ -411,6 +411,8 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
   const bool any_noise = C.any_control_noise || C.any_measurement_noise;
   unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
   const int nsub = do_reset ? 1 : C.nb_substeps;
+  SweepWarmStart sweep_warm_start;  // spans the substeps of this env.step() (dynamics.hpp)
+  sweep_warm_start.swept = 0;
   for (int sub = 0; sub < C.nb_substeps; ++sub) {
     if (sub >= nsub) break;
     float zn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restric
       if constexpr (BULLET_LIKE) {
         contact = physics_substep<(WPS > 1), true>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now, nullptr, &contact_manifold);
       } else {
-        contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now);
+        contact = physics_substep<(WPS > 1)>(*mp, Lm, s, tau, C.h, RAND ? &inertials : nullptr, ext_now, nullptr, nullptr, &sweep_warm_start);
       }
     }
     if (SPINE) {
