@@ -5,7 +5,14 @@ SURVEY.md section 8c). Prints per-step differences of the Pendulum observation
 for the README agent and, with --time, env-steps/s of the reference on one
 core (the B2 baseline of BASELINE.md).
 
-    python tools/compare_with_pybullet.py --steps 200 [--time]
+    python tools/compare_with_pybullet.py --steps 200 [--time] [--contact-model bullet_like]
+
+--contact-model bullet_like (the default here) runs this repository's side
+under the Bullet-like contact specification on the device
+(`upkie_sim_set_contact_manifold`: persistent 4-point manifolds, 50 fixed
+sweeps, cone friction) -- the restatement of what pybullet.stepSimulation() is
+published to do, and the first thing to hold against the real thing;
+--contact-model default runs the product's fast specification.
 
 Expect agreement of the wrapper arithmetic and qualitative agreement of the
 dynamics only: Bullet's contact solver and the real URDF differ from the
@@ -25,6 +32,7 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--time", action="store_true")
+    parser.add_argument("--contact-model", choices=("bullet_like", "default"), default="bullet_like")
     args = parser.parse_args()
     try:
         import gymnasium as gym
@@ -37,7 +45,7 @@ def main():
     from upkie_amd.model.model import Model
 
     ref = gym.make("Upkie-PyBullet-Pendulum", frequency=200.0, gui=False, regulate_frequency=False, frequency_checks=False)
-    ours = envs.make("Upkie-HIP-Pendulum", frequency=200.0, model=Model())  # Model() picks up upkie_description's URDF
+    ours = envs.make("Upkie-HIP-Pendulum", frequency=200.0, model=Model(), contact_model=args.contact_model)  # Model() picks up upkie_description's URDF
     gain = np.array([10.0, 1.0, 0.0, 0.1])
     obs_r, _ = ref.reset(seed=0)
     obs_o, _ = ours.reset(seed=0)
