@@ -103,15 +103,16 @@ class OracleSim:
 
     def reset(self, mask=None):
         m = None if mask is None else mask.to(torch.uint8).numpy()
-        self.obs6 = torch.from_numpy(self._o.reset(m).astype(np.float32))
+        self.obs6.copy_(torch.from_numpy(self._o.reset(m).astype(np.float32)))  # (the same buffer every time, like the handle's)
         return self.obs6
 
     def _out(self, obs, rew, term, trunc, holder):
         obs = torch.from_numpy(np.asarray(obs, dtype=np.float32))
         getattr(self, holder).copy_(obs)
-        self.reward = torch.from_numpy(rew.astype(np.float32))
-        self.terminated = torch.from_numpy(term)
-        self.truncated = torch.from_numpy(trunc)
+        # (persistent buffers, rewritten in place, like the handle's: `UpkieVecEnv._fast_step` returns them as one cached tuple)
+        self.reward.copy_(torch.from_numpy(rew.astype(np.float32)))
+        self.terminated.copy_(torch.from_numpy(term))
+        self.truncated.copy_(torch.from_numpy(trunc))
         return getattr(self, holder), self.reward, self.terminated, self.truncated
 
     final_obs = None
@@ -261,6 +262,21 @@ def _step_into_fn(self, kind, policy=None, mpc=None, mpc_x0=None, mpc_contact=No
 
 
 OracleSim.step_into_fn = _step_into_fn
+
+
+def _stepper(self, kind):
+    """`BatchedSim.stepper` on the oracle: ``step(action_address)`` writing the double's persistent output buffers."""
+    B = self.num_envs
+    words = {"pendulum": 1, "gyropod": 2, "servos": 36}[kind]
+    call = {"pendulum": self.step_pendulum, "gyropod": self.step_gyropod, "servos": self.step_servos}[kind]
+
+    def step(action_address):
+        call(torch.from_numpy(_from_address(action_address, B * words, C.c_float, np.float32).copy()))
+
+    return step
+
+
+OracleSim.stepper = _stepper
 
 
 def oracle_sim_factory(config, model_struct, device):

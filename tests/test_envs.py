@@ -527,3 +527,45 @@ def test_constructor_seed_covers_an_unseeded_first_reset_of_single_envs():
     assert np.array_equal(oa, ob) and not np.array_equal(oa, oc)
     assert not np.array_equal(a.reset()[0], oa)  # the generator moves on: a second unseeded reset is another state
     assert np.array_equal(a.reset(seed=5)[0], b.reset(seed=5)[0])
+
+
+def test_step_returns_one_cached_tuple_of_persistent_buffers():
+    """`env.step` of the fused env kinds: one call into the handle on cached
+    addresses, the five outputs ONE tuple of the handle's persistent buffers
+    (rewritten in place), `reset()` handing out the same observation buffer, so
+    that `obs = env.step(policy(obs))[0]` never leaves one tensor."""
+    for env_id, shape in (("Upkie-HIP-Pendulum-Vec", (1,)), ("Upkie-HIP-Gyropod-Vec", (2,)), ("Upkie-HIP-Servos-Vec", (6, 6))):
+        env = envs.make(env_id, num_envs=4, frequency=200.0, **KW)
+        obs, info = env.reset(seed=0)
+        assert obs is env.observation
+        act = torch.zeros((4,) + shape)
+        if env_id.endswith("Servos-Vec"):
+            act = env.get_neutral_action()
+        first = env.step(act)
+        second = env.step(act)
+        assert first is second and first[0] is obs  # the cached tuple; the observation buffer reset() returned
+        assert first[2].dtype == torch.bool and first[3].dtype == torch.bool
+        assert first[4]["spine_observation"]["base_orientation"]["pitch"].shape == (4,)  # materialises on access
+        # any array-like action still works (converted, reshaped)
+        third = env.step(act.numpy().reshape(4, -1))
+        assert third is first
+        env.close()
+
+
+def test_same_step_info_computes_final_obs_flags_on_access():
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.3))
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=6, frequency=200.0, fall_pitch=0.15, init_state=init, autoreset_mode="same_step", **KW)
+    obs, _ = env.reset(seed=1)
+    act = torch.zeros(6, 1)
+    seen = 0
+    for _ in range(40):
+        obs, reward, terminated, truncated, info = env.step(act)
+        assert "_final_obs" in info and "final_obs" in info and set(info.keys()) >= {"spine_observation", "final_obs", "_final_obs"}
+        done = info["_final_obs"]
+        assert torch.equal(done, terminated | truncated)
+        if bool(done.any()):
+            seen += int(done.sum())
+            # the terminal observation is beyond the fall pitch, the returned one is the next episode's first
+            assert bool((info["final_obs"][done][:, 0].abs() > 0.15).all()) and bool((obs[done][:, 0].abs() <= 0.31).all())
+    assert seen > 0
+    env.close()
