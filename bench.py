@@ -338,16 +338,18 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
 def secondary_bullet_like(envs: int = ENVS_PER_GPU, steps: int = 400, warmup: int = 100, seed: int = 0) -> dict:
     """The headline workload (C2: Upkie-Pendulum, PD agent on device, NEXT_STEP
     autoreset) under the Bullet-like contact model
-    (`upkie_sim_set_contact_manifold`: persistent 4-point manifolds, 50 fixed
-    sequential-impulse sweeps, cone friction) and, on the same handle class and
-    lane mapping (one env per lane), under the default model: what the fidelity
-    option costs."""
+    (`upkie_sim_set_contact_manifold`: persistent manifolds, 50 fixed
+    sequential-impulse sweeps, cone friction) on the lane mapping the handle
+    picks (eight lanes per env at this size: octet.hpp) and on the one-lane
+    kernels that cover every case (bullet_like.hpp), with the default model on
+    the same two mappings beside it: what the fidelity option costs."""
     from upkie_amd.sim import BatchedSim
 
-    out = {"config": "C2 workload, one env per lane (UPKIE_LANES_PER_ENV=1 for the default model's row), one launch per env.step()", "envs": envs, "steps": steps, "warmup": warmup}
-    for name in ("bullet_like", "default_one_lane"):
+    out = {"config": "C2 workload, one launch per env.step(); *_one_lane rows: UPKIE_LANES_PER_ENV=1", "envs": envs, "steps": steps, "warmup": warmup}
+    for name, bullet, forced in (("bullet_like", True, None), ("bullet_like_one_lane", True, "1"), ("default", False, None), ("default_one_lane", False, "1")):
         saved = os.environ.get("UPKIE_LANES_PER_ENV")
-        os.environ["UPKIE_LANES_PER_ENV"] = "1"
+        if forced is not None:
+            os.environ["UPKIE_LANES_PER_ENV"] = forced
         try:
             sim = BatchedSim(make_config(envs, seed=seed))
         finally:
@@ -355,7 +357,7 @@ def secondary_bullet_like(envs: int = ENVS_PER_GPU, steps: int = 400, warmup: in
                 os.environ.pop("UPKIE_LANES_PER_ENV", None)
             else:
                 os.environ["UPKIE_LANES_PER_ENV"] = saved
-        if name == "bullet_like":
+        if bullet:
             sim.use_bullet_like_contacts()
         o6 = sim.reset()
         sim.obs4.copy_(o6[:, [1, 0, 4, 3]])

@@ -255,11 +255,22 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * point's friction pair projected onto the cone), normal impulses warm-started
  * with 0.85 x the last applied ones. Per env and tire four records of 8 words:
  * point in the wheel frame (3), on the plane in world coordinates (3), applied
- * normal impulse, live flag. A reset clears an env's manifold. This model
- * exists in the one-env-per-lane kernels only (upkie_sim_lanes_per_env
- * reports 1 while it is set) and is several times slower than the default:
- * it is there to answer "what would PyBullet's contact pipeline do", e.g. as
- * the first thing tools/compare_with_pybullet.py should be pointed at. */
+ * normal impulse, live flag. A reset clears an env's manifold. Two kernels run
+ * this model: the one-env-per-lane step kernels cover every case (several
+ * points on a tire, joints at their stops in the same solve, any batch size,
+ * every entry point); up to 16384 envs the Pendulum / Gyropod / BaseVelocity
+ * entry points -- whose legs the servos hold -- run it on eight lanes per env,
+ * in the case a rolling wheel produces (one cached point per tire, which the
+ * tire's deepest point replaces every substep: the default model's contact
+ * point with the friction rows rotated into the sliding direction; a joint
+ * at its stop, which those envs do not reach, would take the default model's
+ * joint-stop path for that substep and is counted by the census, word [0]).
+ * Both keep complete manifold records, so upkie_sim_step_servos (one lane)
+ * and upkie_sim_step_pendulum (eight lanes) may alternate on one handle.
+ * 2.5 - 3.5 x the default model's step; the default stays the product's fast
+ * specification. This is the model to answer "what would PyBullet's contact
+ * pipeline do", e.g. the first thing tools/compare_with_pybullet.py holds
+ * against the real thing. */
 #define UPKIE_CONTACT_MANIFOLD_WORDS 64
 int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold);
 

@@ -124,8 +124,8 @@ void spin_barrier_wait(void* b) { static_cast<SpinBarrier*>(b)->wait(); }
 // st: one env's state words (in / out), tau: six commanded torques, records: [70] or null,
 // trunk_wrench: [6] (base frame, about the base origin) or null. Runs `substeps` substeps;
 // status[i] receives OCT_CONTACT / OCT_NO_CONTACT of substep i.
-extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
-                                     const float* trunk_wrench, int substeps, int* status, int limits_in_registers) {
+static int run_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records, const float* trunk_wrench, int substeps,
+                     int* status, int limits_in_registers, float* bullet_applied /* [2]: Bullet-like contacts on these applied impulses, or null */) {
   DevModel M;
   std::string why;
   if (!convert_model(model, &M, &why)) return -1;
@@ -155,10 +155,12 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
       s.q = l > 0 ? st[UPKIE_S_Q + joint] : 0.f;
       s.qd = l > 0 ? st[UPKIE_S_QD + joint] : 0.f;
       const float own_tau = l > 0 ? tau[joint] : 0.f;
+      if (bullet_applied) s.bl_applied = bullet_applied[leg];
       LimitWorkspace workspace;  // (the kernel keeps one per env in LDS; here every lane's thread has its own)
       for (int i = 0; i < substeps; ++i) {
-        const int r = limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
-                                          : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace);
+        const int r = bullet_applied        ? physics_substep_octet<false, false, true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
+                      : limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
+                                            : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace);
         lane_status[t][i] = r;
       }
       result[t] = s;
@@ -189,6 +191,20 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
     st[UPKIE_S_QD + 3 * leg + l - 1] = result[t].qd;
   }
   for (int i = 0; i < substeps; ++i) status[i] = lane_status[0][i];
+  if (bullet_applied) {
+    bullet_applied[0] = result[1].bl_applied;  // (a lane of the left quad, of the right quad)
+    bullet_applied[1] = result[5].bl_applied;
+  }
   return consistent;
+}
+
+extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records,
+                                     const float* trunk_wrench, int substeps, int* status, int limits_in_registers) {
+  return run_octet(model, st, tau, h, records, trunk_wrench, substeps, status, limits_in_registers, nullptr);
+}
+
+// The eight-lane substep under the Bullet-like contact specification: applied[2] = the tires' applied normal impulses (in / out).
+extern "C" int harness_substep_octet_bullet_like(const UpkieModel* model, float* st, const float* tau, float h, int substeps, int* status, float* applied) {
+  return run_octet(model, st, tau, h, nullptr, nullptr, substeps, status, 0, applied);
 }
 #endif  // host pass only

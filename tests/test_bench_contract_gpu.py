@@ -43,8 +43,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     sec = out["secondary"]
     assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law", "c2_bullet_like_contact_model"}
     bl = sec["c2_bullet_like_contact_model"]  # the fidelity option beside the default model on the same mapping
-    assert bl["bullet_like"]["lanes_per_env"] == 1 and bl["default_one_lane"]["lanes_per_env"] == 1
-    assert bl["bullet_like"]["us_per_step"] > bl["default_one_lane"]["us_per_step"] > 0
+    assert bl["bullet_like"]["lanes_per_env"] == 8 and bl["bullet_like_one_lane"]["lanes_per_env"] == 1 and bl["default_one_lane"]["lanes_per_env"] == 1
+    assert bl["bullet_like"]["us_per_step"] > bl["default"]["us_per_step"] > 0
+    assert bl["bullet_like_one_lane"]["us_per_step"] > bl["default_one_lane"]["us_per_step"] > 0
     # the public path: env.step(policy(obs)) of the vector env, NEXT_STEP and SAME_STEP
     api = out["vec_env_api"]
     for mode in ("next_step", "same_step"):

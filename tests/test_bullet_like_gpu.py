@@ -25,18 +25,21 @@ def manifolds(sim, ref):
     return mh, mo
 
 
-def test_c2_rollout_under_the_bullet_like_model_matches_the_oracle():
-    """Upkie-Pendulum, README agent, 2048 envs x 60 steps: observations within
+@pytest.mark.parametrize("lanes", ["8", "1"])
+def test_c2_rollout_under_the_bullet_like_model_matches_the_oracle(lanes, monkeypatch):
+    """Upkie-Pendulum, README agent, 2048 envs x 60 steps, on the eight-lane
+    variant (octet.hpp: what a batch of this size runs) and on the one-lane
+    kernels (bullet_like.hpp: every case, any batch size): observations within
     the closed-loop tolerances of the default model, the same points cached,
     applied normal impulses within 1e-4 N.s."""
     from oracle import oracle as O
 
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
     B = 2048
     cfg = randomized_config(B, seed=3)
     sim = BatchedSim(cfg)
-    assert sim.lanes_per_env == 8
     sim.use_bullet_like_contacts()
-    assert sim.lanes_per_env == 1  # (the model lives in the one-lane kernels)
+    assert sim.lanes_per_env == int(lanes) and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 1  # (Servos: joints may sit at their stops)
     ref = O.Oracle(default_model(), cfg)
     ref.use_bullet_like_contacts()
     sim.reset()
@@ -62,11 +65,13 @@ def test_c2_rollout_under_the_bullet_like_model_matches_the_oracle():
     assert err["pos"] < 1e-3 and err["quat"] < 1e-3 and err["contact"] == 0, err
 
 
-def test_autoreset_clears_the_manifold_and_falls_match_the_oracle():
+@pytest.mark.parametrize("lanes", ["8", "1"])
+def test_autoreset_clears_the_manifold_and_falls_match_the_oracle(lanes, monkeypatch):
     """NEXT_STEP autoreset with a small fall pitch: envs fall and restart inside
     the 80 steps (two thirds of them); a reset drops the env's contact cache on both sides."""
     from oracle import oracle as O
 
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
     B = 512
     cfg = randomized_config(B, seed=5, autoreset=True)
     cfg.fall_pitch = 0.12
@@ -136,6 +141,48 @@ def test_c5_share_under_the_bullet_like_model_matches_the_oracle():
     dq = np.abs(sh[:, :, 0] - so[:, :, 0])
     assert dq[:, [0, 1, 3, 4]].max() <= 1e-3 and np.quantile(dq, 0.5) <= 1e-5, (dq.max(axis=0), np.quantile(dq, [0.5, 0.99]))
     assert np.quantile(dq[:, [2, 5]], 0.99) <= 1e-3, np.quantile(dq[:, [2, 5]], [0.5, 0.99, 1.0])
+
+
+def test_both_bullet_like_kernels_continue_from_each_others_manifold():
+    """A handle steps Pendulum (eight lanes) and Servos (one lane: joints may sit at their stops) on ONE manifold: the
+    eight-lane kernel writes complete records (point in the wheel frame, on the plane, applied impulse, live), so the
+    one-lane kernel finds its cached points where it would have put them itself."""
+    B = 256
+    import os
+
+    a = BatchedSim(randomized_config(B, seed=8))
+    a.use_bullet_like_contacts()
+    assert a.lanes_per_env == 8
+    a.reset()
+    os.environ["UPKIE_LANES_PER_ENV"] = "1"
+    try:
+        c = BatchedSim(randomized_config(B, seed=8))  # the one-lane kernels all the way
+    finally:
+        os.environ.pop("UPKIE_LANES_PER_ENV")
+    c.use_bullet_like_contacts()
+    c.reset()
+    for sim in (a, c):
+        sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    for _ in range(10):
+        a.step_pendulum_agent()
+        c.step_pendulum_agent()
+    ma, mc = a.contact_manifold.cpu().numpy().reshape(2, 4, 8, B), c.contact_manifold.cpu().numpy().reshape(2, 4, 8, B)
+    assert (ma[:, :, 7].sum(axis=1) == 1).all() and (mc[:, :, 7].sum(axis=1) == 1).all()
+    la, lc = ma[:, :, 7] != 0, mc[:, :, 7] != 0
+    pa = np.stack([ma[:, :, i][la] for i in range(7)])  # the live record of every tire, whichever slot holds it
+    pc = np.stack([mc[:, :, i][lc] for i in range(7)])
+    assert np.abs(pa[:3] - pc[:3]).max() < 2e-4 and np.abs(pa[3:5] - pc[3:5]).max() < 2e-4 and np.abs(pa[6] - pc[6]).max() < 2e-4
+    # ... and a Servos step (one lane) continues from the manifold the eight-lane steps left
+    act = torch.zeros((B, 6, 6), device=a.device)
+    act[:, :, 3] = 1.0
+    act[:, :, 4] = 1.0
+    act[:, :, 5] = 16.0
+    act[:, [2, 5], 0] = float("nan")
+    oa = a.step_servos(act)[0].clone()
+    oc = c.step_servos(act)[0]
+    assert (oa[:, :, :2] - oc[:, :, :2]).abs().max() < 5e-3
+    m2 = a.contact_manifold.cpu().numpy().reshape(2, 4, 8, B)
+    assert (m2[:, :, 7].sum(axis=1) == 1).all()  # the cached point was replaced, not doubled
 
 
 def test_switching_the_model_off_restores_the_default_kernels():

@@ -214,3 +214,62 @@ def test_full_manifolds_four_points_per_tire_match_the_oracle(harness):  # noqa:
     assert most_rows >= 21, most_rows  # (full or nearly full manifolds were solved)
     assert worst[0:3].max() < 5e-6 and worst[3:7].max() < 5e-6 and worst[13:19].max() < 5e-5, worst
     assert worst[7:10].max() < 5e-3 and worst[10:13].max() < 2e-2, worst
+
+
+def test_eight_lane_bullet_like_substep_matches_the_oracle(harness):  # noqa: F811
+    """The eight-lane kernel's Bullet-like substep (octet.hpp, oct_bullet_like_solve: the default rows rotated into the
+    sliding direction, dense 6 x 6 sweeps in every lane) run as eight lockstep host threads, substep by substep against
+    the oracle's twin: landed robots rolling and sliding, 30 substeps each; applied normal impulses carried along."""
+    rng = np.random.default_rng(21)
+    model = default_model()
+    harness.harness_substep_octet_bullet_like.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    worst = np.zeros(25)
+    worst_applied = 0.0
+    compared = 0
+    for trial in range(16):
+        s = random_state(rng, True)
+        if trial % 2 == 0:  # upright, rolling
+            s[abi.S_QUAT:abi.S_QUAT + 4] = [1, 0, 0, 0]
+            s[abi.S_Q:abi.S_Q + 6] = 0
+            s[abi.S_LINVEL:abi.S_LINVEL + 3] = rng.uniform(-0.05, 0.05, 3)
+            s[abi.S_ANGVEL:abi.S_ANGVEL + 3] = rng.uniform(-0.1, 0.1, 3)
+        manifold = np.zeros(WORDS)
+        for _ in range(300):  # land on the oracle, legs held at zero by a PD law
+            hold = np.zeros(6)
+            for j in (0, 1, 3, 4):
+                hold[j] = np.clip(20.0 * (0.0 - s[abi.S_Q + j]) - 1.0 * s[abi.S_QD + j], -10.0, 10.0)
+            s, manifold, contact = both(harness, model, s, manifold, hold)
+        if contact != 1:
+            continue
+        so, mo = s.copy(), manifold.copy()
+        sh = s.astype(np.float32)
+        m = manifold.reshape(2, 4, 8)
+        applied = np.array([(m[w, :, 6] * m[w, :, 7]).sum() for w in range(2)], dtype=np.float32)
+        taus = rng.uniform(-0.8, 0.8, (30, 6))
+        status = np.zeros(1, dtype=np.int32)
+        lower, upper = np.array(model.joint_lower[:6]), np.array(model.joint_upper[:6])
+        for tau in taus:
+            q = so[abi.S_Q:abi.S_Q + 6]
+            # legs held by their servos, as in the envs the eight-lane variant serves (a limp leg folds onto its stops,
+            # and a joint at its stop is outside this variant: it takes the default model's joint-stop path there)
+            tau = tau.copy()
+            for j in (0, 1, 3, 4):
+                tau[j] = np.clip(20.0 * (0.0 - q[j]) - 1.0 * so[abi.S_QD + j], -10.0, 10.0)
+            if np.any((q <= lower + 1e-3) | (q >= upper - 1e-3)):
+                break
+            so, mo, co = both(harness, model, so, mo, tau)
+            t32 = np.ascontiguousarray(tau, dtype=np.float32)
+            ok = harness.harness_substep_octet_bullet_like(C.byref(model), p(sh), p(t32), C.c_float(1e-3), 1, p(status), p(applied))
+            assert ok == 1  # the eight lanes agree on the base
+            live = mo.reshape(2, 4, 8)[:, :, 7]
+            if live.sum(axis=1).max() > 1 or (status[0] == 1) != (co == 1):
+                break  # (more than one cached point on a tire: outside the eight-lane variant's case -- not expected)
+            compared += 1
+            worst = np.maximum(worst, np.abs(so[:25] - sh[:25].astype(np.float64)))
+            ref_applied = (mo.reshape(2, 4, 8)[:, :, 6] * live).sum(axis=1)
+            worst_applied = max(worst_applied, float(np.abs(ref_applied - applied).max()))
+    assert compared >= 400, compared
+    assert worst[0:3].max() < 5e-6 and worst[3:7].max() < 5e-6 and worst[13:19].max() < 5e-5, worst
+    assert worst[7:10].max() < 5e-3 and worst[10:13].max() < 2e-2, worst
+    assert worst_applied < 5e-4, worst_applied

@@ -14,9 +14,14 @@ from upkie_amd.sim import BatchedSim
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 32768, 65536, 131072, 262144]
 for B in sizes:
     row = []
-    for model in ("default", "bullet_like"):
-        sim = BatchedSim(bench.make_config(B))
-        if model == "bullet_like":
+    for model in ("default", "bullet_like", "bullet_like, one lane"):
+        if model.endswith("one lane"):
+            os.environ["UPKIE_LANES_PER_ENV"] = "1"
+        try:
+            sim = BatchedSim(bench.make_config(B))
+        finally:
+            os.environ.pop("UPKIE_LANES_PER_ENV", None)
+        if model.startswith("bullet_like"):
             sim.use_bullet_like_contacts()
         o6 = sim.reset()
         sim.obs4.copy_(o6[:, [1, 0, 4, 3]])

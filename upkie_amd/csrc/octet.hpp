@@ -450,6 +450,9 @@ struct OctPhys {
   // contact row the sweeps of the PREVIOUS substep ended on, and whether they ran with both tires on the floor
   float lam_prev = 0.f;
   int swept_prev = 0;  // 0: the previous substep did not sweep; 1 / 2: it did, with one / both tires touching
+  // Bullet-like contact model (BULLET_LIKE instantiations): the applied normal impulse of the own leg's cached contact
+  // point, the same in the four lanes of the quad; persists from step to step in the env's contact manifold
+  float bl_applied = 0.f;
 };
 
 // 6x6 LDL' of the base block of a robot whose legs move in the sagittal plane:
@@ -824,6 +827,149 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
+// The env's 6 x 6 contact system gathered into EVERY lane of the env from its one-column-per-lane form (rows 0-2: the
+// left tire's normal / rolling / lateral row, 3-5: the right tire's): A packed lower by rows, right-hand sides.
+// Dg[a]: entry (a, own row) of the own tire's block, X[a]: entry (other tire's row a, own row) of the coupling block.
+UPKIE_HD void oct_gather_system(const OctLane& L, const float (&Dg)[3], const float (&X)[3], float rhs, float (&A6)[21], float (&rhs6)[6]) {
+  const bool left = L.leg == 0;
+  // diagonal blocks: entry (a, b) of the own tire's block sits in lane b + 1 of the own quad
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const float own = b == 0 ? oct_qb<1>(Dg[a]) : (b == 1 ? oct_qb<2>(Dg[a]) : oct_qb<3>(Dg[a]));
+      const float other = oct_swp(own);
+      A6[a * (a + 1) / 2 + b] = left ? own : other;
+      A6[(3 + a) * (4 + a) / 2 + 3 + b] = left ? other : own;
+    }
+  }
+  // coupling block (right tire's row a, left tire's column b): the left quad's lane b + 1 holds it as X[a]
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float own = b == 0 ? oct_qb<1>(X[a]) : (b == 1 ? oct_qb<2>(X[a]) : oct_qb<3>(X[a]));
+      const float other = oct_swp(own);
+      A6[(3 + a) * (4 + a) / 2 + b] = left ? own : other;
+    }
+  }
+  const float r1 = oct_qb<1>(rhs), r2 = oct_qb<2>(rhs), r3 = oct_qb<3>(rhs);
+  const float p1 = oct_swp(r1), p2 = oct_swp(r2), p3 = oct_swp(r3);
+  rhs6[0] = left ? r1 : p1; rhs6[1] = left ? r2 : p2; rhs6[2] = left ? r3 : p3;
+  rhs6[3] = left ? p1 : r1; rhs6[4] = left ? p2 : r2; rhs6[5] = left ? p3 : r3;
+}
+
+// Contacts of one substep under the Bullet-like specification (bullet_like.hpp: what the one-lane kernels run), in the
+// case a rolling wheel produces -- at most ONE cached point per tire, which the tire's deepest point replaces every
+// substep (it moves <= 5 mm per substep in the wheel's frame at the joint-speed limit, the replacement threshold is
+// 2 cm), so the point IS the default specification's contact point and only the rows differ: friction directions
+// along / across the point's sliding velocity -- a rotation (or reflection) of the default rolling / lateral rows within
+// the tangent plane, per tire --, no friction CFM, a FIXED number of Gauss-Seidel sweeps over the dense 6 x 6 system
+// (normals, then each point's friction pair projected onto the cone), normals warm-started with 0.85 x the last applied
+// impulse. Every lane of the env sweeps the same system in lockstep; returns the own row's impulse in the DEFAULT
+// basis (what the rest of the substep consumes). vt1 / vt2: free velocity of the own tire's point along the default
+// rolling / lateral directions t1 / t2; `applied`: the own tire's applied normal impulse (in / out).
+template <class ModelT>
+UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const BaseFrame& bf, const float (&Dg)[3], const float (&X)[3], float rhs,
+                                     V3 t1, V3 t2, float vt1, float vt2, bool active, bool active_partner, float& applied) {
+  const bool left = L.leg == 0;
+  float A6[21], rhs6[6];
+  oct_gather_system(L, Dg, X, rhs, A6, rhs6);
+  // rows of the Bullet-like basis in the default one, own tire: [t1'; t2'] = R [t1; t2]
+  float R00, R01, R10, R11;
+  {
+    const float lat2 = vt1 * vt1 + vt2 * vt2;
+    if (lat2 > 1.1920929e-07f) {  // SIMD_EPSILON: t1' along the sliding velocity, t2' = t1' x n (= s t1 - c t2: t2 = n x t1)
+      const float inv = 1.f / sqrtf(lat2);
+      const float c = vt1 * inv, sn = vt2 * inv;
+      R00 = c; R01 = sn; R10 = sn; R11 = -c;
+    } else {  // btPlaneSpace1(n) for n = world z: world (0, -1, 0) and (1, 0, 0)
+      const V3 a = v3(-bf.r10, -bf.r11, -bf.r12), b = v3(bf.r00, bf.r01, bf.r02);
+      R00 = dot(a, t1); R01 = dot(a, t2); R10 = dot(b, t1); R11 = dot(b, t2);
+    }
+  }
+  float Q[2][4];  // [tire] R00 R01 R10 R11
+  {
+    const float o0 = oct_swp(R00), o1 = oct_swp(R01), o2 = oct_swp(R10), o3 = oct_swp(R11);
+    Q[0][0] = left ? R00 : o0; Q[0][1] = left ? R01 : o1; Q[0][2] = left ? R10 : o2; Q[0][3] = left ? R11 : o3;
+    Q[1][0] = left ? o0 : R00; Q[1][1] = left ? o1 : R01; Q[1][2] = left ? o2 : R10; Q[1][3] = left ? o3 : R11;
+  }
+  float W[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) W[a][b] = a >= b ? A6[a * (a + 1) / 2 + b] : A6[b * (b + 1) / 2 + a];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {  // W <- Q W Q', rhs <- Q rhs: the friction rows / columns of each tire
+    const int i = 3 * w + 1, j = 3 * w + 2;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float x = W[i][c], y = W[j][c];
+      W[i][c] = Q[w][0] * x + Q[w][1] * y;
+      W[j][c] = Q[w][2] * x + Q[w][3] * y;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const float x = W[r][i], y = W[r][j];
+      W[r][i] = Q[w][0] * x + Q[w][1] * y;
+      W[r][j] = Q[w][2] * x + Q[w][3] * y;
+    }
+    const float x = rhs6[i], y = rhs6[j];
+    rhs6[i] = Q[w][0] * x + Q[w][1] * y;
+    rhs6[j] = Q[w][2] * x + Q[w][3] * y;
+  }
+  const bool on[2] = {left ? active : active_partner, left ? active_partner : active};
+  const float other_applied = oct_swp(applied);
+  float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, inv_diag[6];
+  lam[0] = on[0] ? 0.85f * (left ? applied : other_applied) : 0.f;  // m_warmstartingFactor
+  lam[3] = on[1] ? 0.85f * (left ? other_applied : applied) : 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) inv_diag[r] = 1.f / W[r][r];
+  const float mu = M.friction_mu;
+  for (int it = 0; it < M.pgs_iterations; ++it) {
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {  // the normal rows (their CFM sits on the diagonal of the gathered system)
+      const int r = 3 * w;
+      float wl = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
+      const float x = lam[r] + (rhs6[r] - wl) * inv_diag[r];
+      lam[r] = on[w] ? (x < 0.f ? 0.f : x) : 0.f;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {  // each point's friction pair, projected onto the cone
+      const int r1 = 3 * w + 1, r2 = 3 * w + 2;
+      float w1 = 0.f, w2 = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        w1 = fmaf(W[r1][b], lam[b], w1);
+        w2 = fmaf(W[r2][b], lam[b], w2);
+      }
+      float x1 = lam[r1] + (rhs6[r1] - w1) * inv_diag[r1], x2 = lam[r2] + (rhs6[r2] - w2) * inv_diag[r2];
+      const float lim = mu * lam[3 * w], norm = sqrtf(x1 * x1 + x2 * x2);
+      if (norm > lim) {
+        const float sc = norm > 0.f ? lim / norm : 0.f;
+        x1 *= sc;
+        x2 *= sc;
+      }
+      lam[r1] = on[w] ? x1 : 0.f;
+      lam[r2] = on[w] ? x2 : 0.f;
+    }
+  }
+  applied = left ? lam[0] : lam[3];
+  // back to the default basis: lam = Q' lam'
+  float out[6];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    out[3 * w] = lam[3 * w];
+    out[3 * w + 1] = Q[w][0] * lam[3 * w + 1] + Q[w][2] * lam[3 * w + 2];
+    out[3 * w + 2] = Q[w][1] * lam[3 * w + 1] + Q[w][3] * lam[3 * w + 2];
+  }
+  const float mine_l = L.l == 1 ? out[0] : (L.l == 2 ? out[1] : out[2]);
+  const float mine_r = L.l == 1 ? out[3] : (L.l == 2 ? out[4] : out[5]);
+  return left ? mine_l : mine_r;
+}
+
 // The six model scalars the common path of a substep reads, at the values of the default model (upkie_amd/model/
 // default_model.py; what the reference's wheel / floor settings come to). A handle whose model carries exactly these
 // values runs instantiations in which they are compile-time constants (DEFAULT_SCALARS): no scalar load in the common
@@ -850,9 +996,13 @@ struct OctRare {  // which rare path the env took this substep, Gauss-Seidel swe
 // joint (trunk lane: 0). trunk_forces: sum of the external forces on the trunk
 // in the BASE frame and their moment about the base origin, or nullptr.
 // Returns OCT_CONTACT / OCT_NO_CONTACT (same answer in the env's eight lanes).
-template <bool LIMITS_IN_REGISTERS = false, bool DEFAULT_SCALARS = false, class ModelT, class LimitsT>
+// BULLET_LIKE: contacts by the Bullet-like specification (oct_bullet_like_solve above) instead of the default one; a
+// joint at its stop (which the Pendulum / Gyropod / BaseVelocity envs these instantiations serve do not reach: their
+// legs are held at zero by the servos) still takes the default model's joint-stop path for that substep.
+template <bool LIMITS_IN_REGISTERS = false, bool DEFAULT_SCALARS = false, bool BULLET_LIKE = false, class ModelT, class LimitsT>
 UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const OctLane& L, OctPhys& s, float tau, float h,
-                                   const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr) {
+                                   const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr, float* manifold_out = nullptr,
+                                   size_t manifold_stride = 0) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
   bool at_a_stop = false;
   if (Lm.enforce) {
@@ -1075,8 +1225,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
       oct_rows9(Dg, Jt, Y, Jl, Kv);
     }
     Dg[0] = active ? fmaf(L.e[0], cfm, Dg[0]) : L.e[0];
-    Dg[1] = active ? fmaf(L.e[1], OCT_HOT(friction_cfm), Dg[1]) : L.e[1];
-    Dg[2] = active ? fmaf(L.e[2], OCT_HOT(friction_cfm), Dg[2]) : L.e[2];
+    Dg[1] = active ? (BULLET_LIKE ? Dg[1] : fmaf(L.e[1], OCT_HOT(friction_cfm), Dg[1])) : L.e[1];  // (Bullet: no friction CFM)
+    Dg[2] = active ? (BULLET_LIKE ? Dg[2] : fmaf(L.e[2], OCT_HOT(friction_cfm), Dg[2])) : L.e[2];
     float JtP[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) JtP[i] = oct_swp(Jt[i]);
@@ -1085,6 +1235,11 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     for (int i = 0; i < 3; ++i) X[i] = both ? X[i] : 0.f;
     // block elimination: W = Dg^-1 [X | rhs] in this quad, exchanged; Schur complement of the other tire
     float lam;
+    if constexpr (BULLET_LIKE) {
+      // (vf of the rolling / lateral lanes: the free velocity of the tire's point along t1 / t2)
+      if (!active) s.bl_applied = 0.f;  // no point cached: nothing to warm-start from when the tire comes back
+      lam = oct_bullet_like_solve(M, L, bf, Dg, X, rhs, t1, t2, oct_qb<2>(vf), oct_qb<3>(vf), active, active_partner, s.bl_applied);
+    } else {
     {
       float Dw[3] = {Dg[0], Dg[1], Dg[2]};
       float W[4] = {X[0], X[1], X[2], rhs};
@@ -1120,32 +1275,8 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
           } else {
           const bool left = L.leg == 0;
           float A6[21], rhs6[6], lam6[6];
-          // diagonal blocks: entry (a, b) of the own tire's block sits in lane b + 1 of the own quad
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-              const float own = b == 0 ? oct_qb<1>(Dg[a]) : (b == 1 ? oct_qb<2>(Dg[a]) : oct_qb<3>(Dg[a]));
-              const float other = oct_swp(own);
-              A6[a * (a + 1) / 2 + b] = left ? own : other;
-              A6[(3 + a) * (4 + a) / 2 + 3 + b] = left ? other : own;
-            }
-          }
-          // coupling block (right tire's row a, left tire's column b): the left quad's lane b + 1 holds it as X[a]
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-              const float own = b == 0 ? oct_qb<1>(X[a]) : (b == 1 ? oct_qb<2>(X[a]) : oct_qb<3>(X[a]));
-              const float other = oct_swp(own);
-              A6[(3 + a) * (4 + a) / 2 + b] = left ? own : other;
-            }
-          }
+          oct_gather_system(L, Dg, X, rhs, A6, rhs6);
           {
-            const float r1 = oct_qb<1>(rhs), r2 = oct_qb<2>(rhs), r3 = oct_qb<3>(rhs);
-            const float p1 = oct_swp(r1), p2 = oct_swp(r2), p3 = oct_swp(r3);
-            rhs6[0] = left ? r1 : p1; rhs6[1] = left ? r2 : p2; rhs6[2] = left ? r3 : p3;
-            rhs6[3] = left ? p1 : r1; rhs6[4] = left ? p2 : r2; rhs6[5] = left ? p3 : r3;
             // Warm start: the projected direct solution, or -- when the previous substep swept too, with the same tires
             // on the floor -- the impulses it converged to: a robot that skids or tumbles does so for many substeps in
             // a row and its contact state changes little from one millisecond to the next (same fixed point, fewer
@@ -1176,6 +1307,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
         }
       }
     }
+    }
     lam_now = lam;
     // nu+ = A^-1 rt + sum_b lam_b Y_b: the trunk lane's Y is the free part (counted once)
     const float wgt = L.l == 0 ? L.w0_once : lam;  // (the trunk lane's own `lam` is the by-product of rows it does not have)
@@ -1190,6 +1322,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 #pragma unroll
     for (int i = 0; i < 6; ++i) xb[i] = rt[i];
     ldl6_solve_planar(fac, xb);
+    if (BULLET_LIKE) s.bl_applied = 0.f;
   }
 
   // ---- joint velocity change: Hinv t - D' xb ------------------------------------
@@ -1206,6 +1339,28 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   }
   s.lam_prev = lam_now;
   s.swept_prev = swept_now;
+  if constexpr (BULLET_LIKE) {
+    // The env's contact manifold as the one-lane kernels keep it (bullet_like.hpp: per tire four records of point in the
+    // wheel frame (3), on the plane in world coordinates (3), applied normal impulse, live), written by the last
+    // substep of a step so that both kernels can continue from it: record 0 = this substep's point (the tire's
+    // deepest point: it replaced the cached one), records 1-3 empty. The normal-row lane of each quad writes its tire.
+    if (manifold_out) {
+      float wsn, wcs;  // the wheel body's orientation: the chain's summed joint angles, the wheel's own spin included
+      joint_sincos(oct_qb<3>(oct_chain(L.sg * s.q)), &wsn, &wcs);
+      const V3 local = rot_y(wcs, -wsn, Pc - ow);
+      const float x = s.pos.x + bf.r00 * Pc.x + bf.r01 * Pc.y + bf.r02 * Pc.z, y = s.pos.y + bf.r10 * Pc.x + bf.r11 * Pc.y + bf.r12 * Pc.z;
+      if (L.l == 1) {
+        float* rec = manifold_out + (size_t)(L.leg * 4 * 8) * manifold_stride;
+        const float live = active ? 1.f : 0.f;
+        rec[0] = live * local.x; rec[manifold_stride] = live * local.y; rec[2 * manifold_stride] = live * local.z;
+        rec[3 * manifold_stride] = live * x; rec[4 * manifold_stride] = live * y; rec[5 * manifold_stride] = 0.f;
+        rec[6 * manifold_stride] = active ? s.bl_applied : 0.f;
+        rec[7 * manifold_stride] = live;
+#pragma unroll
+        for (int p = 1; p < 4; ++p) rec[(size_t)(8 * p + 7) * manifold_stride] = 0.f;
+      }
+    }
+  }
   const float n0 = vB.x + xb[0], n1 = vB.y + xb[1], n2 = vB.z + xb[2];
   const float n3 = wB.x + xb[3], n4 = wB.y + xb[4], n5 = wB.z + xb[5];
   integrate_base(bf, n0, n1, n2, n3, n4, n5, h, s.pos, s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
@@ -1221,7 +1376,10 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // One env.step() of B envs on 8 B lanes. Same contract as step_kernel /
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
-template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false>
+// BULLET_LIKE: contacts by the Bullet-like specification on the env's persistent contact manifold `manifold`
+// [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) -- the eight-lane variant of what the one-lane kernels run
+// (oct_bullet_like_solve), for the envs whose legs the servos hold (every mode but Servos).
+template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
 __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
@@ -1229,7 +1387,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ body_inertials,
                                                          const float* __restrict__ ext_force, int packed, BaseVelocityPtrs bv,
                                                          float* __restrict__ final_obs, int n_steps, unsigned* __restrict__ census,
-                                                         ServoPolicyArg<MODE> policy_arg) {
+                                                         ServoPolicyArg<MODE> policy_arg, float* __restrict__ manifold) {
   // Which eight envs this wavefront steps. Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md) and
   // every XCD has its own L2: with envs handed out in launch order the four wavefronts that share a 128-byte line of a
   // state row (32 envs) sit on four different XCDs and each L2 fetches -- and writes back -- the whole line for its
@@ -1267,6 +1425,13 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
     yawvel = SW(UPKIE_S_YAWVEL);
   }
   float done_word = MODE != MODE_RESET ? SW(UPKIE_S_DONE) : 0.f;
+  if constexpr (BULLET_LIKE) {  // the applied normal impulse of the own leg's cached contact point (at most one is live)
+    const float* rec = manifold + (size_t)(leg * 4 * 8) * B + (in_batch ? e : 0);
+    float applied = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) applied = fmaf(rec[(size_t)(8 * p + 6) * B], rec[(size_t)(8 * p + 7) * B], applied);
+    s.bl_applied = applied;
+  }
   // (and the lane's row of constants: eight more loads that wait for nothing but the model pointer)
   // (not in front of the balancer's tile, which wants the registers and has its own loads to wait for: measured, C3)
   constexpr bool ROW_UP_FRONT = MODE != MODE_BASE_VELOCITY;
@@ -1432,6 +1597,7 @@ next_step:
     s.linvel = full.linvel; s.angvel = full.angvel;
     s.q = jointed ? pick6(joint, full.q) : 0.f;
     s.qd = 0.f;
+    s.bl_applied = 0.f;  // (a reset drops the contact cache)
   } else if (MODE == MODE_SERVOS) {
     if (jointed) {
       float a[6];
@@ -1522,7 +1688,8 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS, DEFAULT_SCALARS>(*mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path);
+    const int status = physics_substep_octet<MODE == MODE_SERVOS, DEFAULT_SCALARS, BULLET_LIKE>(
+        *mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path, BULLET_LIKE && sub == nsub - 1 ? manifold + e : nullptr, (size_t)B);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
                    // addresses serialise: 14 k of them per launch cost 140 us when 70 % of the substeps sweep)

@@ -1,7 +1,7 @@
 // step_instances.hpp -- every instantiation of the three step kernels that launch_step (upkie_hip.hip) can launch, as
 // one list read twice: upkie_hip.hip includes it with UPKIE_INSTANCE_KW = `extern` (declarations: the C-ABI's
 // translation unit compiles no step kernel), step_instances.hip with UPKIE_INSTANCE_KW empty and UPKIE_INSTANCE_GROUP = g
-// (definitions of group g). ~115 kernels of 5-20 k instructions each: in one translation unit the library took two
+// (definitions of group g). ~127 kernels of 5-20 k instructions each: in one translation unit the library took two
 // minutes to build; by groups, on eight cores, about forty seconds (upkie_amd/lib.py).
 //
 // The kernels of different groups share no device symbol (every device function is inlined), so no relocatable device
@@ -13,7 +13,7 @@
 #define UPKIE_INSTANCE_KW extern
 #define UPKIE_INSTANCE_GROUP (-1) /* declarations: every group */
 #endif
-#define UPKIE_INSTANCE_GROUPS 9
+#define UPKIE_INSTANCE_GROUPS 10
 
 namespace upkie {
 
@@ -24,7 +24,7 @@ namespace upkie {
 #define UPKIE_ONE_LANE_KERNEL_ARGS UPKIE_ONE_LANE_ARGS, float*
 #define UPKIE_OCTET_ARGS(MODE)                                                                                                          \
   const DevModel*, const DevParams*, int, int, float*, const float*, float*, float*, uint8_t*, uint8_t*, const uint8_t*, const float*, \
-      const float*, int, BaseVelocityPtrs, float*, int, unsigned*, ServoPolicyArg<MODE>
+      const float*, int, BaseVelocityPtrs, float*, int, unsigned*, ServoPolicyArg<MODE>, float*
 
 // one env per lane: <MODE, RAND, waves per SIMD, in-step spine observers>
 #define UPKIE_ONE_LANE(MODE)                                                                                      \
@@ -47,9 +47,13 @@ namespace upkie {
   UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, true, false>(UPKIE_PAIR_ARGS);  \
   UPKIE_INSTANCE_KW template __global__ void step_kernel_pair<MODE, true, true>(UPKIE_PAIR_ARGS);
 // eight lanes per env: <MODE, RAND, default model's scalars as constants, SAME_STEP autoreset inside the launch>
-#define UPKIE_OCTET(MODE, D, IP)                                                                                \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, D, IP>(UPKIE_OCTET_ARGS(MODE)); \
-  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, D, IP>(UPKIE_OCTET_ARGS(MODE));
+#define UPKIE_OCTET(MODE, D, IP)                                                                                       \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, D, IP, false>(UPKIE_OCTET_ARGS(MODE)); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, D, IP, false>(UPKIE_OCTET_ARGS(MODE));
+// eight lanes per env under the Bullet-like contact model: <MODE, RAND, false, false, true>
+#define UPKIE_OCTET_BULLET(MODE)                                                                                         \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, false, false, true>(UPKIE_OCTET_ARGS(MODE)); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, false, false, true>(UPKIE_OCTET_ARGS(MODE));
 
 
 #define UPKIE_IN_GROUP(g) (UPKIE_INSTANCE_GROUP < 0 || UPKIE_INSTANCE_GROUP == (g))
@@ -96,6 +100,14 @@ UPKIE_OCTET(MODE_GYROPOD, false, true)
 UPKIE_OCTET(MODE_SERVOS, false, false)
 UPKIE_OCTET(MODE_SERVOS, false, true)
 UPKIE_OCTET(MODE_BASE_VELOCITY, false, false)
+#endif
+#if UPKIE_IN_GROUP(9)
+UPKIE_OCTET_BULLET(MODE_RESET)
+UPKIE_OCTET_BULLET(MODE_PENDULUM)
+UPKIE_OCTET_BULLET(MODE_PENDULUM_AGENT)
+UPKIE_OCTET_BULLET(MODE_PENDULUM_ROLLOUT)
+UPKIE_OCTET_BULLET(MODE_GYROPOD)
+UPKIE_OCTET_BULLET(MODE_BASE_VELOCITY)
 #endif
 #if UPKIE_IN_GROUP(8)
 UPKIE_ONE_LANE_BULLET(MODE_RESET)

@@ -467,16 +467,17 @@ static const int kOctetBatchServos = 8192;
 // leg: pair.hpp) up to one wave per SIMD, one beyond. The in-step spine
 // observers exist in the one- and two-lane kernels only.
 static int mapped_lanes(const UpkieSim* sim) {
-  if (sim->manifold) return 1;  // the Bullet-like contact model exists in the one-lane kernels only (bullet_like.hpp)
   // the eight-lane kernel restates neither the in-step spine observers nor forces on leg links
   bool eight = !sim->spine_state;
   if (sim->ext_force)
     for (int i = 0; i < sim->config.ext.count; ++i) eight = eight && sim->config.ext.body[i] == 0;
   if (sim->lanes_per_env == 8 || sim->lanes_per_env == 2 || sim->lanes_per_env == 1) {
-    if (sim->lanes_per_env == 8 && !eight) return 2;
+    if (sim->lanes_per_env == 8 && !eight) return sim->manifold ? 1 : 2;
+    if (sim->manifold && sim->lanes_per_env == 2) return 1;
     return sim->lanes_per_env;
   }
   if (sim->config.num_envs <= kOctetBatch && eight) return 8;
+  if (sim->manifold) return 1;  // the Bullet-like contact model exists in the one- and eight-lane kernels (bullet_like.hpp, octet.hpp)
   return sim->config.num_envs <= kPairBatch ? 2 : 1;
 }
 // fewer lanes than envs x 2: several env.step() of the fused agent can share a launch (state in registers)
@@ -487,6 +488,9 @@ extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : 
 // ... of the step kernel a given entry point launches: the Servos kernels leave the eight-lane mapping earlier
 static int mapped_lanes_of_mode(const UpkieSim* sim, int mode) {
   int lanes = mapped_lanes(sim);
+  // Bullet-like contacts on eight lanes exist for the envs whose legs the servos hold; UpkieServos agents may drive
+  // joints into their stops, which only the one-lane kernels solve under that model
+  if (sim->manifold && mode == MODE_SERVOS) return 1;
   if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
   return lanes;
 }
@@ -572,7 +576,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
   constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
   const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
-  const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8;
+  const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8 && !sim->manifold;  // (no IN_PLACE instantiation of the Bullet-like kernels: the DONE pass follows as a second launch)
   if (same_step_in_kernel) final_obs = sim->final_obs;
   const bool rnd = sim->body_inertials || sim->ext_force;
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
@@ -582,7 +586,6 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // more than two waves per SIMD in flight: favour occupancy over registers;
   // fewer lanes than SIMD slots: split every env over two lanes (pair.hpp)
   const bool dense = sim->config.num_envs >= kDenseBatch;
-  const bool paired = uses_lane_pairs(sim);
   // SPINE: the spine observers run inside the step (a separate instantiation:
   // compiled in but switched off they would still cost the common path 2 %)
 #define UPKIE_LAUNCH_S(R, W, S)                                                                                                   \
@@ -600,9 +603,13 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
 #define UPKIE_LAUNCH_OCTET_D(R, D, IP)                                                                                          \
-  hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP, false>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
                      sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
-                     force, packed, bv, final_obs, n_steps, sim->census, policy_arg)
+                     force, packed, bv, final_obs, n_steps, sim->census, policy_arg, (float*)nullptr)
+#define UPKIE_LAUNCH_OCTET_BULLET(R)                                                                                            \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, false, false, true>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+                     sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
+                     force, packed, bv, final_obs, n_steps, sim->census, policy_arg, sim->manifold)
   // which instantiation (step_instances.hpp lists them): the SAME_STEP autoreset inside the launch has its own (the second
   // pass makes the whole step a loop body: spills); the Pendulum / Gyropod steps also exist with the default model's
   // scalars as constants
@@ -626,9 +633,13 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // the eight-lane kernels read limits and config from this handle's device block
   const DevParams* params = lanes == 8 ? current_params(sim, stream) : nullptr;
   if (lanes == 8 && !params) return fail(sim, UPKIE_ERR_HIP, "could not refresh the device block of the handle's settings");
-  if (lanes == 8) {
+  if (lanes == 8 && sim->manifold) {
+    if constexpr (MODE != MODE_SERVOS) {
+      if (rnd) UPKIE_LAUNCH_OCTET_BULLET(true); else UPKIE_LAUNCH_OCTET_BULLET(false);
+    }
+  } else if (lanes == 8) {
     if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
-  } else if (paired) {
+  } else if (lanes == 2) {
     if (rnd) UPKIE_LAUNCH_PAIR(true); else UPKIE_LAUNCH_PAIR(false);
   } else if constexpr (MODE == MODE_PENDULUM_ROLLOUT) {
     return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "several steps per launch need the two-lane mapping");
@@ -640,6 +651,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
     if (dense) UPKIE_LAUNCH(false, 2); else UPKIE_LAUNCH(false, 1);
   }
 #undef UPKIE_LAUNCH_OCTET
+#undef UPKIE_LAUNCH_OCTET_BULLET
 #undef UPKIE_LAUNCH_BULLET
 #undef UPKIE_LAUNCH_OCTET_D
 #undef UPKIE_LAUNCH_PAIR_S

@@ -94,7 +94,7 @@ class UpkieHipError(UpkieRuntimeError):
         self.status = status
 
 
-INSTANCE_GROUPS = 9  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
+INSTANCE_GROUPS = 10  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

@@ -491,8 +491,10 @@ class BatchedSim:
         along the sliding direction, no friction CFM: what
         `pybullet.stepSimulation()` is published to do, pybullet_backend.py:306)
         on a zeroed per-env manifold this handle keeps ``[64, B]``; False = the
-        product's default specification. One env per lane, several times slower
-        than the default: a fidelity option, not the fast path."""
+        product's default specification. Eight lanes per env up to 16384 envs
+        for the Pendulum / Gyropod / BaseVelocity steps, one env per lane
+        otherwise (and always for Servos steps); 2.5-3.5 x the default model's
+        step: a fidelity option, not the fast path."""
         self.contact_manifold = torch.zeros((abi.CONTACT_MANIFOLD_WORDS, self.num_envs), dtype=torch.float32, device=self.device) if on else None
         self._check(self._lib.upkie_sim_set_contact_manifold(self._handle, _ptr(self.contact_manifold)))
         return self.contact_manifold
