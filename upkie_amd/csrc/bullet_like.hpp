@@ -292,9 +292,9 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
           w2 = fmaf(W[r2][b], lam[b], w2);
         }
         float x1 = lam[r1] + (rhs[r1] - w1) * F[r1].inv_diag, x2 = lam[r2] + (rhs[r2] - w2) * F[r2].inv_diag;
-        const float lim = mu * lam[3 * w], norm = sqrtf(x1 * x1 + x2 * x2);
-        if (norm > lim) {
-          const float sc = norm > 0.f ? lim / norm : 0.f;
+        const float lim = mu * lam[3 * w], n2 = x1 * x1 + x2 * x2;
+        if (n2 > lim * lim) {  // outside the cone: scaled back onto it (lim >= 0: the normal impulse was projected above)
+          const float sc = lim * fast_rsqrt(n2);
           x1 *= sc;
           x2 *= sc;
         }
@@ -371,9 +371,9 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
       BlRow& R2 = rows[r + 1];
       const float w1 = along(R1), w2 = along(R2);
       float x1 = R1.lam + (R1.rhs - w1) * R1.inv_diag, x2 = R2.lam + (R2.rhs - w2) * R2.inv_diag;
-      const float lim = mu * rows[R1.normal_row].lam, norm = sqrtf(x1 * x1 + x2 * x2);
-      if (norm > lim) {
-        const float sc = norm > 0.f ? lim / norm : 0.f;
+      const float lim = mu * rows[R1.normal_row].lam, n2 = x1 * x1 + x2 * x2;
+      if (n2 > lim * lim) {
+        const float sc = lim * fast_rsqrt(n2);
         x1 *= sc;
         x2 *= sc;
       }

@@ -946,9 +946,9 @@ UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const Ba
         w2 = fmaf(W[r2][b], lam[b], w2);
       }
       float x1 = lam[r1] + (rhs6[r1] - w1) * inv_diag[r1], x2 = lam[r2] + (rhs6[r2] - w2) * inv_diag[r2];
-      const float lim = mu * lam[3 * w], norm = sqrtf(x1 * x1 + x2 * x2);
-      if (norm > lim) {
-        const float sc = norm > 0.f ? lim / norm : 0.f;
+      const float lim = mu * lam[3 * w], n2 = x1 * x1 + x2 * x2;
+      if (n2 > lim * lim) {  // outside the cone: scaled back onto it (lim >= 0: the normal impulse was projected above)
+        const float sc = lim * fast_rsqrt(n2);
         x1 *= sc;
         x2 *= sc;
       }
@@ -1345,8 +1345,10 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     // substep of a step so that both kernels can continue from it: record 0 = this substep's point (the tire's
     // deepest point: it replaced the cached one), records 1-3 empty. The normal-row lane of each quad writes its tire.
     if (manifold_out) {
-      float wsn, wcs;  // the wheel body's orientation: the chain's summed joint angles, the wheel's own spin included
-      joint_sincos(oct_qb<3>(oct_chain(L.sg * s.q)), &wsn, &wcs);
+      // the wheel body's orientation at the START of this substep (where Pc and ow were taken): the chain's summed joint
+      // angles, the wheel's own spin included; the joints have been integrated above: q - h qd is what they were
+      float wsn, wcs;
+      joint_sincos(oct_qb<3>(oct_chain(L.sg * fmaf(-h, s.qd, s.q))), &wsn, &wcs);
       const V3 local = rot_y(wcs, -wsn, Pc - ow);
       const float x = s.pos.x + bf.r00 * Pc.x + bf.r01 * Pc.y + bf.r02 * Pc.z, y = s.pos.y + bf.r10 * Pc.x + bf.r11 * Pc.y + bf.r12 * Pc.z;
       if (L.l == 1) {
