@@ -20,8 +20,10 @@
 // specification builds (System: 6 x 6 base block + the two 3 x 3 leg blocks). In exact arithmetic the two produce the
 // same impulses after every sweep.
 //
-// One env per lane (the one-lane step kernels only: launch_step sends handles with a contact manifold there whatever
-// the batch size). Rows live in private memory (up to 28 rows x 29 words, indexed dynamically: scratch); the manifold
+// One env per lane: this file serves the one-lane step kernels -- every case, every entry point, any batch size
+// (launch_step sends a handle with a contact manifold here beyond 16384 envs and for Servos steps). Up to 16384 envs the
+// envs whose legs the servos hold run the eight-lane variant of the same algorithm (octet.hpp, oct_bullet_like_solve).
+// Rows of the general path live in private memory (up to 28 rows x 29 words, indexed dynamically: scratch); the manifold
 // (64 words per env) is loaded from / stored to the caller's buffer [BL_MANIFOLD_WORDS][B] once per env.step().
 #pragma once
 #include "dynamics.hpp"
