@@ -1028,6 +1028,7 @@ extern "C" int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConf
     sim->spine_state = nullptr;
     return UPKIE_OK;
   }
+  if (sim->manifold) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "the Bullet-like contact model does not run the in-step spine observers");
   upkie::ObserverDev dev;
   std::string why;
   if (!convert_observer_config(config, (double)sim->config.h, &dev, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);

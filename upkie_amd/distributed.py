@@ -482,7 +482,8 @@ class ShardedVecEnv:
         (``2 * chunk`` steps with collectives, `horizon` steps without)."""
         if actions is None:
             actions = self.actions[self._action_slot]
-        elif not (actions.dtype is torch.float32 and actions.is_contiguous() and actions.numel() == self.num_envs * _prod(self.act_shape)):
+        elif not (actions.dtype is torch.float32 and actions.device == self._device and actions.is_contiguous()
+                  and actions.numel() == self.num_envs * _prod(self.act_shape)):
             actions = actions.to(self._device, torch.float32).reshape((self.num_envs,) + self.act_shape).contiguous()
         views, addresses = self._slot()
         self._step_fn(actions.data_ptr(), *addresses)
