@@ -781,20 +781,6 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
   return pair ? contact_pgs6_sweeps<true>(M, A, rhs, lam) : contact_pgs6_sweeps<false>(M, A, rhs, lam);
 }
 
-// Rare path shared by both lane mappings: some hip/knee joint sits at its
-// position limit. Contacts and limits are solved together as ONE system of ten
-// rows with a fixed layout, so that every index below is a compile-time
-// constant and the whole solve lives in registers (no scratch arrays):
-//   rows 0-2 left tire (normal, rolling, lateral), rows 3-5 right tire,
-//   rows 6-9 limits of left hip, left knee, right hip, right knee.
-// A row that does not exist this substep (tire out of range, joint inside its
-// limits) is masked: unit diagonal, zero couplings, zero right-hand side, so it
-// leaves the other rows' arithmetic untouched and gets lam = 0. Same rows,
-// ordering and numerics as the 6-row path: direct LDL' solve, accepted when
-// feasible, otherwise projected and used as the warm start of projected
-// Gauss-Seidel sweeps (normals, then frictions, then limits). Row data come
-// reduced onto the base: Jt (6) and the leg part (3). On return
-// (tb, tl, tr) += J' lam.
 // What the Gauss-Seidel sweeps of one substep hand to the next substep of the SAME env.step(): the impulses they ended on
 // and with which tires on the floor (0: that substep did not sweep, 1 / 2: it did, with one / both tires touching). A
 // robot that skids or tumbles does so for many substeps in a row and its contact state changes little from one
@@ -840,6 +826,20 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
   return sweeps;
 }
 
+// Rare path shared by both lane mappings: some hip/knee joint sits at its
+// position limit. Contacts and limits are solved together as ONE system of ten
+// rows with a fixed layout, so that every index below is a compile-time
+// constant and the whole solve lives in registers (no scratch arrays):
+//   rows 0-2 left tire (normal, rolling, lateral), rows 3-5 right tire,
+//   rows 6-9 limits of left hip, left knee, right hip, right knee.
+// A row that does not exist this substep (tire out of range, joint inside its
+// limits) is masked: unit diagonal, zero couplings, zero right-hand side, so it
+// leaves the other rows' arithmetic untouched and gets lam = 0. Same rows,
+// ordering and numerics as the 6-row path: direct LDL' solve, accepted when
+// feasible, otherwise projected and used as the warm start of projected
+// Gauss-Seidel sweeps (normals, then frictions, then limits). Row data come
+// reduced onto the base: Jt (6) and the leg part (3). On return
+// (tb, tl, tr) += J' lam.
 constexpr int kRows = 10;
 UPKIE_HD constexpr int row_leg(int r) { return r < 3 ? 0 : (r < 6 ? 1 : (r < 8 ? 0 : 1)); }
 UPKIE_HD constexpr int row_kind(int r) { return r >= 6 ? 2 : (r % 3 == 0 ? 0 : 1); }  // 0 normal, 1 friction, 2 limit
