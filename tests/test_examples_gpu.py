@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXAMPLES = ["pd_balancing", "batched_balancing", "domain_randomization", "count_wheel_contacts", "mpc_balancing", "ppo_rollout", "torque_balancing"]
+EXAMPLES = ["pd_balancing", "batched_balancing", "domain_randomization", "count_wheel_contacts", "mpc_balancing", "ppo_rollout", "torque_balancing", "contact_models",
+            "sharded_servos"]
 
 
 @pytest.mark.parametrize("name", EXAMPLES)
