@@ -208,10 +208,14 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_census.argtypes = [vp, vp]
     lib.upkie_sim_set_final_observation.restype = C.c_int
     lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
-    lib.upkie_sim_lanes_per_env_of.restype = C.c_int
-    lib.upkie_sim_lanes_per_env_of.argtypes = [vp, C.c_int]
-    lib.upkie_sim_set_contact_manifold.restype = C.c_int
-    lib.upkie_sim_set_contact_manifold.argtypes = [vp, vp]
+    # (round-4 entry points: bound when present, so that tools/ab_step.py can still load an OLDER build of the library
+    # through UPKIE_HIP_LIBRARY for an A/B on one box; the shipped library exports them all: tests/test_abi.py)
+    if hasattr(lib, "upkie_sim_lanes_per_env_of"):
+        lib.upkie_sim_lanes_per_env_of.restype = C.c_int
+        lib.upkie_sim_lanes_per_env_of.argtypes = [vp, C.c_int]
+    if hasattr(lib, "upkie_sim_set_contact_manifold"):
+        lib.upkie_sim_set_contact_manifold.restype = C.c_int
+        lib.upkie_sim_set_contact_manifold.argtypes = [vp, vp]
     lib.upkie_sim_servo_policy.restype = C.c_int
     lib.upkie_sim_servo_policy.argtypes = [vp, vp, C.POINTER(abi.UpkieServoPolicy), vp, vp]
     lib.upkie_sim_step_servos_policy.restype = C.c_int
