@@ -524,6 +524,7 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
  * speed clamp, base damping) is shared with the product's specification.
  * Enabled per call through OracleRandomization.bullet_manifold; used by
  * tools/bullet_like_deviation.py and tests/test_oracle_bullet_like.py only. */
+static _Thread_local double* g_contact_sink; /* (defined below: where a contact-point query wants the points of the substep) */
 #define BL_POINTS 4
 #define BL_POINT_WORDS 8 /* point in the wheel frame (3), on the plane (3), applied normal impulse, live */
 #define BL_ROWS (2 * BL_POINTS * 3 + 4)
@@ -537,6 +538,9 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
   int kind[BL_ROWS], normal_row[BL_ROWS];
   double* applied_slot[BL_ROWS];
   int nrows = 0, any_contact = 0;
+  int row_wheel[BL_ROWS]; /* contact rows: their tire and direction, for the contact-point query */
+  double row_dir[BL_ROWS][3], first_point[2][3];
+  int has_point[2] = {0, 0};
   /* joint limits (btMultiBodyJointLimitConstraint, ERP 0.2): solved first in every sweep */
   if (model->enforce_joint_limits) {
     for (int j = 0; j < NJ; ++j) {
@@ -548,6 +552,7 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
       memset(J[nrows], 0, sizeof(double) * NV);
       J[nrows][6 + j] = sign;
       kind[nrows] = 2; normal_row[nrows] = nrows; cfm[nrows] = 0.0; lam[nrows] = 0.0; applied_slot[nrows] = NULL;
+      row_wheel[nrows] = -1;
       rhs[nrows] = -sign * nu[6 + j] + 0.2 * err / h;
       ++nrows;
     }
@@ -625,6 +630,10 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
       m3_mulv(k->R[body], pt, r);
       for (int d = 0; d < 3; ++d) A[d] = k->o[body][d] + r[d];
       point_jacobian(k, body, A, Jv, Jw);
+      if (!has_point[wheel]) {
+        has_point[wheel] = 1;
+        for (int d = 0; d < 3; ++d) first_point[wheel][d] = A[d];
+      }
       for (int d = 0; d < 3; ++d) {
         v[d] = 0.0;
         for (int c = 0; c < NV; ++c) v[d] += Jv[d][c] * nu[c];
@@ -646,6 +655,8 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
         for (int c = 0; c < NV; ++c) J[nrows][c] = dirs[r_][0] * Jv[0][c] + dirs[r_][1] * Jv[1][c] + dirs[r_][2] * Jv[2][c];
         double rel = 0.0;
         for (int c = 0; c < NV; ++c) rel += J[nrows][c] * nu[c];
+        row_wheel[nrows] = wheel;
+        for (int d = 0; d < 3; ++d) row_dir[nrows][d] = dirs[r_][d];
         if (r_ == 0) {
           kind[nrows] = 0; normal_row[nrows] = nrows; cfm[nrows] = cfm_n;
           rhs[nrows] = dist <= 0.0 ? -rel + erp * (-dist) / h : -rel - dist / h;
@@ -704,6 +715,16 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
     if (applied_slot[r_]) *applied_slot[r_] = lam[r_];
     for (int c = 0; c < NV; ++c) nu[c] += MinvJt[r_][c] * lam[r_];
   }
+  if (g_contact_sink) { /* get_contact_points: per tire its (first) cached point and the force its points' impulses sum to */
+    for (int wheel = 0; wheel < 2; ++wheel) {
+      if (!has_point[wheel]) continue;
+      g_contact_sink[8 * wheel] = 1.0;
+      for (int d = 0; d < 3; ++d) g_contact_sink[8 * wheel + 1 + d] = first_point[wheel][d];
+    }
+    for (int r_ = 0; r_ < nrows; ++r_)
+      if (row_wheel[r_] >= 0)
+        for (int d = 0; d < 3; ++d) g_contact_sink[8 * row_wheel[r_] + 4 + d] += lam[r_] * row_dir[r_][d] / h;
+  }
   return any_contact;
 }
 
@@ -718,7 +739,7 @@ static _Thread_local int g_sweep_warm_swept = 0, g_sweep_warm_armed = 0;
 /* Where oracle_substep_ext() leaves the contact points of the substep it
  * solved when asked (oracle_contact_points): [2][8] = per tire {exists,
  * position in world (3), force in world (3), 0}. */
-static _Thread_local double* g_contact_sink = NULL;
+static _Thread_local double* g_contact_sink = NULL; /* (declared above bullet_like_contacts) */
 
 /* --------------------------------------------------------------- substep */
 /* One Bullet-like stepSimulation() (call site pybullet_backend.py:306):
@@ -793,6 +814,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   for (int j = 0; j < NJ; ++j) nu[6 + j] = qd[j] + h * acc[6 + j];
 
   int bullet_contact = -1;
+  if (g_contact_sink) memset(g_contact_sink, 0, sizeof(double) * 16);
   if (g_bullet_active) bullet_contact = bullet_like_contacts(model, &k, L, q, h, nu);
 
   /* constraint rows: per wheel (normal, t1, t2), then joint limits */
@@ -802,7 +824,6 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   int nrows = 0, any_contact = 0;
   int contact_row[2] = {-1, -1};
   double contact_dirs[2][3][3];
-  if (g_contact_sink) memset(g_contact_sink, 0, sizeof(double) * 16);
   double kpc = model->contact_stiffness, kdc = model->contact_damping;
   double denom = h * kpc + kdc;
   double erp = denom > 0 ? h * kpc / denom : 0.2;
@@ -1713,7 +1734,12 @@ void oracle_contact_points(const UpkieModel* model, const UpkieSimConfig* cfg,
     load_env(state, B, e, s);
     env_randomization(rnd, B, e, scale, force, &slots, &scale_p, &force_p, &slots_p);
     g_contact_sink = out + (int64_t)16 * e;
+    if (rnd && rnd->bullet_manifold) { /* a query: the substep runs on a copy of the env's manifold */
+      for (int w = 0; w < ORACLE_BULLET_MANIFOLD_WORDS; ++w) g_bullet_manifold[w] = rnd->bullet_manifold[(int64_t)w * B + e];
+      g_bullet_active = 1;
+    }
     oracle_substep_ext(model, s, s + UPKIE_S_TORQUE, h, scale_p, force_p, slots_p);
+    g_bullet_active = 0;
     g_contact_sink = NULL;
   }
 }

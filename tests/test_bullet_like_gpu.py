@@ -193,6 +193,37 @@ def test_both_bullet_like_kernels_continue_from_each_others_manifold():
     assert (m2[:, :, 7].sum(axis=1) == 1).all()  # the cached point was replaced, not doubled
 
 
+def test_contact_point_query_solves_the_bullet_like_model():
+    """`get_contact_points` (pybullet_backend.py:660-716) on a handle under the
+    Bullet-like model: the cached points and the forces their impulses sum to,
+    device against oracle, and the weight carried by the two tires."""
+    from oracle import oracle as O
+
+    B = 256
+    cfg = randomized_config(B, seed=12)
+    sim = BatchedSim(cfg)
+    sim.use_bullet_like_contacts()
+    ref = O.Oracle(default_model(), cfg)
+    ref.use_bullet_like_contacts()
+    sim.reset()
+    obs_ref = ref.reset()[:, [1, 0, 4, 3]]
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    for _ in range(40):
+        obs_ref = ref.step_pendulum_agent(obs_ref)[0]
+        sim.step_pendulum_agent()
+    ph, po = sim.contact_points().cpu().numpy().astype(np.float64), ref.contact_points()
+    assert np.array_equal(ph[:, :, 0], po[:, :, 0]) and (po[:, :, 0] == 1).all()
+    assert np.abs(ph[:, :, 1:4] - po[:, :, 1:4]).max() < 2e-5  # the cached points, world frame
+    df = np.abs(ph[:, :, 4:7] - po[:, :, 4:7])
+    assert np.quantile(df, 0.5) < 2e-2 and np.quantile(df, 0.99) < 1.0, (np.quantile(df, [0.5, 0.99]), df.max())  # forces [N]: impulses / 1 ms
+    weight = 9.81 * float(sum(default_model().mass[:7]))
+    assert abs(np.median(ph[:, :, 6].sum(axis=1)) - weight) < 0.05 * weight
+    # the query left the manifold alone
+    before = sim.contact_manifold.clone()
+    sim.contact_points()
+    assert torch.equal(before, sim.contact_manifold)
+
+
 def test_switching_the_model_off_restores_the_default_kernels():
     B = 256
     cfg = randomized_config(B, seed=1)

@@ -204,7 +204,7 @@ def test_rolling_without_slipping(kind, monkeypatch):
     assert worst_roll < 2e-3 and worst_side < 2e-3, (worst_roll, worst_side)
 
 
-@pytest.mark.parametrize("kind", [r for r in RIGS if "bullet" not in r.id])  # (the contact-point query reports the default model's solve)
+@pytest.mark.parametrize("kind", RIGS)  # (under the Bullet-like model the contact-point query solves that model, on a copy of the manifold)
 def test_normal_forces_carry_the_weight(kind, monkeypatch):
     """A balanced robot at rest: the two normal forces reported by
     get_contact_points (pybullet_backend.py:660-716) add up to m g, shared

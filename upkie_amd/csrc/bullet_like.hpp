@@ -51,7 +51,13 @@ struct BlRow {
 //   mf: the env's contact manifold (updated). Returns the floor-contact flag (a cached point exists).
 template <class ModelT>
 UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const System& S, const BaseFrame& bf, const Phys& s, float h,
-                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[BL_MANIFOLD_WORDS]) {
+                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[BL_MANIFOLD_WORDS], ContactReport* report) {
+  // (report: PyBulletBackend.get_contact_points for this substep -- per tire whether a point is cached, its (first) point
+  // in base coordinates and the force, in base coordinates, its points' impulses sum to)
+  if (report) {
+    report->active[0] = report->active[1] = false;
+    report->force[0] = report->force[1] = v3(0.f, 0.f, 0.f);
+  }
   // free velocity: nu + M^-1 h (applied - bias)
   system_solve<true, true>(S, tb, tl, tr);
   const V3 vF = bf.vB + v3(tb[0], tb[1], tb[2]), wF = bf.wB + v3(tb[3], tb[4], tb[5]);
@@ -317,6 +323,18 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
         tr[j] = fmaf(F[a].Mr[j], lam[a], tr[j]);
       }
     }
+    if (report) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        if (!on[w]) continue;
+        const float* pt = mf + (w * BL_POINTS + live_slot[w]) * BL_POINT_WORDS;
+        report->active[w] = true;
+        report->point[w] = S.leg[w].o[2] + rot_y(wcs[w], wsn[w], v3(pt[0], pt[1], pt[2]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k)  // (the linear part of a contact row is its direction)
+          report->force[w] = report->force[w] + (ih * lam[3 * w + k]) * v3(F[3 * w + k].Jb[0], F[3 * w + k].Jb[1], F[3 * w + k].Jb[2]);
+      }
+    }
     return true;
   }
   for (int wheel = 0; wheel < 2; ++wheel) {
@@ -388,6 +406,21 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
   }
   for (int r = 0; r < nrows; ++r)
     if (rows[r].slot >= 0) mf[rows[r].slot] = rows[r].lam;
+  if (report) {
+    for (int w = 0; w < 2; ++w)
+      for (int p = BL_POINTS - 1; p >= 0; --p) {  // (the first live point of the tire ends up reported)
+        const float* pt = mf + (w * BL_POINTS + p) * BL_POINT_WORDS;
+        if (pt[7] == 0.f) continue;
+        report->active[w] = true;
+        report->point[w] = S.leg[w].o[2] + rot_y(wcs[w], wsn[w], v3(pt[0], pt[1], pt[2]));
+      }
+    for (int r = 0; r < nrows; ++r) {
+      const BlRow& R = rows[r];
+      if (R.kind == 2) continue;
+      const V3 f = (ih * R.lam) * v3(R.Jb[0], R.Jb[1], R.Jb[2]);
+      if (R.leg == 0) report->force[0] = report->force[0] + f; else report->force[1] = report->force[1] + f;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 6; ++c) tb[c] += dvb[c];
 #pragma unroll

@@ -1339,7 +1339,7 @@ struct ContactReport {
 // manifold `manifold` (upkie_sim_set_contact_manifold) instead of the default one.
 template <class ModelT>
 UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const System& S, const BaseFrame& bf, const Phys& s, float h,
-                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[64]);
+                                   float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&mf)[64], ContactReport* report);
 
 template <bool SCRATCH_LIMITS = false, bool BULLET_LIKE = false, class ModelT>
 UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, const float (&tau)[UPKIE_NJ], float h,
@@ -1471,7 +1471,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
 
   bool any_contact = false;
   if constexpr (BULLET_LIKE) {
-    any_contact = bullet_like_contacts(M, Lm, S, bf, s, h, tb, tl, tr, *manifold);  // (leaves the velocity change in tb, tl, tr)
+    any_contact = bullet_like_contacts(M, Lm, S, bf, s, h, tb, tl, tr, *manifold, report);  // (leaves the velocity change in tb, tl, tr)
   } else {
   // ---- tire / floor contacts -------------------------------------------
   // Rows 3w+0..2 = (normal, t1, t2) of wheel w. Row r of wheel w only touches

@@ -152,9 +152,13 @@ __global__ __launch_bounds__(64) void observe_kernel(DevModel M, DevConfig C, fl
 // commanded torques, run on a register copy (the state is not written).
 // out [B][2][8] = per tire {exists, position in world (3), force in world (3), 0}.
 // Query path, not the step path: one env per lane, any batch size.
+// BULLET_LIKE: the handle's steps run the Bullet-like contact model (upkie_sim_set_contact_manifold): the query solves
+// the same model, on a copy of the env's manifold.
+template <bool BULLET_LIKE>
 __global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
                                                            const float* __restrict__ state, const float* __restrict__ body_inertials,
-                                                           const float* __restrict__ ext_force, float* __restrict__ out) {
+                                                           const float* __restrict__ ext_force, float* __restrict__ out,
+                                                           const float* __restrict__ manifold) {
   const int B = C.num_envs;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
@@ -180,7 +184,13 @@ __global__ __launch_bounds__(64) void contact_points_kernel(const DevModel* __re
   const V3 origin = s.pos;
   ContactReport rep;
   rep.active[0] = rep.active[1] = false;
-  physics_substep<true>(*Mp, Lm, s, tau, C.h, body_inertials ? &inertials : nullptr, ext, &rep);
+  if constexpr (BULLET_LIKE) {
+    float mf[BL_MANIFOLD_WORDS];
+    for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) mf[w] = manifold[(size_t)w * B + e];
+    physics_substep<true, true>(*Mp, Lm, s, tau, C.h, body_inertials ? &inertials : nullptr, ext, &rep, &mf);
+  } else {
+    physics_substep<true>(*Mp, Lm, s, tau, C.h, body_inertials ? &inertials : nullptr, ext, &rep);
+  }
   const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qz * qw), 2.f * (qw * qy + qx * qz),
                       2.f * (qx * qy + qz * qw), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qx * qw),
                       2.f * (qx * qz - qy * qw), 2.f * (qy * qz + qx * qw), 1.f - 2.f * (qx * qx + qy * qy)};
@@ -813,8 +823,12 @@ extern "C" int upkie_sim_observe(UpkieSim* sim, float* state, const UpkieSpineOb
 
 extern "C" int upkie_sim_contact_points(UpkieSim* sim, const float* state, float* out, void* stream) {
   if (!sim || !state || !out) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "null argument");
-  hipLaunchKernelGGL(contact_points_kernel, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model,
-                     sim->limits, sim->config, state, sim->body_inertials, sim->ext_force, out);
+  if (sim->manifold)
+    hipLaunchKernelGGL(contact_points_kernel<true>, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model,
+                       sim->limits, sim->config, state, sim->body_inertials, sim->ext_force, out, sim->manifold);
+  else
+    hipLaunchKernelGGL(contact_points_kernel<false>, grid_for(sim->config.num_envs), dim3(block_lanes()), 0, (hipStream_t)stream, sim->d_model,
+                       sim->limits, sim->config, state, sim->body_inertials, sim->ext_force, out, (const float*)nullptr);
   return check_hip(sim, hipGetLastError(), "contact_points_kernel");
 }
 
