@@ -540,7 +540,10 @@ int upkie_sim_observe(UpkieSim* sim, float* state,
  * The forces are those of the contact solve of one simulator substep from the
  * current state under the last commanded torques (Bullet reports the last
  * solved substep; the two differ by one 1 ms substep of motion). `state` is
- * only read. */
+ * only read. On a handle under the Bullet-like contact model
+ * (upkie_sim_set_contact_manifold) the query solves THAT model, on a copy of
+ * the env's manifold: per tire its (first) cached point and the force the
+ * impulses of its points sum to. */
 #define UPKIE_CONTACT_POINT_WORDS 8
 int upkie_sim_contact_points(UpkieSim* sim, const float* state, float* out, void* stream);
 
