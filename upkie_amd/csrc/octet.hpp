@@ -1378,11 +1378,18 @@ __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
 // One env.step() of B envs on 8 B lanes. Same contract as step_kernel /
 // step_kernel_pair (the in-step spine observers are not restated here: launches
 // with observers attached use the two-lane kernel).
+// Joint stops of the Servos kernels solved in registers (512-entry register file, one wave per SIMD) or, like the other
+// modes', over the LDS workspace (256 registers): a build-time choice while it is being measured
+#if defined(UPKIE_SERVOS_LIMITS_IN_LDS)
+constexpr bool kServosLimitsInRegisters = false;
+#else
+constexpr bool kServosLimitsInRegisters = true;
+#endif
 // BULLET_LIKE: contacts by the Bullet-like specification on the env's persistent contact manifold `manifold`
 // [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) -- the eight-lane variant of what the one-lane kernels run
 // (oct_bullet_like_solve), for the envs whose legs the servos hold (every mode but Servos).
 template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
-__global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
+__global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -1473,7 +1480,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS ? 1 : 2) void step_kernel_o
   // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
   // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
   __shared__ LimitWorkspace limit_workspaces[8];
-  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS ? nullptr : limit_workspaces;
+  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS && kServosLimitsInRegisters ? nullptr : limit_workspaces;
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B, ROW_UP_FRONT ? &lane_row : nullptr);
   const auto& M = *(ConstModelPtr)Mp;
@@ -1690,7 +1697,7 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS, DEFAULT_SCALARS, BULLET_LIKE>(
+    const int status = physics_substep_octet<MODE == MODE_SERVOS && kServosLimitsInRegisters, DEFAULT_SCALARS, BULLET_LIKE>(
         *mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path, BULLET_LIKE && sub == nsub - 1 ? manifold + e : nullptr, (size_t)B);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two
