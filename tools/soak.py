@@ -104,4 +104,49 @@ for lanes in ("8", "2", "1"):
         if k % 1000 == 999:
             check(sim, f"servos lanes={lanes}", k)
     print(f"lanes={lanes} servos random commands, no resets: {steps // 2} steps ok")
+# The Bullet-like contact model (upkie_sim_set_contact_manifold): the Pendulum agent with pushes and noise on eight lanes
+# and on one, then Servos with random commands on one lane -- flailing robots go through the general row list: joints
+# at their stops and tire contacts in ONE fixed-sweep solve -- a tenth of the steps (the model is 4-7 x slower).
+for lanes in ("8", "1"):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
+    sim = BatchedSim(config(5), Model().struct)
+    sim.randomize_inertias(0.3)
+    sim.use_bullet_like_contacts()
+    assert sim.lanes_per_env == int(lanes)
+    sim.reset()
+    sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+    n = max(steps // 10, 200)
+    for k in range(n):
+        if k % 500 == 0:
+            f = (torch.rand((3, B), device=sim.device) * 2 - 1) * torch.tensor([[15.0], [8.0], [5.0]], device=sim.device)
+            sim.set_external_force(f, point=(0.0, 0.0, 0.1))
+        sim.step_pendulum_agent()
+        if k % 200 == 199:
+            check(sim, f"bullet-like pendulum lanes={lanes}", k)
+            m = sim.contact_manifold.reshape(2, 4, 8, B)
+            assert torch.isfinite(m).all() and (m[:, :, 7].sum(dim=1) <= 1).all(), "a rolling wheel holds at most one cached point"
+    print(f"lanes={lanes} Bullet-like contacts, pendulum agent + inertia 0.3 + pushes + noise: {n} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} episode resets")
+os.environ["UPKIE_LANES_PER_ENV"] = "8"
+cfg = config(6)
+cfg.autoreset_mode = abi.AUTORESET_DISABLED
+sim = BatchedSim(cfg)
+sim.use_bullet_like_contacts()
+sim.reset()
+scale = torch.tensor([16.0, 16.0, 1.7, 16.0, 16.0, 1.7], device=sim.device)
+act = torch.zeros((B, 6, 6), device=sim.device)
+n = max(steps // 20, 100)
+for k in range(n):
+    if k % 20 == 0:
+        act[:, :, 0] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 3.0
+        act[:, :, 1] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 10.0
+        act[:, :, 2] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * scale
+        act[:, :, 3] = torch.rand((B, 6), device=sim.device) * 2.0
+        act[:, :, 4] = torch.rand((B, 6), device=sim.device) * 2.0
+        act[:, :, 5] = torch.rand((B, 6), device=sim.device) * scale
+    sim.step_servos(act)
+    if k % 50 == 49:
+        check(sim, "bullet-like servos", k)
+        assert torch.isfinite(sim.contact_manifold).all()
+print(f"Bullet-like contacts, servos random commands (one env per lane, joint stops in the same solve), no resets: {n} steps ok")
+os.environ.pop("UPKIE_LANES_PER_ENV", None)
 print("soak passed")
