@@ -262,7 +262,9 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * entry points -- whose legs the servos hold -- run it on eight lanes per env,
  * in the case a rolling wheel produces (one cached point per tire, which the
  * tire's deepest point replaces every substep: the default model's contact
- * point with the friction rows rotated into the sliding direction; a joint
+ * point with the friction rows rotated into the sliding direction; a robot
+ * lying flat on its side, whose tires may cache several points under
+ * Bullet's rule, keeps the deepest one on this variant; a joint
  * at its stop, which those envs do not reach, would take the default model's
  * joint-stop path for that substep and is counted by the census, word [0]).
  * Both keep complete manifold records, so upkie_sim_step_servos (one lane)

@@ -862,7 +862,10 @@ UPKIE_HD void oct_gather_system(const OctLane& L, const float (&Dg)[3], const fl
 // Contacts of one substep under the Bullet-like specification (bullet_like.hpp: what the one-lane kernels run), in the
 // case a rolling wheel produces -- at most ONE cached point per tire, which the tire's deepest point replaces every
 // substep (it moves <= 5 mm per substep in the wheel's frame at the joint-speed limit, the replacement threshold is
-// 2 cm), so the point IS the default specification's contact point and only the rows differ: friction directions
+// 2 cm; the exception is a robot lying FLAT ON ITS SIDE: with the wheel plane within a few degrees of horizontal the
+// deepest point of the tire circle is ill-defined, jumps along the tire when the robot rocks, and Bullet's rule -- the
+// one-lane kernels' -- caches up to four points there; this variant keeps the deepest one), so the point IS the
+// default specification's contact point and only the rows differ: friction directions
 // along / across the point's sliding velocity -- a rotation (or reflection) of the default rolling / lateral rows within
 // the tangent plane, per tire --, no friction CFM, a FIXED number of Gauss-Seidel sweeps over the dense 6 x 6 system
 // (normals, then each point's friction pair projected onto the cone), normals warm-started with 0.85 x the last applied
