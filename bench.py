@@ -747,12 +747,21 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     if world == 1 and on_gpu and not args.no_secondary:
         del env
         torch.cuda.synchronize()
-        line["vec_env_api"] = vec_env_api(B)
+        def guarded(block, *args):
+            # (the blocks beside the contract figure must never cost the line itself: a failure is reported in place)
+            try:
+                return block(*args)
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+
+                return {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
+
+        line["vec_env_api"] = guarded(vec_env_api, B)
         line["secondary"] = {
-            "c3": secondary_c3(),
-            "c5_share_torque_law": secondary_c5_share("torque"),
-            "c5_share_velocity_law": secondary_c5_share("velocity"),
-            "c2_bullet_like_contact_model": secondary_bullet_like(B),
+            "c3": guarded(secondary_c3),
+            "c5_share_torque_law": guarded(secondary_c5_share, "torque"),
+            "c5_share_velocity_law": guarded(secondary_c5_share, "velocity"),
+            "c2_bullet_like_contact_model": guarded(secondary_bullet_like, B),
         }
     print(json.dumps(line), file=json_out or sys.stdout, flush=True)
 
