@@ -356,7 +356,9 @@ int upkie_sim_sample_pushes(UpkieSim* sim, float* force, uint32_t push_index,
  * system per lane, with this handle's friction coefficient, tolerance and
  * iteration cap: A[n][21] packed lower by rows with the CFM on the diagonal,
  * rhs[n][6], lam[n][6] (in: warm start, out: impulses), both_tires[n] (0: one
- * tire is off the floor, its rows are identity rows), sweeps[n] (may be NULL)
+ * tire is off the floor, its rows are identity rows with zero right-hand
+ * sides and no coupling; informative since round 4: every system runs the
+ * same loop, which such rows pass through unchanged), sweeps[n] (may be NULL)
  * receives the sweeps each system ran. Device pointers. */
 int upkie_sim_contact_sweeps(UpkieSim* sim, int32_t num_systems, const float* A,
                              const float* rhs, float* lam,

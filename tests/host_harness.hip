@@ -78,7 +78,8 @@ extern "C" int harness_contact_pgs6(const UpkieModel* model, const float* A, con
   float a[21], r[6], l[6];
   for (int k = 0; k < 21; ++k) a[k] = A[k];
   for (int k = 0; k < 6; ++k) { r[k] = rhs[k]; l[k] = lam[k]; }
-  const int sweeps = contact_pgs6(M, a, r, l, both_tires != 0);
+  (void)both_tires;  // (the sweeps are one loop for every system: contact_pgs6)
+  const int sweeps = contact_pgs6(M, a, r, l);
   for (int k = 0; k < 6; ++k) lam[k] = l[k];
   return sweeps;
 }

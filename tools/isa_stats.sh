@@ -3,7 +3,7 @@
 # histogram of one of them (default: the bench's eight-lane kernel, step_kernel_octet<MODE_PENDULUM_AGENT, false, true, false>).
 # Usage: tools/isa_stats.sh [mangled-kernel-prefix] [extra hipcc flags]
 set -e
-K=${1:-_ZN5upkie17step_kernel_octetILi2ELb0ELb1ELb0EEE}
+K=${1:-_ZN5upkie17step_kernel_octetILi2ELb0ELb1ELb0ELb0EEE}
 shift || true
 D=$(mktemp -d)
 R=$(cd "$(dirname "$0")/.." && pwd)

@@ -688,9 +688,10 @@ UPKIE_HD float lateral_pair_sweep(float a22, float a25, float a55, float r2, flo
 // left: normal, rolling, lateral; rows 3-5 right), shared by every lane
 // mapping. A packed lower by rows, `lam` comes in as the projected direct
 // solution (the warm start). Normals of both wheels first, then the rolling
-// rows, then the lateral ones -- together (lateral_pair_sweep) when both tires
-// touch. Each env stops on its own criterion: lanes leave the loop one by one.
-template <bool pair, class ModelT>
+// rows, then the two lateral ones together (lateral_pair_sweep; with a tire off
+// the floor that is its partner's row alone, see contact_pgs6). Each env stops
+// on its own criterion: lanes leave the loop one by one.
+template <class ModelT>
 UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   const float mu = M.friction_mu;
   // read before the loop and held in a scalar register: left to the compiler, the tolerance is re-fetched from the
@@ -699,11 +700,11 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
   UPKIE_KEEP_IN_SGPR(tolerance);
   // Rows scaled by their diagonal once, so that a row update is x_r = b_r - sum_{c != r} a_rc lam_c: five multiply-adds
   // (the unscaled form costs eight instructions a row; a launch with many skidding robots is bound by these sweeps).
-  // In pair mode the lateral rows 2 and 5 are swept together from the unscaled entries (lateral_pair_sweep).
+  // The lateral rows 2 and 5 are swept together from the unscaled entries (lateral_pair_sweep).
   float a[6][6], b[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
-    if ((r % 3) == 2 && pair) continue;
+    if ((r % 3) == 2) continue;
     const float inv = fast_rcp(A[r * (r + 1) / 2 + r]);
     b[r] = rhs[r] * inv;
 #pragma unroll
@@ -733,7 +734,7 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const bool is_normal = (r % 3) == 0;
-        if (is_normal != (pass == 0) || ((r % 3) == 2 && pair)) continue;
+        if (is_normal != (pass == 0) || (r % 3) == 2) continue;
         float x = b[r];
 #pragma unroll
         for (int c = 0; c < 6; ++c)
@@ -752,7 +753,7 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
         lam[r] = x;
       }
     }
-    if (pair) {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
+    {  // the two lateral rows together, after the rolling ones (lateral_pair_sweep)
       float r2 = rhs[2], r5 = rhs[5];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -767,10 +768,16 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
   }
   return sweeps;  // for the census (upkie_sim_set_census)
 }
-// (`pair` is a compile-time parameter of the sweeps: decided inside the unrolled loops at run time, the compiler
-// if-converts the row updates of both cases in some instantiations -- 361 instead of 151 instructions per sweep)
+// ONE loop for every env, whether one tire touches or both (round 4). A tire without a contact point has identity rows,
+// zero right-hand sides and no coupling (X = 0): the lateral pair's 2 x 2 block is then diagonal, the box problem
+// separates, and lateral_pair_sweep returns the touching tire's row solved and clamped -- what the row-by-row update
+// of that row gives, at the same place of the sweep (after the rolling row), so the rule of the fp64 checker (a single
+// lateral row is swept like any friction row) holds unchanged. Until then envs with one tire on the floor ran a loop of
+// their own that swept rows 2 and 5 one by one, and a wavefront that held both kinds of env -- most of them, when robots
+// tumble -- ran the two loops one after the other, each to the largest count among its envs: a sweep level cost a
+// launch of the C5 share 2.8 us where one loop's 151 instructions account for 1.4 (tools/c5_sweep_cost.py).
 template <class ModelT>
-UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool pair) {
+UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   // both tires leaving the floor (neither normal row asks for an impulse): lam = 0 is the solution, what the sweeps
   // return after one pass over the projected zeros (a tire without a contact point has an identity row and rhs 0)
   if (rhs[0] <= 0.f && rhs[3] <= 0.f) {
@@ -778,7 +785,7 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
     for (int r = 0; r < 6; ++r) lam[r] = 0.f;
     return 0;
   }
-  return pair ? contact_pgs6_sweeps<true>(M, A, rhs, lam) : contact_pgs6_sweeps<false>(M, A, rhs, lam);
+  return contact_pgs6_sweeps(M, A, rhs, lam);
 }
 
 // What the Gauss-Seidel sweeps of one substep hand to the next substep of the SAME env.step(): the impulses they ended on
@@ -817,7 +824,7 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
     const float lim = mu * lam[3 * (r / 3)];
     lam[r] = fminf(fmaxf(lam[r], -lim), lim);
   }
-  const int sweeps = contact_pgs6(M, A, rhs, lam, both);
+  const int sweeps = contact_pgs6(M, A, rhs, lam);
   if (warm) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) warm->lam[r] = lam[r];

@@ -1300,7 +1300,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
             const float lim = OCT_HOT(friction_mu) * lam6[3 * (r / 3)];
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
-          const int sweeps = contact_pgs6(M, A6, rhs6, lam6, both);
+          const int sweeps = contact_pgs6(M, A6, rhs6, lam6);
           if (census) census->sweeps = sweeps;
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
@@ -1373,6 +1373,18 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// One 4-byte word of the state, as an lvalue: `buffer_load/store_dword v, voffset, s[descriptor], soffset offen`
+struct OctStateWord {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned lane_offset, row_offset;  // bytes: per lane (vector register), per word (scalar register)
+  __device__ __forceinline__ operator float() const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_offset, (int)row_offset, 0));
+  }
+  __device__ __forceinline__ void operator=(float value) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, value), rsrc, (int)lane_offset, (int)row_offset, 0);
+  }
+};
+
 template <class T>
 __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
   return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : (j == 3 ? a[3] : (j == 4 ? a[4] : a[5]))));
@@ -1392,7 +1404,10 @@ constexpr bool kServosLimitsInRegisters = true;
 // [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) -- the eight-lane variant of what the one-lane kernels run
 // (oct_bullet_like_solve), for the envs whose legs the servos hold (every mode but Servos).
 template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
-__global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : 2) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
+#if !defined(UPKIE_PROBE_OCTET_WAVES)
+#define UPKIE_PROBE_OCTET_WAVES 2
+#endif
+__global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : UPKIE_PROBE_OCTET_WAVES) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -1417,8 +1432,18 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   const bool jointed = l != 0;
   const int k = jointed ? l - 1 : 0;
   const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
-  float* st = state + (in_batch ? e : 0);
-#define SW(w) st[(size_t)(w) * B]
+  // State word w of env e lives at state[w * B + e]: reached through ONE buffer descriptor over the whole state (scalar
+  // registers), the word's row as the instruction's scalar offset and the lane's 32-bit byte offset, which every word of
+  // an env shares (OctStateWord). As 64-bit lane addresses -- what `st[w * B]` compiled to -- the thirty-odd words of the
+  // prologue and the epilogue held fifty vector registers between them for the whole launch, and the multi-step kernels
+  // spilled two dozen of them. Byte offsets stay below 2^32: launch_step keeps this mapping to batches that fit.
+  const unsigned row_bytes = (unsigned)B * 4u;
+  const __amdgpu_buffer_rsrc_t state_rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)((unsigned)UPKIE_STATE_WORDS * row_bytes), 0x00020000);
+  const unsigned env_off = (unsigned)(in_batch ? e : 0) * 4u;
+  const unsigned joint_off = env_off + (unsigned)joint * row_bytes;           // the own joint's row of a per-joint block
+  const unsigned legref_off = env_off + (unsigned)(2 * leg + k) * row_bytes;  // the own low-pass target (hip and knee lanes)
+#define SWO(w, off) OctStateWord{state_rsrc, (off), (unsigned)(w) * row_bytes}
+#define SW(w) SWO(w, env_off)
 
   // ---- load: issued first, in flight while the settings below arrive ------------------
   OctPhys s;
@@ -1426,10 +1451,10 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
   s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
   s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
-  s.q = jointed ? SW(UPKIE_S_Q + joint) : 0.f;
-  s.qd = jointed ? SW(UPKIE_S_QD + joint) : 0.f;
+  s.q = jointed ? SWO(UPKIE_S_Q, joint_off) : 0.f;
+  s.qd = jointed ? SWO(UPKIE_S_QD, joint_off) : 0.f;
   const bool legged = l == 1 || l == 2;  // hip and knee lanes carry their low-pass target
-  float legref = legged ? SW(UPKIE_S_LEGREF + 2 * leg + k) : 0.f;
+  float legref = legged ? SWO(UPKIE_S_LEGREF, legref_off) : 0.f;
   constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
   float yaw = 0.f, yawvel = 0.f;
   if (YAWING) {
@@ -1560,6 +1585,12 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   constexpr bool CAN_RESET_IN_PLACE = IN_PLACE && (MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS);
   const bool same_step = CAN_RESET_IN_PLACE && autoreset_mode == UPKIE_AUTORESET_DISABLED && final_obs != nullptr && packed != 1;
   bool second_pass = false;
+  // Several steps in a launch (ROLLOUT): nothing reads the state words back before the launch ends, so the per-step ones
+  // (DONE, ELAPSED, EPISODE, STEP, the applied torque, the words a reset zeroes) go to memory ONCE, behind the last step,
+  // from the registers that mirror them -- the same memory image as one launch per step, and no store address is live
+  // across the step loop (hoisted there, thirteen of them cost the kernel 24 spilled registers reloaded every step).
+  bool reset_seen = false, step_seen = false;
+  float tau_stepped = 0.f;
 next_step:
   s.swept_prev = 0;  // the sweeps' warm start spans the substeps of ONE env.step(): several steps in a launch = as many launches, bit for bit
   bool do_reset;
@@ -1738,11 +1769,18 @@ next_step:
   // ---- wrapper post-processing ---------------------------------------------
   bool fallen = false, timeout = false;
   float obs6[6];
+  if (ROLLOUT) {
+    reset_seen = reset_seen || do_reset;
+    if (!do_reset) {
+      step_seen = true;
+      tau_stepped = tau;
+    }
+  }
   if (do_reset) {
     legref = s.q;
     yaw = 0.f;
     yawvel = 0.f;
-    if (lead) {
+    if (lead && !ROLLOUT) {
       SW(UPKIE_S_YAW) = 0.f;
       SW(UPKIE_S_YAWVEL) = 0.f;
       SW(UPKIE_S_MPC_V) = 0.f;
@@ -1768,22 +1806,22 @@ next_step:
     observe6(yaw, yawvel, obs6);
     if (MODE != MODE_SERVOS) {
       fallen = fabsf(obs6[1]) > C.fall_pitch;
-      if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
+      if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
     }
     if (C.max_episode_steps > 0) {
       const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
       timeout = elapsed >= (float)C.max_episode_steps && !fallen;
       elapsed_word = elapsed;
-      if (lead) {
+      if (lead && !ROLLOUT) {
         SW(UPKIE_S_ELAPSED) = elapsed;
         if (timeout) SW(UPKIE_S_DONE) = 1.f;
       }
     }
     if (fallen || timeout) done_word = 1.f;
-    if (jointed) SW(UPKIE_S_TORQUE + joint) = tau;
+    if (jointed && !ROLLOUT) SWO(UPKIE_S_TORQUE, joint_off) = tau;
     if (any_noise) {
       step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
-      if (lead) SW(UPKIE_S_STEP) = (float)step_count;
+      if (lead && !ROLLOUT) SW(UPKIE_S_STEP) = (float)step_count;
     }
   }
 
@@ -1800,6 +1838,22 @@ next_step:
     steps_left -= 1;
     goto next_step;
   }
+  if (ROLLOUT) {  // the per-step words of the steps of this launch (above)
+    if (lead) {
+      if (reset_seen) {
+        SW(UPKIE_S_YAW) = 0.f;
+        SW(UPKIE_S_YAWVEL) = 0.f;
+        SW(UPKIE_S_MPC_V) = 0.f;
+        SW(UPKIE_S_SE2_X) = 0.f;
+        SW(UPKIE_S_SE2_Y) = 0.f;
+        SW(UPKIE_S_EPISODE) = episode_word;
+      }
+      SW(UPKIE_S_DONE) = done_word;
+      if (reset_seen || C.max_episode_steps > 0) SW(UPKIE_S_ELAPSED) = elapsed_word;
+      if (any_noise && step_seen) SW(UPKIE_S_STEP) = (float)step_count;
+    }
+    if (jointed && step_seen) SWO(UPKIE_S_TORQUE, joint_off) = tau_stepped;
+  }
   if (lead) {
     SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
     SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
@@ -1808,10 +1862,10 @@ next_step:
     SW(UPKIE_S_CONTACT) = contact ? 1.f : 0.f;
   }
   if (jointed) {
-    SW(UPKIE_S_Q + joint) = s.q;
-    SW(UPKIE_S_QD + joint) = s.qd;
+    SWO(UPKIE_S_Q, joint_off) = s.q;
+    SWO(UPKIE_S_QD, joint_off) = s.qd;
   }
-  if (MODE != MODE_SERVOS && legged) SW(UPKIE_S_LEGREF + 2 * leg + k) = legref;
+  if (MODE != MODE_SERVOS && legged) SWO(UPKIE_S_LEGREF, legref_off) = legref;
 
   if (MODE == MODE_RESET) {
     if (obs && lead) {
@@ -1830,7 +1884,7 @@ next_step:
       zm = pick6(joint, z6);
     }
     if (jointed) {
-      const float o2 = (do_reset ? SW(UPKIE_S_TORQUE + joint) : tau) + L.measurement_noise * zm;
+      const float o2 = (do_reset ? SWO(UPKIE_S_TORQUE, joint_off) : tau) + L.measurement_noise * zm;
       float* o = obs + (size_t)30 * e + 5 * joint;
       o[0] = s.q;
       o[1] = s.qd;
@@ -1897,5 +1951,6 @@ next_step:
     goto next_step;
   }
 #undef SW
+#undef SWO
 }
 #endif

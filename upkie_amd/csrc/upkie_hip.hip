@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64) void contact_sweeps_kernel(const DevModel* __re
     r[k] = rhs[(size_t)6 * i + k];
     l[k] = lam[(size_t)6 * i + k];
   }
-  const int count = contact_pgs6(*Mp, a, r, l, pair[i] != 0);
+  (void)pair;  // (one loop for every system since round 4: a lifted tire's identity rows need no other code, contact_pgs6)
+  const int count = contact_pgs6(*Mp, a, r, l);
 #pragma unroll
   for (int k = 0; k < 6; ++k) lam[(size_t)6 * i + k] = l[k];
   if (sweeps) sweeps[i] = count;
