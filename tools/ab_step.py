@@ -2,7 +2,8 @@
 step) or, with --c5, one GPU's share of BASELINE's C5 (Servos, randomised inertias, pushes, servo policy on the
 device: plenty of Gauss-Seidel sweeps); each build in its own process, interleaved, several rounds (box-to-box
 differences are larger than the few-percent effects this is for).
-Usage: python tools/ab_step.py libA.so libB.so ... [--rounds N] [--c5] [--fall]"""
+With --rollout the same workload as 32 env.step() per launch (upkie_sim_step_pendulum_agent_rollout).
+Usage: python tools/ab_step.py libA.so libB.so ... [--rounds N] [--c5] [--fall] [--rollout]"""
 import os, subprocess, sys
 
 CHILD_C5 = r'''
@@ -51,6 +52,28 @@ for rep in range(3):
 print(" ".join(f"{t:.2f}" for t in out))
 '''
 
+CHILD_ROLLOUT = r'''
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), ".."))
+import torch, bench
+from upkie_amd.sim import BatchedSim
+sim = BatchedSim(bench.make_config(4096)); sim.reset()
+prev = torch.zeros(4096, 8, device="cuda:0"); prev[:, :4] = sim.obs6[:, [1, 0, 4, 3]]
+ring = torch.zeros(32, 4096, 8, device="cuda:0")
+def launch():
+    sim.rollout_pendulum_records(prev, ring)
+    prev.copy_(ring[-1])
+for _ in range(int(os.environ.get("AB_WARMUP", "100")) // 32 + 1): launch()
+out = []
+for rep in range(3):
+    a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20): launch()
+    z.record(); torch.cuda.synchronize()
+    out.append(a.elapsed_time(z) * 1e3 / 640)
+print(" ".join(f"{t:.2f}" for t in out))
+'''
+
 args = sys.argv[1:]
 rounds = 3
 if "--rounds" in args:
@@ -63,9 +86,12 @@ if c5:
 if "--fall" in args:  # the windows of the bench workload in which robots fall (steps 1200-2400)
     args.remove("--fall")
     os.environ["AB_WARMUP"] = "1200"
+rollout = "--rollout" in args
+if rollout:
+    args.remove("--rollout")
 libs = args
 for r in range(rounds):
     for lib in libs:
         env = dict(os.environ, UPKIE_HIP_LIBRARY=os.path.abspath(lib))
-        res = subprocess.run([sys.executable, "-c", CHILD_C5 if c5 else CHILD, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
+        res = subprocess.run([sys.executable, "-c", CHILD_C5 if c5 else (CHILD_ROLLOUT if rollout else CHILD), os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         print(f"round {r} {os.path.basename(lib):28s} us/step (three consecutive windows): {res.stdout.strip() or res.stderr[-300:]}", flush=True)

@@ -409,7 +409,7 @@ UPKIE_HD OctLane load_oct_lane(const ModelT& M, const LimitsT& Lm, const ConfigT
   L.damping = t[OT_DAMPING];
   L.lower = t[OT_LOWER];
   L.upper = t[OT_UPPER];
-  L.bounded = t[OT_BOUNDED] != 0.f;
+  L.bounded = t[OT_BOUNDED] != 0.f && Lm.enforce != 0;  // (the handle's switch folded in here, once per launch: the substep reads no setting)
   L.effort = t[OT_EFFORT];
   L.velocity = t[OT_VELOCITY];
   L.wj = t[OT_WJ];
@@ -1007,8 +1007,10 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
                                    const float* trunk_wrench, LimitWorkspace* ws, OctRare* census = nullptr, float* manifold_out = nullptr,
                                    size_t manifold_stride = 0) {
   // ---- a joint at its stop (rare): its row joins the contact rows in the general solve below
+  // (L.bounded carries the handle's `enforce` switch: read from the settings block here, `if (Lm.enforce)` was a scalar
+  // load and a wait for it in every substep, 86-160 cycles of a lone wavefront each)
   bool at_a_stop = false;
-  if (Lm.enforce) {
+  {
     const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
     if (__builtin_expect(oct_wave_any(own_limit), 0)) at_a_stop = oct_env_any(own_limit);
   }
@@ -1373,7 +1375,12 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-// One 4-byte word of the state, as an lvalue: `buffer_load/store_dword v, voffset, s[descriptor], soffset offen`
+// A value every lane of the wavefront computed identically, moved to a scalar register
+__device__ __forceinline__ float oct_uniform(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+// One 4-byte word of the state, as an lvalue: `buffer_load/store_dword v, voffset, s[descriptor], soffset offen` ...
 struct OctStateWord {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned lane_offset, row_offset;  // bytes: per lane (vector register), per word (scalar register)
@@ -1384,6 +1391,27 @@ struct OctStateWord {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, value), rsrc, (int)lane_offset, (int)row_offset, 0);
   }
 };
+// ... or through the lane's own 64-bit address
+struct OctStateWordAt {
+  float* word;
+  __device__ __forceinline__ operator float() const { return *word; }
+  __device__ __forceinline__ void operator=(float value) const { *word = value; }
+};
+template <bool BUFFERED>
+__device__ __forceinline__ auto oct_state_word(__amdgpu_buffer_rsrc_t rsrc, float* st, size_t word_index, unsigned lane_offset, unsigned row_offset) {
+  if constexpr (BUFFERED) {
+    return OctStateWord{rsrc, lane_offset, row_offset};
+  } else {
+    return OctStateWordAt{st + word_index};
+  }
+}
+// Which instantiations address the state through the descriptor: the multi-step kernels (-0.2 us per step: no spill left);
+// the one-step kernels measured 0.2 us per launch SLOWER that way on the bench workload (profiles/r04_ab_state_addressing.txt)
+#if defined(UPKIE_OCTET_BUFFERED_STATE)
+constexpr bool octet_state_through_descriptor(int) { return UPKIE_OCTET_BUFFERED_STATE != 0; }
+#else
+constexpr bool octet_state_through_descriptor(int mode) { return mode == MODE_PENDULUM_ROLLOUT; }
+#endif
 
 template <class T>
 __device__ __forceinline__ T pick6(int j, const T (&a)[6]) {
@@ -1432,18 +1460,22 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   const bool jointed = l != 0;
   const int k = jointed ? l - 1 : 0;
   const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
-  // State word w of env e lives at state[w * B + e]: reached through ONE buffer descriptor over the whole state (scalar
-  // registers), the word's row as the instruction's scalar offset and the lane's 32-bit byte offset, which every word of
-  // an env shares (OctStateWord). As 64-bit lane addresses -- what `st[w * B]` compiled to -- the thirty-odd words of the
-  // prologue and the epilogue held fifty vector registers between them for the whole launch, and the multi-step kernels
-  // spilled two dozen of them. Byte offsets stay below 2^32: launch_step keeps this mapping to batches that fit.
+  // State word w of env e lives at state[w * B + e]. Reached through 64-bit lane addresses (`st[w * B]`), or -- BUFFERED --
+  // through ONE buffer descriptor over the whole state (scalar registers), the word's row as the instruction's scalar
+  // offset and the lane's 32-bit byte offset, which every word of an env shares (OctStateWord). The lane addresses of the
+  // thirty-odd words of the prologue and the epilogue hold fifty vector registers between them for the whole launch: the
+  // multi-step kernels spilled two dozen of them and reloaded them every step. Byte offsets stay below 2^32: launch_step
+  // keeps this mapping to batches that fit.
+  constexpr bool BUFFERED = octet_state_through_descriptor(MODE);
   const unsigned row_bytes = (unsigned)B * 4u;
   const __amdgpu_buffer_rsrc_t state_rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)((unsigned)UPKIE_STATE_WORDS * row_bytes), 0x00020000);
+  float* const st = state + (in_batch ? e : 0);
   const unsigned env_off = (unsigned)(in_batch ? e : 0) * 4u;
   const unsigned joint_off = env_off + (unsigned)joint * row_bytes;           // the own joint's row of a per-joint block
   const unsigned legref_off = env_off + (unsigned)(2 * leg + k) * row_bytes;  // the own low-pass target (hip and knee lanes)
-#define SWO(w, off) OctStateWord{state_rsrc, (off), (unsigned)(w) * row_bytes}
-#define SW(w) SWO(w, env_off)
+  // word w + i of the env (i: a lane-dependent index into a block of words); off: the byte offset that goes with i
+#define SWI(w, i, off) oct_state_word<BUFFERED>(state_rsrc, st, (size_t)((w) + (i)) * B, (off), (unsigned)(w) * row_bytes)
+#define SW(w) SWI(w, 0, env_off)
 
   // ---- load: issued first, in flight while the settings below arrive ------------------
   OctPhys s;
@@ -1451,10 +1483,10 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   s.qw = SW(UPKIE_S_QUAT); s.qx = SW(UPKIE_S_QUAT + 1); s.qy = SW(UPKIE_S_QUAT + 2); s.qz = SW(UPKIE_S_QUAT + 3);
   s.linvel = v3(SW(UPKIE_S_LINVEL), SW(UPKIE_S_LINVEL + 1), SW(UPKIE_S_LINVEL + 2));
   s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
-  s.q = jointed ? SWO(UPKIE_S_Q, joint_off) : 0.f;
-  s.qd = jointed ? SWO(UPKIE_S_QD, joint_off) : 0.f;
+  s.q = jointed ? SWI(UPKIE_S_Q, joint, joint_off) : 0.f;
+  s.qd = jointed ? SWI(UPKIE_S_QD, joint, joint_off) : 0.f;
   const bool legged = l == 1 || l == 2;  // hip and knee lanes carry their low-pass target
-  float legref = legged ? SWO(UPKIE_S_LEGREF, legref_off) : 0.f;
+  float legref = legged ? SWI(UPKIE_S_LEGREF, 2 * leg + k, legref_off) : 0.f;
   constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
   float yaw = 0.f, yawvel = 0.f;
   if (YAWING) {
@@ -1493,6 +1525,32 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   UPKIE_KEEP_IN_SGPR(kp_gain);
   UPKIE_KEEP_IN_SGPR(kd_gain);
   UPKIE_KEEP_IN_SGPR(substep_h);
+  // ... and what a step reads of it OUTSIDE its substeps (action map, fall and time-limit tests), as one batch of scalar
+  // loads: read where they are used they are a dozen load-and-wait pairs one after the other (86-160 cycles each for a
+  // lone wavefront) -- once per launch in front of the first substep, but once per env.step() in the multi-step kernels
+  constexpr bool WHEELED = MODE != MODE_SERVOS && MODE != MODE_RESET;  // the modes that map a ground velocity to the wheels
+  float agent_gain0 = 0.f, agent_gain1 = 0.f, agent_gain2 = 0.f, agent_gain3 = 0.f, agent_clip = 0.f;
+  float max_ground_velocity = 0.f, max_yaw_velocity = 0.f, leg_gain_scale = 0.f, max_gain_scale = 0.f, fall_pitch_limit = 0.f, step_dt = 0.f;
+  int max_episode_steps = C.max_episode_steps;
+  if (fused_agent(MODE)) {
+    agent_gain0 = C.agent_gains[0]; agent_gain1 = C.agent_gains[1]; agent_gain2 = C.agent_gains[2]; agent_gain3 = C.agent_gains[3];
+    agent_clip = C.agent_clip;
+  }
+  if (WHEELED) {
+    max_ground_velocity = C.max_ground_velocity; max_yaw_velocity = C.max_yaw_velocity; leg_gain_scale = C.leg_gain_scale;
+    fall_pitch_limit = C.fall_pitch; step_dt = C.dt;
+  }
+  if (MODE != MODE_RESET) max_gain_scale = C.max_gain_scale;
+  if (fused_agent(MODE)) {
+    UPKIE_KEEP_IN_SGPR(agent_gain0); UPKIE_KEEP_IN_SGPR(agent_gain1); UPKIE_KEEP_IN_SGPR(agent_gain2); UPKIE_KEEP_IN_SGPR(agent_gain3);
+    UPKIE_KEEP_IN_SGPR(agent_clip);
+  }
+  if (WHEELED) {
+    UPKIE_KEEP_IN_SGPR(max_ground_velocity); UPKIE_KEEP_IN_SGPR(max_yaw_velocity); UPKIE_KEEP_IN_SGPR(leg_gain_scale);
+    UPKIE_KEEP_IN_SGPR(fall_pitch_limit); UPKIE_KEEP_IN_SGPR(step_dt);
+  }
+  if (MODE != MODE_RESET) UPKIE_KEEP_IN_SGPR(max_gain_scale);
+  UPKIE_KEEP_IN_SGPR(max_episode_steps);
   // UpkieBaseVelocity with its MPC balancer in the same launch (upkie_sim_step_base_velocity_mpc): the wavefront first
   // solves the condensed QPs of its eight envs on the matrix cores -- columns 0-7 of one 16-column MFMA tile, all 64
   // lanes at work under the tile's own lane mapping (mpc_tile) -- and hands the commanded velocities to the lanes that
@@ -1538,10 +1596,16 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   int steps_left = ROLLOUT && packed && n_steps > 1 ? n_steps : 1;
   float* records_out = obs;
   float episode_word = ROLLOUT ? SW(UPKIE_S_EPISODE) : 0.f;
-  float elapsed_word = ROLLOUT && C.max_episode_steps > 0 ? SW(UPKIE_S_ELAPSED) : 0.f;
+  float elapsed_word = ROLLOUT && max_episode_steps > 0 ? SW(UPKIE_S_ELAPSED) : 0.f;
   const bool any_noise = C.any_control_noise || C.any_measurement_noise;
   unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
   const float signed_radius = M.left_sign * M.wheel_radius;
+  // (the wheel map's constants, upkie_gyropod.py:216-234, once per launch as well)
+  float left_sign = M.left_sign;
+  const float inv_radius_lanes = fast_rcp(M.wheel_radius);
+  const float inv_radius = oct_uniform(inv_radius_lanes);  // (vector-unit results, the same in every lane: back to scalar registers)
+  const float yaw_to_wheel = oct_uniform(M.left_sign * (0.5f * M.wheel_base) * inv_radius_lanes);
+  if (WHEELED) UPKIE_KEEP_IN_SGPR(left_sign);
 
   // Gyropod observation (upkie_gyropod.py:186-214): the wheel lanes hold what it needs
   auto observe6 = [&](float yaw_, float yawvel_, float (&o6)[6]) {
@@ -1662,32 +1726,30 @@ next_step:
       cmd.position = clamp_ref(a[0], L.lower, L.upper);
       cmd.velocity = clamp_ref(a[1], -vel, vel);
       cmd.feedforward_torque = clamp_ref(a[2], -eff, eff);
-      cmd.kp_scale = clamp_ref(a[3], 0.f, C.max_gain_scale);
-      cmd.kd_scale = clamp_ref(a[4], 0.f, C.max_gain_scale);
+      cmd.kp_scale = clamp_ref(a[3], 0.f, max_gain_scale);
+      cmd.kd_scale = clamp_ref(a[4], 0.f, max_gain_scale);
       cmd.maximum_torque = clamp_ref(a[5], 0.f, eff);
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
       const float4 o = prev_obs;
-      a0 = C.agent_gains[0] * o.x + C.agent_gains[1] * o.y + C.agent_gains[2] * o.z + C.agent_gains[3] * o.w;
-      a0 = clamp_ref(a0, -C.agent_clip, C.agent_clip);
+      a0 = agent_gain0 * o.x + agent_gain1 * o.y + agent_gain2 * o.z + agent_gain3 * o.w;
+      a0 = clamp_ref(a0, -agent_clip, agent_clip);
     } else {
       a0 = act0;
       a1 = act1;
     }
-    const float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
-    const float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
-    const float inv_radius = fast_rcp(M.wheel_radius);
+    const float v = clamp_ref(a0, -max_ground_velocity, max_ground_velocity);
+    const float yawd = clamp_ref(a1, -max_yaw_velocity, max_yaw_velocity);
     const float wheel_velocity = v * inv_radius;
-    float left = M.left_sign * wheel_velocity, right = -M.left_sign * wheel_velocity;
-    const float yaw_to_wheel = M.left_sign * (0.5f * M.wheel_base) * inv_radius;
+    float left = left_sign * wheel_velocity, right = -left_sign * wheel_velocity;
     left = fmaf(yaw_to_wheel, yawd, left);
     right = fmaf(yaw_to_wheel, yawd, right);
-    const float alpha = C.dt / 1.0f;
+    const float alpha = step_dt / 1.0f;
     legref = legref + alpha * (0.f - legref);
     if (legged) {
       cmd.position = clamp_ref(legref, L.lower, L.upper);
-      cmd.kp_scale = clamp_ref(C.leg_gain_scale, 0.f, C.max_gain_scale);
+      cmd.kp_scale = clamp_ref(leg_gain_scale, 0.f, max_gain_scale);
       cmd.kd_scale = cmd.kp_scale;
       cmd.maximum_torque = L.effort;
     } else if (l == 3) {
@@ -1796,7 +1858,7 @@ next_step:
     observe6(yaw, yawvel, obs6);
   } else {
     if (YAWING) {
-      yaw = fmaf(a1, C.dt, yaw);
+      yaw = fmaf(a1, step_dt, yaw);
       yawvel = a1;
       if (lead) {
         SW(UPKIE_S_YAW) = yaw;
@@ -1805,12 +1867,12 @@ next_step:
     }
     observe6(yaw, yawvel, obs6);
     if (MODE != MODE_SERVOS) {
-      fallen = fabsf(obs6[1]) > C.fall_pitch;
+      fallen = fabsf(obs6[1]) > fall_pitch_limit;
       if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
     }
-    if (C.max_episode_steps > 0) {
+    if (max_episode_steps > 0) {
       const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
-      timeout = elapsed >= (float)C.max_episode_steps && !fallen;
+      timeout = elapsed >= (float)max_episode_steps && !fallen;
       elapsed_word = elapsed;
       if (lead && !ROLLOUT) {
         SW(UPKIE_S_ELAPSED) = elapsed;
@@ -1818,7 +1880,7 @@ next_step:
       }
     }
     if (fallen || timeout) done_word = 1.f;
-    if (jointed && !ROLLOUT) SWO(UPKIE_S_TORQUE, joint_off) = tau;
+    if (jointed && !ROLLOUT) SWI(UPKIE_S_TORQUE, joint, joint_off) = tau;
     if (any_noise) {
       step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
       if (lead && !ROLLOUT) SW(UPKIE_S_STEP) = (float)step_count;
@@ -1849,10 +1911,10 @@ next_step:
         SW(UPKIE_S_EPISODE) = episode_word;
       }
       SW(UPKIE_S_DONE) = done_word;
-      if (reset_seen || C.max_episode_steps > 0) SW(UPKIE_S_ELAPSED) = elapsed_word;
+      if (reset_seen || max_episode_steps > 0) SW(UPKIE_S_ELAPSED) = elapsed_word;
       if (any_noise && step_seen) SW(UPKIE_S_STEP) = (float)step_count;
     }
-    if (jointed && step_seen) SWO(UPKIE_S_TORQUE, joint_off) = tau_stepped;
+    if (jointed && step_seen) SWI(UPKIE_S_TORQUE, joint, joint_off) = tau_stepped;
   }
   if (lead) {
     SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
@@ -1862,10 +1924,10 @@ next_step:
     SW(UPKIE_S_CONTACT) = contact ? 1.f : 0.f;
   }
   if (jointed) {
-    SWO(UPKIE_S_Q, joint_off) = s.q;
-    SWO(UPKIE_S_QD, joint_off) = s.qd;
+    SWI(UPKIE_S_Q, joint, joint_off) = s.q;
+    SWI(UPKIE_S_QD, joint, joint_off) = s.qd;
   }
-  if (MODE != MODE_SERVOS && legged) SWO(UPKIE_S_LEGREF, legref_off) = legref;
+  if (MODE != MODE_SERVOS && legged) SWI(UPKIE_S_LEGREF, 2 * leg + k, legref_off) = legref;
 
   if (MODE == MODE_RESET) {
     if (obs && lead) {
@@ -1884,7 +1946,7 @@ next_step:
       zm = pick6(joint, z6);
     }
     if (jointed) {
-      const float o2 = (do_reset ? SWO(UPKIE_S_TORQUE, joint_off) : tau) + L.measurement_noise * zm;
+      const float o2 = (do_reset ? SWI(UPKIE_S_TORQUE, joint, joint_off) : tau) + L.measurement_noise * zm;
       float* o = obs + (size_t)30 * e + 5 * joint;
       o[0] = s.q;
       o[1] = s.qd;
@@ -1918,8 +1980,8 @@ next_step:
         const float lin = act[2 * (size_t)e];
         float sy, cy;
         sincosf(yaw, &sy, &cy);
-        x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));
-        y = fmaf(lin * sy, C.dt, SW(UPKIE_S_SE2_Y));
+        x = fmaf(lin * cy, step_dt, SW(UPKIE_S_SE2_X));
+        y = fmaf(lin * sy, step_dt, SW(UPKIE_S_SE2_Y));
         SW(UPKIE_S_SE2_X) = x;
         SW(UPKIE_S_SE2_Y) = y;
       }
@@ -1951,6 +2013,6 @@ next_step:
     goto next_step;
   }
 #undef SW
-#undef SWO
+#undef SWI
 }
 #endif
