@@ -1655,6 +1655,11 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   // across the step loop (hoisted there, thirteen of them cost the kernel 24 spilled registers reloaded every step).
   bool reset_seen = false, step_seen = false;
   float tau_stepped = 0.f;
+  // Every load of the prologue lands BEFORE the step loop. Left pending, the compiler waits for them where the loop first
+  // reads their registers -- the same instructions in every iteration, and from the second step on those waits
+  // (`s_waitcnt vmcnt(0)`: the counter is in order) are waits for the record stores the previous step has just issued:
+  // a store's whole round trip, ~0.8 us, once per env.step().
+  if (ROLLOUT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 next_step:
   s.swept_prev = 0;  // the sweeps' warm start spans the substeps of ONE env.step(): several steps in a launch = as many launches, bit for bit
   bool do_reset;

@@ -564,6 +564,9 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
 
   SweepWarmStart sweep_warm_start;  // spans the substeps of ONE env.step() (dynamics.hpp): several steps in a launch = as many launches
+  // (the prologue's loads land before the step loop: left pending they are waited for inside it, by instructions that
+  // from the second step on wait for the record stores of the step before -- step_kernel_octet)
+  if (ROLLOUT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 next_step:
   sweep_warm_start.swept = 0;
   bool do_reset;
