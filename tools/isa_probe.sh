@@ -1,6 +1,6 @@
 #!/bin/bash
 # ISA of ONE eight-lane step kernel in ~15 s (tools/isa_stats.sh compiles all instantiations: minutes).
-# Usage: tools/isa_probe.sh <mode 0..6> [true|false (RAND)] [extra hipcc flags, e.g. -DUPKIE_PROBE_DEFAULT_SCALARS=true -DUPKIE_PROBE_IN_PLACE=true]; leaves k.s / remarks.txt in $OUT (default /tmp/isa_probe)
+# Usage: tools/isa_probe.sh <mode 0..6> [true|false (RAND)] [extra hipcc flags, e.g. -DUPKIE_PROBE_DEFAULT_SCALARS=true -DUPKIE_PROBE_IN_PLACE=true -DUPKIE_PROBE_OCTET_WAVES=1 -DUPKIE_OCTET_BUFFERED_STATE=1]; leaves k.s / remarks.txt in $OUT (default /tmp/isa_probe)
 set -e
 MODE=${1:-2}; RAND=${2:-false}; shift || true; shift || true
 R=$(cd "$(dirname "$0")/.." && pwd)

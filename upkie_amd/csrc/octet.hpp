@@ -1405,12 +1405,14 @@ __device__ __forceinline__ auto oct_state_word(__amdgpu_buffer_rsrc_t rsrc, floa
     return OctStateWordAt{st + word_index};
   }
 }
-// Which instantiations address the state through the descriptor: the multi-step kernels (-0.2 us per step: no spill left);
-// the one-step kernels measured 0.2 us per launch SLOWER that way on the bench workload (profiles/r04_ab_state_addressing.txt)
+// Which instantiations address the state through the descriptor: those whose step is a loop body -- the multi-step kernels
+// (-0.2 us per step: no spill left) and the ones that complete a SAME_STEP autoreset inside the launch (IN_PLACE: 80-112 B of
+// scratch and 19-21 spilled registers -> none; 23.2 -> 22.2 us per env.step() of the public loop); the plain one-step
+// kernels measured 0.1-0.2 us per launch SLOWER that way on the bench workload (profiles/r04_ab_state_addressing.txt)
 #if defined(UPKIE_OCTET_BUFFERED_STATE)
-constexpr bool octet_state_through_descriptor(int) { return UPKIE_OCTET_BUFFERED_STATE != 0; }
+constexpr bool octet_state_through_descriptor(int, bool) { return UPKIE_OCTET_BUFFERED_STATE != 0; }
 #else
-constexpr bool octet_state_through_descriptor(int mode) { return mode == MODE_PENDULUM_ROLLOUT; }
+constexpr bool octet_state_through_descriptor(int mode, bool in_place) { return mode == MODE_PENDULUM_ROLLOUT || in_place; }
 #endif
 
 template <class T>
@@ -1431,10 +1433,12 @@ constexpr bool kServosLimitsInRegisters = true;
 // BULLET_LIKE: contacts by the Bullet-like specification on the env's persistent contact manifold `manifold`
 // [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) -- the eight-lane variant of what the one-lane kernels run
 // (oct_bullet_like_solve), for the envs whose legs the servos hold (every mode but Servos).
-template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
+// Wavefronts per SIMD the register budget allows: two (256 registers; up to 16384 envs put two on every SIMD). An ISA probe
+// may set one (tools/isa_probe.sh -DUPKIE_PROBE_OCTET_WAVES=1: spills then go to AGPRs instead of scratch memory).
 #if !defined(UPKIE_PROBE_OCTET_WAVES)
 #define UPKIE_PROBE_OCTET_WAVES 2
 #endif
+template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
 __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : UPKIE_PROBE_OCTET_WAVES) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
@@ -1466,7 +1470,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   // thirty-odd words of the prologue and the epilogue hold fifty vector registers between them for the whole launch: the
   // multi-step kernels spilled two dozen of them and reloaded them every step. Byte offsets stay below 2^32: launch_step
   // keeps this mapping to batches that fit.
-  constexpr bool BUFFERED = octet_state_through_descriptor(MODE);
+  constexpr bool BUFFERED = octet_state_through_descriptor(MODE, IN_PLACE);
   const unsigned row_bytes = (unsigned)B * 4u;
   const __amdgpu_buffer_rsrc_t state_rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)((unsigned)UPKIE_STATE_WORDS * row_bytes), 0x00020000);
   float* const st = state + (in_batch ? e : 0);
