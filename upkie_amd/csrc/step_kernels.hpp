@@ -232,8 +232,13 @@ __device__ __forceinline__ void gyropod_observation(const DevModel& M, const Phy
 // ~90 spilled: +25 % throughput once the batch oversubscribes the chip).
 // BULLET_LIKE: contacts by the Bullet-like specification (bullet_like.hpp) on the env's persistent contact manifold
 // `manifold` [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) instead of the default one; its own instantiations.
+// (WPS = 2 is the register-capped build of very large batches: two wavefronts per SIMD; an experiment may cap it harder,
+// tools/build_variant.py -DUPKIE_DENSE_WAVES=3: profiles/r04_dense_waves_per_simd.txt)
+#if !defined(UPKIE_DENSE_WAVES)
+#define UPKIE_DENSE_WAVES 2
+#endif
 template <int MODE, bool RAND, int WPS, bool SPINE, bool BULLET_LIKE = false>
-__global__ __launch_bounds__(64, WPS) void step_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C, float* __restrict__ state,
+__global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_kernel(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C, float* __restrict__ state,
                                                    const float* __restrict__ act, float* __restrict__ obs,
                                                    float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                    uint8_t* __restrict__ truncated, const uint8_t* __restrict__ mask,
