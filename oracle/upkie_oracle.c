@@ -28,6 +28,7 @@ long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they ne
 double oracle_debug_capture[ORACLE_CAPTURE_CASES][1 + 36 + 18] = {{0}};
 long oracle_debug_captured = 0;
 long oracle_debug_capture_threshold = 0; /* capture systems that needed at least this many sweeps (0: the iteration cap) */
+long oracle_debug_capture_rows = 0; /* capture systems of this many rows only (0: any) */
 
 /* ------------------------------------------------------------------ vec3 */
 static void v3_cross(const double a[3], const double b[3], double c[3]) {
@@ -1007,7 +1008,8 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
        * the largest one (each env stops on its own criterion) */
       if (change <= model->pgs_tolerance * scale) break;
     }
-    if (need_pgs && sweeps_here >= (oracle_debug_capture_threshold > 0 ? oracle_debug_capture_threshold : model->pgs_iterations) && nrows <= 6) {
+    if (need_pgs && sweeps_here >= (oracle_debug_capture_threshold > 0 ? oracle_debug_capture_threshold : model->pgs_iterations) && nrows <= 6 &&
+        (oracle_debug_capture_rows == 0 || nrows == oracle_debug_capture_rows)) {
       long slot;
 #pragma omp atomic capture
       slot = oracle_debug_captured++;

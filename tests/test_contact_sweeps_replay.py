@@ -62,6 +62,56 @@ def test_host_sweeps_reach_the_oracle_solution(harness):  # noqa: F811
     check(A, rhs, want, got, sweeps)
 
 
+def one_tire_systems(envs=128, steps=300):
+    """Contact systems of robots with ONE tire on the floor (three rows in the oracle), laid out as the kernels gather
+    them: the touching tire's block in its slot, identity rows with zero right-hand sides and no coupling for the other."""
+    cases, mu = run_c5_share_on_the_oracle(B=envs, steps=steps, threshold=2, law="torque", rows=3)
+    cases = cases[cases[:, 0] == 3]
+    A3 = cases[:, 1:37].reshape(-1, 6, 6)[:, :3, :3]
+    rhs3, warm3, lam3 = cases[:, 37:40], cases[:, 43:46], cases[:, 49:52]
+    out = []
+    for slot in (0, 3):  # the left tire touches / the right one does
+        A = np.tile(np.eye(6), (len(A3), 1, 1))
+        A[:, slot:slot + 3, slot:slot + 3] = A3
+        rhs, warm, lam = (np.zeros((len(A3), 6)) for _ in range(3))
+        rhs[:, slot:slot + 3], warm[:, slot:slot + 3], lam[:, slot:slot + 3] = rhs3, warm3, lam3
+        packed = np.stack([A[:, r, c] for r in range(6) for c in range(r + 1)], axis=1)
+        out.append((A, packed, rhs, warm, lam))
+    return out
+
+
+def test_host_sweeps_of_one_tire_systems_reach_the_oracle_solution(harness):  # noqa: F811
+    """Round 4: one sweep loop for every env. A lifted tire's identity rows go through the lateral-pair solve, which
+    must then return the touching tire's lateral row solved and clamped -- the oracle's row-by-row rule for it."""
+    model = Model().struct
+    harness.harness_contact_pgs6.restype = C.c_int
+    for A, packed, rhs, warm, want in one_tire_systems():
+        assert len(A) > 300
+        got = np.zeros_like(want)
+        sweeps = np.zeros(len(A), dtype=np.int64)
+        for i in range(len(A)):
+            a32, r32, l32 = (np.ascontiguousarray(x[i], dtype=np.float32) for x in (packed, rhs, warm))
+            sweeps[i] = harness.harness_contact_pgs6(C.byref(model), a32.ctypes.data_as(C.c_void_p), r32.ctypes.data_as(C.c_void_p),
+                                                    l32.ctypes.data_as(C.c_void_p), 0)
+            got[i] = l32
+        lifted = [r for r in range(6) if (rhs[:, r] == 0).all() and (A[:, r, r] == 1).all()]  # the other tire's identity rows
+        assert len(lifted) == 3 and (got[:, lifted] == 0).all()
+        check(A, rhs, want, got, sweeps)
+
+
+@pytest.mark.gpu
+def test_device_sweeps_of_one_tire_systems_reach_the_oracle_solution():
+    import torch
+
+    from tests.helpers import randomized_config
+    from upkie_amd.sim import BatchedSim
+
+    sim = BatchedSim(randomized_config(64), Model().struct)
+    for A, packed, rhs, warm, want in one_tire_systems(envs=256, steps=300):
+        lam, sweeps = sim.contact_sweeps(torch.from_numpy(packed), torch.from_numpy(rhs), torch.from_numpy(warm), torch.zeros(len(A), dtype=torch.uint8))
+        check(A, rhs, want, lam.cpu().numpy().astype(np.float64), sweeps.cpu().numpy())
+
+
 @pytest.mark.gpu
 def test_device_sweeps_reach_the_oracle_solution():
     import torch

@@ -22,7 +22,7 @@ from upkie_amd import abi
 from upkie_amd.model.model import Model
 
 
-def run_c5_share_on_the_oracle(B, steps, threshold, law="velocity"):
+def run_c5_share_on_the_oracle(B, steps, threshold, law="velocity", rows=0):
     cfg = randomized_config(B, seed=0)
     cfg.rand_pitch = 0.1
     cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
@@ -38,6 +38,7 @@ def run_c5_share_on_the_oracle(B, steps, threshold, law="velocity"):
     lib = O.lib()
     C.c_long.in_dll(lib, "oracle_debug_captured").value = 0
     C.c_long.in_dll(lib, "oracle_debug_capture_threshold").value = threshold
+    C.c_long.in_dll(lib, "oracle_debug_capture_rows").value = rows  # (0: systems of any size)
     r, sign = float(model.wheel_radius), float(model.left_sign)
     act = np.zeros((B, 6, 6))
     act[:, :, 3] = 1.0
@@ -63,6 +64,7 @@ def run_c5_share_on_the_oracle(B, steps, threshold, law="velocity"):
     captured = max(0, min(C.c_long.in_dll(lib, "oracle_debug_captured").value, 4096))
     cases = np.ctypeslib.as_array((C.c_double * (4096 * 55)).in_dll(lib, "oracle_debug_capture")).reshape(4096, 55)[:captured].copy()
     C.c_long.in_dll(lib, "oracle_debug_capture_threshold").value = 0
+    C.c_long.in_dll(lib, "oracle_debug_capture_rows").value = 0
     return cases, float(model.friction_mu)
 
 
