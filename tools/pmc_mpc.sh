@@ -1,6 +1,6 @@
 #!/bin/bash
-# MFMA counters of mpc_step_kernel (BASELINE C3: 16384 envs, N = 16, 30 ADMM
-# iterations): instruction count, MFMA busy cycles, wave cycles; one kernel
+# MFMA counters of mpc_step_kernel (BASELINE C3: 16384 envs, N = 16, 15 over-relaxed ADMM
+# iterations by default since round 4): instruction count, MFMA busy cycles, wave cycles; one kernel
 # trace + stats pass beside the counter passes. Usage: bash tools/pmc_mpc.sh <tag>
 set -u
 TAG=${1:-r02}
@@ -12,7 +12,7 @@ i=0
 for C in "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
   "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- python $R/tools/mpc_loop.py 16384 200 > $OUT/pass$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- python $R/tools/mpc_loop.py 16384 200 > $OUT/pass$i.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o ks -- python $R/tools/mpc_loop.py 16384 300 > $OUT/stats.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o ks -- python $R/tools/mpc_loop.py 16384 300 > $OUT/stats.log 2>&1
 ls -R $OUT | head -30
