@@ -1380,31 +1380,6 @@ __device__ __forceinline__ float oct_uniform(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
 
-// One 4-byte word of the state, as an lvalue: `buffer_load/store_dword v, voffset, s[descriptor], soffset offen` ...
-struct OctStateWord {
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned lane_offset, row_offset;  // bytes: per lane (vector register), per word (scalar register)
-  __device__ __forceinline__ operator float() const {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_offset, (int)row_offset, 0));
-  }
-  __device__ __forceinline__ void operator=(float value) const {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, value), rsrc, (int)lane_offset, (int)row_offset, 0);
-  }
-};
-// ... or through the lane's own 64-bit address
-struct OctStateWordAt {
-  float* word;
-  __device__ __forceinline__ operator float() const { return *word; }
-  __device__ __forceinline__ void operator=(float value) const { *word = value; }
-};
-template <bool BUFFERED>
-__device__ __forceinline__ auto oct_state_word(__amdgpu_buffer_rsrc_t rsrc, float* st, size_t word_index, unsigned lane_offset, unsigned row_offset) {
-  if constexpr (BUFFERED) {
-    return OctStateWord{rsrc, lane_offset, row_offset};
-  } else {
-    return OctStateWordAt{st + word_index};
-  }
-}
 // Which instantiations address the state through the descriptor: those whose step is a loop body -- the multi-step kernels
 // (-0.2 us per step: no spill left) and the ones that complete a SAME_STEP autoreset inside the launch (IN_PLACE: 80-112 B of
 // scratch and 19-21 spilled registers -> none; 23.2 -> 22.2 us per env.step() of the public loop); the plain one-step
@@ -1464,21 +1439,17 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   const bool jointed = l != 0;
   const int k = jointed ? l - 1 : 0;
   const int joint = 3 * leg + k;  // the own joint's index in the state / action / observation layouts
-  // State word w of env e lives at state[w * B + e]. Reached through 64-bit lane addresses (`st[w * B]`), or -- BUFFERED --
-  // through ONE buffer descriptor over the whole state (scalar registers), the word's row as the instruction's scalar
-  // offset and the lane's 32-bit byte offset, which every word of an env shares (OctStateWord). The lane addresses of the
-  // thirty-odd words of the prologue and the epilogue hold fifty vector registers between them for the whole launch: the
-  // multi-step kernels spilled two dozen of them and reloaded them every step. Byte offsets stay below 2^32: launch_step
-  // keeps this mapping to batches that fit.
+  // State word w of env e: through 64-bit lane addresses (`st[w * B]`) or -- BUFFERED -- the state's buffer descriptor
+  // (state_words.hpp)
   constexpr bool BUFFERED = octet_state_through_descriptor(MODE, IN_PLACE);
   const unsigned row_bytes = (unsigned)B * 4u;
-  const __amdgpu_buffer_rsrc_t state_rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)((unsigned)UPKIE_STATE_WORDS * row_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t state_rsrc = state_descriptor(state, B);
   float* const st = state + (in_batch ? e : 0);
   const unsigned env_off = (unsigned)(in_batch ? e : 0) * 4u;
   const unsigned joint_off = env_off + (unsigned)joint * row_bytes;           // the own joint's row of a per-joint block
   const unsigned legref_off = env_off + (unsigned)(2 * leg + k) * row_bytes;  // the own low-pass target (hip and knee lanes)
   // word w + i of the env (i: a lane-dependent index into a block of words); off: the byte offset that goes with i
-#define SWI(w, i, off) oct_state_word<BUFFERED>(state_rsrc, st, (size_t)((w) + (i)) * B, (off), (unsigned)(w) * row_bytes)
+#define SWI(w, i, off) state_word<BUFFERED>(state_rsrc, st, (size_t)((w) + (i)) * B, (off), (unsigned)(w) * row_bytes)
 #define SW(w) SWI(w, 0, env_off)
 
   // ---- load: issued first, in flight while the settings below arrive ------------------
@@ -1661,8 +1632,8 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   float tau_stepped = 0.f;
   // Every load of the prologue lands BEFORE the step loop. Left pending, the compiler waits for them where the loop first
   // reads their registers -- the same instructions in every iteration, and from the second step on those waits
-  // (`s_waitcnt vmcnt(0)`: the counter is in order) are waits for the record stores the previous step has just issued:
-  // a store's whole round trip, ~0.8 us, once per env.step().
+  // (`s_waitcnt vmcnt(0)`: the counter is in order) are waits for the record stores the previous step has just issued
+  // (measured: 0.12 us per env.step(), tools/ab_step.py --rollout).
   if (ROLLOUT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 next_step:
   s.swept_prev = 0;  // the sweeps' warm start spans the substeps of ONE env.step(): several steps in a launch = as many launches, bit for bit

@@ -459,6 +459,14 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   return any_contact;
 }
 
+// Which two-lane instantiations address the state through its buffer descriptor (state_words.hpp): the multi-step ones
+// (their step is a loop body: lane addresses hoisted across it are what they spill); an experiment may force it either way
+#if defined(UPKIE_PAIR_BUFFERED_STATE)
+constexpr bool pair_state_through_descriptor(int) { return UPKIE_PAIR_BUFFERED_STATE != 0; }
+#else
+constexpr bool pair_state_through_descriptor(int mode) { return mode == MODE_PENDULUM_ROLLOUT; }
+#endif
+
 // One env.step() of B envs on 2 B lanes. Same contract as step_kernel.
 template <int MODE, bool RAND, bool SPINE>
 __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restrict__ Mp, DevLimits Lm, DevConfig C,
@@ -486,8 +494,16 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   }
   if (e >= B) return;  // both lanes of a pair leave together
   const bool lead = leg == 0;  // the lane that writes per-env (not per-leg) words
-  float* st = state + e;
-#define SW(w) st[(size_t)(w) * B]
+  // state word w of env e: through 64-bit lane addresses or -- BUFFERED -- the state's buffer descriptor (state_words.hpp);
+  // the per-leg blocks (three joints, two low-pass targets) start at the own leg's row
+  constexpr bool BUFFERED = pair_state_through_descriptor(MODE);
+  const unsigned row_bytes = (unsigned)B * 4u;
+  const __amdgpu_buffer_rsrc_t state_rsrc = state_descriptor(state, B);
+  float* const st = state + e;
+  const unsigned env_off = (unsigned)e * 4u;
+  const unsigned leg3_off = env_off + (unsigned)(3 * leg) * row_bytes, leg2_off = env_off + (unsigned)(2 * leg) * row_bytes;
+#define SWI(w, i, off) state_word<BUFFERED>(state_rsrc, st, (size_t)((w) + (i)) * B, (off), (unsigned)(w) * row_bytes)
+#define SW(w) SWI(w, 0, env_off)
 
   // ---- load ----------------------------------------------------------
   PhysPair s;
@@ -497,10 +513,10 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   s.angvel = v3(SW(UPKIE_S_ANGVEL), SW(UPKIE_S_ANGVEL + 1), SW(UPKIE_S_ANGVEL + 2));
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    s.q[k] = SW(UPKIE_S_Q + 3 * leg + k);
-    s.qd[k] = SW(UPKIE_S_QD + 3 * leg + k);
+    s.q[k] = SWI(UPKIE_S_Q + k, 3 * leg, leg3_off);
+    s.qd[k] = SWI(UPKIE_S_QD + k, 3 * leg, leg3_off);
   }
-  float legref[2] = {SW(UPKIE_S_LEGREF + 2 * leg), SW(UPKIE_S_LEGREF + 2 * leg + 1)};
+  float legref[2] = {SWI(UPKIE_S_LEGREF, 2 * leg, leg2_off), SWI(UPKIE_S_LEGREF + 1, 2 * leg, leg2_off)};
   constexpr bool YAWING = MODE == MODE_GYROPOD || MODE == MODE_BASE_VELOCITY;
   float yaw = 0.f, yawvel = 0.f;
   if (YAWING) {
@@ -564,6 +580,10 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   unsigned step_count = any_noise ? (unsigned)SW(UPKIE_S_STEP) : 0u;
 
   SweepWarmStart sweep_warm_start;  // spans the substeps of ONE env.step() (dynamics.hpp): several steps in a launch = as many launches
+  // several steps in a launch: the per-step state words go to memory once, behind the last step, from the registers that
+  // mirror them (step_kernel_octet: same memory image as one launch per step, no store address live across the step loop)
+  bool reset_seen = false, step_seen = false;
+  float tau_stepped[3] = {0.f, 0.f, 0.f};
   // (the prologue's loads land before the step loop: left pending they are waited for inside it, by instructions that
   // from the second step on wait for the record stores of the step before -- step_kernel_octet)
   if (ROLLOUT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -733,12 +753,20 @@ next_step:
   // ---- wrapper post-processing ---------------------------------------------
   bool fallen = false, timeout = false;
   float obs6[6];
+  if (ROLLOUT) {
+    reset_seen = reset_seen || do_reset;
+    if (!do_reset) {
+      step_seen = true;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tau_stepped[k] = tau[k];
+    }
+  }
   if (do_reset) {
     legref[0] = s.q[0];
     legref[1] = s.q[1];
     yaw = 0.f;
     yawvel = 0.f;
-    if (lead) {
+    if (lead && !ROLLOUT) {
       SW(UPKIE_S_YAW) = 0.f;
       SW(UPKIE_S_YAWVEL) = 0.f;
       SW(UPKIE_S_MPC_V) = 0.f;
@@ -764,23 +792,25 @@ next_step:
     observe6(yaw, yawvel, obs6);
     if (MODE != MODE_SERVOS) {
       fallen = fabsf(obs6[1]) > C.fall_pitch;
-      if (fallen && lead) SW(UPKIE_S_DONE) = 1.f;
+      if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
     }
     if (C.max_episode_steps > 0) {  // time limit, see step_kernel
       const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
       timeout = elapsed >= (float)C.max_episode_steps && !fallen;
       elapsed_word = elapsed;
-      if (lead) {
+      if (lead && !ROLLOUT) {
         SW(UPKIE_S_ELAPSED) = elapsed;
         if (timeout) SW(UPKIE_S_DONE) = 1.f;
       }
     }
     if (fallen || timeout) done_word = 1.f;
+    if (!ROLLOUT) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) SW(UPKIE_S_TORQUE + 3 * leg + k) = tau[k];
+      for (int k = 0; k < 3; ++k) SWI(UPKIE_S_TORQUE + k, 3 * leg, leg3_off) = tau[k];
+    }
     if (any_noise) {
       step_count = (step_count + 1u) & UPKIE_COUNTER_MASK;
-      if (lead) SW(UPKIE_S_STEP) = (float)step_count;
+      if (lead && !ROLLOUT) SW(UPKIE_S_STEP) = (float)step_count;
     }
   }
 
@@ -799,6 +829,25 @@ next_step:
     steps_left -= 1;
     goto next_step;
   }
+  if (ROLLOUT) {  // the per-step words of the steps of this launch (above)
+    if (lead) {
+      if (reset_seen) {
+        SW(UPKIE_S_YAW) = 0.f;
+        SW(UPKIE_S_YAWVEL) = 0.f;
+        SW(UPKIE_S_MPC_V) = 0.f;
+        SW(UPKIE_S_SE2_X) = 0.f;
+        SW(UPKIE_S_SE2_Y) = 0.f;
+        SW(UPKIE_S_EPISODE) = episode_word;
+      }
+      SW(UPKIE_S_DONE) = done_word;
+      if (reset_seen || C.max_episode_steps > 0) SW(UPKIE_S_ELAPSED) = elapsed_word;
+      if (any_noise && step_seen) SW(UPKIE_S_STEP) = (float)step_count;
+    }
+    if (step_seen) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) SWI(UPKIE_S_TORQUE + k, 3 * leg, leg3_off) = tau_stepped[k];
+    }
+  }
   if (lead) {
     SW(UPKIE_S_POS) = s.pos.x; SW(UPKIE_S_POS + 1) = s.pos.y; SW(UPKIE_S_POS + 2) = s.pos.z;
     SW(UPKIE_S_QUAT) = s.qw; SW(UPKIE_S_QUAT + 1) = s.qx; SW(UPKIE_S_QUAT + 2) = s.qy; SW(UPKIE_S_QUAT + 3) = s.qz;
@@ -808,12 +857,12 @@ next_step:
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    SW(UPKIE_S_Q + 3 * leg + k) = s.q[k];
-    SW(UPKIE_S_QD + 3 * leg + k) = s.qd[k];
+    SWI(UPKIE_S_Q + k, 3 * leg, leg3_off) = s.q[k];
+    SWI(UPKIE_S_QD + k, 3 * leg, leg3_off) = s.qd[k];
   }
   if (MODE != MODE_SERVOS) {
-    SW(UPKIE_S_LEGREF + 2 * leg) = legref[0];
-    SW(UPKIE_S_LEGREF + 2 * leg + 1) = legref[1];
+    SWI(UPKIE_S_LEGREF, 2 * leg, leg2_off) = legref[0];
+    SWI(UPKIE_S_LEGREF + 1, 2 * leg, leg2_off) = legref[1];
   }
 
   if (MODE == MODE_RESET) {
@@ -832,7 +881,7 @@ next_step:
     for (int k = 0; k < 3; ++k) {
       o[5 * k + 0] = s.q[k];
       o[5 * k + 1] = s.qd[k];
-      o[5 * k + 2] = (do_reset ? SW(UPKIE_S_TORQUE + 3 * leg + k) : tau[k]) + PL.measurement_noise[k] * pick(leg, zm[k], zm[3 + k]);
+      o[5 * k + 2] = (do_reset ? SWI(UPKIE_S_TORQUE + k, 3 * leg, leg3_off) : tau[k]) + PL.measurement_noise[k] * pick(leg, zm[k], zm[3 + k]);
       o[5 * k + 3] = 42.0f;
       o[5 * k + 4] = 18.0f;
     }
@@ -874,4 +923,5 @@ next_step:
   terminated[e] = fallen ? 1 : 0;
   truncated[e] = timeout ? 1 : 0;
 #undef SW
+#undef SWI
 }

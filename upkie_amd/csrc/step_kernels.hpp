@@ -616,6 +616,7 @@ struct NoServoPolicy {};
 template <int MODE>
 using ServoPolicyArg = std::conditional_t<MODE == MODE_SERVOS, UpkieServoPolicy, NoServoPolicy>;
 
+#include "state_words.hpp"
 #include "pair.hpp"
 #include "octet.hpp"
 

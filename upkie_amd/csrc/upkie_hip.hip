@@ -479,7 +479,7 @@ static const int kOctetBatchServos = 8192;
 // observers exist in the one- and two-lane kernels only.
 static int mapped_lanes(const UpkieSim* sim) {
   // the eight-lane kernel restates neither the in-step spine observers nor forces on leg links, and addresses the state
-  // with 32-bit byte offsets (octet.hpp, OctStateWord): a forced eight-lane mapping yields to the others beyond 2^32 bytes
+  // with 32-bit byte offsets (state_words.hpp): a forced eight-lane mapping yields to the others beyond 2^32 bytes
   bool eight = !sim->spine_state && (unsigned long long)sim->config.num_envs * UPKIE_STATE_WORDS * sizeof(float) < (1ull << 32);
   if (sim->ext_force)
     for (int i = 0; i < sim->config.ext.count; ++i) eight = eight && sim->config.ext.body[i] == 0;

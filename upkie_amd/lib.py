@@ -22,6 +22,8 @@ SOURCES = [
     os.path.join(_HERE, "csrc", "step_kernels.hpp"),
     os.path.join(_HERE, "csrc", "host_setup.hpp"),
     os.path.join(_HERE, "csrc", "dynamics.hpp"),
+    os.path.join(_HERE, "csrc", "bullet_like.hpp"),
+    os.path.join(_HERE, "csrc", "state_words.hpp"),
     os.path.join(_HERE, "csrc", "mpc.hpp"),
     os.path.join(_HERE, "csrc", "pair.hpp"),
     os.path.join(_HERE, "csrc", "octet.hpp"),
