@@ -115,6 +115,21 @@ def test_product_never_imports_the_oracle():
                 assert "upkie_oracle" not in text, name
 
 
+def test_the_build_watches_every_source_of_the_library():
+    """`lib.build()` rebuilds when a source is newer than the library: every file under csrc/ (and the header) must be
+    on its list, or an edited kernel header ships with a stale `.so`."""
+    import os
+
+    from upkie_amd import lib
+
+    csrc = os.path.join(os.path.dirname(os.path.abspath(lib.__file__)), "csrc")
+    watched = {os.path.realpath(s) for s in lib.SOURCES}
+    for name in os.listdir(csrc):
+        if name.endswith((".hpp", ".hip", ".h")):
+            assert os.path.realpath(os.path.join(csrc, name)) in watched, name
+    assert any(s.endswith("upkie_hip.h") for s in watched)
+
+
 def test_observer_filter_error_is_reported_without_a_gpu(library):
     """low_pass_filter throws FilterError when cutoff <= 2 dt
     (upkie/cpp/utils/low_pass_filter.h:22-30): the C-ABI reports it at create,
