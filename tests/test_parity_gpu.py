@@ -849,6 +849,37 @@ def test_time_limit_in_the_kernel_matches_oracle(lanes, monkeypatch):
     assert sim.state_numpy()[abi.S_ELAPSED].max() <= 7
 
 
+@pytest.mark.parametrize("B", [16381, 8])
+def test_rollout_in_one_launch_equals_step_by_step_at_the_ends_of_the_eight_lane_range(B):
+    """The multi-step kernel reaches the state through a buffer descriptor with 32-bit offsets (state_words.hpp): the
+    same bit-for-bit equality with chained launches at the largest batch the eight-lane mapping serves (two wavefronts
+    per SIMD, a ragged last wavefront) and at a single wavefront's worth of envs."""
+    from upkie_amd.sim import BatchedSim
+
+    K = 16
+    cfg = randomized_config(B, seed=3, autoreset=True)
+    cfg.fall_pitch = 0.11
+    cfg.max_episode_steps = 11
+    a, b = BatchedSim(cfg), BatchedSim(cfg)
+    assert a.lanes_per_env == 8
+    o6 = a.reset()
+    b.reset()
+    prev = torch.zeros((B, 8), device=a.device)
+    prev[:, :4] = o6[:, [1, 0, 4, 3]]
+    for window in range(2):
+        fused = torch.zeros((K, B, 8), device=a.device)
+        a.rollout_pendulum_records(prev, fused)
+        chained = torch.zeros((K, B, 8), device=a.device)
+        p = prev
+        for k in range(K):
+            b.step_pendulum_records(p, chained[k])
+            p = chained[k]
+        assert torch.equal(fused, chained), window
+        assert torch.equal(a.state[:48], b.state[:48]), window
+        prev = fused[K - 1].clone()
+    assert float(fused[:, :, 5].sum()) + float(fused[:, :, 6].sum()) > 0  # falls / time limits happened
+
+
 @pytest.mark.parametrize("lanes", ["8", "2", "1"])
 def test_rollout_in_one_launch_equals_step_by_step(lanes, monkeypatch):
     """upkie_sim_step_pendulum_agent_rollout: K fused-agent steps in one launch
