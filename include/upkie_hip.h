@@ -687,6 +687,17 @@ int upkie_sim_attach_observers(UpkieSim* sim, const UpkieObserverConfig* config,
 int upkie_observers_step(UpkieObservers* observers, float* state, const UpkieObserverInput* in,
                          const UpkieObserverOutput* out, void* stream);
 
+/* A linear policy in one launch, for the loop `obs, ... = env.step(policy(obs))`
+ * that the reference leaves to the agent (README.md:60-67: action = clamp(gains
+ * . obs)): act[n][a] = clamp(sum_d obs[n][d] weights[d][a] + bias[a], -clip,
+ * clip) for n < num_envs; bias may be NULL, clip <= 0 disables the clamp. obs
+ * [num_envs][obs_dim], weights [obs_dim][act_dim], act [num_envs][act_dim],
+ * contiguous fp32 device buffers. (As torch ops the same policy is two or
+ * three launches of 2-5 us each behind a 14.5 us step.) */
+int upkie_linear_policy(int32_t num_envs, int32_t obs_dim, int32_t act_dim, const float* obs,
+                        const float* weights, const float* bias, double clip, float* act,
+                        void* stream);
+
 /* ---- Rollout consumer (BASELINE.json configs[3]) ---
  * Generalized advantage estimation over a rollout resident in HBM: rewards,
  * values, episode_starts, advantages, returns are [num_steps][num_envs]

@@ -1087,6 +1087,30 @@ extern "C" int upkie_observers_step(UpkieObservers* h, float* state, const Upkie
 }
 
 // ============================================================ rollout consumer
+extern "C" int upkie_linear_policy(int32_t num_envs, int32_t obs_dim, int32_t act_dim, const float* obs, const float* weights, const float* bias,
+                                  double clip, float* act, void* stream) {
+  if (num_envs <= 0 || obs_dim <= 0 || act_dim <= 0) {
+    g_create_error = "num_envs, obs_dim and act_dim must be positive";
+    return UPKIE_ERR_INVALID_ARGUMENT;
+  }
+  if (!obs || !weights || !act) {
+    g_create_error = "null argument";
+    return UPKIE_ERR_INVALID_ARGUMENT;
+  }
+  if (upkie_hip_device_count() <= 0) {
+    g_create_error = "no HIP device visible";
+    return UPKIE_ERR_NO_DEVICE;
+  }
+  hipLaunchKernelGGL(upkie::linear_policy_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, num_envs, obs_dim,
+                     act_dim, obs, weights, bias, (float)clip, act);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    g_create_error = hipGetErrorString(err);
+    return UPKIE_ERR_HIP;
+  }
+  return UPKIE_OK;
+}
+
 extern "C" int upkie_rollout_gae(int32_t num_steps, int32_t num_envs, const float* rewards, const float* values,
                                  const uint8_t* episode_starts, const float* last_values, const uint8_t* last_dones, double gamma,
                                  double gae_lambda, float* advantages, float* returns, void* stream) {

@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = (
     "upkie_observers_reset",
     "upkie_observers_step",
     "upkie_rollout_gae",
+    "upkie_linear_policy",
 )
 
 
@@ -302,6 +303,9 @@ def load() -> C.CDLL:
         C.POINTER(abi.UpkieObserverOutput),
         vp,
     ]
+    if hasattr(lib, "upkie_linear_policy"):  # (round 4; older builds loaded for A/B runs lack it)
+        lib.upkie_linear_policy.restype = C.c_int
+        lib.upkie_linear_policy.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_double, vp, vp]
     lib.upkie_rollout_gae.restype = C.c_int
     lib.upkie_rollout_gae.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
     _lib = lib
