@@ -29,3 +29,14 @@ if __name__ == "__main__":
         restarts = int(env.sim.state[abi.S_EPISODE].sum()) - B  # falls + time limits, counted by the kernel
         print(f"{B} envs x {n} steps in {dt:.3f} s = {B * n / dt:.3e} env-steps/s "
               f"({restarts} episodes restarted, mean |pitch| {float(obs[:, 0].abs().mean()):.4f} rad)")
+        # the same policy as ONE launch between two steps instead of torch's two (upkie_amd.policies.LinearPolicy)
+        from upkie_amd.policies import LinearPolicy
+
+        policy = LinearPolicy(gain, clip=0.9)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            obs, reward, terminated, truncated, info = env.step(policy(obs))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"with the policy as one launch: {B * n / dt:.3e} env-steps/s")
