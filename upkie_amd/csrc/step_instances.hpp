@@ -86,6 +86,7 @@ UPKIE_OCTET(MODE_RESET, false, false)
 UPKIE_OCTET(MODE_PENDULUM, false, false)
 UPKIE_OCTET(MODE_PENDULUM, true, false)
 UPKIE_OCTET(MODE_PENDULUM, false, true)
+UPKIE_OCTET(MODE_PENDULUM, true, true)
 UPKIE_OCTET(MODE_PENDULUM_AGENT, false, false)
 UPKIE_OCTET(MODE_PENDULUM_AGENT, true, false)
 #endif
@@ -95,6 +96,7 @@ UPKIE_OCTET(MODE_PENDULUM_ROLLOUT, true, false)
 UPKIE_OCTET(MODE_GYROPOD, false, false)
 UPKIE_OCTET(MODE_GYROPOD, true, false)
 UPKIE_OCTET(MODE_GYROPOD, false, true)
+UPKIE_OCTET(MODE_GYROPOD, true, true)
 #endif
 #if UPKIE_IN_GROUP(7)
 UPKIE_OCTET(MODE_SERVOS, false, false)

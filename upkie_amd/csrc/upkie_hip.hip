@@ -628,8 +628,11 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
 #define UPKIE_LAUNCH_OCTET(R)                                                                    \
   do {                                                                                           \
     bool launched = false;                                                                       \
+    if constexpr (octet_resets_in_place(MODE) && octet_has_default_scalars(MODE)) {              \
+      if (same_step_in_kernel && sim->default_scalars) { UPKIE_LAUNCH_OCTET_D(R, true, true); launched = true; } \
+    }                                                                                            \
     if constexpr (octet_resets_in_place(MODE)) {                                                 \
-      if (same_step_in_kernel) { UPKIE_LAUNCH_OCTET_D(R, false, true); launched = true; }        \
+      if (!launched && same_step_in_kernel) { UPKIE_LAUNCH_OCTET_D(R, false, true); launched = true; } \
     }                                                                                            \
     if constexpr (octet_has_default_scalars(MODE)) {                                             \
       if (!launched && sim->default_scalars) { UPKIE_LAUNCH_OCTET_D(R, true, false); launched = true; } \
