@@ -228,7 +228,8 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
            "note": "the loop is GPU bound: step kernel (step_kernel_octet<MODE_PENDULUM>, ~14.5 us) + the policy's two kernels (rocblas gemv ~4.5 us, clamp ~2 us) "
                    "+ three dependent-launch gaps; rocprofv3 per-kernel times under profiles/ (r04_vec_env_kernel_stats.csv). A hipGraph of the same "
                    "three kernels replays SLOWER than the eager loop on ROCm 7.2 (per-node latency), see graphed_us_per_env_step; "
-                   "python_loop_one_launch_policy_us_per_env_step: the same policy as ONE kernel (upkie_amd.policies.LinearPolicy) in the same Python loop"}
+                   "python_loop_one_launch_policy_us_per_env_step: the same policy as ONE kernel (upkie_amd.policies.LinearPolicy) in the same Python loop; "
+                   "python_loop_policy_in_the_step_launch_us_per_env_step: env.step_linear_policy(gains, clip), the policy evaluated by the step kernel itself"}
     for mode in ("next_step", "same_step"):
         init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
         env = envs_mod.make("Upkie-HIP-Pendulum-Vec", num_envs=envs, frequency=200.0, autoreset_mode=mode, init_state=init, seed=seed)
@@ -261,12 +262,18 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
             state["obs"] = env.step(one_launch(state["obs"]))[0]
 
         wall_one, _ = _timed_loop(eager_one_launch, steps, warmup)
+        # ... and with the policy inside the step's launch (`UpkiePendulumVecEnv.step_linear_policy`: NEXT_STEP / disabled autoreset)
+        wall_in = None
+        if mode != "same_step":
+            host_gains = [10.0, 1.0, 0.0, 0.1]
+            wall_in, _ = _timed_loop(lambda k: env.step_linear_policy(host_gains, clip=0.99), steps, warmup)
         episodes = int(env.sim.state[40].sum().item())
         out[mode] = {
             "python_loop_us_per_env_step": wall / steps * 1e6, "python_loop_device_us": device_ms * 1e3 / steps,
             "policy_ops_alone_us": wall_policy / steps * 1e6, "host_time_to_issue_one_iteration_us": host_issue / steps * 1e6,
             "graphed_us_per_env_step": wall_graph / steps * 1e6,
             "python_loop_one_launch_policy_us_per_env_step": wall_one / steps * 1e6,
+            "python_loop_policy_in_the_step_launch_us_per_env_step": None if wall_in is None else wall_in / steps * 1e6,
             "env_steps_per_s_python_loop": envs * steps / wall, "env_steps_per_s_graphed": envs * steps / wall_graph,
             "episodes": episodes, "lanes_per_env": env.sim.lanes_per_env,
         }

@@ -45,6 +45,32 @@ def test_readme_agent_loop_single_env():
     assert abs(observation[0]) < 0.1
 
 
+def test_vec_step_linear_policy_is_step_of_the_linear_policy():
+    """`UpkiePendulumVecEnv.step_linear_policy`: README.md:60-67's agent evaluated inside the step's launch gives what
+    `step(clamp(gains . obs))` gives, gains and clip handed over when they change."""
+    import torch
+
+    from upkie_amd.exceptions import UpkieException
+
+    a = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=5, frequency=200.0, autoreset_mode="next_step", seed=2, **KW)
+    b = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=5, frequency=200.0, autoreset_mode="next_step", seed=2, **KW)
+    oa, _ = a.reset(seed=2)
+    ob, _ = b.reset(seed=2)
+    gains = torch.tensor([8.0, 1.5, 0.0, 0.2])
+    for k in range(30):
+        g = gains if k < 15 else 0.5 * gains  # (a change of gains reaches the library)
+        oa, ra, ta, ua, _ = a.step_linear_policy(g, clip=0.7)
+        ob, rb, tb, ub, _ = b.step(((ob.double() @ g.double()).clamp(-0.7, 0.7)).float().unsqueeze(1))
+        assert torch.allclose(oa.double(), ob.double(), atol=1e-6) and torch.equal(ta, tb) and torch.equal(ua, ub)
+    assert list(a.sim.config.agent_gains) == pytest.approx([4.0, 0.75, 0.0, 0.1]) and a.sim.config.agent_clip == pytest.approx(0.7)
+    same = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=2, frequency=200.0, autoreset_mode="same_step", **KW)
+    same.reset(seed=0)
+    with pytest.raises(UpkieException):
+        same.step_linear_policy()
+    with pytest.raises(UpkieException):
+        a.step_linear_policy([1.0, 2.0])
+
+
 def test_pendulum_observation_layout_and_dtypes():
     """tests/envs/test_upkie_pendulum.py:34-40,75-87."""
     env = envs.make("Upkie-HIP-Pendulum", frequency=100.0, **KW)

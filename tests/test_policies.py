@@ -51,3 +51,27 @@ def test_linear_policy_drives_the_public_loop_like_the_torch_policy():
         outs.append(obs.clone())
         env.close()
     assert torch.allclose(outs[0], outs[1], atol=1e-4)  # (the two sums associate differently: last-bit differences in the action)
+
+
+@pytest.mark.gpu
+def test_step_linear_policy_on_the_device_matches_step_of_the_torch_policy():
+    """`UpkiePendulumVecEnv.step_linear_policy` (the policy inside the step's launch, `upkie_sim_step_pendulum_agent`)
+    against `step(policy(obs))` on the device, through falls and NEXT_STEP autoresets."""
+    import upkie_amd.envs as envs
+
+    gains = [10.0, 1.0, 0.0, 0.1]
+    a = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=512, frequency=200.0, autoreset_mode="next_step", seed=11, fall_pitch=0.2)
+    b = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=512, frequency=200.0, autoreset_mode="next_step", seed=11, fall_pitch=0.2)
+    oa, _ = a.reset(seed=11)
+    ob, _ = b.reset(seed=11)
+    g = torch.tensor(gains, device=a.device)
+    ends = 0
+    for _ in range(200):
+        oa, ra, ta, ua, ia = a.step_linear_policy(gains, clip=0.99)
+        ob, rb, tb, ub, ib = b.step((ob @ g).clamp(-0.99, 0.99).unsqueeze(1))
+        assert torch.equal(ta, tb)
+        ends += int(ta.sum())
+        assert torch.allclose(oa, ob, atol=2e-4)
+    assert a.step_linear_policy()[0] is oa  # the env's persistent observation buffer, as `step` returns it
+    a.close()
+    b.close()

@@ -413,6 +413,8 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
         return self.sim.obs4, self._info()  # (the buffer step() rewrites: `obs = env.step(policy(obs))[0]` stays on one tensor)
 
     _stepper_kind, _action_words = "pendulum", 1
+    _linear_policy_gains = None
+    _agent_stepper = None
 
     def step(self, action):
         out = self._fast_step(action, (self.num_envs,))
@@ -420,6 +422,53 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
             return out
         obs, reward, terminated, truncated = self.sim.step_pendulum(action)  # (converted / reshaped to [B] there)
         return self._finish_step(obs, reward, terminated, truncated)
+
+    def step_linear_policy(self, gains=None, clip: Optional[float] = None):
+        """``env.step(clamp(gains . obs, -clip, clip))`` with the policy evaluated INSIDE the step's launch, on the
+        observation the previous step (or `reset`) left in the env's observation buffer: the README agent
+        (README.md:60-67, examples/pybullet/pd_balancing.py) costs no launch of its own between two steps
+        (`upkie_sim_step_pendulum_agent`). ``gains`` (four numbers, over [pitch, position, pitch rate, velocity]) and
+        ``clip`` default to what the config holds (README's [10, 1, 0, 0.1], 0.99); they are handed to the library
+        when they change (a NEW ``gains`` object is compared value by value; the same object as in the previous call
+        is taken as unchanged). Same return value as `step`. NEXT_STEP or disabled autoreset (a SAME_STEP env steps with
+        `step(policy(obs))`)."""
+        if self.autoreset_mode == "same_step" or not hasattr(self.sim, "step_pendulum_agent"):
+            raise UpkieException("step_linear_policy runs under NEXT_STEP or disabled autoreset; use step(policy(obs))")
+        cfg, changed = self.sim.config, False
+        if gains is not None and gains is not self._linear_policy_gains:  # (the same object as last time: nothing to convert)
+            self._linear_policy_gains = gains
+            # (a device tensor is read back here: a synchronisation -- hand over host numbers, or the same object every step)
+            gains = [float(g) for g in (gains.tolist() if hasattr(gains, "tolist") else gains)]
+            if len(gains) != 4:
+                raise UpkieException("a linear policy over the Pendulum observation has four gains")
+            if list(cfg.agent_gains) != gains:
+                cfg.agent_gains[:] = gains
+                changed = True
+        if clip is not None and float(cfg.agent_clip) != float(clip):
+            cfg.agent_clip = float(clip)
+            changed = True
+        if changed:
+            self.sim.push_config()
+        agent_step = self._agent_stepper
+        if agent_step is None and hasattr(self.sim, "stepper"):
+            try:
+                agent_step = self._agent_stepper = self.sim.stepper("pendulum_agent")  # one ctypes call on cached addresses
+            except KeyError:  # (test doubles without this kind)
+                agent_step = self._agent_stepper = False
+        if agent_step:
+            agent_step()
+            sim = self.sim
+            obs, reward, terminated, truncated = sim.obs4, sim.reward, sim.terminated, sim.truncated
+        else:
+            obs, reward, terminated, truncated = self.sim.step_pendulum_agent()
+        out = self._step_out
+        if out is None or self._observers is not None or self.eager_spine_observation:
+            out = self._finish_step(obs, reward, terminated, truncated)
+            if self._observers is None and not self.eager_spine_observation:
+                self._step_out = out  # (the same persistent buffers `step` returns)
+            return out
+        self._spine._fresh = False
+        return out
 
 
 class UpkieGyropodVecEnv(UpkieVecEnv):

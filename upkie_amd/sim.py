@@ -250,11 +250,23 @@ class BatchedSim:
         if kind == "servos" and self.obs_servos is None:
             self.obs_servos = torch.zeros((self.num_envs, 6, 5), dtype=torch.float32, device=self.device)
         fn, obs = {"pendulum": (self._lib.upkie_sim_step_pendulum, self.obs4), "gyropod": (self._lib.upkie_sim_step_gyropod, self.obs6),
-                   "servos": (self._lib.upkie_sim_step_servos, self.obs_servos)}[kind]
+                   "servos": (self._lib.upkie_sim_step_servos, self.obs_servos),
+                   "pendulum_agent": (self._lib.upkie_sim_step_pendulum_agent, self.obs4)}[kind]
         handle, index, raw_stream = self._handle, self._device_index, _raw_stream
         state, obs_p, rew, term, trunc = self.state.data_ptr(), obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr()
         current_device = torch.cuda.current_device
         slow = self._launch
+        if kind == "pendulum_agent":  # (no action buffer: the linear agent acts on the observation held in `obs4`)
+
+            def step_agent() -> None:
+                if raw_stream is not None and current_device() == index:
+                    status = fn(handle, state, obs_p, rew, term, trunc, raw_stream(index))
+                    if status < 0:
+                        lib.check(status, handle)
+                else:
+                    slow(fn, state, obs_p, rew, term, trunc)
+
+            return step_agent
 
         def step(action_address: int) -> None:
             if raw_stream is not None and current_device() == index:
