@@ -51,6 +51,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     for mode in ("next_step", "same_step"):
         assert api[mode]["python_loop_us_per_env_step"] > 0 and api[mode]["lanes_per_env"] == 8 and api[mode]["episodes"] > 0
         assert 0 < api[mode]["python_loop_one_launch_policy_us_per_env_step"] < api[mode]["python_loop_us_per_env_step"]  # the same policy as ONE kernel
+    assert 0 < api["next_step"]["python_loop_policy_in_the_step_launch_us_per_env_step"] < api["next_step"]["python_loop_us_per_env_step"]  # env.step_linear_policy
+    assert api["same_step"]["python_loop_policy_in_the_step_launch_us_per_env_step"] is None
     assert sec["c3"]["envs"] == 16384 and "resampled every 400 steps" in sec["c3"]["config"] and sec["c3"]["algorithmic_bytes_per_env_step"] == 554
     for key in ("c5_share_torque_law", "c5_share_velocity_law"):
         c5 = sec[key]
