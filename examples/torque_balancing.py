@@ -29,7 +29,7 @@ if __name__ == "__main__":
             else:
                 policy = abi.velocity_balancing_policy(float(model.wheel_radius), fall_pitch=1.0, left_sign=float(model.left_sign))
             for _ in range(n):
-                env.sim.step_servos_policy(policy)  # the policy inside the step's launch (one launch per step up to 8192 envs)
+                env.step_servo_policy(policy)  # the policy inside the step's launch (one launch per step up to 8192 envs)
             torch.cuda.synchronize()
             falls = int(env.sim.state[abi.S_EPISODE].sum()) - B
             pitch = 2.0 * env.sim.state[abi.S_QUAT + 2]

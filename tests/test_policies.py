@@ -75,3 +75,24 @@ def test_step_linear_policy_on_the_device_matches_step_of_the_torch_policy():
     assert a.step_linear_policy()[0] is oa  # the env's persistent observation buffer, as `step` returns it
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_step_servo_policy_of_the_vector_env_is_the_library_call():
+    """`UpkieServosVecEnv.step_servo_policy(policy)` returns the env's step outputs for `upkie_sim_step_servos_policy`."""
+    import upkie_amd.envs as envs
+    from upkie_amd import abi
+
+    a = envs.make("Upkie-HIP-Servos-Vec", num_envs=256, frequency=200.0, autoreset_mode="next_step", seed=4)
+    b = envs.make("Upkie-HIP-Servos-Vec", num_envs=256, frequency=200.0, autoreset_mode="next_step", seed=4)
+    a.reset(seed=4)
+    b.reset(seed=4)
+    m = a.model.struct
+    policy = abi.velocity_balancing_policy(float(m.wheel_radius), 1.0, float(m.left_sign))
+    for _ in range(60):
+        obs, reward, terminated, truncated, info = a.step_servo_policy(policy)
+        want = b.sim.step_servos_policy(policy)
+        assert torch.equal(obs, want[0]) and obs.shape == (256, 6, 5) and terminated.dtype == torch.bool
+    assert "spine_observation" in info
+    a.close()
+    b.close()

@@ -596,6 +596,24 @@ class UpkieServosVecEnv(UpkieVecEnv):
         obs, reward, terminated, truncated = self.sim.step_servos(act)
         return self._finish_step(obs, reward, terminated, truncated)
 
+    def step_servo_policy(self, policy: "abi.UpkieServoPolicy"):
+        """`step` with the action computed on the device by a servo-level law (`abi.torque_balancing_policy`:
+        examples/pybullet/torque_balancing.py:15-37; `abi.velocity_balancing_policy`: the README balancer through the
+        wheels' velocity loop) from the state the step starts from -- inside the step's own launch on eight lanes per
+        env (`upkie_sim_step_servos_policy`), a launch in front of it otherwise. The law flags robots that fell past
+        its `fall_pitch` for the NEXT_STEP autoreset. Same return value as `step`; NEXT_STEP or disabled autoreset."""
+        if self.autoreset_mode == "same_step" or not hasattr(self.sim, "step_servos_policy"):
+            raise UpkieException("step_servo_policy runs under NEXT_STEP or disabled autoreset; use step(action)")
+        obs, reward, terminated, truncated = self.sim.step_servos_policy(policy)
+        out = self._step_out
+        if out is None or out[0] is not obs or self._observers is not None or self.eager_spine_observation:
+            out = self._finish_step(obs, reward, terminated, truncated)
+            if self._observers is None and not self.eager_spine_observation:
+                self._step_out = out
+            return out
+        self._spine._fresh = False
+        return out
+
 
 class UpkieBaseVelocityVecEnv(UpkieGyropodVecEnv):
     """Batched ``UpkieBaseVelocity``: action [linear velocity, yaw velocity]
