@@ -7,7 +7,6 @@ of 2-5 us each (rocBLAS's gemv for a four-column matrix: 4.9 us) behind a
 14.5 us step; `LinearPolicy` is one launch (`upkie_linear_policy`,
 csrc/rollout.hpp) writing into a persistent action buffer."""
 
-import ctypes as C
 from typing import Optional
 
 import torch
