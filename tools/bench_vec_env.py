@@ -2,7 +2,9 @@
 `env.step(policy(obs))` from a Python loop, policy evaluated with torch ops on
 the device; the same recorded into a hipGraph (`GraphedEnvStep`, 1 / 4 / 16
 steps per graph launch).
-Usage: python tools/bench_vec_env.py [B] [steps] [modes, e.g. next_step,same_step] [--no-graph] [--limit]"""
+With --policy one_launch the same policy is ONE kernel (`upkie_amd.policies.LinearPolicy`), with --policy in_launch it is
+evaluated inside the step's launch (`env.step_linear_policy`, NEXT_STEP only).
+Usage: python tools/bench_vec_env.py [B] [steps] [modes, e.g. next_step,same_step] [--no-graph] [--limit] [--policy torch|one_launch|in_launch]"""
 import os
 import sys
 import time
@@ -16,6 +18,11 @@ from upkie_amd.graphs import GraphedEnvStep
 from upkie_amd.utils.robot_state import RobotState
 from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 
+policy_kind = "torch"
+if "--policy" in sys.argv:
+    i = sys.argv.index("--policy")
+    policy_kind = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if len(args) > 0 else 4096
 steps = int(args[1]) if len(args) > 1 else 2000
@@ -39,14 +46,22 @@ for mode in modes:
         obs, _ = env.reset(seed=0)
         gain = torch.tensor([10.0, 1.0, 0.0, 0.1], device=env.device)
         policy = lambda o: (o @ gain).clamp(-0.99, 0.99).unsqueeze(1)
+        if policy_kind == "one_launch":
+            from upkie_amd.policies import LinearPolicy
+
+            policy = LinearPolicy(gain, clip=0.99)
         state = {"obs": obs}
+        host_gains = [10.0, 1.0, 0.0, 0.1]
 
         def eager():
-            state["obs"], reward, terminated, truncated, info = env.step(policy(state["obs"]))
+            if policy_kind == "in_launch":
+                state["obs"], reward, terminated, truncated, info = env.step_linear_policy(host_gains, clip=0.99)
+            else:
+                state["obs"], reward, terminated, truncated, info = env.step(policy(state["obs"]))
 
         timed(eager, 200)
         us = timed(eager, steps)
-        print(f"B={B} autoreset={mode} max_episode_steps={limit}: {us:.1f} us per env.step() from Python, {B / us * 1e6:.3e} env-steps/s")
+        print(f"B={B} autoreset={mode} max_episode_steps={limit} policy={policy_kind}: {us:.1f} us per env.step() from Python, {B / us * 1e6:.3e} env-steps/s")
         # where the loop's time goes: the policy's kernels alone (same ops, result dropped), and the host side alone
         us_policy = timed(lambda: policy(state["obs"]), steps)
         t0 = time.perf_counter()
@@ -55,7 +70,7 @@ for mode in modes:
         host = (time.perf_counter() - t0) / steps * 1e6  # (no synchronisation: what the interpreter needs to ISSUE a step)
         torch.cuda.synchronize()
         print(f"    policy ops alone {us_policy:.1f} us per call; host time to issue one loop iteration {host:.1f} us")
-        if "--no-graph" not in sys.argv:
+        if "--no-graph" not in sys.argv and policy_kind != "in_launch":
             for unroll in (1, 4, 16):
                 graphed = GraphedEnvStep(env, policy, unroll=unroll)
                 timed(graphed, 50)

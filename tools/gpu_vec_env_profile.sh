@@ -10,3 +10,10 @@ timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vec 
 echo "rocprofv3 rc $?"
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -8 "$f" | cut -c1-220
+# the same loop with the policy as ONE launch / inside the step's launch
+for P in one_launch in_launch; do
+  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$P -o vec -- python $R/tools/bench_vec_env.py 4096 1500 next_step --no-graph --policy $P > $OUT/run_$P.log 2>&1
+  echo "$P rocprofv3 rc $?"; grep "us per env.step" $OUT/run_$P.log
+  f=$(find $OUT/$P -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -5 "$f" | cut -c1-220
+  find $OUT/$P -name "*kernel_trace.csv" -delete
+done
