@@ -529,6 +529,7 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
     elapsed, device_ms, resets = timed(args.steps)
     if rank != 0:
         env.shutdown()
+        base.close()  # (the handle is `base`'s: ShardedVecEnv leaves a caller's handle open)
         return
     step_us = device_ms * 1e3 / args.steps
     achieved = C5_BYTES_PER_ENV_STEP * B / (step_us * 1e-6) / 1e9
@@ -562,6 +563,7 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
         line["steady_state"] = {"value": counted_envs * STEADY_STEPS / s_elapsed, "unit": "env-steps/s", "steps": STEADY_STEPS, "warmup": STEADY_WARMUP,
                                 "ms_per_step": s_elapsed / STEADY_STEPS * 1e3, "avg_launch_us": s_ms * 1e3 / STEADY_STEPS, "autoresets_in_timed_region": s_resets}
     env.shutdown()
+    base.close()
     print(json.dumps(line), file=json_out or sys.stdout, flush=True)
 
 

@@ -185,6 +185,53 @@ typedef struct UpkieSim UpkieSim;
  * or a negative status. */
 int upkie_hip_device_count(void);
 
+/* sizeof() of a public struct AS THIS BUILD OF THE LIBRARY SEES IT (-1 for an
+ * unknown id): a binding written against one version of this header checks it
+ * against its own mirror of the struct before the first call -- the config
+ * structs grow at the tail from release to release (UpkieMpcConfig gained
+ * admm_relaxation), and a library loaded from elsewhere (UPKIE_HIP_LIBRARY)
+ * that reads a longer struct than the caller wrote reads garbage silently.
+ * upkie_amd/lib.py refuses to load a library whose sizes differ from
+ * upkie_amd/abi.py's. No counterpart in the reference (its backends are
+ * Python objects). */
+enum UpkieStructId {
+  UPKIE_STRUCT_MODEL = 0,
+  UPKIE_STRUCT_SIM_CONFIG = 1,
+  UPKIE_STRUCT_EXTERNAL_FORCES = 2,
+  UPKIE_STRUCT_SERVO_POLICY = 3,
+  UPKIE_STRUCT_SPINE_OBSERVATION = 4,
+  UPKIE_STRUCT_MPC_CONFIG = 5,
+  UPKIE_STRUCT_OBSERVER_CONFIG = 6,
+  UPKIE_STRUCT_OBSERVER_INPUT = 7,
+  UPKIE_STRUCT_OBSERVER_OUTPUT = 8,
+  UPKIE_STRUCT_COUNT = 9
+};
+int64_t upkie_hip_struct_bytes(int which);
+
+/* Streams and hipGraphs. Every launching entry point takes the caller's
+ * hipStream_t (`stream`, NULL = the default stream) and only enqueues work on
+ * it. The eight-lane step kernels read the handle's limits and configuration
+ * from a block in device memory, refreshed by a small store kernel enqueued in
+ * front of the step whenever a setting changed (upkie_sim_set_config, ...) or
+ * the launching stream did. What that allows:
+ *   - eager launches: the handle keeps TWO such blocks and alternates, so the
+ *     steps of one handle may be in flight on up to two streams at a time
+ *     (a third stream must wait for the first to drain: the handle does not
+ *     track completion);
+ *   - launches recorded into a hipGraph (stream capture, e.g.
+ *     torch.cuda.graph / upkie_amd.graphs): each CAPTURE gets a block of its
+ *     own and records its own store of the settings as they are at capture
+ *     time, so several graphs of one handle -- recorded at different settings,
+ *     replayed in any order, mixed with eager launches -- each replay with the
+ *     settings they were recorded with. The blocks are allocated with the
+ *     handle (a capture cannot allocate): at most UPKIE_MAX_GRAPH_CAPTURES
+ *     captures per handle, the next one is refused with UPKIE_ERR_HIP and a
+ *     message; blocks are not recycled when a graph is destroyed (the library
+ *     cannot see that). A setting changed AFTER a capture does not reach that
+ *     graph's replays: re-capture.
+ * The one- and two-lane kernels take their settings by value: no limit. */
+#define UPKIE_MAX_GRAPH_CAPTURES 8
+
 /* Create a simulation handle on the current HIP device: validates the model
  * (all joint axes must be lateral, i.e. +-y of the base frame, as on every
  * Upkie; UPKIE_ERR_UNSUPPORTED_MODEL otherwise) and uploads constants.

@@ -182,3 +182,30 @@ def test_observer_config_from_spine_config():
     assert cfg.upper_leg_torque_threshold == 7.0 and cfg.wheel_cutoff_period == 0.1 and cfg.touchdown_inertia == 0.005
     assert list(cfg.signed_radius) == [0.06, -0.06]
     assert list(cfg.rotation_base_to_imu) == [0, -1, 0, 1, 0, 0, 0, 0, 1]
+
+
+def test_library_reports_the_struct_sizes_the_bindings_were_written_for(library):
+    """`upkie_hip_struct_bytes` (what lib.load() checks before any call): every public struct, as the built library
+    sees it, is as long as its ctypes mirror; an unknown id answers -1; a mismatching library is refused."""
+    assert set(abi.STRUCT_IDS) == set(range(len(abi.STRUCT_IDS)))
+    for which, cls in abi.STRUCT_IDS.items():
+        assert library.upkie_hip_struct_bytes(which) == C.sizeof(cls), cls.__name__
+    assert library.upkie_hip_struct_bytes(len(abi.STRUCT_IDS)) == -1
+
+    class Shorter:  # a library built from an older header: UpkieMpcConfig without its last field
+        def upkie_hip_struct_bytes(self, which):
+            return C.sizeof(abi.STRUCT_IDS[which]) - (8 if abi.STRUCT_IDS[which] is abi.UpkieMpcConfig else 0)
+
+    fake = Shorter()
+    fake.upkie_hip_struct_bytes = type("F", (), {"__call__": lambda self, which: Shorter.upkie_hip_struct_bytes(fake, which), "restype": None, "argtypes": None})()
+    with pytest.raises(Exception, match="UpkieMpcConfig"):
+        lib._check_struct_sizes(fake)
+
+
+def test_header_documents_streams_and_graph_captures():
+    """The limits of the handle's settings blocks are part of the interface: stated in the header,
+    the constant mirrored in abi.py."""
+    with open(HEADER) as f:
+        text = f.read()
+    assert "Streams and hipGraphs" in text and "UPKIE_MAX_GRAPH_CAPTURES" in text
+    assert int(re.search(r"#define UPKIE_MAX_GRAPH_CAPTURES (\d+)", text).group(1)) == abi.MAX_GRAPH_CAPTURES

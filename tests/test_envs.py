@@ -595,3 +595,69 @@ def test_same_step_info_computes_final_obs_flags_on_access():
             assert bool((info["final_obs"][done][:, 0].abs() > 0.15).all()) and bool((obs[done][:, 0].abs() <= 0.31).all())
     assert seen > 0
     env.close()
+
+
+def test_same_step_info_keeps_its_mask_under_every_dictionary_protocol():
+    """wrappers and rollout code copy or iterate `info`; `dict(info)`, `{**info}`, iteration, `len`,
+    `copy.copy` and pickling must all carry the gymnasium SAME_STEP mask `_final_obs` -- once, not twice -- and a
+    snapshot taken at step t must keep step t's flags when the env steps on."""
+    import copy
+    import pickle
+
+    init = RobotState(randomization=RobotStateRandomization(pitch=0.3))
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=6, frequency=200.0, fall_pitch=0.15, init_state=init, autoreset_mode="same_step", **KW)
+    env.reset(seed=1)
+    act = torch.zeros(6, 1)
+    snapshots = []
+    for _ in range(40):
+        _, _, terminated, truncated, info = env.step(act)
+        done = terminated | truncated
+        keys = list(info)
+        assert keys.count("_final_obs") == 1 and len(info) == len(keys) == len(info.keys()) == len(info.items()) == len(info.values())
+        for plain in (dict(info), {**info}, copy.copy(info), info.copy(), dict(info.items())):
+            assert type(plain) is dict and set(plain) == set(keys)
+            assert torch.equal(plain["_final_obs"], done) and plain["final_obs"] is info["final_obs"]
+        assert list(copy.copy(info)).count("_final_obs") == 1
+        restored = pickle.loads(pickle.dumps({k: v for k, v in dict(info).items() if k != "spine_observation"}))
+        assert torch.equal(restored["_final_obs"], done)
+        assert "_final_obs" in repr(info)
+        snapshots.append((dict(info)["_final_obs"], done.clone()))
+    assert any(bool(d.any()) for _, d in snapshots)
+    for kept, was in snapshots:  # a snapshot holds a tensor of its own: later steps did not rewrite it
+        assert torch.equal(kept, was)
+    env.close()
+
+
+def test_step_linear_policy_sees_gains_mutated_in_place_and_forgets_rejected_ones():
+    """host gains are compared by value on every call; an object that failed validation is not remembered."""
+    env = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=4, frequency=200.0, **KW)
+    env.reset(seed=0)
+    gains = [10.0, 1.0, 0.0, 0.1]
+    env.step_linear_policy(gains, 0.99)
+    assert list(env.sim.config.agent_gains) == gains
+    gains[0] = 12.0  # the same list object, mutated: a sweep over gains
+    env.step_linear_policy(gains, 0.99)
+    assert list(env.sim.config.agent_gains) == [12.0, 1.0, 0.0, 0.1]
+    bad = [1.0, 2.0, 3.0]
+    for _ in range(2):  # rejected the second time as well
+        with pytest.raises(Exception, match="four gains"):
+            env.step_linear_policy(bad, 0.99)
+    assert list(env.sim.config.agent_gains) == [12.0, 1.0, 0.0, 0.1]
+    env.close()
+
+
+def test_sharded_env_leaves_a_callers_handle_open():
+    """`ShardedVecEnv(sim=base.sim).shutdown()` must not close the handle `base` owns."""
+    from upkie_amd.distributed import ShardedVecEnv
+
+    base = envs.make("Upkie-HIP-Pendulum-Vec", num_envs=4, frequency=200.0, **KW)
+    closed = []
+    original = base.sim.close
+    base.sim.close = lambda: (closed.append(1), original())
+    env = ShardedVecEnv("pendulum", None, "cpu", rank=0, world_size=1, chunk=4, collectives=False, sim=base.sim)
+    env.reset()
+    env.step(torch.zeros(4, 1))
+    env.shutdown()
+    assert closed == []
+    base.close()
+    assert closed == [1]

@@ -280,6 +280,20 @@ class UpkieObserverOutput(C.Structure):
     ]
 
 
+# enum UpkieStructId -> the mirror of that struct here (`upkie_hip_struct_bytes`: lib.load() compares sizes)
+STRUCT_IDS = {
+    0: UpkieModel,
+    1: UpkieSimConfig,
+    2: UpkieExternalForces,
+    3: UpkieServoPolicy,
+    4: UpkieSpineObservation,
+    5: UpkieMpcConfig,
+    6: UpkieObserverConfig,
+    7: UpkieObserverInput,
+    8: UpkieObserverOutput,
+}
+MAX_GRAPH_CAPTURES = 8  # UPKIE_MAX_GRAPH_CAPTURES
+
 # observer memory words (enum UpkieObserverStateWord)
 O_WHEEL = 0
 O_UPPER_LEG_TORQUE = 10

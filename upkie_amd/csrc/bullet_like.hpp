@@ -34,7 +34,7 @@ enum {
   BL_POINTS = 4,
   BL_POINT_WORDS = 8,  // point in the wheel frame (3), on the plane in world coordinates (3), applied normal impulse, live
   BL_MANIFOLD_WORDS = 2 * BL_POINTS * BL_POINT_WORDS,  // == UPKIE_CONTACT_MANIFOLD_WORDS
-  BL_ROWS = 2 * BL_POINTS * 3 + 4
+  BL_ROWS = 2 * BL_POINTS * 3 + UPKIE_NJ  // every cached point's three rows + a limit row for EVERY joint (a model may bound its wheel joints too)
 };
 
 struct BlRow {

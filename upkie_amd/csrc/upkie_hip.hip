@@ -294,11 +294,15 @@ struct UpkieSim {
   // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
   // stream when a setting changed or the stream did (a launch still running on the other stream keeps its block:
   // up to two streams may step one handle at a time)
-  DevParams* d_params[3] = {nullptr, nullptr, nullptr};  // [2]: the block of launches recorded into a hipGraph
+  // (include/upkie_hip.h, "Streams and hipGraphs": every hipGraph capture gets a block of its OWN -- UPKIE_MAX_GRAPH_CAPTURES
+  // of them, allocated with the handle since a capture cannot allocate -- so that graphs recorded at different settings
+  // replay each with its own, in any order, beside eager launches)
+  DevParams* d_params[2 + UPKIE_MAX_GRAPH_CAPTURES] = {};  // [0], [1]: eager launches; [2 + c]: the launches recorded into the handle's c-th hipGraph capture
   int params_slot = 0;
   unsigned long long params_version = 1, eager_version = 0, capture_version = 0;  // settings changed / last uploaded
   void* params_stream = nullptr;
-  unsigned long long capture_id = ~0ull;  // the hipGraph capture whose launches read d_params[2]
+  unsigned long long capture_id = ~0ull;  // the hipGraph capture being recorded
+  int captures = 0;                       // blocks handed to captures so far
   std::string error;
 };
 
@@ -313,6 +317,21 @@ static int fail(UpkieSim* sim, int status, const std::string& msg) {
 static int check_hip(UpkieSim* sim, hipError_t err, const char* what) {
   if (err == hipSuccess) return UPKIE_OK;
   return fail(sim, UPKIE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+extern "C" int64_t upkie_hip_struct_bytes(int which) {
+  switch (which) {
+    case UPKIE_STRUCT_MODEL: return (int64_t)sizeof(UpkieModel);
+    case UPKIE_STRUCT_SIM_CONFIG: return (int64_t)sizeof(UpkieSimConfig);
+    case UPKIE_STRUCT_EXTERNAL_FORCES: return (int64_t)sizeof(UpkieExternalForces);
+    case UPKIE_STRUCT_SERVO_POLICY: return (int64_t)sizeof(UpkieServoPolicy);
+    case UPKIE_STRUCT_SPINE_OBSERVATION: return (int64_t)sizeof(UpkieSpineObservation);
+    case UPKIE_STRUCT_MPC_CONFIG: return (int64_t)sizeof(UpkieMpcConfig);
+    case UPKIE_STRUCT_OBSERVER_CONFIG: return (int64_t)sizeof(UpkieObserverConfig);
+    case UPKIE_STRUCT_OBSERVER_INPUT: return (int64_t)sizeof(UpkieObserverInput);
+    case UPKIE_STRUCT_OBSERVER_OUTPUT: return (int64_t)sizeof(UpkieObserverOutput);
+    default: return -1;
+  }
 }
 
 extern "C" int upkie_hip_device_count(void) {
@@ -351,11 +370,11 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
   sim->default_scalars = oct_model_has_default_scalars(sim->model) && !(generic && generic[0] == '1');
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
-  for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
+  for (int i = 0; i < 2 + UPKIE_MAX_GRAPH_CAPTURES && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
   if (err != hipSuccess) {
     std::string msg = std::string("hipMalloc/hipMemcpy(model): ") + hipGetErrorString(err);
     if (sim->d_model) (void)hipFree(sim->d_model);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 2 + UPKIE_MAX_GRAPH_CAPTURES; ++i)
       if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
     delete sim;
     return fail(nullptr, UPKIE_ERR_HIP, msg);
@@ -379,7 +398,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
-  for (int i = 0; sim && i < 3; ++i)
+  for (int i = 0; sim && i < 2 + UPKIE_MAX_GRAPH_CAPTURES; ++i)
     if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
   delete sim;
   return UPKIE_OK;
@@ -542,18 +561,23 @@ static const DevParams* current_params(UpkieSim* sim, void* stream) {
   unsigned long long capture_id = 0;
   if (hipStreamGetCaptureInfo((hipStream_t)stream, &capturing, &capture_id) == hipSuccess && capturing == hipStreamCaptureStatusActive) {
     // a launch recorded into a hipGraph: the graph carries its own store of the settings as they are now into a block
-    // no eager launch uses (a replay must neither see later settings nor leave stale ones behind for eager launches);
-    // one store per capture, again when a setting changes while capturing
-    if (sim->capture_version != sim->params_version || sim->capture_id != capture_id) {
+    // no eager launch and no OTHER graph uses (a replay must neither see later settings nor leave stale ones behind
+    // for eager launches or for another graph's replay): one block and one store per capture, the store again when a
+    // setting changes while capturing
+    const bool new_capture = sim->capture_id != capture_id;
+    if (new_capture && sim->captures >= UPKIE_MAX_GRAPH_CAPTURES) return nullptr;  // (launch_step reports it)
+    if (sim->capture_version != sim->params_version || new_capture) {
       DevParams block;
       block.limits = sim->limits;
       block.config = sim->config;
-      hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, sim->d_params[2]);
+      DevParams* target = sim->d_params[2 + (new_capture ? sim->captures : sim->captures - 1)];
+      hipLaunchKernelGGL(store_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, block, target);
       if (hipGetLastError() != hipSuccess) return nullptr;  // (nothing recorded: the step launch behind it is refused too)
+      if (new_capture) sim->captures += 1;
       sim->capture_id = capture_id;
       sim->capture_version = sim->params_version;
     }
-    return sim->d_params[2];
+    return sim->d_params[2 + sim->captures - 1];
   }
   if (sim->eager_version != sim->params_version || stream != sim->params_stream) {
     sim->params_slot ^= 1;
@@ -647,7 +671,10 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   }
   // the eight-lane kernels read limits and config from this handle's device block
   const DevParams* params = lanes == 8 ? current_params(sim, stream) : nullptr;
-  if (lanes == 8 && !params) return fail(sim, UPKIE_ERR_HIP, "could not refresh the device block of the handle's settings");
+  if (lanes == 8 && !params)
+    return fail(sim, UPKIE_ERR_HIP, sim->captures >= UPKIE_MAX_GRAPH_CAPTURES
+                                        ? "this handle's steps have been recorded into UPKIE_MAX_GRAPH_CAPTURES hipGraph captures already (include/upkie_hip.h, Streams and hipGraphs)"
+                                        : "could not refresh the device block of the handle's settings");
   if (lanes == 8 && sim->manifold) {
     if constexpr (MODE != MODE_SERVOS) {
       if (rnd) UPKIE_LAUNCH_OCTET_BULLET(true); else UPKIE_LAUNCH_OCTET_BULLET(false);

@@ -400,6 +400,7 @@ class ShardedVecEnv:
         # `sim`: an existing handle (e.g. the `.sim` of a vector env built with this rank's `env_id_offset`, its
         # inertia randomisation and joint properties already applied) instead of a new one from `config`
         # (sim_factory / mpc_factory: test doubles only; the product always builds a BatchedSim / BatchedMpc)
+        self._owns_sim = sim is None  # (a caller's handle stays the caller's to close: `shutdown` leaves it open)
         if sim is not None:
             self.sim = sim
         else:
@@ -568,6 +569,7 @@ class ShardedVecEnv:
         self.gather.flush()
         if self.mpc is not None:
             self.mpc.close()
-        self.sim.close()
+        if self._owns_sim:
+            self.sim.close()
         if self._collectives and dist.is_initialized():
             dist.destroy_process_group()

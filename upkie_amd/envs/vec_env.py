@@ -57,28 +57,59 @@ class _SameStepInfo(dict):
     """`info` of a SAME_STEP env whose step call completes the autoreset
     itself: one persistent dictionary (``spine_observation``, ``final_obs``);
     ``_final_obs`` = terminated | truncated is computed when it is read (a
-    device op per step that most steps of a rollout never look at)."""
+    device op per step that most steps of a rollout never look at).
+
+    The key behaves like a stored one under every dictionary protocol --
+    iteration, ``len``, ``keys / values / items``, ``dict(info)``, ``{**info}``,
+    ``copy.copy``, ``pickle`` (the last four give a plain ``dict`` holding the
+    mask as a tensor of its own). Like ``obs``, ``terminated`` and
+    ``truncated`` -- persistent buffers the next step rewrites in place -- the
+    mask read from THIS object is that of the latest step: a rollout that keeps
+    the info of step t takes ``dict(info)`` (a snapshot of the mask) at step t."""
+
+    _LAZY = "_final_obs"
 
     def __init__(self, terminated, truncated, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._flags = (terminated, truncated)
 
     def __missing__(self, key):
-        if key == "_final_obs":
+        if key == self._LAZY:
             return self._flags[0] | self._flags[1]
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == "_final_obs" or super().__contains__(key)
+        return key == self._LAZY or super().__contains__(key)
+
+    def __iter__(self):  # (overriding it also takes dict(info) / {**info} off CPython's exact-dict fast path: they go through keys())
+        yield from super().__iter__()
+        yield self._LAZY
+
+    def __len__(self):
+        return super().__len__() + 1
 
     def get(self, key, default=None):
         return self[key] if key in self else default
 
     def keys(self):
-        return list(super().keys()) + ["_final_obs"]
+        return list(self)
+
+    def values(self):
+        return [self[k] for k in self]
 
     def items(self):
-        return [(k, self[k]) for k in self.keys()]
+        return [(k, self[k]) for k in self]
+
+    def copy(self):
+        return dict(self.items())
+
+    __copy__ = copy
+
+    def __reduce__(self):
+        return (dict, (self.items(),))
+
+    def __repr__(self):
+        return repr(dict(self.items()))
 
 
 class UpkieVecEnv:
@@ -429,26 +460,31 @@ class UpkiePendulumVecEnv(UpkieVecEnv):
         (README.md:60-67, examples/pybullet/pd_balancing.py) costs no launch of its own between two steps
         (`upkie_sim_step_pendulum_agent`). ``gains`` (four numbers, over [pitch, position, pitch rate, velocity]) and
         ``clip`` default to what the config holds (README's [10, 1, 0, 0.1], 0.99); they are handed to the library
-        when they change (a NEW ``gains`` object is compared value by value; the same object as in the previous call
-        is taken as unchanged). Same return value as `step`. NEXT_STEP or disabled autoreset (a SAME_STEP env steps with
-        `step(policy(obs))`)."""
+        when they change: host sequences (lists, tuples, numpy arrays) are compared VALUE BY VALUE on every call
+        (four floats; mutating the same list in place is seen); a DEVICE tensor is read back -- a synchronisation --
+        only when it is a different object from the previous call's (the identity shortcut: write new gains into a new
+        tensor, or hand over host numbers). Same return value as `step`. NEXT_STEP or disabled autoreset (a SAME_STEP
+        env steps with `step(policy(obs))`)."""
         if self.autoreset_mode == "same_step" or not hasattr(self.sim, "step_pendulum_agent"):
             raise UpkieException("step_linear_policy runs under NEXT_STEP or disabled autoreset; use step(policy(obs))")
         cfg, changed = self.sim.config, False
-        if gains is not None and gains is not self._linear_policy_gains:  # (the same object as last time: nothing to convert)
-            self._linear_policy_gains = gains
-            # (a device tensor is read back here: a synchronisation -- hand over host numbers, or the same object every step)
-            gains = [float(g) for g in (gains.tolist() if hasattr(gains, "tolist") else gains)]
-            if len(gains) != 4:
+        on_device = isinstance(gains, torch.Tensor) and gains.device.type != "cpu"
+        if gains is not None and not (on_device and gains is self._linear_policy_gains):
+            values = [float(g) for g in (gains.tolist() if hasattr(gains, "tolist") else gains)]
+            if len(values) != 4:
                 raise UpkieException("a linear policy over the Pendulum observation has four gains")
-            if list(cfg.agent_gains) != gains:
-                cfg.agent_gains[:] = gains
+            if list(cfg.agent_gains) != values:
+                cfg.agent_gains[:] = values
                 changed = True
+            remember = gains if on_device else None
+        else:
+            remember = self._linear_policy_gains
         if clip is not None and float(cfg.agent_clip) != float(clip):
             cfg.agent_clip = float(clip)
             changed = True
         if changed:
             self.sim.push_config()
+        self._linear_policy_gains = remember  # (only once the gains were validated and handed over)
         agent_step = self._agent_stepper
         if agent_step is None and hasattr(self.sim, "stepper"):
             try:
@@ -581,9 +617,12 @@ class UpkieServosVecEnv(UpkieVecEnv):
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask: Optional[torch.Tensor] = None):
         self._reset_sim(seed, mask)
         obs = self._servo_obs()
-        if getattr(self.sim, "obs_servos", None) is not None and self.sim.obs_servos.shape == obs.shape:
-            self.sim.obs_servos.copy_(obs)
-            obs = self.sim.obs_servos  # (the buffer step() rewrites)
+        if hasattr(self.sim, "obs_servos"):
+            if self.sim.obs_servos is None:  # (allocated here, not by the first step: `env.observation` holds the reset observation from the start)
+                self.sim.obs_servos = torch.zeros((self.num_envs, 6, 5), dtype=torch.float32, device=self.device)
+            if self.sim.obs_servos.shape == obs.shape:
+                self.sim.obs_servos.copy_(obs)
+                obs = self.sim.obs_servos  # (the buffer step() rewrites)
         return obs, self._info()
 
     _stepper_kind, _action_words = "servos", 36

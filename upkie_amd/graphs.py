@@ -58,17 +58,44 @@ class GraphedEnvStep:
     `policy` maps the env's observation buffer (`env.observation`: rewritten in
     place by every step) to an action tensor with PyTorch ops only (no
     synchronisation, no data-dependent shapes: the rules of graph capture).
-    The outputs are the env's persistent buffers, as with `env.step`."""
+    The outputs are the env's persistent buffers, as with `env.step`.
 
-    def __init__(self, env, policy: Callable, unroll: int = 1, warmup: int = 3):
+    Capture runs `warmup` real steps and records `unroll` more (torch needs
+    the kernels warmed up off the capture; a captured launch is recorded, not
+    executed). So that the loop above does start from the `reset()` state,
+    the simulation state, the observation buffer and the step's output flags
+    are SNAPSHOT before the warm-up and RESTORED after the capture: the first
+    `step()` call steps the state `reset()` left, with the random streams of a
+    first step (`restore_state=False` keeps the advanced state). Call `reset()`
+    before constructing this object: the policy's first evaluation reads the
+    env's observation buffer."""
+
+    def __init__(self, env, policy: Callable, unroll: int = 1, warmup: int = 3, restore_state: bool = True):
         self.env = env
         obs = env.observation
+        if obs is None or getattr(env, "_stepper_kind", None) is None:
+            raise UpkieRuntimeError(
+                f"{type(env).__name__} has no persistent observation buffer / single-call step to capture "
+                "(UpkieBaseVelocityVecEnv composes its step: capture its loop with GraphedLoop instead)"
+            )
         holder = {}
 
         def body():
             holder["out"] = env.step(policy(obs))
 
+        sim = env.sim
+        keep = [t for t in (getattr(sim, n, None) for n in ("state", "reward", "terminated", "truncated", "contact_manifold", "observer_state")) if t is not None]
+        keep.append(obs)
+        if getattr(env, "_final_obs", None) is not None:
+            keep.append(env._final_obs)
+        saved = [t.clone() for t in keep] if restore_state else []
         self._loop = GraphedLoop(body, unroll=unroll, warmup=warmup, device=env.device)
+        if restore_state:
+            final_obs = getattr(env, "_final_obs", None)  # (a SAME_STEP env arms this buffer on its first step: not among the saved ones then)
+            for t, s in zip(keep, saved):
+                t.copy_(s)
+            if final_obs is not None and all(final_obs is not t for t in keep):
+                final_obs.copy_(obs)
         self.out = holder["out"]
         self.steps_per_call = self._loop.unroll
 

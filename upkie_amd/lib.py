@@ -38,6 +38,7 @@ INSTANCES_SOURCE = SOURCES[1]
 ## Every symbol `include/upkie_hip.h` declares.
 EXPORTED_SYMBOLS = (
     "upkie_hip_device_count",
+    "upkie_hip_struct_bytes",
     "upkie_sim_create",
     "upkie_sim_destroy",
     "upkie_sim_set_config",
@@ -170,6 +171,29 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
 _lib = None
 
 
+def _check_struct_sizes(lib) -> None:
+    """The structs this package writes (`abi.py`) must be the structs the library reads: a build of another version of
+    the header, loaded through UPKIE_HIP_LIBRARY for an A/B run, may have shorter or longer config structs (they grow
+    at the tail) and would read past what ctypes hands over. `upkie_hip_struct_bytes` (round 5) tells; a library
+    without it is accepted only as such an override and only with a warning."""
+    if not hasattr(lib, "upkie_hip_struct_bytes"):
+        if os.environ.get("UPKIE_HIP_LIBRARY"):
+            import warnings
+
+            warnings.warn(f"{LIB_PATH} predates upkie_hip_struct_bytes: struct layouts not checked against upkie_amd/abi.py")
+            return
+        raise UpkieRuntimeError(f"{LIB_PATH} does not export upkie_hip_struct_bytes: rebuild it (`__graft_entry__.build()`)")
+    lib.upkie_hip_struct_bytes.restype = C.c_int64
+    lib.upkie_hip_struct_bytes.argtypes = [C.c_int]
+    for which, cls in abi.STRUCT_IDS.items():
+        theirs, ours = int(lib.upkie_hip_struct_bytes(which)), C.sizeof(cls)
+        if theirs != ours:
+            raise UpkieRuntimeError(
+                f"{LIB_PATH} was built from another version of include/upkie_hip.h: sizeof({cls.__name__}) is {theirs} B there, "
+                f"{ours} B in upkie_amd/abi.py; rebuild the library or point UPKIE_HIP_LIBRARY at a matching build"
+            )
+
+
 def load() -> C.CDLL:
     """Load the library (never falls back to anything else)."""
     global _lib
@@ -188,6 +212,7 @@ def load() -> C.CDLL:
 
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
+    _check_struct_sizes(lib)
     lib.upkie_hip_device_count.restype = C.c_int
     lib.upkie_sim_create.restype = C.c_int
     lib.upkie_sim_create.argtypes = [
