@@ -126,7 +126,8 @@ void spin_barrier_wait(void* b) { static_cast<SpinBarrier*>(b)->wait(); }
 // trunk_wrench: [6] (base frame, about the base origin) or null. Runs `substeps` substeps;
 // status[i] receives OCT_CONTACT / OCT_NO_CONTACT of substep i.
 static int run_octet(const UpkieModel* model, float* st, const float* tau, float h, const float* records, const float* trunk_wrench, int substeps,
-                     int* status, int limits_in_registers, float* bullet_applied /* [2]: Bullet-like contacts on these applied impulses, or null */) {
+                     int* status, int limits_in_registers, float* bullet_applied /* [2]: Bullet-like contacts on these applied impulses, or null */,
+                     int* sweeps_out = nullptr /* [substeps]: sweeps the contact solve of each substep ran, or null */) {
   DevModel M;
   std::string why;
   if (!convert_model(model, &M, &why)) return -1;
@@ -139,6 +140,7 @@ static int run_octet(const UpkieModel* model, float* st, const float* tau, float
   float slots[8];
   OctPhys result[8];
   int lane_status[8][64];
+  int lane_sweeps[64];
   std::thread threads[8];
   if (substeps > 64) substeps = 64;
   for (int t = 0; t < 8; ++t) {
@@ -159,10 +161,12 @@ static int run_octet(const UpkieModel* model, float* st, const float* tau, float
       if (bullet_applied) s.bl_applied = bullet_applied[leg];
       LimitWorkspace workspace;  // (the kernel keeps one per env in LDS; here every lane's thread has its own)
       for (int i = 0; i < substeps; ++i) {
-        const int r = bullet_applied        ? physics_substep_octet<false, false, true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
-                      : limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace)
-                                            : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace);
+        OctRare rare{0, 0};
+        const int r = bullet_applied        ? physics_substep_octet<false, false, true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace, &rare)
+                      : limits_in_registers ? physics_substep_octet<true>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace, &rare)
+                                            : physics_substep_octet<false>(M, Lm, L, s, own_tau, h, trunk_wrench, &workspace, &rare);
         lane_status[t][i] = r;
+        if (t == 1) lane_sweeps[i] = rare.sweeps;
       }
       result[t] = s;
       g_oct_lane = nullptr;
@@ -192,6 +196,8 @@ static int run_octet(const UpkieModel* model, float* st, const float* tau, float
     st[UPKIE_S_QD + 3 * leg + l - 1] = result[t].qd;
   }
   for (int i = 0; i < substeps; ++i) status[i] = lane_status[0][i];
+  if (sweeps_out)
+    for (int i = 0; i < substeps; ++i) sweeps_out[i] = lane_sweeps[i];
   if (bullet_applied) {
     bullet_applied[0] = result[1].bl_applied;  // (a lane of the left quad, of the right quad)
     bullet_applied[1] = result[5].bl_applied;
@@ -208,4 +214,8 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
 extern "C" int harness_substep_octet_bullet_like(const UpkieModel* model, float* st, const float* tau, float h, int substeps, int* status, float* applied) {
   return run_octet(model, st, tau, h, nullptr, nullptr, substeps, status, 0, applied);
 }
+// Test hook: the eight-lane Bullet-like solves that follow record the system they sweep and every sweep's impulses into `probe`
+// (BulletLikeProbe: system [50], change [64], lam [64][6], sweeps); null: off.
+extern "C" void harness_bullet_like_probe(void* probe) { g_bullet_like_probe = static_cast<BulletLikeProbe*>(probe); }
+extern "C" int harness_bullet_like_probe_bytes(void) { return (int)sizeof(BulletLikeProbe); }
 #endif  // host pass only

@@ -1,0 +1,44 @@
+"""Why the Bullet-like contact model keeps its FIXED 50 sweeps: how early the sweeps of the
+eight-lane solve could stop, measured on the host build of the device arithmetic (no GPU needed).
+
+    python tools/bullet_like_sweeps.py > profiles/r05_bullet_like_sweeps.txt
+"""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests.test_bullet_like_on_host import bullet_like_sweep_statistics  # noqa: E402
+from tests.test_device_arithmetic_on_host import harness as harness_fixture  # noqa: E402
+
+
+def main():
+    harness = harness_fixture.__wrapped__()
+    rows, cap = bullet_like_sweep_statistics(harness, trials=16, substeps=300)
+    exact, cycle, resolution, loose, deviation = rows.T
+    rng = np.random.default_rng(0)
+    print(f"eight-lane Bullet-like solve (octet.hpp, oct_bullet_like_solve), host build of the device arithmetic; {len(rows)} solves of rolling robots")
+    print(f"(legs held by their servos, random wheel torques within +-0.8 N m), {cap} sweeps each; 'never' = not within the {cap} sweeps\n")
+    print(f"{'leave the loop when a sweep ...':58s} {'median':>7s} {'mean':>6s} {'p90':>5s} {'never':>6s}   {'a wavefront of 8 envs (max), mean':>34s}")
+    for name, counts in (("changed no bit of any impulse (exact fixed point)", exact),
+                         ("... or reproduced the impulses of 1-8 sweeps earlier", cycle),
+                         ("moved no impulse by > 2.4e-7 of the largest (fp32)", resolution),
+                         ("moved no impulse by > 1e-5 of the largest", loose)):
+        c = np.minimum(counts, cap)
+        wave = np.mean([c[rng.integers(0, len(c), 8)].max() for _ in range(4000)])
+        print(f"{name:58s} {np.median(c):7.1f} {c.mean():6.1f} {np.quantile(c, 0.9):5.0f} {np.mean(counts > cap):6.2f}   {wave:34.1f}")
+    print(f"\nimpulses at the fp32-resolution stop against those after all {cap} sweeps, relative to the largest: median {np.median(deviation):.1e}, "
+          f"p99 {np.quantile(deviation, 0.99):.1e}, max {deviation.max():.1e}")
+    print("\nReading: fp32 settles into 1-2 ulp limit cycles rather than exact fixed points (9 solves in 10 never repeat a bit pattern")
+    print("exactly within 50 sweeps), and the two tires' friction rows -- nearly parallel, no friction CFM in this model -- converge")
+    print("slowly (about 0.74^sweep) in close to half of the solves: those are still moving at fp32 resolution after 50 sweeps. One")
+    print("env alone would save a quarter of its sweeps at fp32 resolution; a wavefront sweeps its eight envs in lockstep and leaves")
+    print("with the slowest: 0.1 sweep of 50 saved. The test itself costs 8 instructions per sweep (6 compares, a ballot, a branch)")
+    print("against ~95: an early exit is a net LOSS on this workload, whatever the criterion. The sweeps stay fixed.")
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,20 @@ enum {
   BL_ROWS = 2 * BL_POINTS * 3 + UPKIE_NJ  // every cached point's three rows + a limit row for EVERY joint (a model may bound its wheel joints too)
 };
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host tests only (tests/test_bullet_like_on_host.py): the eight-lane solve (octet.hpp) records here the system it
+// sweeps -- W [36], right-hand sides [6], warm start [6], tires on the floor [2] -- and, per sweep, the largest change of
+// an impulse. That is the measurement behind "the FIXED sweeps stay fixed" (profiles/r05_bullet_like_sweeps.txt): leaving
+// the loop at the exact fixed point, at a short limit cycle or at fp32 resolution does not shorten a wavefront's loop.
+struct BulletLikeProbe {
+  float system[50];
+  float change[64];  // [it]: max |lam after sweep it - before|
+  float lam[64][6];  // impulses after sweep it
+  int sweeps;
+};
+inline BulletLikeProbe* g_bullet_like_probe = nullptr;
+#endif
+
 struct BlRow {
   float Jb[6];   // base part of the row (base frame: linear 0-2, angular 3-5)
   float Jl[3];   // joint part: the three joints of leg `leg` (the other leg's entries are zero)

@@ -928,8 +928,25 @@ UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const Ba
   lam[3] = on[1] ? 0.85f * (left ? other_applied : applied) : 0.f;
 #pragma unroll
   for (int r = 0; r < 6; ++r) inv_diag[r] = 1.f / W[r][r];
+#if !defined(__HIP_DEVICE_COMPILE__)
+  BulletLikeProbe* const probe = L.l == 1 && L.leg == 0 ? g_bullet_like_probe : nullptr;
+  if (probe) {
+    float* out = probe->system;
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) *out++ = W[a][b];
+    for (int a = 0; a < 6; ++a) *out++ = rhs6[a];
+    for (int a = 0; a < 6; ++a) *out++ = lam[a];
+    *out++ = on[0] ? 1.f : 0.f;
+    *out++ = on[1] ? 1.f : 0.f;
+    probe->sweeps = 0;
+  }
+#endif
   const float mu = M.friction_mu;
   for (int it = 0; it < M.pgs_iterations; ++it) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    float before[6];
+    for (int a = 0; a < 6; ++a) before[a] = lam[a];
+#endif
 #pragma unroll
     for (int w = 0; w < 2; ++w) {  // the normal rows (their CFM sits on the diagonal of the gathered system)
       const int r = 3 * w;
@@ -958,6 +975,17 @@ UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const Ba
       lam[r1] = on[w] ? x1 : 0.f;
       lam[r2] = on[w] ? x2 : 0.f;
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (probe && it < 64) {
+      float change = 0.f;
+      for (int a = 0; a < 6; ++a) {
+        change = fmaxf(change, fabsf(lam[a] - before[a]));
+        probe->lam[it][a] = lam[a];
+      }
+      probe->change[it] = change;
+      probe->sweeps = it + 1;
+    }
+#endif
   }
   applied = left ? lam[0] : lam[3];
   // back to the default basis: lam = Q' lam'
