@@ -163,13 +163,15 @@ def _timed_loop(step, steps: int, warmup: int):
     return time.perf_counter() - t0, start.elapsed_time(stop)
 
 
-def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0) -> dict:
+def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, horizon: int = 16) -> dict:
     """BASELINE.json configs[2] as SURVEY.md section 8d writes it (C3):
     UpkieBaseVelocity (the MPC balancer in front of UpkieGyropod,
     upkie_base_velocity.py:164-202), horizon N = 16 (T = 0.02 s), leg length
     0.58 m, a_max 10, v_max 3 (mpc_balancer.py:170-178), target
-    v* ~ U(-0.5, 0.5) per env RESAMPLED every 400 steps, yaw rate 0, 30 warm
-    started ADMM iterations on the fp32 MFMA, NEXT_STEP autoreset."""
+    v* ~ U(-0.5, 0.5) per env RESAMPLED every 400 steps, yaw rate 0, warm
+    started over-relaxed ADMM iterations on the fp32 MFMA (15 at N <= 16, 30
+    beyond), NEXT_STEP autoreset. `horizon` = 50: the reference's own default
+    (mpc_balancer.py:174), reported beside BASELINE's N = 16 as `n50`."""
     import numpy as np
     import torch
 
@@ -178,7 +180,7 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
 
     init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
-    env = envs_mod.make("Upkie-HIP-BaseVelocity-Vec", num_envs=envs, frequency=200.0, nb_timesteps=16, init_state=init, seed=seed)
+    env = envs_mod.make("Upkie-HIP-BaseVelocity-Vec", num_envs=envs, frequency=200.0, nb_timesteps=horizon, init_state=init, seed=seed)
     env.reset(seed=seed)
     gen = torch.Generator(device=env.device)
     gen.manual_seed(seed)
@@ -192,10 +194,11 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     wall, device_ms = _timed_loop(step, steps, warmup)
     us = wall / steps * 1e6
     out = {
-        "config": "C3: UpkieBaseVelocity + MPC balancer N = 16 (30 ADMM iterations, v_mfma_f32_16x16x4_f32), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
-                  + ("ONE launch per env.step() (upkie_sim_step_base_velocity_mpc: the balancer's QPs solved by the step's own wavefronts)" if env.fuse_mpc
-                     else "two launches per env.step() (upkie_mpc_step_env + upkie_sim_step_base_velocity)") + ", Python loop",
-        "launches_per_step": 1 if env.fuse_mpc else 2,
+        "config": f"C3: UpkieBaseVelocity + MPC balancer N = {horizon} ({int(env.mpc_balancer.config.admm_iterations)} over-relaxed ADMM iterations, v_mfma_f32_16x16x4_f32), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
+                  + ("ONE launch per env.step() (upkie_sim_step_base_velocity_mpc: the balancer's QPs solved by the step's own wavefronts)" if env.fuse_mpc and horizon <= 16
+                     else "two launches per env.step() (the balancer's kernel, then the step)") + ", Python loop",
+        "horizon": horizon,
+        "launches_per_step": 1 if env.fuse_mpc and horizon <= 16 else 2,
         "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
         "lanes_per_env": env.sim.lanes_per_env, "episodes": int(env.sim.state[40].sum().item()),
         "algorithmic_bytes_per_env_step": C3_BYTES_PER_ENV_STEP,
@@ -281,7 +284,8 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
     return out
 
 
-def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, census_steps: int = 400) -> dict:
+def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, census_steps: int = 400,
+                       contact_model: str = "default") -> dict:
     """One GPU's share of BASELINE.json configs[4] as SURVEY.md section 8d
     writes it (C5: 32768 envs over 8 GPUs): UpkieServos, inertia_variation 0.2
     per env and link (pybullet_backend.py:571-601), wheel friction 0.1
@@ -293,7 +297,9 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
     step's own lanes, fallen robots restart (NEXT_STEP): one launch per step.
     `law`: "torque" = examples/pybullet/torque_balancing.py:15-37 (8d's law:
     wheel torques +-10 x pitch, kd_scale 0), "velocity" = the README balancer
-    through the wheels' velocity loop."""
+    through the wheels' velocity loop. `contact_model`: "default" or
+    "bullet_like" (persistent manifolds, 50 fixed sweeps, cone friction: on
+    eight lanes per env for Servos steps too since round 5)."""
     import numpy as np
     import torch
 
@@ -305,7 +311,7 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
 
     init = RobotState(randomization=RobotStateRandomization(pitch=0.1, x=0.05, omega_y=0.1, linear_velocity=np.array([0.05, 0, 0])))
     env = envs_mod.make("Upkie-HIP-Servos-Vec", num_envs=envs, frequency=200.0, inertia_variation=0.2, init_state=init, autoreset_mode="next_step", seed=seed,
-                        joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
+                        contact_model=contact_model, joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
     env.reset(seed=seed)
     sim = env.sim
     push = torch.zeros((3, envs), dtype=torch.float32, device=env.device)
@@ -327,13 +333,15 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
     out = {
         "config": f"C5 share: UpkieServos, inertia_variation 0.2, wheel friction 0.1, torso push every {PUSH_PERIOD} steps (norm ~ U(0, {PUSH_MAX_NORM:g}) N, random heading, "
                   f"held {PUSH_HOLD} steps, drawn on device), servo-level law = " + ("examples/pybullet/torque_balancing.py (wheel torque +-10 x pitch, kd_scale 0)" if law == "torque"
-                  else "README balancer through the wheel velocity loop") + ", evaluated inside the step's launch, NEXT_STEP autoreset of fallen robots; one launch per step, Python loop",
+                  else "README balancer through the wheel velocity loop") + ", evaluated inside the step's launch, NEXT_STEP autoreset of fallen robots; one launch per step, Python loop"
+                  + ("" if contact_model == "default" else "; contact model: Bullet-like (upkie_sim_set_contact_manifold)"),
+        "contact_model": contact_model,
         "envs": envs, "steps": steps, "warmup": warmup, "us_per_step": us, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs / (us * 1e-6),
         "lanes_per_env": sim.lanes_per_env_of(abi.OBSERVATION_SERVOS), "episodes": int(sim.state[40].sum().item()),
         "algorithmic_bytes_per_env_step": C5_BYTES_PER_ENV_STEP,
         "hbm_frac": C5_BYTES_PER_ENV_STEP * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
     }
-    if census_steps and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8:  # (the census is counted by the eight-lane kernels)
+    if census_steps and contact_model == "default" and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8:  # (the census is counted by the eight-lane kernels)
         # rare-path census on its own steps afterwards (its atomics are not free), continuing the same schedule
         sim.enable_census()
         for k in range(warmup + steps, warmup + steps + census_steps):
@@ -778,10 +786,14 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
                 return {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
 
         line["vec_env_api"] = guarded(vec_env_api, B)
+        c3 = guarded(secondary_c3)
+        if isinstance(c3, dict):
+            c3["n50"] = guarded(secondary_c3, 16384, 600, 100, 0, 50)  # the reference's default horizon (missing #6)
         line["secondary"] = {
-            "c3": guarded(secondary_c3),
+            "c3": c3,
             "c5_share_torque_law": guarded(secondary_c5_share, "torque"),
             "c5_share_velocity_law": guarded(secondary_c5_share, "velocity"),
+            "c5_share_bullet_like": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 0, "bullet_like") for law in ("torque", "velocity")},
             "c2_bullet_like_contact_model": guarded(secondary_bullet_like, B),
         }
     print(json.dumps(line), file=json_out or sys.stdout, flush=True)

@@ -39,7 +39,7 @@ def test_c2_rollout_under_the_bullet_like_model_matches_the_oracle(lanes, monkey
     cfg = randomized_config(B, seed=3)
     sim = BatchedSim(cfg)
     sim.use_bullet_like_contacts()
-    assert sim.lanes_per_env == int(lanes) and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 1  # (Servos: joints may sit at their stops)
+    assert sim.lanes_per_env == int(lanes) and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == int(lanes)  # (round 5: Servos steps too)
     ref = O.Oracle(default_model(), cfg)
     ref.use_bullet_like_contacts()
     sim.reset()
@@ -103,18 +103,22 @@ def test_autoreset_clears_the_manifold_and_falls_match_the_oracle(lanes, monkeyp
     assert np.array_equal((mh[:, :, 7].sum(axis=1) != 0)[:, in_phase], (mo[:, :, 7].sum(axis=1) != 0)[:, in_phase])  # which tires hold a point
 
 
-def test_c5_share_under_the_bullet_like_model_matches_the_oracle():
+@pytest.mark.parametrize("lanes", ["8", "1"])
+def test_c5_share_under_the_bullet_like_model_matches_the_oracle(lanes, monkeypatch):
     """Servos env, per-link inertia randomisation, a push on the torso, wheel
     friction, the torque-balancing action: 1024 envs x 10 steps (the RAND
-    instantiations of the Bullet-like kernels)."""
+    instantiations of the Bullet-like kernels): the eight-lane Servos kernel
+    (round 5) and the one-lane kernels."""
     from oracle import oracle as O
 
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
     B = 1024
     cfg = randomized_config(B, seed=2)
     cfg.joint_friction[2] = cfg.joint_friction[5] = 0.1
     model = Model().struct
     sim = BatchedSim(cfg, model)
     sim.use_bullet_like_contacts()
+    assert sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == int(lanes)
     ref = O.Oracle(model, cfg)
     ref.use_bullet_like_contacts()
     sim.randomize_inertias(0.2)
@@ -152,9 +156,11 @@ def test_c5_share_under_the_bullet_like_model_matches_the_oracle():
 
 
 def test_both_bullet_like_kernels_continue_from_each_others_manifold():
-    """A handle steps Pendulum (eight lanes) and Servos (one lane: joints may sit at their stops) on ONE manifold: the
-    eight-lane kernel writes complete records (point in the wheel frame, on the plane, applied impulse, live), so the
-    one-lane kernel finds its cached points where it would have put them itself."""
+    """Two handles, one on the eight-lane kernels and one on the one-lane kernels all the way, step Pendulum and then
+    Servos on their manifolds: the eight-lane kernel writes complete records (point in the wheel frame, on the plane,
+    applied impulse, live) -- what the one-lane kernel keeps -- so either kernel finds its cached points where it would
+    have put them itself (a handle whose Servos batch outgrows the eight-lane mapping, or whose caller forces a mapping,
+    continues on the other kernel's manifold)."""
     B = 256
     import os
 

@@ -51,6 +51,84 @@ struct BulletLikeProbe {
 inline BulletLikeProbe* g_bullet_like_probe = nullptr;
 #endif
 
+// ---- the sweeps of the six-row case, shared by the one-lane and the eight-lane kernels (round 5) --------------------
+// Six rows: [normal, friction 1, friction 2] of the left tire's point, then of the right tire's. W: their Delassus
+// matrix (symmetric; only entries between live tires are read as couplings), rhs, lam: the warm start in / the impulses
+// out (0 on a tire that is off), cfm_n: constraint force mixing added to the two normal rows' diagonal, mu: friction
+// coefficient. A FIXED number of Gauss-Seidel sweeps in the published order -- left normal, right normal (which sees
+// the left one's new impulse), the left point's friction pair projected onto its cone, the right point's --, each
+// update x_r = lam_r + (rhs_r - sum_c W_rc lam_c - cfm lam_r) / (W_rr + cfm), restated with every row divided by its
+// diagonal ONCE: x_r = b_r - sum_{c != r} a_rc lam_c (five multiply-adds a row instead of six plus two instructions;
+// a tire that is off has zero rows: its impulses stay 0 without a select per update). The two rows a stage updates
+// from the same impulses -- a point's friction pair; the two normals up to the one term that couples them -- are
+// accumulated as PACKED fp32 pairs (v_pk_fma_f32: the broadcast of an impulse to both halves, and the swap inside the
+// pair's own 2 x 2 block, are the instruction's op_sel modifiers, no move). The projection onto the cone is the scale
+// min(mu lam_n / |x|, 1) (one v_rsq, no compare / select; |x| = 0 gives inf or NaN, which min() turns into 1).
+// About 36 vector instructions a sweep (the row-by-row form both kernels carried until round 4: ~85), the same update rule
+// and row order: the fp64 checker's `bullet_like_contacts` remains its twin.
+typedef float BlPair __attribute__((ext_vector_type(2)));
+UPKIE_HD BlPair bl_fma(BlPair a, BlPair b, BlPair c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  return BlPair{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
+#endif
+}
+UPKIE_HD BlPair bl_lo(BlPair v) { return __builtin_shufflevector(v, v, 0, 0); }
+UPKIE_HD BlPair bl_hi(BlPair v) { return __builtin_shufflevector(v, v, 1, 1); }
+UPKIE_HD BlPair bl_swap(BlPair v) { return __builtin_shufflevector(v, v, 1, 0); }
+
+UPKIE_HD void bullet_like_sweeps6(const float (&W)[6][6], const float (&rhs)[6], float (&lam)[6], const bool (&on)[2], float cfm_n, float mu,
+                                  int iterations) {
+  // rows divided by their diagonal, negated (x = b + sum na lam); a tire that is off: zero rows
+  float ninv[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) ninv[r] = on[r / 3] ? -fast_rcp(W[r][r] + ((r % 3) == 0 ? cfm_n : 0.f)) : 0.f;
+  auto na = [&](int r, int c) { return W[r][c] * ninv[r]; };
+  auto b = [&](int r) { return -(rhs[r] * ninv[r]); };
+  const BlPair N0 = {na(0, 1), na(3, 1)}, N1 = {na(0, 2), na(3, 2)}, N2 = {na(0, 4), na(3, 4)}, N3 = {na(0, 5), na(3, 5)}, Nb = {b(0), b(3)};
+  const float n03 = na(0, 3), n30 = na(3, 0);
+  const BlPair L0 = {na(1, 0), na(2, 0)}, L1 = {na(1, 3), na(2, 3)}, L2 = {na(1, 4), na(2, 4)}, L3 = {na(1, 5), na(2, 5)}, L4 = {na(1, 2), na(2, 1)},
+               Lb = {b(1), b(2)};
+  const BlPair R0 = {na(4, 0), na(5, 0)}, R1 = {na(4, 3), na(5, 3)}, R2 = {na(4, 1), na(5, 1)}, R3 = {na(4, 2), na(5, 2)}, R4 = {na(4, 5), na(5, 4)},
+               Rb = {b(4), b(5)};
+  BlPair Pn = {lam[0], lam[3]}, PL = {lam[1], lam[2]}, PR = {lam[4], lam[5]};
+  for (int it = 0; it < iterations; ++it) {
+    // (two short accumulation chains per stage rather than one long one: a packed multiply-add that reads the result of
+    // the one just before it costs a wait state on gfx950, a lone wavefront's issue slot like any instruction)
+    {  // the normal rows: the terms both read from the friction impulses as pairs, then the one that chains them
+      BlPair p = bl_fma(N0, bl_lo(PL), Nb), q = N2 * bl_lo(PR);
+      p = bl_fma(N1, bl_hi(PL), p);
+      q = bl_fma(N3, bl_hi(PR), q);
+      p = p + q;
+      const float l0 = fmaxf(fmaf(n03, Pn.y, p.x), 0.f);
+      const float l3 = fmaxf(fmaf(n30, l0, p.y), 0.f);
+      Pn = BlPair{l0, l3};
+    }
+    // the left point's friction pair, and what the right point's already knows (the normals, its own old impulses)
+    BlPair x = bl_fma(L0, bl_lo(Pn), Lb), y = bl_fma(R0, bl_lo(Pn), Rb);
+    x = bl_fma(L1, bl_hi(Pn), x);
+    y = bl_fma(R1, bl_hi(Pn), y);
+    x = bl_fma(L2, bl_lo(PR), x);
+    y = bl_fma(R4, bl_swap(PR), y);
+    x = bl_fma(L3, bl_hi(PR), x);
+    x = bl_fma(L4, bl_swap(PL), x);
+    {  // projected onto the cone |f| <= mu f_n
+      const float scale = fminf((mu * Pn.x) * fast_rsqrt(fmaf(x.x, x.x, x.y * x.y)), 1.f);
+      PL = x * BlPair{scale, scale};
+    }
+    y = bl_fma(R2, bl_lo(PL), y);  // the right point's pair sees the left one's new impulses
+    y = bl_fma(R3, bl_hi(PL), y);
+    {
+      const float scale = fminf((mu * Pn.y) * fast_rsqrt(fmaf(y.x, y.x, y.y * y.y)), 1.f);
+      PR = y * BlPair{scale, scale};
+    }
+  }
+  lam[0] = Pn.x; lam[3] = Pn.y;
+  lam[1] = PL.x; lam[2] = PL.y;
+  lam[4] = PR.x; lam[5] = PR.y;
+}
+
 struct BlRow {
   float Jb[6];   // base part of the row (base frame: linear 0-2, angular 3-5)
   float Jl[3];   // joint part: the three joints of leg `leg` (the other leg's entries are zero)
@@ -293,37 +371,7 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
       lam[a] = on[a / 3] ? F[a].lam : 0.f;
       rhs[a] = F[a].rhs;
     }
-    const float mu = M.friction_mu;
-    for (int it = 0; it < M.pgs_iterations; ++it) {
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {  // the normal rows
-        const int r = 3 * w;
-        float wl = 0.f;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
-        const float x = lam[r] + (rhs[r] - wl - F[r].cfm * lam[r]) * F[r].inv_diag;
-        lam[r] = on[w] ? (x < 0.f ? 0.f : x) : 0.f;
-      }
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {  // each point's friction pair, projected onto the cone
-        const int r1 = 3 * w + 1, r2 = 3 * w + 2;
-        float w1 = 0.f, w2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          w1 = fmaf(W[r1][b], lam[b], w1);
-          w2 = fmaf(W[r2][b], lam[b], w2);
-        }
-        float x1 = lam[r1] + (rhs[r1] - w1) * F[r1].inv_diag, x2 = lam[r2] + (rhs[r2] - w2) * F[r2].inv_diag;
-        const float lim = mu * lam[3 * w], n2 = x1 * x1 + x2 * x2;
-        if (n2 > lim * lim) {  // outside the cone: scaled back onto it (lim >= 0: the normal impulse was projected above)
-          const float sc = lim * fast_rsqrt(n2);
-          x1 *= sc;
-          x2 *= sc;
-        }
-        lam[r1] = on[w] ? x1 : 0.f;
-        lam[r2] = on[w] ? x2 : 0.f;
-      }
-    }
+    bullet_like_sweeps6(W, rhs, lam, on, cfm_n, M.friction_mu, M.pgs_iterations);
 #pragma unroll
     for (int w = 0; w < 2; ++w)
       if (on[w]) mf[(w * BL_POINTS + live_slot[w]) * BL_POINT_WORDS + 6] = lam[3 * w];

@@ -923,11 +923,9 @@ UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const Ba
   }
   const bool on[2] = {left ? active : active_partner, left ? active_partner : active};
   const float other_applied = oct_swp(applied);
-  float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, inv_diag[6];
+  float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   lam[0] = on[0] ? 0.85f * (left ? applied : other_applied) : 0.f;  // m_warmstartingFactor
   lam[3] = on[1] ? 0.85f * (left ? other_applied : applied) : 0.f;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) inv_diag[r] = 1.f / W[r][r];
 #if !defined(__HIP_DEVICE_COMPILE__)
   BulletLikeProbe* const probe = L.l == 1 && L.leg == 0 ? g_bullet_like_probe : nullptr;
   if (probe) {
@@ -941,52 +939,25 @@ UPKIE_HD float oct_bullet_like_solve(const ModelT& M, const OctLane& L, const Ba
     probe->sweeps = 0;
   }
 #endif
-  const float mu = M.friction_mu;
-  for (int it = 0; it < M.pgs_iterations; ++it) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-    float before[6];
-    for (int a = 0; a < 6; ++a) before[a] = lam[a];
+  if (probe) {  // (host tests: sweep by sweep, to record every sweep's impulses -- the same arithmetic as the one call below)
+    for (int it = 0; it < M.pgs_iterations; ++it) {
+      float before[6];
+      for (int a = 0; a < 6; ++a) before[a] = lam[a];
+      bullet_like_sweeps6(W, rhs6, lam, on, 0.f, M.friction_mu, 1);
+      if (it < 64) {
+        float change = 0.f;
+        for (int a = 0; a < 6; ++a) {
+          change = fmaxf(change, fabsf(lam[a] - before[a]));
+          probe->lam[it][a] = lam[a];
+        }
+        probe->change[it] = change;
+        probe->sweeps = it + 1;
+      }
+    }
+  } else
 #endif
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {  // the normal rows (their CFM sits on the diagonal of the gathered system)
-      const int r = 3 * w;
-      float wl = 0.f;
-#pragma unroll
-      for (int b = 0; b < 6; ++b) wl = fmaf(W[r][b], lam[b], wl);
-      const float x = lam[r] + (rhs6[r] - wl) * inv_diag[r];
-      lam[r] = on[w] ? (x < 0.f ? 0.f : x) : 0.f;
-    }
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {  // each point's friction pair, projected onto the cone
-      const int r1 = 3 * w + 1, r2 = 3 * w + 2;
-      float w1 = 0.f, w2 = 0.f;
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        w1 = fmaf(W[r1][b], lam[b], w1);
-        w2 = fmaf(W[r2][b], lam[b], w2);
-      }
-      float x1 = lam[r1] + (rhs6[r1] - w1) * inv_diag[r1], x2 = lam[r2] + (rhs6[r2] - w2) * inv_diag[r2];
-      const float lim = mu * lam[3 * w], n2 = x1 * x1 + x2 * x2;
-      if (n2 > lim * lim) {  // outside the cone: scaled back onto it (lim >= 0: the normal impulse was projected above)
-        const float sc = lim * fast_rsqrt(n2);
-        x1 *= sc;
-        x2 *= sc;
-      }
-      lam[r1] = on[w] ? x1 : 0.f;
-      lam[r2] = on[w] ? x2 : 0.f;
-    }
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (probe && it < 64) {
-      float change = 0.f;
-      for (int a = 0; a < 6; ++a) {
-        change = fmaxf(change, fabsf(lam[a] - before[a]));
-        probe->lam[it][a] = lam[a];
-      }
-      probe->change[it] = change;
-      probe->sweeps = it + 1;
-    }
-#endif
-  }
+    bullet_like_sweeps6(W, rhs6, lam, on, 0.f, M.friction_mu, M.pgs_iterations);  // (the normal rows' CFM sits on the diagonal of the gathered system)
   applied = left ? lam[0] : lam[3];
   // back to the default basis: lam = Q' lam'
   float out[6];
@@ -1435,7 +1406,8 @@ constexpr bool kServosLimitsInRegisters = true;
 #endif
 // BULLET_LIKE: contacts by the Bullet-like specification on the env's persistent contact manifold `manifold`
 // [BL_MANIFOLD_WORDS][B] (upkie_sim_set_contact_manifold) -- the eight-lane variant of what the one-lane kernels run
-// (oct_bullet_like_solve), for the envs whose legs the servos hold (every mode but Servos).
+// (oct_bullet_like_solve); since round 5 for every mode: a Servos env whose joint sits at its stop takes the default model's
+// joint-stop solve for that substep (the one-lane kernels keep the limit row inside the same sweeps).
 // Wavefronts per SIMD the register budget allows: two (256 registers; up to 16384 envs put two on every SIMD). An ISA probe
 // may set one (tools/isa_probe.sh -DUPKIE_PROBE_OCTET_WAVES=1: spills then go to AGPRs instead of scratch memory).
 #if !defined(UPKIE_PROBE_OCTET_WAVES)

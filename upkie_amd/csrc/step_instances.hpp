@@ -110,6 +110,7 @@ UPKIE_OCTET_BULLET(MODE_PENDULUM_AGENT)
 UPKIE_OCTET_BULLET(MODE_PENDULUM_ROLLOUT)
 UPKIE_OCTET_BULLET(MODE_GYROPOD)
 UPKIE_OCTET_BULLET(MODE_BASE_VELOCITY)
+UPKIE_OCTET_BULLET(MODE_SERVOS)
 #endif
 #if UPKIE_IN_GROUP(8)
 UPKIE_ONE_LANE_BULLET(MODE_RESET)

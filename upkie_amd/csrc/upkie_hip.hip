@@ -519,10 +519,10 @@ extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : 
 // ... of the step kernel a given entry point launches: the Servos kernels leave the eight-lane mapping earlier
 static int mapped_lanes_of_mode(const UpkieSim* sim, int mode) {
   int lanes = mapped_lanes(sim);
-  // Bullet-like contacts on eight lanes exist for the envs whose legs the servos hold; UpkieServos agents may drive
-  // joints into their stops, which only the one-lane kernels solve under that model
-  if (sim->manifold && mode == MODE_SERVOS) return 1;
-  if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = 2;
+  // (round 5: the Bullet-like contact model's eight-lane variant serves UpkieServos steps too; a joint at its stop takes
+  // the default model's joint-stop path for that substep there -- counted by the census, word [0] -- where the one-lane
+  // kernels put the limit row into the same 50 sweeps: UPKIE_LANES_PER_ENV=1 selects those)
+  if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = sim->manifold ? 1 : 2;
   return lanes;
 }
 extern "C" int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout) {
@@ -676,9 +676,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
                                         ? "this handle's steps have been recorded into UPKIE_MAX_GRAPH_CAPTURES hipGraph captures already (include/upkie_hip.h, Streams and hipGraphs)"
                                         : "could not refresh the device block of the handle's settings");
   if (lanes == 8 && sim->manifold) {
-    if constexpr (MODE != MODE_SERVOS) {
-      if (rnd) UPKIE_LAUNCH_OCTET_BULLET(true); else UPKIE_LAUNCH_OCTET_BULLET(false);
-    }
+    if (rnd) UPKIE_LAUNCH_OCTET_BULLET(true); else UPKIE_LAUNCH_OCTET_BULLET(false);
   } else if (lanes == 8) {
     if (rnd) UPKIE_LAUNCH_OCTET(true); else UPKIE_LAUNCH_OCTET(false);
   } else if (lanes == 2) {

@@ -504,9 +504,11 @@ class BatchedSim:
         `pybullet.stepSimulation()` is published to do, pybullet_backend.py:306)
         on a zeroed per-env manifold this handle keeps ``[64, B]``; False = the
         product's default specification. Eight lanes per env up to 16384 envs
-        for the Pendulum / Gyropod / BaseVelocity steps, one env per lane
-        otherwise (and always for Servos steps); 2.5-3.5 x the default model's
-        step: a fidelity option, not the fast path."""
+        (Servos steps: up to 8192; there a joint AT ITS STOP takes the default
+        model's joint-stop solve for that substep), one env per lane
+        otherwise (every case inside the same 50 sweeps; forced by
+        UPKIE_LANES_PER_ENV=1); about 2 x the default model's step: a fidelity
+        option, not the fast path."""
         self.contact_manifold = torch.zeros((abi.CONTACT_MANIFOLD_WORDS, self.num_envs), dtype=torch.float32, device=self.device) if on else None
         self._check(self._lib.upkie_sim_set_contact_manifold(self._handle, _ptr(self.contact_manifold)))
         return self.contact_manifold
