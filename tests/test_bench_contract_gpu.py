@@ -41,7 +41,11 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert steady["avg_launch_us"] <= steady["ms_per_step"] * 1e3 * 1.001
     # the secondary BASELINE configs as SURVEY 8d writes them
     sec = out["secondary"]
-    assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law", "c2_bullet_like_contact_model"}
+    assert set(sec) == {"c3", "c5_share_torque_law", "c5_share_velocity_law", "c5_share_bullet_like", "c2_bullet_like_contact_model"}
+    assert sec["c3"]["n50"]["horizon"] == 50 and sec["c3"]["n50"]["us_per_step"] > 0  # the reference's default horizon beside BASELINE's N = 16
+    for law in ("torque", "velocity"):
+        block = sec["c5_share_bullet_like"][law]
+        assert block["contact_model"] == "bullet_like" and block["lanes_per_env"] == 8 and block["us_per_step"] > 0, block
     bl = sec["c2_bullet_like_contact_model"]  # the fidelity option beside the default model on the same mapping
     assert bl["bullet_like"]["lanes_per_env"] == 8 and bl["bullet_like_one_lane"]["lanes_per_env"] == 1 and bl["default_one_lane"]["lanes_per_env"] == 1
     assert bl["bullet_like"]["us_per_step"] > bl["default"]["us_per_step"] > 0

@@ -93,37 +93,62 @@ UPKIE_HD void bullet_like_sweeps6(const float (&W)[6][6], const float (&rhs)[6],
   const BlPair R0 = {na(4, 0), na(5, 0)}, R1 = {na(4, 3), na(5, 3)}, R2 = {na(4, 1), na(5, 1)}, R3 = {na(4, 2), na(5, 2)}, R4 = {na(4, 5), na(5, 4)},
                Rb = {b(4), b(5)};
   BlPair Pn = {lam[0], lam[3]}, PL = {lam[1], lam[2]}, PR = {lam[4], lam[5]};
-  for (int it = 0; it < iterations; ++it) {
-    // (two short accumulation chains per stage rather than one long one: a packed multiply-add that reads the result of
-    // the one just before it costs a wait state on gfx950, a lone wavefront's issue slot like any instruction)
-    {  // the normal rows: the terms both read from the friction impulses as pairs, then the one that chains them
-      BlPair p = bl_fma(N0, bl_lo(PL), Nb), q = N2 * bl_lo(PR);
-      p = bl_fma(N1, bl_hi(PL), p);
-      q = bl_fma(N3, bl_hi(PR), q);
-      p = p + q;
-      const float l0 = fmaxf(fmaf(n03, Pn.y, p.x), 0.f);
-      const float l3 = fmaxf(fmaf(n30, l0, p.y), 0.f);
-      Pn = BlPair{l0, l3};
+  // The order of the instructions in the loop is set BY HAND (BL_KEEP_ORDER: a scheduling barrier between statements
+  // that are one instruction each; hazard wait states stay the compiler's business). On gfx950 a packed multiply-add that
+  // reads the result of the instruction just in front of it costs a wait state -- an issue slot of a lone wavefront, like
+  // any instruction: 8.5 instead of 4.9 cycles a link, profiles/r05_pk_rate.txt -- and the scheduler, left alone, lines
+  // each accumulation chain up back to back (8 wait states in a 48-slot loop). So every stage keeps two chains in
+  // flight, and the loop is ROTATED: the terms that do not wait for this sweep's normal impulses (the friction pairs'
+  // own 2 x 2 blocks and their couplings to each other) are accumulated while the normal rows finish, and the part of
+  // the NEXT sweep's normal rows that reads the left point's friction impulses as soon as those are final.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BL_KEEP_ORDER __builtin_amdgcn_sched_barrier(0)
+#else
+#define BL_KEEP_ORDER (void)0
+#endif
+  BlPair p = bl_fma(N1, bl_hi(PL), bl_fma(N0, bl_lo(PL), Nb));
+  auto sweep = [&]() {
+    // normal rows: the right point's friction impulses; beside them the friction pairs' terms that know no normal impulse
+    BlPair q = N2 * bl_lo(PR);              BL_KEEP_ORDER;
+    BlPair x = bl_fma(L2, bl_lo(PR), Lb);   BL_KEEP_ORDER;
+    q = bl_fma(N3, bl_hi(PR), q);           BL_KEEP_ORDER;
+    x = bl_fma(L3, bl_hi(PR), x);           BL_KEEP_ORDER;
+    p = p + q;                              BL_KEEP_ORDER;
+    x = bl_fma(L4, bl_swap(PL), x);         BL_KEEP_ORDER;
+    BlPair y = bl_fma(R4, bl_swap(PR), Rb); BL_KEEP_ORDER;
+    // ... and the term that chains the two normal rows: left, then right with the left one's new impulse
+    const float l0 = fmaxf(fmaf(n03, Pn.y, p.x), 0.f);
+    const float l3 = fmaxf(fmaf(n30, l0, p.y), 0.f);
+    Pn = BlPair{l0, l3};                    BL_KEEP_ORDER;
+    // the friction pairs: their coupling to the new normal impulses
+    x = bl_fma(L0, bl_lo(Pn), x);           BL_KEEP_ORDER;
+    y = bl_fma(R0, bl_lo(Pn), y);           BL_KEEP_ORDER;
+    x = bl_fma(L1, bl_hi(Pn), x);           BL_KEEP_ORDER;
+    y = bl_fma(R1, bl_hi(Pn), y);           BL_KEEP_ORDER;
+    const float lim_left = mu * Pn.x;       BL_KEEP_ORDER;
+    {  // the left point's pair projected onto the cone |f| <= mu f_n
+      const float rs = fast_rsqrt(fmaf(x.x, x.x, x.y * x.y));  BL_KEEP_ORDER;
+      const float lim_right = mu * Pn.y;    BL_KEEP_ORDER;  // (an independent instruction behind the v_rsq: its result is not read by the next one)
+      const float scale = fminf(lim_left * rs, 1.f);
+      PL = x * BlPair{scale, scale};        BL_KEEP_ORDER;
+      // the right point's pair sees the left one's new impulses -- and so do the next sweep's normal rows
+      p = bl_fma(N0, bl_lo(PL), Nb);        BL_KEEP_ORDER;
+      y = bl_fma(R2, bl_lo(PL), y);         BL_KEEP_ORDER;
+      p = bl_fma(N1, bl_hi(PL), p);         BL_KEEP_ORDER;
+      y = bl_fma(R3, bl_hi(PL), y);         BL_KEEP_ORDER;
+      const float scale_right = fminf(lim_right * fast_rsqrt(fmaf(y.x, y.x, y.y * y.y)), 1.f);
+      PR = y * BlPair{scale_right, scale_right};  BL_KEEP_ORDER;
     }
-    // the left point's friction pair, and what the right point's already knows (the normals, its own old impulses)
-    BlPair x = bl_fma(L0, bl_lo(Pn), Lb), y = bl_fma(R0, bl_lo(Pn), Rb);
-    x = bl_fma(L1, bl_hi(Pn), x);
-    y = bl_fma(R1, bl_hi(Pn), y);
-    x = bl_fma(L2, bl_lo(PR), x);
-    y = bl_fma(R4, bl_swap(PR), y);
-    x = bl_fma(L3, bl_hi(PR), x);
-    x = bl_fma(L4, bl_swap(PL), x);
-    {  // projected onto the cone |f| <= mu f_n
-      const float scale = fminf((mu * Pn.x) * fast_rsqrt(fmaf(x.x, x.x, x.y * x.y)), 1.f);
-      PL = x * BlPair{scale, scale};
-    }
-    y = bl_fma(R2, bl_lo(PL), y);  // the right point's pair sees the left one's new impulses
-    y = bl_fma(R3, bl_hi(PL), y);
-    {
-      const float scale = fminf((mu * Pn.y) * fast_rsqrt(fmaf(y.x, y.x, y.y * y.y)), 1.f);
-      PR = y * BlPair{scale, scale};
-    }
+  };
+  // (two sweeps per trip: the impulses ping-pong between two register pairs instead of being copied back, and the loop's
+  // own three instructions are paid once per two sweeps)
+  int it = 0;
+  for (; it + 1 < iterations; it += 2) {
+    sweep();
+    sweep();
   }
+  if (it < iterations) sweep();
+#undef BL_KEEP_ORDER
   lam[0] = Pn.x; lam[3] = Pn.y;
   lam[1] = PL.x; lam[2] = PL.y;
   lam[4] = PR.x; lam[5] = PR.y;
