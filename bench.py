@@ -550,6 +550,7 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
         "config": {
             "workload": f"UpkieServos batched env.step() (C5): inertia_variation 0.2, wheel friction 0.1, torso push every {PUSH_PERIOD} steps (norm ~ U(0, {PUSH_MAX_NORM:g}) N, held {PUSH_HOLD}, "
                         f"drawn on device), servo-level law '{args.law}' inside the launch, NEXT_STEP autoreset",
+            "baseline_config": f"configs[4] (full 6-DoF UpkieServos, floor contact, push + inertia randomisation, 32768 envs at 8 GPUs): {B} envs per GPU x {world} GPU(s) = {counted_envs} envs",
             "envs_per_gpu": B, "total_envs": counted_envs, "ghost_envs": B * world - counted_envs,
             "gather": (f"RCCL gather of every step's outputs (servo observations [B, 6, 5], reward, flags: {blob} B per rank and step) into rank 0's ring, one asynchronous "
                        f"collective per {env.gather.chunk}-step chunk ({blob * env.gather.chunk / 1e6:.1f} MB per rank), overlapped with the next chunk's kernels") if env.gather.collectives
@@ -584,7 +585,7 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=2000)
     parser.add_argument("--warmup", type=int, default=200)
-    parser.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    parser.add_argument("--envs-per-gpu", type=int, default=None, help=f"default: {ENVS_PER_GPU} (BASELINE configs[1] at one GPU); --config c4: 8192 (configs[3]: 65536 envs at 8 GPUs)")
     parser.add_argument("--total-envs", type=int, default=0,
                         help="strong scaling (SURVEY 8d): this many envs in total, split evenly over the ranks; default: --envs-per-gpu each (weak)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
@@ -596,11 +597,16 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     parser.add_argument("--steps-per-launch", type=int, default=1,
                         help="env.step() per kernel launch in the TIMED region: 1 (the contract figure: one launch per env.step(), what "
                              "VecEnv.step gives a policy on the host side of the boundary); > 1 times the fused rollout instead (profiling runs)")
-    parser.add_argument("--config", choices=("c2", "c5"), default="c2",
-                        help="c2 (default): the headline, Upkie-Pendulum with the PD agent on device (BASELINE configs[1], [3] with --envs-per-gpu 8192); "
-                             "c5: UpkieServos with push / inertia randomisation, every env kind's sharded runner (BASELINE configs[4])")
+    parser.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
+                        help="c2 (default): the headline, Upkie-Pendulum with the PD agent on device, 4096 envs per GPU (BASELINE configs[1]; with --gpus N the "
+                             "weak-scaling line of that per-GPU workload); c4: BASELINE configs[3] -- the same env at 8192 envs per GPU (65536 at --gpus 8), every "
+                             "step's records gathered to rank 0 AND consumed there by a PPO rollout consumer (generalized advantage estimation over each "
+                             "gathered chunk, upkie_rollout_gae); c5: UpkieServos with push / inertia randomisation (BASELINE configs[4]: 4096 envs per GPU, "
+                             "32768 at --gpus 8), every env kind's sharded runner")
     parser.add_argument("--law", choices=("torque", "velocity"), default="torque", help="--config c5: the servo-level law evaluated inside the launch")
     args = parser.parse_args(argv)
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = 8192 if args.config == "c4" else ENVS_PER_GPU
     if args.config == "c5":
         return main_c5(args, sim_factory=sim_factory, backend=backend, json_out=json_out)
 
@@ -624,6 +630,29 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     env = ShardedPendulum(make_config(B, env_id_offset=rank * B), device=device, rank=rank, world_size=world, collectives=forced, chunk=args.gather_chunk,
                           sim_factory=sim_factory)
     env.reset()
+    consumed = {"chunks": 0}
+    if args.config == "c4" and rank == 0:
+        # BASELINE configs[3]'s "PPO rollout consumer" on rank 0: every chunk of K steps x (all ranks' envs) that lands in the
+        # rollout ring is turned into advantages and returns where it lies (a linear value function of the observation, the
+        # rewards and episode ends the step kernels wrote, upkie_rollout_gae / the oracle-free torch twin on the CPU double):
+        # stream-ordered behind the gather that delivered the chunk, in front of rank 0's next step -- part of the timed work
+        from upkie_amd.rollout import compute_gae
+
+        value_weights = torch.tensor([0.5, 0.1, 0.05, 0.02], device=env.gather.rollout.device)
+
+        def consume(chunk_index: int) -> None:
+            ring = env.gather.rollout[chunk_index % env.gather.num_chunks]  # [world, K, B, 8]
+            K, N = ring.shape[1], ring.shape[0] * ring.shape[2]
+            rec = ring.permute(1, 0, 2, 3).reshape(K, N, ring.shape[3])
+            values = rec[:, :, :4] @ value_weights
+            ended = (rec[:, :, 5] != 0) | (rec[:, :, 6] != 0)
+            starts = torch.zeros_like(ended)
+            starts[1:] = ended[:-1]
+            if on_gpu:
+                consumed["advantages"], consumed["returns"] = compute_gae(rec[:, :, 4], values, starts, values[-1], ended[-1], 0.99, 0.95)
+            consumed["chunks"] += 1
+
+        env.gather.consumer = consume
 
     def advance(total: int, per_launch: int) -> int:
         """`total` env.step() of every local env, up to `per_launch` of them per
@@ -705,7 +734,14 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset",
+            "workload": "Upkie-Pendulum batched env.step(), PD-gain balancer on device, 200 Hz (5 x 1 ms substeps), NEXT_STEP autoreset"
+                        + ("; every gathered chunk consumed on rank 0 by generalized advantage estimation (the PPO rollout consumer)" if args.config == "c4" else ""),
+            # which BASELINE.json config this line is, in words (the driver's 1 / 2 / 4 / 8-GPU runs use the default flags: weak scaling at 4096 envs per GPU)
+            "baseline_config": (f"configs[3] (Upkie-Pendulum 65536 envs sharded over 8 GPUs, RCCL gather, PPO rollout consumer): {B} envs per GPU x {world} GPU(s) = {total_envs} envs"
+                                if args.config == "c4" else
+                                ("configs[1] (Upkie-Pendulum batched 4096 envs on one GPU, PD-gain balancer)" if (world, B) == (1, ENVS_PER_GPU) else
+                                 f"weak-scaling line of configs[1]'s per-GPU workload: {B} envs per GPU x {world} GPU(s) = {total_envs} envs"
+                                 + (" (configs[3] itself -- 65536 envs at 8 GPUs with the rollout consumer -- is `--config c4`; configs[4] is `--config c5`)" if world > 1 else ""))),
             "envs_per_gpu": B,
             "total_envs": total_envs,
             "ghost_envs": B * world - total_envs,  # strong scaling with N not dividing the total: simulated, not counted
@@ -731,6 +767,12 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
             "valu": valu_roofline(pmc, launch_us),
         },
     }
+    if args.config == "c4":
+        line["config"]["rollout_consumer"] = {
+            "what": "generalized advantage estimation (gamma 0.99, lambda 0.95, linear value function of the observation) over every K-step chunk of all "
+                    "ranks' records as it lands in rank 0's ring (upkie_rollout_gae), stream-ordered between the gather and rank 0's next step",
+            "chunks_consumed": consumed["chunks"], "steps_per_chunk": env.gather.chunk, "envs_per_chunk": total_envs + B * world - total_envs,
+        }
     if env.gather.collectives:
         # DESIGN.md section 7's model, printed beside the measurement so that a multi-GPU run can be judged against it:
         # ranks share nothing but one asynchronous gather per chunk of K steps, which costs ~27 us of queue time whatever

@@ -113,3 +113,17 @@ print("RCCL_GATHER_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     result = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert result.returncode == 0 and "RCCL_GATHER_OK" in result.stdout, (result.stdout[-1000:], result.stderr[-3000:])
+
+
+def test_bench_config_c4_runs_the_rollout_consumer_on_the_device():
+    """`bench.py --config c4` (BASELINE configs[3]: 8192 envs per GPU, every chunk of gathered records consumed on rank 0
+    by generalized advantage estimation) on one GPU: the consumer's kernel runs inside the timed work, the line says
+    which BASELINE config it is."""
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--steps", "200", "--warmup", "20", "--no-secondary",
+                             "--no-cpu-baseline", "--no-steady-state", "--no-fused"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert result.returncode == 0, result.stderr[-2000:]
+    out = json.loads([line for line in result.stdout.splitlines() if line.startswith("{")][0])
+    cfg = out["config"]
+    assert cfg["envs_per_gpu"] == 8192 and cfg["baseline_config"].startswith("configs[3]") and cfg["lanes_per_env"] == 8
+    assert cfg["rollout_consumer"]["chunks_consumed"] >= 3 and cfg["rollout_consumer"]["steps_per_chunk"] == 64
+    assert out["value"] > 1e8  # (16.5 us per step of 8192 envs is 5e8; the consumer costs a few per cent of it)

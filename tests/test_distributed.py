@@ -219,6 +219,7 @@ def test_eight_ranks_shard_arithmetic_and_gather(tmp_path):
 @pytest.mark.parametrize("world,flags,total,per_rank,ghosts", [
     (2, ["--envs-per-gpu", "6"], 12, 6, 0),  # weak scaling
     (3, ["--total-envs", "16"], 16, 6, 2),  # strong scaling, 3 does not divide 16: blocks of 6, two ghost envs on the last rank
+    (2, ["--config", "c4", "--envs-per-gpu", "6"], 12, 6, 0),  # BASELINE configs[3]: gather + the rollout consumer on rank 0
 ])
 def test_bench_launch_line_on_cpu_doubles(world, flags, total, per_rank, ghosts):
     """The driver's launch line (`python -m torch.distributed.run --nnodes=1
@@ -252,6 +253,11 @@ def test_bench_launch_line_on_cpu_doubles(world, flags, total, per_rank, ghosts)
     steady = out["steady_state"]  # the window of SURVEY 8d, timed before the contract region (shrunk by the double)
     assert steady["steps"] == 6 and steady["warmup"] == 2 and steady["value"] == pytest.approx(total * 6 / (steady["ms_per_step"] * 1e-3 * 6), rel=1e-6)
     assert "secondary" not in out  # one GPU, rank 0 only
+    if "c4" in flags:  # every completed chunk of the timed and untimed steps went through the consumer, in order
+        assert cfg["baseline_config"].startswith("configs[3]") and "rollout consumer" in cfg["workload"]
+        assert cfg["rollout_consumer"]["chunks_consumed"] >= (12 + 3 + 6 + 2) // 4 - 1 and cfg["rollout_consumer"]["steps_per_chunk"] == 4
+    else:
+        assert cfg["baseline_config"].startswith("weak-scaling line of configs[1]") and "--config c4" in cfg["baseline_config"]
 
 
 def test_a_flush_ships_only_the_steps_it_has_not_shipped(monkeypatch):

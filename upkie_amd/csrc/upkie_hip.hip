@@ -614,7 +614,11 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
   const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8 && !sim->manifold;  // (no IN_PLACE instantiation of the Bullet-like kernels: the DONE pass follows as a second launch)
   if (same_step_in_kernel) final_obs = sim->final_obs;
-  const bool rnd = sim->body_inertials || sim->ext_force;
+  // (UPKIE_ALWAYS_RAND_KERNELS=1: launch the randomisation-capable instantiation even without inertial records or forces
+  // -- null pointers, tested at run time --: the A/B that decides whether the RAND = false instantiations of the one- and
+  // two-lane kernels earn their place in the library, profiles/r05_ab_rand_instantiations.txt)
+  static const bool always_rand = [] { const char* v = std::getenv("UPKIE_ALWAYS_RAND_KERNELS"); return v && v[0] == '1'; }();
+  const bool rnd = sim->body_inertials || sim->ext_force || (always_rand && mapped_lanes_of_mode(sim, MODE) != 8);
   dim3 grid = grid_for(sim->config.num_envs), block(block_lanes());
   const float* scale = rnd ? sim->body_inertials : nullptr;
   const float* force = rnd ? sim->ext_force : nullptr;

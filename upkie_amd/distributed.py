@@ -98,6 +98,11 @@ class RolloutGather:
         f32 = dict(dtype=torch.float32, device=device)
         self.staging = torch.zeros((2, K, local_envs, words), **f32) if self.collectives else None
         self._work = [None, None]
+        self._work_chunk = [None, None]  # which chunk of the rollout each gather in flight fills
+        # rank 0: `consumer(chunk_index)` is called, in step order, once chunk `chunk_index % num_chunks` of `rollout` holds
+        # every rank's records of those `chunk` steps (stream-ordered behind the gather that delivered them): the rollout
+        # consumer of BASELINE configs[3] (bench.py --config c4 hangs generalized advantage estimation here)
+        self.consumer = None
         self._step = 0  # index of the step being produced
         self._flushed_to = 0  # steps of the current chunk that a flush has already shipped
         self.rollout: Optional[torch.Tensor] = None
@@ -138,9 +143,7 @@ class RolloutGather:
     def begin_step(self) -> torch.Tensor:
         if self.collectives and self._step % self.chunk == 0:
             c = (self._step // self.chunk) % 2
-            if self._work[c] is not None:
-                self._work[c].wait()  # the gather issued two chunks ago has read this buffer
-                self._work[c] = None
+            self._landed(c)  # the gather issued two chunks ago has read this buffer
         return self.current
 
     def begin_steps(self, n: int) -> torch.Tensor:
@@ -169,16 +172,30 @@ class RolloutGather:
         gather_list: Optional[List[torch.Tensor]] = None
         if self.rank == 0:
             gather_list = [block[first:stop] for block in self.rollout[chunk_index % self.num_chunks].unbind(0)]
-        if self._work[c] is not None:
-            self._work[c].wait()
+        self._landed(c)
         self._work[c] = dist.gather(self.staging[c, first:stop], gather_list, dst=0, async_op=True)
+        self._work_chunk[c] = chunk_index if stop == self.chunk else None  # (a flush's partial chunk is not handed to the consumer)
+
+    def _landed(self, c: int) -> None:
+        """Wait (on the stream) for the gather in flight on staging buffer `c`; rank 0 hands the chunk it completed to the consumer."""
+        work = self._work[c]
+        if work is None:
+            return
+        work.wait()
+        self._work[c] = None
+        chunk_index, self._work_chunk[c] = self._work_chunk[c], None
+        if chunk_index is not None and self.consumer is not None and self.rank == 0:
+            self.consumer(chunk_index)
 
     def end_step(self) -> None:
         step = self._step
         self._step += 1
-        if self.collectives and step % self.chunk == self.chunk - 1:
-            self._gather_chunk(step // self.chunk, self._flushed_to)  # (what a flush has shipped is on rank 0 already)
-            self._flushed_to = 0
+        if step % self.chunk == self.chunk - 1:
+            if self.collectives:
+                self._gather_chunk(step // self.chunk, self._flushed_to)  # (what a flush has shipped is on rank 0 already)
+                self._flushed_to = 0
+            elif self.consumer is not None:
+                self.consumer(step // self.chunk)  # one rank: the step kernels wrote the chunk straight into the ring
 
     def flush(self) -> None:
         """Ship a partially filled chunk and wait for every gather in flight
@@ -191,10 +208,9 @@ class RolloutGather:
             # full, when it completed)
             self._gather_chunk(self._step // self.chunk, self._flushed_to, filled)
             self._flushed_to = filled
-        for i, work in enumerate(self._work):
-            if work is not None:
-                work.wait()
-                self._work[i] = None
+        first = 0 if (self._work_chunk[0] or 0) <= (self._work_chunk[1] or 0) else 1  # (in step order)
+        for c in (first, 1 - first):
+            self._landed(c)
 
     def records(self, step: int) -> Optional[torch.Tensor]:
         """Rank 0: records ``[world, B, words]`` of absolute step `step` (one of
