@@ -10,6 +10,7 @@ import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+CURRENT_ROUND = "r05"  # the round whose bench line and rocprofv3 summary this tree claims (the test read round 3's files)
 
 
 def test_pmc_file_describes_the_timed_launch_shape():
@@ -21,6 +22,9 @@ def test_pmc_file_describes_the_timed_launch_shape():
     with open(bench.PMC_FILE) as f:
         pmc = json.load(f)
     assert pmc["launch_envs"] == bench.ENVS_PER_GPU and pmc["steps_per_launch"] == 1
+    # collected on THIS version of the headline kernel (sources without comments + compiler flags): a kernel change without
+    # a fresh `bash tools/pmc_pass.sh rNN; python tools/pmc_summary.py rNN --out profiles/pmc_step_b4096.json` fails here
+    assert pmc.get("kernel_fingerprint") == bench.kernel_fingerprint(), "profiles/pmc_step_b4096.json is older than the headline kernel"
     assert bench.pmc_of_launch_shape(bench.ENVS_PER_GPU, 1) is not None
     assert bench.pmc_of_launch_shape(bench.ENVS_PER_GPU, 32) is None and bench.pmc_of_launch_shape(8192, 1) is None
     c = pmc["counters"]
@@ -38,8 +42,11 @@ def test_pmc_file_describes_the_timed_launch_shape():
 def test_kernel_stats_and_bench_line_agree():
     """The committed bench line of this round and the rocprofv3 --stats summary
     of the same command: the dominant kernel's average duration agrees."""
-    lines = sorted(glob.glob(os.path.join(P, "r03_bench_n1*.json")))
-    stats = sorted(glob.glob(os.path.join(P, "r03_kernel_stats_b4096*.csv")))
+    # the latest round that committed both
+    rounds = sorted({os.path.basename(p)[:3] for p in glob.glob(os.path.join(P, "r[0-9][0-9]_kernel_stats_b4096*.csv"))})
+    assert rounds and rounds[-1] == CURRENT_ROUND, f"no rocprofv3 summary of round {CURRENT_ROUND} under profiles/ (latest: {rounds[-1:]})"
+    lines = sorted(glob.glob(os.path.join(P, f"{rounds[-1]}_bench_n1.json")))
+    stats = sorted(glob.glob(os.path.join(P, f"{rounds[-1]}_kernel_stats_b4096*.csv")))
     assert lines and stats
     with open(lines[-1]) as f:
         line = json.loads(f.read().strip().splitlines()[-1])

@@ -56,6 +56,14 @@ out = {
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     out["hbm_bytes_per_launch"] = round((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
     out["hbm_bytes_per_launch_fetch_doubled"] = round((2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
+if args.envs == 4096 and args.steps_per_launch == 1 and "octet" in kernel:
+    # the version of the kernel these counters belong to (bench.py refuses them for any other: tests/test_profiles_consistency.py)
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+
+    out["kernel_fingerprint"] = bench.kernel_fingerprint()
 if durations.get(kernel):
     d = durations[kernel]
     out["avg_launch_us"] = sum(d) / len(d) / 1e3  # under counter collection (slightly slower than an unprofiled launch)
