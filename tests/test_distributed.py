@@ -354,6 +354,12 @@ def _run_kind(env, kind, mode, steps):
             obs = env.step(policy(obs))[0]
         elif mode == "root":
             obs = env.step_from_root(policy)[0]
+        elif mode == "root_stale":  # rank 0's policy one step behind, its gather overlapped with the step (round 5)
+            obs = env.step_from_root(policy, stale=1)[0]
+        elif mode == "local_stale":  # what `root_stale` must equal: one process acting on the observation of one step earlier
+            before, older = obs, getattr(env, "_test_older", None)
+            obs = env.step(policy(older if older is not None else before))[0]
+            env._test_older = before.clone()
         else:
             obs = env.step(None)[0]
     env.flush()
@@ -373,7 +379,7 @@ def _sharded_kinds_worker(rank: int, world: int, port: int, per_rank: int, total
         if rank == 0:
             # one process stepping all envs (ghost envs of an uneven split included: they are simulated, not counted)
             whole = _make_sharded(kind, world * per_rank, 0, 0, 1, collectives=False, servo_policy=law)
-            _run_kind(whole, kind, "local" if mode == "root" else mode, steps)
+            _run_kind(whole, kind, {"root": "local", "root_stale": "local_stale"}.get(mode, mode), steps)
             for step in range(steps - 8, steps):  # what the 16-step ring still holds of both
                 got = env.records(step)
                 ref = whole.records(step)
@@ -401,7 +407,8 @@ def _sharded_kinds_worker(rank: int, world: int, port: int, per_rank: int, total
 
 
 ALL_KIND_CASES = [("pendulum", "local"), ("pendulum", "root"), ("gyropod", "local"), ("gyropod", "root"), ("servos", "local"), ("servos", "root"),
-                  ("servos", "policy"), ("base_velocity", "local"), ("base_velocity", "root")]
+                  ("servos", "policy"), ("base_velocity", "local"), ("base_velocity", "root"),
+                  ("pendulum", "root_stale"), ("gyropod", "root_stale"), ("servos", "root_stale")]
 
 
 def test_sharded_vec_env_every_kind_two_ranks_equal_one_rank(tmp_path):
@@ -418,7 +425,7 @@ def test_sharded_vec_env_eight_ranks_equal_one_rank(tmp_path):
     """BASELINE configs[4]'s shape (Servos over 8 ranks, the law inside the
     launch) and the rank-0 policy path on eight ranks, tiny shards."""
     out = tmp_path / "kinds8.txt"
-    cases = [("servos", "policy"), ("servos", "root"), ("pendulum", "root")]
+    cases = [("servos", "policy"), ("servos", "root"), ("pendulum", "root"), ("pendulum", "root_stale")]
     mp.spawn(_sharded_kinds_worker, args=(8, free_port(), 3, 24, cases, str(out)), nprocs=8, join=True)
     assert out.read_text() == "ok"
 

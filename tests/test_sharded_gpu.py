@@ -81,6 +81,9 @@ def test_rank_zero_policy_path_through_rccl_on_one_rank():
     for kind in ("pendulum", "gyropod", "servos", "base_velocity"):
         assert out[kind]["bit_equal"], out
         assert out[kind]["resets"] == out[kind]["resets_plain"], out
+    assert out["pendulum"]["stale_bit_equal"] and out["servos"]["stale_bit_equal"], out  # step_from_root(policy, stale=1)
+    print("rank-0-policy loop, one-rank RCCL group:", out["root_policy_loop_4096_envs_one_rank"])
+    assert out["root_policy_loop_4096_envs_one_rank"]["stale_1_us_per_step"] > 0
 
 
 def test_bench_c5_under_torchrun_through_rccl_on_one_rank():

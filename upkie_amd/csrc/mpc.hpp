@@ -50,7 +50,11 @@ __device__ __forceinline__ int mpc_index(int t, int g, int r) { return 16 * t + 
 // velocities as well, for a step fused behind the solve in the same launch.
 // COLUMNS: how many of the tile's 16 columns carry an env (16; 8 when the eight-lane step kernel solves the QPs of
 // its wavefront's eight envs in front of their step: the other columns compute on zeros).
-template <int T, int COLUMNS = 16>
+// KS: how many of the 4 T k-steps (four horizon indices each) of a row tile's product are issued. The padding beyond the
+// horizon N carries zeros for ever (its rows of Minv are the identity / (1 + rho), its right-hand sides start at 0), so the
+// k-steps that only read padding, 4 s >= N, contribute nothing: the reference's default N = 50 on four tiles needs 13 of
+// its 16 (round 5: the launch is bound by the matrix pipe at this size, 64 -> 52 MFMAs per iteration).
+template <int T, int COLUMNS = 16, int KS = 4 * T>
 __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
                                          const float* __restrict__ v_target, int v_target_stride,
                                          const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
@@ -149,9 +153,10 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
       asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(acc0[t]) : "v"(a[t][0]), "v"(rbp[0][0].x), "v"(yv[t]));
       asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rbp[0][0].y));
 #pragma unroll
-      for (int s = 2; s < 4 * T; s += 2) {
+      for (int s = 2; s < KS; s += 2) {
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rbp[s / 4][(s % 4) / 2].x));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rbp[(s + 1) / 4][((s + 1) % 4) / 2].y));
+        if (s + 1 < KS)
+          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rbp[(s + 1) / 4][((s + 1) % 4) / 2].y));
       }
     }
 #pragma unroll
@@ -209,7 +214,7 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   }
 }
 
-template <int T>
+template <int T, int KS = 4 * T>
 __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
                                                        const float* __restrict__ v_target, int v_target_stride,
                                                        const uint8_t* __restrict__ contact,
@@ -218,7 +223,8 @@ __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restric
   // (XCD-aware: the two wavefronts that share a 128-byte line of a workspace row run on one XCD, see step_kernel_octet)
   unsigned block = blockIdx.x;
   if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
-  mpc_tile<T>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16, nullptr);
+  static_assert(KS >= 2 && KS <= 4 * T, "k-steps of a row tile");
+  mpc_tile<T, 16, KS>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16, nullptr);
 }
 
 

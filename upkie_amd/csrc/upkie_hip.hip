@@ -963,7 +963,12 @@ static int mpc_launch(UpkieMpc* mpc, float* workspace, const float* x0, const fl
     case 1: hipLaunchKernelGGL(mpc_step_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
     case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
     case 3: hipLaunchKernelGGL(mpc_step_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
-    default: hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+    default:
+      if (mpc->dev.n <= 52)  // (the reference's default horizon N = 50: k-steps 13-15 of every row tile only read padding, mpc.hpp)
+        hipLaunchKernelGGL((mpc_step_kernel<4, 13>), grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input);
+      else
+        hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input);
+      break;
   }
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));

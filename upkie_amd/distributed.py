@@ -417,6 +417,7 @@ class ShardedVecEnv:
         # inertia randomisation and joint properties already applied) instead of a new one from `config`
         # (sim_factory / mpc_factory: test doubles only; the product always builds a BatchedSim / BatchedMpc)
         self._owns_sim = sim is None  # (a caller's handle stays the caller's to close: `shutdown` leaves it open)
+        self._stale_primed, self._stale_scatter = False, None  # `step_from_root(policy, stale=1)`
         if sim is not None:
             self.sim = sim
         else:
@@ -467,6 +468,9 @@ class ShardedVecEnv:
         """Reset every local env; returns this rank's first observation ``[B, *obs_shape]``."""
         from . import abi
 
+        if self._stale_scatter is not None and self._stale_scatter[0] is not None:
+            self._stale_scatter[0].wait()  # (a lagged exchange still in flight: its actions die with the episode)
+        self._stale_primed, self._stale_scatter = False, None
         obs6 = self.sim.reset()
         self.gather.flush()
         if self.kind == "pendulum":
@@ -538,13 +542,68 @@ class ShardedVecEnv:
         work.wait()
         return mine
 
-    def step_from_root(self, policy):
+    def step_from_root(self, policy, stale: int = 0):
         """``obs -> policy (rank 0) -> actions -> step`` with the policy on rank 0
         only: `policy` maps ``[world * B, *obs_shape]`` to ``[world * B, *act_shape]``
-        there and is not called on the other ranks."""
-        obs_all = self.gather_observations()
-        self.scatter_actions(policy(obs_all) if self.rank == 0 else None)
-        return self.step(None)
+        there and is not called on the other ranks.
+
+        ``stale=0``: step k + 1 acts on ``policy(o_k)`` -- gather, policy and
+        scatter all sit between two steps (two latency-bound collectives on every
+        step's critical path).
+        ``stale=1`` (round 5): step k + 1 acts on ``policy(o_{k-1})``, the
+        observation of ONE STEP EARLIER (the first two steps both on
+        ``policy(o_0)``): the gather of ``o_k`` is issued in front of step
+        k + 1's launch and collected behind it, so it overlaps the step; rank 0
+        then evaluates the policy and issues the scatter whose actions step
+        k + 2 waits for. What is left between two steps is the policy and one
+        scatter; an on-policy learner must know that its actions are one step
+        late (asynchronous / "lagged" actors accept exactly this)."""
+        if not stale:
+            obs_all = self.gather_observations()
+            self.scatter_actions(policy(obs_all) if self.rank == 0 else None)
+            return self.step(None)
+        if stale != 1:
+            raise ValueError("stale must be 0 or 1")
+        if not self._stale_primed:
+            # the first step: nothing older than the reset observation exists; its actions also serve the second step
+            obs_all = self.gather_observations()
+            self.scatter_actions(policy(obs_all) if self.rank == 0 else None)
+            self._stale_primed = True
+            self._stale_scatter = None
+            return self.step(None)
+        # the scatter issued behind the previous step delivers this step's actions, policy(o_{k-1})
+        if self._stale_scatter is not None:
+            work, ready_slot = self._stale_scatter
+            if work is not None:
+                work.wait()
+            self._action_slot = ready_slot
+            self._stale_scatter = None
+        # gather of the latest observation o_k: issued now, collected behind the step
+        obs = self.last[0]
+        slot = self._action_slot ^ 1  # (the exchange in flight uses the OTHER half of both double buffers: this step reads `_action_slot`'s)
+        gather_work = None
+        if self._collectives:
+            out = list(self._root_obs[slot].unbind(0)) if self.rank == 0 else None
+            gather_work = dist.gather(obs.contiguous(), out, dst=0, async_op=True)
+        views = self.step(None)
+        # rank 0: policy on o_k (which the gather has delivered meanwhile), scatter for the step after the next call's
+        if gather_work is not None:
+            gather_work.wait()
+        obs_all = None
+        if self.rank == 0:
+            obs_all = (self._root_obs[slot].reshape((self.world_size * self.num_envs,) + self.obs_shape) if self._collectives
+                       else obs.reshape((self.num_envs,) + self.obs_shape))
+        actions = policy(obs_all) if self.rank == 0 else None
+        mine = self.actions[slot]
+        if not self._collectives:
+            mine.copy_(actions.reshape(mine.shape))
+            self._stale_scatter = (None, slot)
+        else:
+            chunks = None
+            if self.rank == 0:
+                chunks = list(actions.to(torch.float32).reshape((self.world_size, self.num_envs) + self.act_shape).contiguous().unbind(0))
+            self._stale_scatter = (dist.scatter(mine, chunks, src=0, async_op=True), slot)
+        return views
 
     # ------------------------------------------------------------ rank 0 reads
     def records(self, step: int):
