@@ -10,13 +10,13 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 cd $D
 # the library's flags (upkie_amd/lib.py): SLP-packing scalar fp32 chains into v_pk_* costs registers and moves; the step
 # kernels are compiled by groups (csrc/step_instances.hpp), side by side
-for g in 0 1 2 3 4 5 6 7 8 9; do
+for g in 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1 -S --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" \
     -DUPKIE_INSTANCE_GROUP=$g $R/upkie_amd/csrc/step_instances.hip -o k$g.s 2> remarks$g.txt &
 done
 wait
-cat remarks?.txt > remarks.txt
-cat k?.s > k.s
+cat remarks*.txt > remarks.txt
+cat k[0-9]*.s > k.s
 grep -q "error:" remarks.txt && { grep -A5 "error:" remarks.txt | head -40; exit 1; }
 python3 - "$K" <<'PY'
 import collections, re, sys

@@ -1,5 +1,5 @@
 // step_instances.hip -- definitions of one group of step-kernel instantiations (step_instances.hpp):
-//   hipcc -c -DUPKIE_INSTANCE_GROUP=<0..9> step_instances.hip
+//   hipcc -c -DUPKIE_INSTANCE_GROUP=<0..15> step_instances.hip
 // or, for a look at ONE eight-lane kernel's ISA in seconds (tools/isa_probe.sh):
 //   hipcc -S --cuda-device-only -DUPKIE_PROBE_OCTET_MODE=<Mode> [-DUPKIE_PROBE_RAND=true] [-DUPKIE_PROBE_DEFAULT_SCALARS=true]
 //         [-DUPKIE_PROBE_IN_PLACE=true] step_instances.hip
@@ -23,7 +23,7 @@ template __global__ void upkie::step_kernel_octet<UPKIE_PROBE_OCTET_MODE, UPKIE_
     const float*, const float*, int, upkie::BaseVelocityPtrs, float*, int, unsigned*, upkie::ServoPolicyArg<UPKIE_PROBE_OCTET_MODE>, float*);
 #else
 #if !defined(UPKIE_INSTANCE_GROUP)
-#error "compile with -DUPKIE_INSTANCE_GROUP=<0..9> (upkie_amd/lib.py builds every group)"
+#error "compile with -DUPKIE_INSTANCE_GROUP=<0..15> (upkie_amd/lib.py builds every group)"
 #endif
 #define UPKIE_INSTANCE_KW
 #include "step_instances.hpp"

@@ -13,7 +13,7 @@
 #define UPKIE_INSTANCE_KW extern
 #define UPKIE_INSTANCE_GROUP (-1) /* declarations: every group */
 #endif
-#define UPKIE_INSTANCE_GROUPS 10
+#define UPKIE_INSTANCE_GROUPS 16
 
 namespace upkie {
 
@@ -58,67 +58,81 @@ namespace upkie {
 
 #define UPKIE_IN_GROUP(g) (UPKIE_INSTANCE_GROUP < 0 || UPKIE_INSTANCE_GROUP == (g))
 
+// (sixteen groups, the one-lane kernels -- the largest and slowest to compile -- one mode per group: on eight cores the
+// build is as long as its total work allows, not as long as its largest group; lib.build starts the heavy groups first)
 #if UPKIE_IN_GROUP(0)
-UPKIE_ONE_LANE(MODE_RESET)
 UPKIE_ONE_LANE(MODE_PENDULUM)
-UPKIE_ONE_LANE(MODE_PENDULUM_AGENT)
 #endif
 #if UPKIE_IN_GROUP(1)
-UPKIE_ONE_LANE(MODE_GYROPOD)
-UPKIE_ONE_LANE(MODE_BASE_VELOCITY)
+UPKIE_ONE_LANE(MODE_PENDULUM_AGENT)
 #endif
 #if UPKIE_IN_GROUP(2)
-UPKIE_ONE_LANE(MODE_SERVOS)
-UPKIE_PAIR(MODE_RESET)
-UPKIE_PAIR(MODE_PENDULUM)
+UPKIE_ONE_LANE(MODE_GYROPOD)
 #endif
 #if UPKIE_IN_GROUP(3)
-UPKIE_PAIR(MODE_PENDULUM_AGENT)
-UPKIE_PAIR(MODE_PENDULUM_ROLLOUT)
-UPKIE_PAIR(MODE_GYROPOD)
+UPKIE_ONE_LANE(MODE_BASE_VELOCITY)
 #endif
 #if UPKIE_IN_GROUP(4)
-UPKIE_PAIR(MODE_SERVOS)
-UPKIE_PAIR(MODE_BASE_VELOCITY)
-UPKIE_OCTET(MODE_RESET, false, false)
+UPKIE_ONE_LANE(MODE_SERVOS)
 #endif
 #if UPKIE_IN_GROUP(5)
+UPKIE_ONE_LANE(MODE_RESET)
+UPKIE_PAIR(MODE_RESET)
+UPKIE_OCTET(MODE_RESET, false, false)
+#endif
+#if UPKIE_IN_GROUP(6)
+UPKIE_ONE_LANE_BULLET(MODE_RESET)
+UPKIE_ONE_LANE_BULLET(MODE_PENDULUM)
+UPKIE_ONE_LANE_BULLET(MODE_PENDULUM_AGENT)
+#endif
+#if UPKIE_IN_GROUP(7)
+UPKIE_ONE_LANE_BULLET(MODE_GYROPOD)
+UPKIE_ONE_LANE_BULLET(MODE_SERVOS)
+UPKIE_ONE_LANE_BULLET(MODE_BASE_VELOCITY)
+#endif
+#if UPKIE_IN_GROUP(8)
+UPKIE_PAIR(MODE_PENDULUM)
+UPKIE_PAIR(MODE_PENDULUM_AGENT)
+UPKIE_PAIR(MODE_PENDULUM_ROLLOUT)
+#endif
+#if UPKIE_IN_GROUP(9)
+UPKIE_PAIR(MODE_GYROPOD)
+UPKIE_PAIR(MODE_SERVOS)
+UPKIE_PAIR(MODE_BASE_VELOCITY)
+#endif
+#if UPKIE_IN_GROUP(10)
 UPKIE_OCTET(MODE_PENDULUM, false, false)
 UPKIE_OCTET(MODE_PENDULUM, true, false)
 UPKIE_OCTET(MODE_PENDULUM, false, true)
 UPKIE_OCTET(MODE_PENDULUM, true, true)
+#endif
+#if UPKIE_IN_GROUP(11)
 UPKIE_OCTET(MODE_PENDULUM_AGENT, false, false)
 UPKIE_OCTET(MODE_PENDULUM_AGENT, true, false)
-#endif
-#if UPKIE_IN_GROUP(6)
 UPKIE_OCTET(MODE_PENDULUM_ROLLOUT, false, false)
 UPKIE_OCTET(MODE_PENDULUM_ROLLOUT, true, false)
+#endif
+#if UPKIE_IN_GROUP(12)
 UPKIE_OCTET(MODE_GYROPOD, false, false)
 UPKIE_OCTET(MODE_GYROPOD, true, false)
 UPKIE_OCTET(MODE_GYROPOD, false, true)
 UPKIE_OCTET(MODE_GYROPOD, true, true)
 #endif
-#if UPKIE_IN_GROUP(7)
+#if UPKIE_IN_GROUP(13)
 UPKIE_OCTET(MODE_SERVOS, false, false)
 UPKIE_OCTET(MODE_SERVOS, false, true)
 UPKIE_OCTET(MODE_BASE_VELOCITY, false, false)
 #endif
-#if UPKIE_IN_GROUP(9)
+#if UPKIE_IN_GROUP(14)
 UPKIE_OCTET_BULLET(MODE_RESET)
 UPKIE_OCTET_BULLET(MODE_PENDULUM)
 UPKIE_OCTET_BULLET(MODE_PENDULUM_AGENT)
 UPKIE_OCTET_BULLET(MODE_PENDULUM_ROLLOUT)
+#endif
+#if UPKIE_IN_GROUP(15)
 UPKIE_OCTET_BULLET(MODE_GYROPOD)
 UPKIE_OCTET_BULLET(MODE_BASE_VELOCITY)
 UPKIE_OCTET_BULLET(MODE_SERVOS)
-#endif
-#if UPKIE_IN_GROUP(8)
-UPKIE_ONE_LANE_BULLET(MODE_RESET)
-UPKIE_ONE_LANE_BULLET(MODE_PENDULUM)
-UPKIE_ONE_LANE_BULLET(MODE_PENDULUM_AGENT)
-UPKIE_ONE_LANE_BULLET(MODE_GYROPOD)
-UPKIE_ONE_LANE_BULLET(MODE_SERVOS)
-UPKIE_ONE_LANE_BULLET(MODE_BASE_VELOCITY)
 #endif
 
 }  // namespace upkie

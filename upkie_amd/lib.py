@@ -98,7 +98,7 @@ class UpkieHipError(UpkieRuntimeError):
         self.status = status
 
 
-INSTANCE_GROUPS = 10  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
+INSTANCE_GROUPS = 16  # UPKIE_INSTANCE_GROUPS of csrc/step_instances.hpp
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -130,8 +130,11 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     if stale:
         os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
         tag = f"{LIB_PATH}.{os.getpid()}"
-        units = [(SOURCES[0], [], f"{tag}.abi.o")]
-        units += [(INSTANCES_SOURCE, [f"-DUPKIE_INSTANCE_GROUP={g}"], f"{tag}.g{g}.o") for g in range(INSTANCE_GROUPS)]
+        # (the heaviest units first -- the one-lane kernels, groups 0-7, then the C-ABI's own unit --: the build ends when the
+        # total work does, not when a late-started heavy group does)
+        units = [(INSTANCES_SOURCE, [f"-DUPKIE_INSTANCE_GROUP={g}"], f"{tag}.g{g}.o") for g in range(8)]
+        units += [(SOURCES[0], [], f"{tag}.abi.o")]
+        units += [(INSTANCES_SOURCE, [f"-DUPKIE_INSTANCE_GROUP={g}"], f"{tag}.g{g}.o") for g in range(8, INSTANCE_GROUPS)]
         jobs = jobs or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         partial = f"{tag}.partial"  # (a library is never loadable half-written: built beside it, renamed into place)
         objects = [obj for _, _, obj in units]
