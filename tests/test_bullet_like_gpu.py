@@ -245,3 +245,49 @@ def test_switching_the_model_off_restores_the_default_kernels():
         oa = a.step_pendulum_agent()[0]
         ob = b.step_pendulum_agent()[0]
     assert torch.equal(oa, ob)
+
+
+def test_same_step_autoreset_inside_the_bullet_like_launch_matches_the_oracle():
+    """Round 5: the eight-lane Bullet-like kernels have their IN_PLACE instantiations -- a SAME_STEP env under
+    `contact_model="bullet_like"` ends an episode, keeps its last observation and restarts the env (dropping its contact
+    cache) inside ONE launch, as the default model's kernels do. Public vector env on the device against the same env on
+    the oracle double, robots left to fall (fall pitch 0.12): a third of the envs fall and restart within the 90 steps."""
+    import upkie_amd.envs as envs
+    from upkie_amd.utils.robot_state import RobotState
+    from upkie_amd.utils.robot_state_randomization import RobotStateRandomization
+
+    from .fake_sim import oracle_sim_factory
+    from .test_timed_windows_gpu import compare_falls
+
+    B, steps = 512, 90
+    init = lambda: RobotState(randomization=RobotStateRandomization(pitch=0.05, x=0.02, omega_y=0.05))  # noqa: E731
+    kw = dict(num_envs=B, frequency=200.0, seed=4, autoreset_mode="same_step", contact_model="bullet_like", fall_pitch=0.12)
+    gpu = envs.make("Upkie-HIP-Pendulum-Vec", init_state=init(), **kw)
+    cpu = envs.make("Upkie-HIP-Pendulum-Vec", init_state=init(), sim_factory=oracle_sim_factory, **kw)
+    assert gpu.sim.lanes_per_env == 8
+    gpu.reset(seed=4)
+    cpu.reset(seed=4)
+    act_g, act_c = torch.zeros(B, 1, device=gpu.device), torch.zeros(B, 1)
+    ends_g, ends_c = np.zeros((steps, B), dtype=np.uint8), np.zeros((steps, B), dtype=np.uint8)
+    final_err, restart_err = [], []
+    for k in range(steps):
+        og, _, tg, _, ig = gpu.step(act_g)
+        oc, _, tc, _, ic = cpu.step(act_c)
+        ends_g[k], ends_c[k] = tg.cpu().numpy(), tc.numpy()
+        same = (ends_g[k] != 0) & (ends_c[k] != 0) & (ends_g[:k].sum(axis=0) == ends_c[:k].sum(axis=0))
+        if same.any():
+            final_err.append(np.abs(ig["final_obs"].cpu().numpy()[same].astype(np.float64) - ic["final_obs"].numpy()[same])[:, :2].max())
+            restart_err.append(np.abs(og.cpu().numpy()[same].astype(np.float64) - oc.numpy()[same])[:, :2].max())
+            assert torch.equal(ig["_final_obs"].cpu(), tg.cpu())
+    report = compare_falls(ends_g, ends_c)
+    print("bullet-like SAME_STEP in the launch:", report, "final_obs", max(final_err), "restart", max(restart_err))
+    assert report["episodes_ended_oracle"] >= B // 4 and report["envs_every_end_within_1_step"] >= 0.99, report  # (measured: 175 ends in 90 steps, every one on the oracle's step)
+    assert abs(report["episodes_ended_device"] - report["episodes_ended_oracle"]) <= 3, report
+    assert max(final_err) < 2e-3 and max(restart_err) < 2e-5  # robots tipping over on locked wheels; the restarted env: the same draw
+    # the restarted envs' manifolds: one fresh point per tire on both sides
+    mh = gpu.sim.contact_manifold.cpu().numpy().reshape(2, 4, 8, B)
+    mo = cpu.sim._o.bullet_manifold.reshape(2, 4, 8, B)
+    in_phase = (ends_g == ends_c).all(axis=0)
+    assert np.array_equal((mh[:, :, 7].sum(axis=1) != 0)[:, in_phase], (mo[:, :, 7].sum(axis=1) != 0)[:, in_phase])
+    gpu.close()
+    cpu.close()

@@ -56,6 +56,11 @@ namespace upkie {
   UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, false, false, true>(UPKIE_OCTET_ARGS(MODE));
 
 
+// ... with the SAME_STEP autoreset inside the launch (the modes that reset in place): <MODE, RAND, false, true, true>
+#define UPKIE_OCTET_BULLET_IN_PLACE(MODE)                                                                               \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, false, false, true, true>(UPKIE_OCTET_ARGS(MODE)); \
+  UPKIE_INSTANCE_KW template __global__ void step_kernel_octet<MODE, true, false, true, true>(UPKIE_OCTET_ARGS(MODE));
+
 #define UPKIE_IN_GROUP(g) (UPKIE_INSTANCE_GROUP < 0 || UPKIE_INSTANCE_GROUP == (g))
 
 // (sixteen groups, the one-lane kernels -- the largest and slowest to compile -- one mode per group: on eight cores the
@@ -79,6 +84,7 @@ UPKIE_ONE_LANE(MODE_SERVOS)
 UPKIE_ONE_LANE(MODE_RESET)
 UPKIE_PAIR(MODE_RESET)
 UPKIE_OCTET(MODE_RESET, false, false)
+UPKIE_OCTET_BULLET_IN_PLACE(MODE_SERVOS)
 #endif
 #if UPKIE_IN_GROUP(6)
 UPKIE_ONE_LANE_BULLET(MODE_RESET)
@@ -122,12 +128,14 @@ UPKIE_OCTET(MODE_GYROPOD, true, true)
 UPKIE_OCTET(MODE_SERVOS, false, false)
 UPKIE_OCTET(MODE_SERVOS, false, true)
 UPKIE_OCTET(MODE_BASE_VELOCITY, false, false)
+UPKIE_OCTET_BULLET_IN_PLACE(MODE_GYROPOD)
 #endif
 #if UPKIE_IN_GROUP(14)
 UPKIE_OCTET_BULLET(MODE_RESET)
 UPKIE_OCTET_BULLET(MODE_PENDULUM)
 UPKIE_OCTET_BULLET(MODE_PENDULUM_AGENT)
 UPKIE_OCTET_BULLET(MODE_PENDULUM_ROLLOUT)
+UPKIE_OCTET_BULLET_IN_PLACE(MODE_PENDULUM)
 #endif
 #if UPKIE_IN_GROUP(15)
 UPKIE_OCTET_BULLET(MODE_GYROPOD)

@@ -612,7 +612,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // eight-lane mapping, by a second launch (the DONE pass) behind this one on the others
   constexpr bool RESETS_IN_PLACE = MODE == MODE_PENDULUM || MODE == MODE_GYROPOD || MODE == MODE_SERVOS;
   const bool same_step = RESETS_IN_PLACE && !done_pass && packed != 1 && sim->final_obs != nullptr && config.autoreset_mode == UPKIE_AUTORESET_DISABLED;
-  const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8 && !sim->manifold;  // (no IN_PLACE instantiation of the Bullet-like kernels: the DONE pass follows as a second launch)
+  const bool same_step_in_kernel = same_step && mapped_lanes_of_mode(sim, MODE) == 8;  // (round 5: the Bullet-like eight-lane kernels have their IN_PLACE instantiations too)
   if (same_step_in_kernel) final_obs = sim->final_obs;
   // (UPKIE_ALWAYS_RAND_KERNELS=1: launch the randomisation-capable instantiation even without inertial records or forces
   // -- null pointers, tested at run time --: the A/B that decides whether the RAND = false instantiations of the one- and
@@ -646,10 +646,18 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP, false>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
                      sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg, (float*)nullptr)
-#define UPKIE_LAUNCH_OCTET_BULLET(R)                                                                                            \
-  hipLaunchKernelGGL((step_kernel_octet<MODE, R, false, false, true>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+#define UPKIE_LAUNCH_OCTET_BULLET_IP(R, IP)                                                                                     \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, false, IP, true>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
                      sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg, sim->manifold)
+#define UPKIE_LAUNCH_OCTET_BULLET(R)                                                             \
+  do {                                                                                           \
+    bool launched = false;                                                                       \
+    if constexpr (octet_resets_in_place(MODE)) {                                                 \
+      if (same_step_in_kernel) { UPKIE_LAUNCH_OCTET_BULLET_IP(R, true); launched = true; }       \
+    }                                                                                            \
+    if (!launched) UPKIE_LAUNCH_OCTET_BULLET_IP(R, false);                                       \
+  } while (0)
   // which instantiation (step_instances.hpp lists them): the SAME_STEP autoreset inside the launch has its own (the second
   // pass makes the whole step a loop body: spills); the Pendulum / Gyropod steps also exist with the default model's
   // scalars as constants
@@ -696,6 +704,7 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   }
 #undef UPKIE_LAUNCH_OCTET
 #undef UPKIE_LAUNCH_OCTET_BULLET
+#undef UPKIE_LAUNCH_OCTET_BULLET_IP
 #undef UPKIE_LAUNCH_BULLET
 #undef UPKIE_LAUNCH_OCTET_D
 #undef UPKIE_LAUNCH_PAIR_S
