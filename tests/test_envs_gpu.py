@@ -237,6 +237,58 @@ def test_graph_captured_loop_equals_eager():
     assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs4, graphed.obs4)
 
 
+def test_two_graphs_of_one_handle_replay_each_with_its_own_settings():
+    """include/upkie_hip.h, "Streams and hipGraphs" (round 5; ADVICE r3 #4 / VERDICT r4 #12): every hipGraph capture of a
+    handle's steps gets a settings block of its own. Two graphs of ONE handle recorded at different settings (the fused
+    agent's clip: 0.99 and 0 -- the second one commands no velocity at all), replayed alternately between eager launches
+    at a third setting, each step with the settings it was recorded with: bit-equal to an eager handle whose settings are
+    changed before every step. (Until round 4 all captures of a handle shared one block: the graph recorded first would
+    have replayed with the second one's clip.) The ninth capture of a handle is refused with a message."""
+    from upkie_amd.graphs import GraphedLoop
+    from upkie_amd.lib import UpkieHipError
+    from upkie_amd.sim import BatchedSim
+
+    def make():
+        cfg = abi.default_sim_config(512, seed=5)
+        cfg.rand_pitch = 0.1
+        cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
+        sim = BatchedSim(cfg)
+        sim.reset()
+        sim.obs4.copy_(sim.obs6[:, [1, 0, 4, 3]])
+        return sim
+
+    def set_clip(sim, clip):
+        sim.config.agent_clip = clip
+        sim.push_config()
+
+    eager, graphed = make(), make()
+    assert graphed.lanes_per_env == 8  # (the eight-lane kernels are the ones that read the settings from device blocks)
+    set_clip(graphed, 0.99)
+    loop_a = GraphedLoop(lambda: graphed.step_pendulum_agent(), unroll=1, warmup=2)
+    set_clip(graphed, 0.0)
+    loop_b = GraphedLoop(lambda: graphed.step_pendulum_agent(), unroll=1, warmup=2)
+    set_clip(graphed, 0.5)  # what eager launches of this handle use from here on
+    eager.state.copy_(graphed.state)
+    eager.obs4.copy_(graphed.obs4)
+    schedule = ["a", "b", "e", "a", "a", "b", "e", "b", "a"]
+    for what in schedule:
+        {"a": loop_a.replay, "b": loop_b.replay, "e": graphed.step_pendulum_agent}[what]()
+        set_clip(eager, {"a": 0.99, "b": 0.0, "e": 0.5}[what])
+        eager.step_pendulum_agent()
+    torch.cuda.synchronize()
+    assert torch.equal(eager.state, graphed.state) and torch.equal(eager.obs4, graphed.obs4)
+    assert float(graphed.state[abi.S_QD + 2].abs().max()) > 0.0
+    # captures beyond UPKIE_MAX_GRAPH_CAPTURES are refused, loudly, and eager launches go on working
+    loops = [loop_a, loop_b]
+    with pytest.raises((UpkieHipError, RuntimeError)):
+        for _ in range(abi.MAX_GRAPH_CAPTURES):
+            loops.append(GraphedLoop(lambda: graphed.step_pendulum_agent(), unroll=1, warmup=1))
+    torch.cuda.synchronize()
+    assert len(loops) == abi.MAX_GRAPH_CAPTURES  # two + six more were recorded, the ninth was not
+    graphed.step_pendulum_agent()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("lanes", ["1", "2", "8"])
 @pytest.mark.parametrize("env_id,limit", [("Upkie-HIP-Pendulum-Vec", None), ("Upkie-HIP-Gyropod-Vec", 25), ("Upkie-HIP-Servos-Vec", 12)])
 def test_same_step_autoreset_is_one_launch_and_matches_the_double(env_id, limit, lanes, monkeypatch):
@@ -409,3 +461,45 @@ def test_fused_servo_policy_step_and_same_step_resets_replay_from_a_graph():
     for sim in (eager, graphed):
         sim.step_servos_policy(changed)
     assert torch.equal(eager.state, graphed.state)
+
+
+@pytest.mark.parametrize("env_id", ["Upkie-HIP-Pendulum-Vec", "Upkie-HIP-Servos-Vec"])
+def test_graphed_env_step_starts_from_the_reset_state(env_id):
+    """`GraphedEnvStep`'s warm-up used to advance the env three steps (possibly through autoresets) between
+    the user's `reset()` and the first graphed step, and a Servos env's policy read an all-zero observation first. Now
+    the state is snapshot before the warm-up and restored after the capture: the graphed loop replays, bit for bit,
+    what the eager loop `obs = env.step(policy(obs))` does from `reset()`; env kinds that compose their step refuse."""
+    from upkie_amd.exceptions import UpkieRuntimeError
+    from upkie_amd.graphs import GraphedEnvStep
+
+    B = 384
+    init = lambda: RobotState(randomization=RobotStateRandomization(pitch=0.2))  # noqa: E731
+    kw = dict(num_envs=B, frequency=200.0, seed=9, fall_pitch=0.3) if "Pendulum" in env_id else dict(num_envs=B, frequency=200.0, seed=9)
+    eager, graphed = envs.make(env_id, init_state=init(), **kw), envs.make(env_id, init_state=init(), **kw)
+    if "Pendulum" in env_id:
+        gain = torch.tensor([10.0, 1.0, 0.0, 0.1], device="cuda:0")
+        policy = lambda o: (o @ gain).clamp(-0.99, 0.99).unsqueeze(1)  # noqa: E731
+    else:
+        neutral = eager.get_neutral_action()
+
+        def policy(o):
+            a = neutral.clone()
+            a[:, 2, 1] = (20.0 * o[:, 0, 0]).clamp(-5.0, 5.0)  # any function of the observation: wheel velocity from the hip angle
+            a[:, 5, 1] = -a[:, 2, 1]
+            return a
+    oe, _ = eager.reset(seed=9)
+    og, _ = graphed.reset(seed=9)
+    assert graphed.observation is og and float(og.abs().sum()) > 0.0  # (Servos: allocated and filled by reset, not by the first step)
+    step = GraphedEnvStep(graphed, policy, warmup=3)
+    assert torch.equal(eager.sim.state, graphed.sim.state) and torch.equal(oe, og)  # nothing moved
+    for _ in range(12):
+        oe = eager.step(policy(oe))[0]
+        og = step()[0]
+    torch.cuda.synchronize()
+    assert torch.equal(eager.sim.state, graphed.sim.state) and torch.equal(oe, og)
+    bv = envs.make("Upkie-HIP-BaseVelocity-Vec", num_envs=64, frequency=200.0, nb_timesteps=16)
+    bv.reset(seed=0)
+    with pytest.raises(UpkieRuntimeError, match="GraphedLoop"):
+        GraphedEnvStep(bv, lambda o: torch.zeros(64, 2, device="cuda:0"))
+    for e in (eager, graphed, bv):
+        e.close()
