@@ -559,6 +559,10 @@ class ShardedVecEnv:
         scatter; an on-policy learner must know that its actions are one step
         late (asynchronous / "lagged" actors accept exactly this)."""
         if not stale:
+            if self._stale_scatter is not None:  # (a lagged exchange left in flight by an earlier stale=1 call: finished and dropped)
+                if self._stale_scatter[0] is not None:
+                    self._stale_scatter[0].wait()
+                self._stale_primed, self._stale_scatter = False, None
             obs_all = self.gather_observations()
             self.scatter_actions(policy(obs_all) if self.rank == 0 else None)
             return self.step(None)
