@@ -1,8 +1,8 @@
 // step_instances.hpp -- every instantiation of the three step kernels that launch_step (upkie_hip.hip) can launch, as
 // one list read twice: upkie_hip.hip includes it with UPKIE_INSTANCE_KW = `extern` (declarations: the C-ABI's
 // translation unit compiles no step kernel), step_instances.hip with UPKIE_INSTANCE_KW empty and UPKIE_INSTANCE_GROUP = g
-// (definitions of group g). ~130 kernels of 5-20 k instructions each: in one translation unit the library took two
-// minutes to build; by groups, on eight cores, about forty seconds (upkie_amd/lib.py).
+// (definitions of group g). ~140 kernels of 5-20 k instructions each: in one translation unit the library took two
+// minutes to build; by sixteen groups, on eight cores, about thirty seconds (upkie_amd/lib.py).
 //
 // The kernels of different groups share no device symbol (every device function is inlined), so no relocatable device
 // code is needed: each object carries its own code object, the host-side launch stubs are ordinary weak symbols.
