@@ -269,8 +269,9 @@ def _c5_env(B, seed, contact_model="default"):
                      contact_model=contact_model, joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
 
 
-@pytest.mark.parametrize("law, contact_model", [("velocity", "default"), ("torque", "default"), ("velocity", "bullet_like"), ("torque", "bullet_like")])
-def test_c5_share_window_pushes_and_falls_match_the_oracle(law, contact_model):
+@pytest.mark.parametrize("law, contact_model, lanes", [("velocity", "default", 8), ("torque", "default", 8), ("velocity", "bullet_like", 8), ("torque", "bullet_like", 8),
+                                                      ("velocity", "bullet_like", 1)])
+def test_c5_share_window_pushes_and_falls_match_the_oracle(law, contact_model, lanes, monkeypatch):
     """`bench.secondary_c5_share`'s loop on 4096 envs over three pushes (1200
     steps): per-link inertia randomisation 0.2, wheel friction 0.1, the push
     schedule drawn on the device -- compared draw for draw with the oracle's
@@ -282,15 +283,19 @@ def test_c5_share_window_pushes_and_falls_match_the_oracle(law, contact_model):
     Round 5: the same window under the Bullet-like contact model -- the Servos
     steps on the EIGHT-lane Bullet-like kernel (new this round) against the
     oracle's `bullet_like` mode: persistent manifolds carried through the pushes,
-    the falls and the NEXT_STEP autoresets, which clear them."""
+    the falls and the NEXT_STEP autoresets, which clear them -- and once on
+    the ONE-lane Bullet-like kernels (UPKIE_LANES_PER_ENV=1: the kernels that
+    keep several points per tire and limit rows inside the same sweeps)."""
     import bench
     from oracle import oracle as O
 
+    if lanes != 8:
+        monkeypatch.setenv("UPKIE_LANES_PER_ENV", str(lanes))
     B, steps, seed = 4096, 1200, 0
     env = _c5_env(B, seed, contact_model)
     env.reset(seed=seed)
     sim = env.sim
-    assert sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8
+    assert sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == lanes
     m = env.model.struct
     ref = O.Oracle(m, env.config)
     if contact_model == "bullet_like":
@@ -347,7 +352,7 @@ def test_c5_share_window_pushes_and_falls_match_the_oracle(law, contact_model):
     report["envs_fell_on_device_only"] = int((fell_h & ~fell_r).sum())
     report["envs_fell_on_oracle_only"] = int((~fell_h & fell_r).sum())
     report["envs_fell_on_both"] = int((fell_h & fell_r).sum())
-    write_report(f"c5_share_window_{law}_law" + ("" if contact_model == "default" else "_" + contact_model), report)
+    write_report(f"c5_share_window_{law}_law" + ("" if contact_model == "default" else "_" + contact_model) + ("" if lanes == 8 else f"_{lanes}_lane"), report)
     env.close()
     assert len(push_err) == 3 and max(push_err) <= 2e-5, report  # fp32 draw of a 20 N force against the fp64 twin
     n_h, n_r = report["episodes_ended_device"], report["episodes_ended_oracle"]
