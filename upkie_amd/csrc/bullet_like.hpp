@@ -140,14 +140,18 @@ UPKIE_HD void bullet_like_sweeps6(const float (&W)[6][6], const float (&rhs)[6],
       PR = y * BlPair{scale_right, scale_right};  BL_KEEP_ORDER;
     }
   };
-  // (two sweeps per trip: the impulses ping-pong between two register pairs instead of being copied back, and the loop's
-  // own three instructions are paid once per two sweeps)
+  // (five sweeps per trip -- the published 50 are ten trips --: the impulses ping-pong between register pairs instead of
+  // being copied back, and the loop's own instructions -- counter, compare, branch, the copies a loop-carried pair costs
+  // -- are paid once per five sweeps)
   int it = 0;
-  for (; it + 1 < iterations; it += 2) {
+  for (; it + 4 < iterations; it += 5) {
+    sweep();
+    sweep();
+    sweep();
     sweep();
     sweep();
   }
-  if (it < iterations) sweep();
+  for (; it < iterations; ++it) sweep();
 #undef BL_KEEP_ORDER
   lam[0] = Pn.x; lam[3] = Pn.y;
   lam[1] = PL.x; lam[2] = PL.y;
