@@ -317,7 +317,7 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * is counted by the census, word [0]; UPKIE_LANES_PER_ENV=1 selects the
  * one-lane kernels, which keep limit rows inside the same sweeps).
  * Both keep complete manifold records, so either continues from a manifold the
- * other wrote. About 2 x the default model's step (the sweeps are ~36 packed-
+ * other wrote. About 2.3 x the default model's Pendulum step (the sweeps are ~36 packed-
  * fp32 instructions each); the default stays the product's fast
  * specification. This is the model to answer "what would PyBullet's contact
  * pipeline do", e.g. the first thing tools/compare_with_pybullet.py holds
