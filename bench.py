@@ -129,7 +129,7 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{steps} env.step() of {envs} envs, fp64 C oracle ({'-O3 -march=native' if native else '-O2'}), one OpenMP region over the rollout, {cores} threads ({elapsed:.1f} s)",
+        "sample": f"{steps} env.step() of {envs} envs, fp64 C oracle ({'-O3 -march=native' if native else '-O3'}), one OpenMP region over the rollout, {cores} threads ({elapsed:.1f} s)",
         "hardware_threads": os.cpu_count(),
         "one_thread": {"value": one_thread, "unit": "env-steps/s", "sample": f"{steps1} env.step() of {per_thread_envs} envs on 1 thread ({elapsed1:.1f} s)"},
         "scaling_vs_one_thread": all_cores / one_thread,
