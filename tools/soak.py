@@ -131,27 +131,31 @@ for lanes in ("8", "1"):
                 un = torch.hypot(2 * (q[1] * q[3] - q[2] * q[0]), 1 - 2 * (q[1] ** 2 + q[2] ** 2))  # |world z projected on the wheel plane|
                 assert lanes == "1" and float(un[several.any(dim=0)].max()) < 0.5, "several cached points on a tire of a robot that is not lying on its side"
     print(f"lanes={lanes} Bullet-like contacts, pendulum agent + inertia 0.3 + pushes + noise: {n} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} episode resets")
-os.environ["UPKIE_LANES_PER_ENV"] = "8"
-cfg = config(6)
-cfg.autoreset_mode = abi.AUTORESET_DISABLED
-sim = BatchedSim(cfg)
-sim.use_bullet_like_contacts()
-sim.reset()
-scale = torch.tensor([16.0, 16.0, 1.7, 16.0, 16.0, 1.7], device=sim.device)
-act = torch.zeros((B, 6, 6), device=sim.device)
-n = max(steps // 20, 100)
-for k in range(n):
-    if k % 20 == 0:
-        act[:, :, 0] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 3.0
-        act[:, :, 1] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 10.0
-        act[:, :, 2] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * scale
-        act[:, :, 3] = torch.rand((B, 6), device=sim.device) * 2.0
-        act[:, :, 4] = torch.rand((B, 6), device=sim.device) * 2.0
-        act[:, :, 5] = torch.rand((B, 6), device=sim.device) * scale
-    sim.step_servos(act)
-    if k % 50 == 49:
-        check(sim, "bullet-like servos", k)
-        assert torch.isfinite(sim.contact_manifold).all()
-print(f"Bullet-like contacts, servos random commands (one env per lane, joint stops in the same solve), no resets: {n} steps ok")
+# (round 5: Servos steps run the eight-lane Bullet-like kernel too -- a joint at its stop takes the default model's joint-stop
+# solve for that substep there --; the one-lane kernels keep limit rows and tire contacts in ONE fixed-sweep solve)
+for lanes in ("8", "1"):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
+    cfg = config(6)
+    cfg.autoreset_mode = abi.AUTORESET_DISABLED
+    sim = BatchedSim(cfg)
+    sim.use_bullet_like_contacts()
+    assert sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == int(lanes)
+    sim.reset()
+    scale = torch.tensor([16.0, 16.0, 1.7, 16.0, 16.0, 1.7], device=sim.device)
+    act = torch.zeros((B, 6, 6), device=sim.device)
+    n = max(steps // 20, 100)
+    for k in range(n):
+        if k % 20 == 0:
+            act[:, :, 0] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 3.0
+            act[:, :, 1] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 10.0
+            act[:, :, 2] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * scale
+            act[:, :, 3] = torch.rand((B, 6), device=sim.device) * 2.0
+            act[:, :, 4] = torch.rand((B, 6), device=sim.device) * 2.0
+            act[:, :, 5] = torch.rand((B, 6), device=sim.device) * scale
+        sim.step_servos(act)
+        if k % 50 == 49:
+            check(sim, f"bullet-like servos lanes={lanes}", k)
+            assert torch.isfinite(sim.contact_manifold).all()
+    print(f"lanes={lanes} Bullet-like contacts, servos random commands, no resets: {n} steps ok")
 os.environ.pop("UPKIE_LANES_PER_ENV", None)
 print("soak passed")
