@@ -60,27 +60,6 @@ def make_config(num_envs: int, env_id_offset: int = 0, seed: int = 0):
     return cfg
 
 
-def usable_cores() -> int:
-    """Host cores this process may actually run on: the scheduler affinity
-    mask capped by the cgroup CPU quota (os.cpu_count() reports the machine's
-    hardware threads, which a container is rarely given in full: timing 256
-    OpenMP threads on a 16-core quota measures oversubscription, not the CPU)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path, parse in (
-        ("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
-        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())),
-    ):
-        try:
-            with open(path) as f:
-                quota = parse(f.read().strip())
-            if quota:
-                n = max(1, min(n, int(quota)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
-
-
 def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     """The fp64 C oracle (a port: the reference's PyBullet path cannot run
     here) on the host cores, same workload, bounded to ~budget_s of CPU work:
@@ -90,22 +69,15 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
     threads = the cores this process may use. Beside it: the same code on ONE
     thread (the scaling factor follows) and one env on one thread (the
     reference's own execution model)."""
-    import ctypes
-
     from oracle import oracle as O
 
     native = O.use_native_build()  # before anything touches the oracle
     from upkie_amd.model.default_model import default_model
 
-    cores = usable_cores()
-    try:
-        omp = ctypes.CDLL("libgomp.so.1")
-    except OSError:
-        omp = None
+    cores = O.usable_cores()
 
     def rate(num_envs: int, threads: int, seconds: float):
-        if omp is not None:
-            omp.omp_set_num_threads(threads)
+        O.set_threads(threads)
         ref = O.Oracle(default_model(), make_config(num_envs))
         obs = ref.reset()[:, [1, 0, 4, 3]]
         obs, _ = ref.rollout_pendulum_agent(obs, 2)  # warm up (thread team, caches)

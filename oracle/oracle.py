@@ -127,6 +127,41 @@ def use_native_build() -> bool:
         return False
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually run on: the scheduler affinity
+    mask capped by the cgroup CPU quota (os.cpu_count() reports the machine's
+    hardware threads, which a container is rarely given in full: 256 OpenMP
+    threads on a 16-core quota measure oversubscription, not the CPU -- and
+    make every oracle window of the test suite three times slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (
+        ("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
+        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())),
+    ):
+        try:
+            with open(path) as f:
+                quota = parse(f.read().strip())
+            if quota:
+                n = max(1, min(n, int(quota)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_threads(threads: int = 0) -> int:
+    """Size of the OpenMP team of the oracle's parallel loops (0: the usable
+    cores, unless OMP_NUM_THREADS says otherwise). Returns what was set."""
+    if threads <= 0:
+        env = os.environ.get("OMP_NUM_THREADS", "")
+        threads = int(env) if env.isdigit() and int(env) > 0 else usable_cores()
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    except OSError:
+        return 0
+    return int(threads)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -157,6 +192,7 @@ def _load(path):
     _lib.oracle_observers_check.restype = C.c_int
     _lib.oracle_pitch_frame_in_parent.restype = C.c_double
     _lib.oracle_rollout_pendulum_agent.restype = C.c_int64
+    set_threads()
     return _lib
 
 

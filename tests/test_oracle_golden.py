@@ -144,3 +144,20 @@ def test_philox_known_answer():
     assert O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
         0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_the_oracle_sizes_its_thread_team_to_the_cores_this_process_may_use(monkeypatch):
+    """A GPU box reports 256 hardware threads under a 16-core quota: the
+    default OpenMP team would be 256 threads taking turns on 16 cores."""
+    import ctypes
+
+    omp = ctypes.CDLL("libgomp.so.1")
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    cores = O.usable_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1)
+    assert O.set_threads() == cores and omp.omp_get_max_threads() == cores
+    assert O.set_threads(1) == 1 and omp.omp_get_max_threads() == 1
+    monkeypatch.setenv("OMP_NUM_THREADS", "2")
+    assert O.set_threads() == 2 and omp.omp_get_max_threads() == 2
+    monkeypatch.delenv("OMP_NUM_THREADS")
+    O.set_threads()
