@@ -113,6 +113,7 @@ def cpu_baseline(envs: int, budget_s: float = 15.0) -> dict:
 STEADY_WARMUP, STEADY_STEPS = 200, 2000  # "measured over >= 2000 steps after 200 warm-up steps ... autoresets included"
 PUSH_PERIOD, PUSH_HOLD, PUSH_MAX_NORM = 400, 20, 20.0  # every 400 steps a force of norm ~ U(0, 20) N, held 20 steps
 TARGET_PERIOD = 400  # v* ~ U(-0.5, 0.5) per env resampled every 400 steps
+C4_VALUE_WEIGHTS, C4_GAMMA, C4_LAMBDA = (0.5, 0.1, 0.05, 0.02), 0.99, 0.95  # the rollout consumer of --config c4
 C3_BYTES_PER_ENV_STEP, C5_BYTES_PER_ENV_STEP = 554, 630  # SURVEY 8d, algorithmic bytes
 
 
@@ -574,6 +575,33 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
     print(json.dumps(line), file=json_out or sys.stdout, flush=True)
 
 
+def c4_rollout_consumer(env, consumed: dict, on_gpu: bool = True):
+    """BASELINE configs[3]'s "PPO rollout consumer" on rank 0: every chunk of K steps x (all ranks' envs) that lands in the
+    rollout ring is turned into advantages and returns where it lies (a linear value function of the observation, the
+    rewards and episode ends the step kernels wrote, upkie_rollout_gae / nothing on the CPU double): stream-ordered
+    behind the gather that delivered the chunk, in front of rank 0's next step -- part of the timed work. Returns
+    `consume(chunk_index)` for `env.gather.consumer`; it leaves its last results in `consumed`."""
+    import torch
+
+    from upkie_amd.rollout import compute_gae
+
+    value_weights = torch.tensor(C4_VALUE_WEIGHTS, device=env.gather.rollout.device)
+
+    def consume(chunk_index: int) -> None:
+        ring = env.gather.rollout[chunk_index % env.gather.num_chunks]  # [world, K, B, 8]: records = obs (4), reward, terminated, truncated, 0
+        K, N = ring.shape[1], ring.shape[0] * ring.shape[2]
+        time_major = lambda t: t.permute(1, 0, 2).reshape(K, N)  # noqa: E731  ([world, K, B] -> [K, world * B])
+        values = time_major((ring[..., :4] * value_weights).sum(-1))
+        ended = time_major((ring[..., 5] + ring[..., 6]) != 0)
+        starts = torch.zeros_like(ended)
+        starts[1:] = ended[:-1]
+        if on_gpu:
+            consumed["advantages"], consumed["returns"] = compute_gae(time_major(ring[..., 4]), values, starts, values[-1], ended[-1], C4_GAMMA, C4_LAMBDA)
+        consumed["chunks"] += 1
+
+    return consume
+
+
 def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     """`sim_factory` / `backend` exist for tests/ only (a CPU double of the
     simulation handle over gloo, so that the N > 1 launch line, the shard
@@ -630,26 +658,7 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
     env.reset()
     consumed = {"chunks": 0}
     if args.config == "c4" and rank == 0:
-        # BASELINE configs[3]'s "PPO rollout consumer" on rank 0: every chunk of K steps x (all ranks' envs) that lands in the
-        # rollout ring is turned into advantages and returns where it lies (a linear value function of the observation, the
-        # rewards and episode ends the step kernels wrote, upkie_rollout_gae / the oracle-free torch twin on the CPU double):
-        # stream-ordered behind the gather that delivered the chunk, in front of rank 0's next step -- part of the timed work
-        from upkie_amd.rollout import compute_gae
-
-        value_weights = torch.tensor([0.5, 0.1, 0.05, 0.02], device=env.gather.rollout.device)
-
-        def consume(chunk_index: int) -> None:
-            ring = env.gather.rollout[chunk_index % env.gather.num_chunks]  # [world, K, B, 8]: records = obs (4), reward, terminated, truncated, 0
-            K, N = ring.shape[1], ring.shape[0] * ring.shape[2]
-            time_major = lambda t: t.permute(1, 0, 2).reshape(K, N)  # noqa: E731  ([world, K, B] -> [K, world * B])
-            values = time_major((ring[..., :4] * value_weights).sum(-1))
-            ended = time_major((ring[..., 5] + ring[..., 6]) != 0)
-            starts = torch.zeros_like(ended)
-            starts[1:] = ended[:-1]
-            if on_gpu:
-                consumed["advantages"], consumed["returns"] = compute_gae(time_major(ring[..., 4]), values, starts, values[-1], ended[-1], 0.99, 0.95)
-            consumed["chunks"] += 1
-
+        consume = c4_rollout_consumer(env, consumed, on_gpu)
         consume(0)  # (once, untimed: the first call loads the kernels' code objects)
         sync()
         consumed["chunks"] = 0

@@ -182,6 +182,152 @@ def test_c2_rollout_window_equals_step_by_step_window_bit_for_bit():
     assert np.array_equal(a["episodes"], b["episodes"])
 
 
+@pytest.mark.parametrize("lanes, steps", [("8", 2200), ("1", 600)])
+def test_c2_window_under_the_bullet_like_model_matches_the_oracle(lanes, steps, monkeypatch):
+    """`bench.secondary_bullet_like`'s loop (the `c2_bullet_like_contact_model`
+    block: `step_pendulum_agent` under `upkie_sim_set_contact_manifold`) on the
+    bench's config: on eight lanes per env over the headline's whole window --
+    2200 steps of 4096 envs, every env falls once, its manifold is cleared by
+    the autoreset inside the launch -- and on the one-lane kernels over the
+    window the block times (100 + 400 steps, no falls yet). Against the
+    oracle's Bullet-like twin, same criteria as the default model's window."""
+    import bench
+    from oracle import oracle as O
+
+    monkeypatch.setenv("UPKIE_LANES_PER_ENV", lanes)
+    B = bench.ENVS_PER_GPU
+    sim = BatchedSim(bench.make_config(B))
+    sim.use_bullet_like_contacts()
+    assert sim.lanes_per_env == int(lanes)
+    ref = O.Oracle(default_model(), bench.make_config(B))
+    ref.use_bullet_like_contacts()
+    o6 = sim.reset()
+    sim.obs4.copy_(o6[:, [1, 0, 4, 3]])
+    obs_ref = ref.reset()[:, [1, 0, 4, 3]]
+    term_h = torch.zeros((steps, B), dtype=torch.uint8, device=sim.device)
+    term_r = np.zeros((steps, B), dtype=np.uint8)
+    marks = [m for m in (100, 500, 1000, 1500) if m <= steps]
+    at_h, at_r = {}, {}
+    for k in range(steps):
+        obs_ref, _, t, trunc = ref.step_pendulum_agent(obs_ref)
+        obs, _, term, trunc_h = sim.step_pendulum_agent()
+        term_r[k] = t
+        term_h[k] = term
+        assert not trunc.any()
+        if k + 1 in marks:
+            at_h[k + 1], at_r[k + 1] = obs.cpu().numpy(), obs_ref.copy()
+    term_h = term_h.cpu().numpy()
+    report = compare_falls(term_h, term_r)
+    report["steps"], report["lanes_per_env"] = steps, int(lanes)
+    for m in marks:
+        in_phase = np.array([np.array_equal(np.nonzero(term_h[:m, e])[0], np.nonzero(term_r[:m, e])[0]) for e in range(B)])
+        err = np.abs(at_h[m] - at_r[m])[in_phase]
+        report[f"obs_error_step_{m}"] = dict(quantiles(err), envs_in_phase=int(in_phase.sum()), columns=["pitch", "position", "pitch rate", "velocity"])
+    mh = sim.contact_manifold.cpu().numpy().astype(np.float64).reshape(2, 4, 8, -1)
+    mo = ref.bullet_manifold.reshape(2, 4, 8, -1)
+    same_phase = np.array([np.array_equal(np.nonzero(term_h[:, e])[0], np.nonzero(term_r[:, e])[0]) for e in range(B)])
+    report["envs_with_the_same_cached_points"] = float(np.all((mh[:, :, 7] != 0) == (mo[:, :, 7] != 0), axis=(0, 1))[same_phase].mean())
+    episodes = sim.state[abi.S_EPISODE].cpu().numpy()
+    sim.close()
+    write_report(f"c2_window_bullet_like_{lanes}_lanes", report)
+    n_ref = report["episodes_ended_oracle"]
+    if steps >= 2000:
+        assert n_ref >= 0.5 * B, report  # the window does reach the falls
+    assert report["envs_every_end_within_1_step"] >= 0.99, report
+    assert abs(report["episodes_ended_device"] - n_ref) <= max(1, 0.005 * n_ref), report
+    assert np.abs(episodes - ref.state[abi.S_EPISODE]).max() <= 1, report
+    assert report["envs_with_the_same_cached_points"] >= 0.99, report
+    for m in marks:
+        q = report[f"obs_error_step_{m}"]
+        assert q["envs_in_phase"] >= 0.99 * B, report
+        assert q["q0.5"][0] <= 1e-4 and q["q0.5"][1] <= 1e-4, report
+        assert q["q0.99"][0] <= 5e-3 and q["q0.99"][1] <= 5e-3, report
+
+
+def test_c4_window_rollout_ring_and_advantages_match_the_oracle():
+    """`bench.py --config c4` on one GPU (BASELINE configs[3]: 8192 envs per GPU,
+    a wavefront on every SIMD; records produced into rank 0's rollout ring in
+    chunks of 64 steps, every chunk turned into advantages and returns by the
+    bench's own consumer, `bench.c4_rollout_consumer`) for 1920 steps = 30
+    chunks, through the first falls. The oracle steps the same 8192 envs; its
+    records of the chunks looked at and `oracle_gae` of them are what the ring
+    and the consumer's outputs are held to -- and, for every env whatever its
+    phase, the consumer's outputs to `oracle_gae` of the ring's own records."""
+    import bench
+    from oracle import oracle as O
+    from oracle.rollout_oracle import gae as oracle_gae
+    from upkie_amd.distributed import ShardedPendulum
+
+    B, K, chunks = 8192, bench.GATHER_CHUNK, 30
+    looked_at = (0, 9, 26, 27, 28, 29)
+    env = ShardedPendulum(bench.make_config(B), device="cuda:0", chunk=K)
+    assert env.lanes_per_env == 8 and env.gather.num_chunks == 2
+    env.reset()
+    consumed, seen = {"chunks": 0}, {}
+    consume = bench.c4_rollout_consumer(env, consumed)
+
+    def consumer(chunk_index):
+        consume(chunk_index)
+        if chunk_index in looked_at:
+            seen[chunk_index] = (env.gather.rollout[chunk_index % 2, 0].clone(), consumed["advantages"].clone(), consumed["returns"].clone())
+
+    env.gather.consumer = consumer
+    ref = O.Oracle(default_model(), bench.make_config(B))
+    obs = ref.reset()[:, [1, 0, 4, 3]]
+    records = {c: np.zeros((K, B, 7)) for c in looked_at}
+    term_r = np.zeros((chunks * K, B), dtype=np.uint8)
+    term_h = torch.zeros((chunks * K, B), dtype=torch.uint8, device="cuda:0")
+    for k in range(chunks * K):
+        env.step_agent()
+        term_h[k] = env.gather.previous[:, 5] != 0
+        obs, rew, term, trunc = ref.step_pendulum_agent(obs)
+        term_r[k] = term
+        if k // K in records:
+            records[k // K][k % K] = np.column_stack([obs, rew, term, trunc])
+    env.flush()
+    assert consumed["chunks"] == chunks and sorted(seen) == sorted(looked_at)
+    term_h = term_h.cpu().numpy()
+    report = compare_falls(term_h, term_r)
+    report["steps"], report["chunk"] = chunks * K, K
+    weights = np.array(bench.C4_VALUE_WEIGHTS)
+
+    def gae_of(rec):
+        values = rec[..., :4] @ weights
+        ended = ((rec[..., 5] + rec[..., 6]) != 0).astype(np.uint8)
+        starts = np.zeros_like(ended)
+        starts[1:] = ended[:-1]
+        return oracle_gae(rec[..., 4], values, starts, values[-1], ended[-1], bench.C4_GAMMA, bench.C4_LAMBDA)
+
+    for c in looked_at:
+        ring, adv, ret = (t.cpu().numpy().astype(np.float64) for t in seen[c])
+        stop = (c + 1) * K
+        in_phase = np.array([np.array_equal(np.nonzero(term_h[:stop, e])[0], np.nonzero(term_r[:stop, e])[0]) for e in range(B)])
+        # the consumer's chain on the ring's own records, every env: fp32 recursion against fp64
+        own_adv, own_ret = gae_of(ring)
+        np.testing.assert_allclose(adv, own_adv, rtol=1e-5, atol=5e-5)
+        np.testing.assert_allclose(ret, own_ret, rtol=1e-5, atol=5e-5)
+        # ring and consumer against the oracle's rollout, envs whose episodes ended on the oracle's steps
+        ref_adv, ref_ret = gae_of(records[c])
+        assert np.array_equal(ring[:, in_phase, 4:7], records[c][:, in_phase, 4:7])  # reward, terminated, truncated
+        report[f"chunk_{c}"] = {
+            "envs_in_phase": int(in_phase.sum()),
+            "episode_ends_in_the_chunk": int(records[c][..., 5].sum()),
+            "observation_error": quantiles(np.abs(ring[..., :4] - records[c][..., :4]).max(axis=0)[in_phase]),
+            "advantage_error": quantiles(np.abs(adv - ref_adv).max(axis=0)[in_phase, None]),
+            "return_error": quantiles(np.abs(ret - ref_ret).max(axis=0)[in_phase, None]),
+            "advantage_range": [float(ref_adv.min()), float(ref_adv.max())],
+        }
+    env.sim.close()
+    write_report("c4_window_rollout_consumer", report)
+    assert report["envs_every_end_within_1_step"] >= 0.99, report
+    assert report["episodes_ended_oracle"] >= 0.25 * B, report  # the window reaches the falls
+    for c in looked_at:
+        q = report[f"chunk_{c}"]
+        assert q["envs_in_phase"] >= 0.99 * B, report
+        assert q["advantage_error"]["q0.5"][0] <= 2e-4 and q["advantage_error"]["q0.99"][0] <= 2e-2, report
+        assert q["return_error"]["q0.5"][0] <= 2e-4 and q["return_error"]["q0.99"][0] <= 2e-2, report
+
+
 # ------------------------------------------------------------------ C3
 @pytest.mark.parametrize("B, steps, horizon", [(4096, 1000, 16), (16384, 900, 16), (2048, 600, 50)])
 def test_c3_timed_window_with_resampled_targets_matches_the_oracle_doubles(B, steps, horizon):
