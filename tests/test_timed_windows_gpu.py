@@ -329,11 +329,12 @@ def test_c4_window_rollout_ring_and_advantages_match_the_oracle():
 
 
 # ------------------------------------------------------------------ C3
-@pytest.mark.parametrize("B, steps, horizon", [(4096, 1000, 16), (16384, 900, 16), (2048, 600, 50)])
+@pytest.mark.parametrize("B, steps, horizon", [(4096, 1000, 16), (16384, 900, 16), (2048, 600, 50), (16384, 450, 50)])
 def test_c3_timed_window_with_resampled_targets_matches_the_oracle_doubles(B, steps, horizon):
     """`bench.secondary_c3`'s loop on 4096 envs for 1000 steps -- and (round 5) at the size the bench TIMES it, 16384 envs
     (two wavefronts per SIMD, half-filled MFMA tiles) for 900 steps, and with the reference's DEFAULT horizon N = 50
-    (mpc_balancer.py:174; the balancer's own launch in front of the step) for 600 closed-loop steps: UpkieBaseVelocity
+    (mpc_balancer.py:174; the balancer's own launch in front of the step) for 600 closed-loop steps of 2048 envs and 450
+    of the 16384 the `c3.n50` block times (sixteen envs per wavefront: 1024 wavefronts of four tiles): UpkieBaseVelocity
     with the MPC balancer in the launch (N = 16), v* ~ U(-0.5, 0.5) redrawn at
     steps 0, 400, 800 from the generator the bench uses, NEXT_STEP autoreset;
     the same env on the oracle doubles (fp64 dynamics + fp64 ADMM) is handed
