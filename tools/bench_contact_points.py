@@ -1,6 +1,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, time
+import torch
 from upkie_amd import abi
 from upkie_amd.sim import BatchedSim
 for B in (4096, 65536):

@@ -1,7 +1,7 @@
 """Fixed and per-substep cost of a step launch: the same Pendulum step with 1 .. 5 physics substeps
 (frequency adjusted so that h stays 1 ms), per lane mapping; with --rollout the same for 32 env.step() per launch
 (upkie_sim_step_pendulum_agent_rollout): what a step costs there beyond its substeps. Usage: python tools/fixed_cost.py [B] [--rollout]"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from upkie_amd import abi

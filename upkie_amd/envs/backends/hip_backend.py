@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from ... import abi
-from ...exceptions import UpkieException, UpkieRuntimeError
+from ...exceptions import UpkieException
 from ...model.joint_properties import JointProperties
 from ...model.model import Model
 from ...utils.external_force import ExternalForce

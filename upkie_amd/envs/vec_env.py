@@ -24,7 +24,7 @@ from ..exceptions import UpkieException, UpkieRuntimeError
 from ..model.joint_properties import JointProperties
 from ..model.model import Model
 from ..utils.robot_state import RobotState
-from .spaces import Box, Dict as DictSpace, batch_box
+from .spaces import Box, batch_box
 from .external_forces import ExternalForceSet
 from .spine_observation import LazySpineObservation
 
