@@ -1413,8 +1413,14 @@ constexpr bool kServosLimitsInRegisters = true;
 #if !defined(UPKIE_PROBE_OCTET_WAVES)
 #define UPKIE_PROBE_OCTET_WAVES 2
 #endif
+// Lanes per workgroup of the eight-lane kernels: one wavefront. (An A/B probe may set 128 or 256 -- wavefronts of one
+// workgroup share a CU --: tools/ab_octet_block.py, profiles/r05_ab_octet_block.txt: nothing to gain. Not for
+// MODE_BASE_VELOCITY, whose balancer tile is per workgroup.)
+#if !defined(UPKIE_OCTET_BLOCK)
+#define UPKIE_OCTET_BLOCK 64
+#endif
 template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
-__global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : UPKIE_PROBE_OCTET_WAVES) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
+__global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : UPKIE_PROBE_OCTET_WAVES) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -1540,7 +1546,7 @@ __global__ __launch_bounds__(64, MODE == MODE_SERVOS && kServosLimitsInRegisters
   if (!in_batch) return;
   // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
   // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
-  __shared__ LimitWorkspace limit_workspaces[8];
+  __shared__ LimitWorkspace limit_workspaces[UPKIE_OCTET_BLOCK / 8];
   LimitWorkspace* const limit_ws = MODE == MODE_SERVOS && kServosLimitsInRegisters ? nullptr : limit_workspaces;
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B, ROW_UP_FRONT ? &lane_row : nullptr);

@@ -452,6 +452,8 @@ extern "C" int upkie_sim_set_external_forces(UpkieSim* sim, const float* forces,
 
 static int block_lanes() { return 64; }  // one wavefront per block
 static dim3 grid_for(int B) { return dim3((unsigned)((B + block_lanes() - 1) / block_lanes())); }
+// eight lanes per env, envs in pairs (a row of 16 lanes steps two)
+static dim3 octet_grid_for(int B) { return dim3((unsigned)((8 * B + (B & 1) * 8 + UPKIE_OCTET_BLOCK - 1) / UPKIE_OCTET_BLOCK)); }
 
 extern "C" int upkie_sim_sample_body_inertials(UpkieSim* sim, float* body_inertials, float* link_scale, double inertia_variation,
                                                void* stream) {
@@ -643,11 +645,11 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
 #define UPKIE_LAUNCH_PAIR(R) \
   do { if (spine) UPKIE_LAUNCH_PAIR_S(R, true); else UPKIE_LAUNCH_PAIR_S(R, false); } while (0)
 #define UPKIE_LAUNCH_OCTET_D(R, D, IP)                                                                                          \
-  hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP, false>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, D, IP, false>), octet_grid_for(sim->config.num_envs), dim3(UPKIE_OCTET_BLOCK), 0, st, \
                      sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg, (float*)nullptr)
 #define UPKIE_LAUNCH_OCTET_BULLET_IP(R, IP)                                                                                     \
-  hipLaunchKernelGGL((step_kernel_octet<MODE, R, false, IP, true>), grid_for(8 * sim->config.num_envs + (sim->config.num_envs & 1) * 8), block, 0, st, \
+  hipLaunchKernelGGL((step_kernel_octet<MODE, R, false, IP, true>), octet_grid_for(sim->config.num_envs), dim3(UPKIE_OCTET_BLOCK), 0, st, \
                      sim->d_model, params, done_pass ? 1 : 0, sim->config.num_envs, state, act, obs, reward, terminated, truncated, mask, scale, \
                      force, packed, bv, final_obs, n_steps, sim->census, policy_arg, sim->manifold)
 #define UPKIE_LAUNCH_OCTET_BULLET(R)                                                             \
