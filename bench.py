@@ -323,9 +323,10 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
         sim.enable_census(False)
         substeps = envs * 5 * census_steps
         out["census"] = {
-            "env_substeps_in_gauss_seidel_sweeps": c["friction_cone"] / substeps,
+            "env_substeps_in_gauss_seidel_sweeps": c["friction_cone"] / substeps,  # (those whose direct solution was not admissible)
             "env_substeps_with_a_joint_at_its_stop": c["joint_limit"] / substeps,
             "sweeps_per_infeasible_env_substep": c["sweeps_total"] / max(c["friction_cone"], 1),
+            "infeasible_env_substeps_answered_by_an_active_set": c["active_set_solves"] / max(c["friction_cone"], 1),
             "sweep_cap_hits": c["sweep_cap_hits"],
             "sweeps_max": c["sweeps_max"],
             # per wavefront-substep that swept: the most sweeps among its eight envs (what the launch waits for); quantiles

@@ -330,12 +330,13 @@ int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold);
  * caller) or NULL to switch the census off (the default). Env-substeps:
  *   [0] a hip / knee at its stop (contacts and limit rows through the general
  *       solver over scratch memory)
- *   [2] contact impulses outside the friction cone / pulling (projected
- *       Gauss-Seidel sweeps)
+ *   [2] contact impulses outside the friction cone / pulling (an active-set
+ *       solve, then projected Gauss-Seidel sweeps)
+ *   [3] those of [2] an active-set solve answered (no sweep; since round 5)
  * wavefront-substeps (what the paths cost) that took, for at least one of their
  * eight envs, [4] the joint-stop path, [5] the sweeps. Sweeps run by the
  * env-substeps of [2]: [6] their sum, [7] the largest count, [1] how many
- * stopped at the iteration cap. Word [3] is unused. Words [8 .. 71]: histogram
+ * stopped at the iteration cap. Words [8 .. 71]: histogram
  * over the wavefront-substeps of [5] of the LARGEST sweep count among the
  * wavefront's envs (bin 63: 63 or more) -- what a launch waits for, since a
  * wavefront leaves the sweeps with its slowest env. Diagnostics only: no entry

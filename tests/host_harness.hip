@@ -84,6 +84,20 @@ extern "C" int harness_contact_pgs6(const UpkieModel* model, const float* A, con
   return sweeps;
 }
 
+// contact_solve6() on the host: the same system through the active-set solve first (returns -1 / -2: the attempt that
+// was accepted), then the sweeps (returns their count)
+extern "C" int harness_contact_solve6(const UpkieModel* model, const float* A, const float* rhs, float* lam) {
+  DevModel M;
+  std::string why;
+  if (!convert_model(model, &M, &why)) return -100;
+  float a[21], r[6], l[6];
+  for (int k = 0; k < 21; ++k) a[k] = A[k];
+  for (int k = 0; k < 6; ++k) { r[k] = rhs[k]; l[k] = lam[k]; }
+  const int code = contact_solve6(M, a, r, l);
+  for (int k = 0; k < 6; ++k) lam[k] = l[k];
+  return code;
+}
+
 // fuse_links() on the host: link factors [UPKIE_MAX_LINKS] -> records [70]
 extern "C" int harness_fuse_links(const UpkieModel* model, const float* factors, float* records) {
   DevLinks L;

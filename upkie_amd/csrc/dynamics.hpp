@@ -788,6 +788,166 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
   return contact_pgs6_sweeps(M, A, rhs, lam);
 }
 
+// An active-set solve of the same problem, tried before the sweeps (round 5). A robot that skids does so for many
+// substeps in a row with the same rows on their bounds, so the warm start -- the previous substep's impulses, or the
+// projected direct solution -- usually names the right set: which tires push, which friction rows sit on +-mu lam_n.
+// With the set fixed the conditions are LINEAR: a free row keeps its equation, a friction row on a bound is replaced by
+// lam_t -+ mu lam_n = 0, the rows of a tire that does not push by lam = 0; one 6 x 6 elimination (no pivoting: the
+// normal rows' pivots are A_nn > 0, a bounded row's is the 1 +- mu A_nt / A_nn the sweeps' slide step divides by)
+// gives the impulses, and the answer is ACCEPTED only if every condition of the problem holds for it -- equations of
+// the free rows to the sweeps' tolerance (which also catches an inaccurate elimination: NaN and infinities fail every
+// test), normals >= 0, free friction rows inside their bounds, bounded rows pushed outward, idle tires separating.
+// Otherwise the violated conditions name the next set and a second solve is tried; then the sweeps run from the
+// unchanged warm start, as before. On 4096 systems of robots skidding and tumbling under torque_balancing.py's law
+// (tests/test_contact_active_set.py, the host build of this code): 87.7 % accepted at the first set, 99.2 % by the
+// second (one tire on the floor: 99.2 %); accepted impulses within 3e-6 (p99) of the oracle's converged sweeps, contact
+// velocities within 1.6e-6 (worst) -- tighter than the sweeps' own stopping rule. An attempt is ~390 instructions, three
+// sweeps' worth; what it replaces: 5.3 sweeps per env, 7.3 per wavefront. On the device (C5 share under that law, 77 % of
+// the env-substeps not admissible): 93 % of them answered here, 0.17 sweeps each instead of 4.75, 39.4 -> 36.5 us per
+// env.step() (profiles/r05_active_set.txt). Returns the attempt that was accepted (1, 2) or 0.
+#if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)
+#define UPKIE_ACTIVE_SET_ATTEMPTS 2
+#endif
+template <class ModelT>
+UPKIE_HD int contact_active_set6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
+  const float mu = M.friction_mu;
+  float tolerance = M.pgs_tolerance;
+  UPKIE_KEEP_IN_SGPR(tolerance);
+  // The set, as numbers (the build and the tests below are arithmetic and selects, no branches: a wavefront runs this for
+  // the one env in eight that needs it, and scalar branching cost more issue slots than the elimination itself):
+  // push[w] 1 / 0: the tire pushes / all three of its rows are lam = 0; side[r] of a friction row: 0 free, +-1 on the
+  // upper / lower bound (0 on the rows of an idle tire).
+  float push[2], side[6];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int n = 3 * w;
+    // A warm start without an impulse on this tire (the direct solution pulled there and was projected to zero) while
+    // the normal row asks for one: the tire is landing or barely loaded, and what barely loaded tires do under a spinning
+    // wheel is slide -- both friction rows on the bound their right-hand side points to.
+    const bool landing = !(lam[n] > 0.f) && rhs[n] > 0.f;
+    push[w] = lam[n] > 0.f || landing ? 1.f : 0.f;
+    side[n] = 0.f;
+#pragma unroll
+    for (int r = n + 1; r < n + 3; ++r) {
+      const float towards = landing ? rhs[r] : lam[r];
+      side[r] = !landing && fabsf(lam[r]) < mu * lam[n] ? 0.f : (towards > 0.f ? push[w] : -push[w]);
+    }
+  }
+  const float vs = fmaxf(fmaxf(fmaxf(fabsf(rhs[0]), fabsf(rhs[1])), fmaxf(fabsf(rhs[2]), fabsf(rhs[3]))), fmaxf(fabsf(rhs[4]), fabsf(rhs[5])));
+  const float vtol = tolerance * vs;
+  for (int attempt = 1; attempt <= UPKIE_ACTIVE_SET_ATTEMPTS; ++attempt) {
+    // rows: keep[r] = 1 the row's own equation, 0 replaced by x_r - side mu x_n = 0 (bounded) or x_r = 0 (idle tire)
+    float m[6][6], b[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int w = r / 3, n = 3 * w;
+      const float keep = r == n ? push[w] : (side[r] == 0.f ? push[w] : 0.f);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) m[r][c] = keep * A[r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r];
+      m[r][r] += 1.f - keep;
+      if (r != n) m[r][n] = fmaf(-mu, side[r], m[r][n]);  // (side != 0 only on a replaced row, whose entry here is 0)
+      b[r] = keep * rhs[r];
+    }
+    float inv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      inv[k] = fast_rcp(m[k][k]);
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        const float f = m[i][k] * inv[k];
+#pragma unroll
+        for (int j = k + 1; j < 6; ++j) m[i][j] = fmaf(-f, m[k][j], m[i][j]);
+        b[i] = fmaf(-f, b[k], b[i]);
+      }
+    }
+    float x[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+      float acc = b[k];
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) acc = fmaf(-m[k][j], x[j], acc);
+      x[k] = acc * inv[k];
+    }
+    // what the impulses do: v = A x - rhs, every row, from the untouched system
+    float v[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float acc = -rhs[r];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc = fmaf(A[r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r], x[c], acc);
+      v[r] = acc;
+    }
+    const float xs = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))), fmaxf(fabsf(x[4]), fabsf(x[5])));
+    const float xtol = tolerance * xs;
+    // Every condition as an excess over what it allows (<= 0: met); `worst` is the largest. The conditions that name the next
+    // set are kept apart: `enters` (an idle tire would sink into the floor), `pulls` (a pushing tire pulls), `leaves[r]` (a free
+    // friction row outside its bound), `returns[r]` (a bounded row that wants back inside, held ten times tighter than the
+    // equations: the two tires' lateral rows are nearly parallel, and a set with the wrong one of them on its bound can
+    // meet every equation to 1e-5 with impulses 13 % off).
+    float worst = -vtol;  // the kept rows' own equations, all at once: largest |v_r| of a row that kept its equation
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int w = r / 3, n = 3 * w;
+      const float keep = r == n ? push[w] : (side[r] == 0.f ? push[w] : 0.f);
+      worst = fmaxf(worst, fmaf(keep, fabsf(v[r]), -vtol));
+    }
+    float push_next[2], side_next[6];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int n = 3 * w;
+      const bool pushing = push[w] != 0.f;
+      const float enters = pushing ? -1.f : -v[n] - vtol;
+      const float pulls = pushing ? -x[n] - xtol : -1.f;
+      worst = fmaxf(worst, fmaxf(enters, pulls));
+      const bool flips = enters > 0.f || pulls > 0.f;
+      push_next[w] = flips ? 1.f - push[w] : push[w];
+      side_next[n] = 0.f;
+      const float lim = mu * x[n];
+#pragma unroll
+      for (int r = n + 1; r < n + 3; ++r) {
+        const bool free_row = side[r] == 0.f;
+        const float leaves = pushing && free_row ? fabsf(x[r]) - lim - xtol : -1.f;
+        const float returns = free_row ? -1.f : v[r] * side[r] - 0.1f * vtol;
+        worst = fmaxf(worst, fmaxf(leaves, returns));
+        const float out = x[r] > 0.f ? 1.f : -1.f;
+        side_next[r] = flips ? 0.f : (leaves > 0.f ? out : (returns > 0.f ? 0.f : side[r]));
+      }
+    }
+    if (worst <= 0.f && xs <= 3.0e38f) {  // (NaN fails both)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int n = 3 * w;
+        const float ln = push[w] != 0.f ? fmaxf(x[n], 0.f) : 0.f, lim = mu * ln;
+        lam[n] = ln;
+        // (a bounded row sits ON its bound: the elimination returns side * mu * x_n to rounding only)
+        lam[n + 1] = side[n + 1] != 0.f ? side[n + 1] * lim : fminf(fmaxf(x[n + 1], -lim), lim);
+        lam[n + 2] = side[n + 2] != 0.f ? side[n + 2] * lim : fminf(fmaxf(x[n + 2], -lim), lim);
+      }
+      return attempt;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) push[w] = push_next[w];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) side[r] = side_next[r];
+  }
+  return 0;
+}
+
+// The contact impulses of a system whose direct solution is not admissible, from the warm start `lam`: nothing to do when
+// both tires unload, else the active-set solve above, else the sweeps. Returns the sweeps run, or -1 / -2: the active
+// set that was accepted (for the census).
+template <class ModelT>
+UPKIE_HD int contact_solve6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
+  if (rhs[0] <= 0.f && rhs[3] <= 0.f) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) lam[r] = 0.f;
+    return 0;
+  }
+  const int accepted = contact_active_set6(M, A, rhs, lam);
+  if (accepted) return -accepted;
+  return contact_pgs6_sweeps(M, A, rhs, lam);
+}
+
 // What the Gauss-Seidel sweeps of one substep hand to the next substep of the SAME env.step(): the impulses they ended on
 // and with which tires on the floor (0: that substep did not sweep, 1 / 2: it did, with one / both tires touching). A
 // robot that skids or tumbles does so for many substeps in a row and its contact state changes little from one
@@ -824,7 +984,7 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
     const float lim = mu * lam[3 * (r / 3)];
     lam[r] = fminf(fmaxf(lam[r], -lim), lim);
   }
-  const int sweeps = contact_pgs6(M, A, rhs, lam);
+  const int sweeps = contact_solve6(M, A, rhs, lam);
   if (warm) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) warm->lam[r] = lam[r];

@@ -1301,7 +1301,9 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
             const float lim = OCT_HOT(friction_mu) * lam6[3 * (r / 3)];
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
-          const int sweeps = contact_pgs6(M, A6, rhs6, lam6);
+          // (round 5: the active-set solve first -- contact_active_set6 --, the sweeps when neither of its two sets is
+          // accepted; negative: the set that was)
+          const int sweeps = contact_solve6(M, A6, rhs6, lam6);
           if (census) census->sweeps = sweeps;
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
@@ -1796,15 +1798,18 @@ next_step:
         atomicAdd(&census[5], 1u);
       }
       if (swept) {  // the sweeps those envs ran, summed over the wavefront first (at most eight envs: a scalar loop over their lead lanes)
-        unsigned total = 0, most = 0, capped = 0;
+        unsigned total = 0, most = 0, capped = 0, direct = 0;
         for (unsigned long long left = swept; left; left &= left - 1) {
-          const unsigned count = (unsigned)__builtin_amdgcn_readlane(rare_path.sweeps, __builtin_ctzll(left));
+          const int code = __builtin_amdgcn_readlane(rare_path.sweeps, __builtin_ctzll(left));
+          const unsigned count = code > 0 ? (unsigned)code : 0u;  // (negative: solved by an active set, no sweep)
+          direct += code < 0 ? 1u : 0u;
           total += count;
           most = count > most ? count : most;
           capped += count >= (unsigned)M.pgs_iterations ? 1u : 0u;
         }
         if (first) {
           atomicAdd(&census[6], total);
+          if (direct) atomicAdd(&census[3], direct);
           atomicMax(&census[7], most);
           if (capped) atomicAdd(&census[1], capped);
           atomicAdd(&census[8 + (most < 63u ? most : 63u)], 1u);  // what the wavefront waited for in this substep

@@ -586,7 +586,7 @@ class BatchedSim:
         mapping at 8192 envs, the others at 16384."""
         return int(self._lib.upkie_sim_lanes_per_env_of(self._handle, int(observation_layout)))
 
-    CENSUS_FIELDS = ("joint_limit", "sweep_cap_hits", "friction_cone", "unused_3", "wavefront_substeps_limit", "wavefront_substeps_sweeps", "sweeps_total", "sweeps_max")
+    CENSUS_FIELDS = ("joint_limit", "sweep_cap_hits", "friction_cone", "active_set_solves", "wavefront_substeps_limit", "wavefront_substeps_sweeps", "sweeps_total", "sweeps_max")
 
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
         """Rare-path census of the eight-lane step kernel (`upkie_sim_set_census`):
