@@ -804,15 +804,15 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
 // velocities within 1.6e-6 (worst) -- tighter than the sweeps' own stopping rule. An attempt is ~390 instructions, three
 // sweeps' worth; what it replaces: 5.3 sweeps per env, 7.3 per wavefront. On the device (C5 share under that law, 77 % of
 // the env-substeps not admissible): 93 % of them answered here, 0.17 sweeps each instead of 4.75, 39.4 -> 36.5 us per
-// env.step() (profiles/r05_active_set.txt). Returns the attempt that was accepted (1, 2) or 0.
+// env.step() (profiles/r05_active_set.txt). Called by the eight-lane kernel (contact_solve6); the one- and two-lane kernels
+// keep the sweeps alone (contact_sweeps_warm says why). Returns the attempt that was accepted (1, 2) or 0.
 #if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)
 #define UPKIE_ACTIVE_SET_ATTEMPTS 2
 #endif
 template <class ModelT>
 UPKIE_HD int contact_active_set6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   const float mu = M.friction_mu;
-  float tolerance = M.pgs_tolerance;
-  UPKIE_KEEP_IN_SGPR(tolerance);
+  const float tolerance = M.pgs_tolerance;
   // The set, as numbers (the build and the tests below are arithmetic and selects, no branches: a wavefront runs this for
   // the one env in eight that needs it, and scalar branching cost more issue slots than the elimination itself):
   // push[w] 1 / 0: the tire pushes / all three of its rows are lam = 0; side[r] of a friction row: 0 free, +-1 on the
@@ -984,7 +984,11 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
     const float lim = mu * lam[3 * (r / 3)];
     lam[r] = fminf(fmaxf(lam[r], -lim), lim);
   }
-  const int sweeps = contact_solve6(M, A, rhs, lam);
+  // (the sweeps alone: the one- and two-lane kernels that come through here serve batches of 20 000 envs and more, and the
+  // active-set solve inlined into them -- 800 instructions of a path one substep in five hundred takes -- cost their COMMON
+  // path 3-6 %: register allocation of a body that much larger, 25.9 -> 27.4 us at 32768 envs, 494 -> 523 us at a
+  // million; as a call it cost the dense kernels 40 %. The eight-lane kernel, whose common path it leaves alone, has it.)
+  const int sweeps = contact_pgs6(M, A, rhs, lam);
   if (warm) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) warm->lam[r] = lam[r];
@@ -1148,8 +1152,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
 #pragma unroll
     for (int r = 0; r < kRows; ++r) idiag[r] = fast_rcp(A[sym(r, r)]);
     float tolerance = M.pgs_tolerance;  // held in a scalar register across the sweeps (see contact_pgs6_sweeps)
-    UPKIE_KEEP_IN_SGPR(tolerance);
-    for (int it = 0; it < M.pgs_iterations; ++it) {
+      for (int it = 0; it < M.pgs_iterations; ++it) {
       float change = 0.f, scale = 0.f;
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
