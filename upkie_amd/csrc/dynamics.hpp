@@ -806,7 +806,7 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
 // the env-substeps not admissible): 93 % of them answered here, 0.17 sweeps each instead of 4.75, 39.4 -> 36.5 us per
 // env.step() (profiles/r05_active_set.txt). Called by the eight-lane kernel (contact_solve6); the one- and two-lane kernels
 // keep the sweeps alone (contact_sweeps_warm says why). Returns the attempt that was accepted (1, 2) or 0.
-#if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)
+#if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)  // (an A/B switch: 1 and 3 attempts are in profiles/r05_active_set.txt)
 #define UPKIE_ACTIVE_SET_ATTEMPTS 2
 #endif
 template <class ModelT>
