@@ -224,6 +224,12 @@ extern "C" int harness_substep_octet(const UpkieModel* model, float* st, const f
   return run_octet(model, st, tau, h, records, trunk_wrench, substeps, status, limits_in_registers, nullptr);
 }
 
+// The same, reporting what the contact solve of each substep did: codes[substeps] = sweeps run (> 0), the active set that was
+// accepted (-1 / -2, oct_active_set), 0 (admissible direct solution, both tires unloading, or no contact)
+extern "C" int harness_substep_octet_codes(const UpkieModel* model, float* st, const float* tau, float h, int substeps, int* status, int* codes) {
+  return run_octet(model, st, tau, h, nullptr, nullptr, substeps, status, 0, nullptr, codes);
+}
+
 // The eight-lane substep under the Bullet-like contact specification: applied[2] = the tires' applied normal impulses (in / out).
 extern "C" int harness_substep_octet_bullet_like(const UpkieModel* model, float* st, const float* tau, float h, int substeps, int* status, float* applied) {
   return run_octet(model, st, tau, h, nullptr, nullptr, substeps, status, 0, applied);

@@ -74,3 +74,74 @@ def test_one_tire_systems_go_through_the_same_solve(harness):  # noqa: F811
         print(f"one tire: accepted {(code < 0).mean():.4f}, sweeps {(code > 0).mean():.4f}")
         assert (code < 0).mean() >= 0.97  # measured: 0.992 (0.913 before landing tires were guessed as sliding)
         check(A, rhs, want, got, np.maximum(code, 0))
+
+
+def test_the_eight_lane_substep_answers_skids_one_row_per_lane(harness):  # noqa: F811
+    """oct_active_set (octet.hpp): the same active-set solve WITHOUT gathering the system -- every lane rewrites its own
+    row, the direct solve's block elimination runs again, every lane checks its own row. On the host build (eight threads
+    stand for the env's lanes): a standing robot whose wheels are driven past the tires' grip (mu = 0.2), 60 substeps, and
+    robots tumbling onto the floor; against the one-lane substep, which sweeps."""
+    from tests.test_device_arithmetic_on_host import one_lane, random_state
+    from upkie_amd import abi
+    from upkie_amd.model.default_model import default_model
+
+    harness.harness_substep_octet_codes.restype = C.c_int
+
+    def octet(model, s64, tau, substeps=1):
+        s32 = np.ascontiguousarray(s64, dtype=np.float32)
+        t32 = np.ascontiguousarray(tau, dtype=np.float32)
+        status = np.zeros(substeps, dtype=np.int32)
+        codes = np.zeros(substeps, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        assert harness.harness_substep_octet_codes(C.byref(model), p(s32), p(t32), C.c_float(1e-3), C.c_int(substeps), p(status), p(codes)) == 1
+        return s32.astype(np.float64), status, codes
+
+    model = default_model()
+    s = np.zeros(abi.STATE_WORDS)
+    s[abi.S_QUAT] = 1.0
+    s[abi.S_POS + 2] = 0.6
+
+    def hold(s, wheel):
+        tau = np.zeros(6)
+        for j in (0, 1, 3, 4):
+            tau[j] = np.clip(20.0 * (0.0 - s[abi.S_Q + j]) - 1.0 * s[abi.S_QD + j], -16.0, 16.0)
+        tau[2], tau[5] = wheel, -wheel
+        return tau
+
+    for _ in range(300):
+        s, _ = one_lane(harness, model, s, hold(s, 0.0))
+    model.friction_mu = 0.2
+    s1, s8 = s.copy(), s.copy()
+    codes = []
+    worst = np.zeros(25)
+    for _ in range(60):
+        s1, contact = one_lane(harness, model, s1, hold(s1, 1.7))
+        s8, status, code = octet(model, s8, hold(s8, 1.7))
+        codes.append(int(code[0]))
+        worst = np.maximum(worst, np.abs(s8[:25] - s1[:25]))
+    codes = np.array(codes)
+    print("skidding wheels: codes", np.unique(codes, return_counts=True), "worst |octet - one lane|", worst[0:7].max(), worst[7:13].max(), worst[19:25].max())
+    # every skidding substep answered by a set, none swept (measured: 56 at the second set, 4 at the first: the harness
+    # steps one substep per call, so the warm start is the projected direct solution, whose lateral rows mislead)
+    assert (codes < 0).sum() >= 58 and (codes > 0).sum() == 0
+    assert worst[0:7].max() < 2e-6 and worst[7:13].max() < 5e-3 and worst[13:19].max() < 1e-4
+    # robots dropped onto the floor at random attitudes with random joint rates: landings, one tire, slips
+    rng = np.random.default_rng(5)
+    model = default_model()
+    total = answered = swept = 0
+    for trial in range(40):
+        s = random_state(rng, on_floor=True)
+        s[abi.S_QD + 2], s[abi.S_QD + 5] = rng.uniform(-60, 60, 2)  # spinning wheels
+        tau = rng.uniform(-1.7, 1.7, 6)
+        s1, s8 = s.copy(), s.copy()
+        for _ in range(12):
+            s1, contact = one_lane(harness, model, s1, tau)
+            s8, status, code = octet(model, s8, tau)
+            total += 1
+            answered += int(code[0] < 0)
+            swept += int(code[0] > 0)
+            assert np.abs(s8[0:7] - s1[0:7]).max() < 5e-6, (trial, np.abs(s8[0:7] - s1[0:7]).max())
+            assert np.abs(s8[7:13] - s1[7:13]).max() < 2e-2 and np.abs(s8[19:25] - s1[19:25]).max() < 0.5
+            s8 = s1.copy()  # (compare substep by substep from the same state)
+    print(f"random landings: {total} substeps, {answered} answered by a set, {swept} swept")
+    assert answered >= 30 and swept <= answered // 2  # measured: 39 / 12 of 480 substeps (the rest: admissible direct solutions)

@@ -797,17 +797,18 @@ UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&r
 // gives the impulses, and the answer is ACCEPTED only if every condition of the problem holds for it -- equations of
 // the free rows to the sweeps' tolerance (which also catches an inaccurate elimination: NaN and infinities fail every
 // test), normals >= 0, free friction rows inside their bounds, bounded rows pushed outward, idle tires separating.
-// Otherwise the violated conditions name the next set and a second solve is tried; then the sweeps run from the
+// Otherwise the violated conditions name the next set, up to three solves in all; then the sweeps run from the
 // unchanged warm start, as before. On 4096 systems of robots skidding and tumbling under torque_balancing.py's law
 // (tests/test_contact_active_set.py, the host build of this code): 87.7 % accepted at the first set, 99.2 % by the
-// second (one tire on the floor: 99.2 %); accepted impulses within 3e-6 (p99) of the oracle's converged sweeps, contact
-// velocities within 1.6e-6 (worst) -- tighter than the sweeps' own stopping rule. An attempt is ~390 instructions, three
-// sweeps' worth; what it replaces: 5.3 sweeps per env, 7.3 per wavefront. On the device (C5 share under that law, 77 % of
-// the env-substeps not admissible): 93 % of them answered here, 0.17 sweeps each instead of 4.75, 39.4 -> 36.5 us per
-// env.step() (profiles/r05_active_set.txt). Called by the eight-lane kernel (contact_solve6); the one- and two-lane kernels
-// keep the sweeps alone (contact_sweeps_warm says why). Returns the attempt that was accepted (1, 2) or 0.
-#if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)  // (an A/B switch: 1 and 3 attempts are in profiles/r05_active_set.txt)
-#define UPKIE_ACTIVE_SET_ATTEMPTS 2
+// second, 99.9 % by the third (one tire on the floor: 99.5 %); accepted impulses within 3e-6 (p99) of the oracle's
+// converged sweeps, contact velocities within 1.6e-6 (worst) -- tighter than the sweeps' own stopping rule.
+// THIS function works on the gathered 6 x 6 system: the statement of the method, what the host tests hold to the
+// oracle's systems, and the first device version (an attempt: ~390 instructions, 39.5 -> 36.5 us on the C5 share under
+// that law). What the eight-lane kernel runs is the same method one row per lane, without gathering anything --
+// oct_active_set, octet.hpp: ~150 issue slots an attempt, 31.8 us -- and the one- and two-lane kernels keep the sweeps
+// alone (contact_sweeps_warm says why). profiles/r05_active_set.txt. Returns the attempt that was accepted (1 .. 3) or 0.
+#if !defined(UPKIE_ACTIVE_SET_ATTEMPTS)  // (an A/B switch: 2 and 4 attempts are in profiles/r05_active_set.txt)
+#define UPKIE_ACTIVE_SET_ATTEMPTS 3
 #endif
 template <class ModelT>
 UPKIE_HD int contact_active_set6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {

@@ -117,6 +117,12 @@ UPKIE_HD void oct_esum(float (&x)[N]) {  // step by step over all values: indepe
   for (int i = 0; i < N; ++i) x[i] += oct_swp(x[i]);
 }
 UPKIE_HD bool oct_env_any(bool b) { return oct_esum(b ? 1.f : 0.f) != 0.f; }
+// largest value among the env's eight lanes, in every lane
+UPKIE_HD float oct_emax(float x) {
+  x = fmaxf(x, oct_qperm<1, 0, 3, 2>(x));
+  x = fmaxf(x, oct_qperm<2, 3, 0, 1>(x));
+  return fmaxf(x, oct_swp(x));
+}
 // some lane of the wavefront (device) / of the env (host): a uniform branch guards the rare paths
 UPKIE_HD bool oct_wave_any(bool b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -827,6 +833,82 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   xl = L.l == 0 ? 0.f : (left ? mine_l : mine_r);
 }
 
+// The active-set solve of a substep whose direct contact solution is not admissible (contact_active_set6, dynamics.hpp, says
+// what that is), WITHOUT gathering the system: one row per lane, as the direct solve has it. The block elimination of the
+// direct solve (oct_gauss_jordan on the own tire's block, exchange, Schur complement, oct_gauss_jordan again) computes
+// lam' N = b' for ANY matrix N stored one column per lane -- nothing in it uses symmetry --, i.e. it solves M lam = b for M = N'
+// stored one ROW per lane. A row of the contact matrix A is its column (A is symmetric): what the lane already holds. And
+// the rows an active set replaces -- a friction row on its bound: lam_t -+ mu lam_n = 0; the rows of a tire that does not
+// push: lam = 0 -- are each one lane's own (Dg, X, rhs). So an attempt is: every lane rewrites its own row or keeps it, the
+// same elimination runs again, and every lane checks ITS row's condition on the result. About 150 issue slots an attempt
+// against 150 for the gather plus 390 for the gathered solve (profiles/r05_active_set.txt). `start`: the own row's warm
+// start (previous substep's impulse or the direct solution, not projected). Returns the attempt accepted (1 .. 3; `lam` =
+// the own row's impulse then) or 0 (`lam` untouched): the same rules, tolerances and first guess as contact_active_set6.
+UPKIE_HD void oct_block_solve(const OctLane& L, const float (&D)[3], const float (&Xc)[3], float b, float& x) {
+  float Dw[3] = {D[0], D[1], D[2]};
+  float W[4] = {Xc[0], Xc[1], Xc[2], b};
+  oct_gauss_jordan<4>(L, Dw, W);
+  float WP[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) WP[i] = oct_swp(W[i]);
+  float acc[4] = {D[0], D[1], D[2], b};
+  oct_sumj_neg4(acc, WP, Xc[0], Xc[1], Xc[2]);
+  float Sd[3] = {acc[0], acc[1], acc[2]}, rr[1] = {acc[3]};
+  oct_gauss_jordan<1>(L, Sd, rr);
+  x = rr[0];
+}
+UPKIE_HD int oct_active_set(const OctLane& L, const float (&Dg)[3], const float (&X)[3], float rhs, float start, float mu, float tolerance, float& lam) {
+  const bool normal = L.l == 1, friction = L.l >= 2;
+  // the first set, from the projected warm start (tire-level facts come from the quad's normal lane)
+  const float start_n = fmaxf(oct_qb<1>(start), 0.f);
+  const float rhs_n = oct_qb<1>(rhs);
+  const bool landing = !(start_n > 0.f) && rhs_n > 0.f;
+  bool push = start_n > 0.f || landing;
+  const float towards = landing ? rhs : start;
+  float side = friction && push && (landing || !(fabsf(start) < mu * start_n)) ? (towards > 0.f ? 1.f : -1.f) : 0.f;
+  const float vtol = tolerance * oct_emax(L.wj * fabsf(rhs));
+#pragma nounroll  // (one copy of the body: three would be 1.3 k instructions in each of fifty kernels, for a path that loops rarely)
+  for (int attempt = 1; attempt <= UPKIE_ACTIVE_SET_ATTEMPTS; ++attempt) {
+    const bool kept = L.l == 0 || (push && side == 0.f);  // (the trunk lane has no row: its by-product column stays as it is)
+    float Dm[3], Xm[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Dm[a] = kept ? Dg[a] : L.e[a];
+      Xm[a] = kept ? X[a] : 0.f;
+    }
+    Dm[0] = fmaf(-mu, side, Dm[0]);  // (side != 0 only on a replaced friction row, whose entry here is 0)
+    float x;
+    oct_block_solve(L, Dm, Xm, kept ? rhs : 0.f, x);
+    // what the impulses do in the own row: v = (A x - rhs)_own, from the untouched row (= column) of A
+    const float x1 = oct_qb<1>(x), x2 = oct_qb<2>(x), x3 = oct_qb<3>(x);
+    float v = -rhs;
+    v = fmaf(Dg[0], x1, v); v = fmaf(Dg[1], x2, v); v = fmaf(Dg[2], x3, v);
+    v = fmaf(X[0], oct_swp(x1), v); v = fmaf(X[1], oct_swp(x2), v); v = fmaf(X[2], oct_swp(x3), v);
+    const float xs = oct_emax(L.wj * fabsf(x));
+    const float xtol = tolerance * xs;
+    // the own row's conditions as excesses (<= 0: met), as in contact_active_set6
+    const float equation = kept && L.l != 0 ? fabsf(v) - vtol : -1.f;
+    const float enters = normal && !push ? -v - vtol : -1.f;
+    const float pulls = normal && push ? -x - xtol : -1.f;
+    const float lim = mu * x1;
+    const float leaves = friction && push && side == 0.f ? fabsf(x) - lim - xtol : -1.f;
+    const float returns = side != 0.f ? v * side - 0.1f * vtol : -1.f;
+    const float worst = fmaxf(fmaxf(fmaxf(equation, enters), fmaxf(pulls, leaves)), returns);
+    const bool bad = !(worst <= 0.f) || !(xs <= 3.0e38f);
+    if (!oct_env_any(bad)) {
+      const float ln = push ? fmaxf(x1, 0.f) : 0.f, bound = mu * ln;
+      lam = normal ? ln : (side != 0.f ? side * bound : fminf(fmaxf(x, -bound), bound));
+      if (L.l == 0) lam = x;  // (the trunk lane's by-product, as after the direct solve)
+      return attempt;
+    }
+    // the next set: the tire flips when its normal lane says so, else each friction lane moves its own row
+    const bool flips = oct_qb<1>(enters > 0.f || pulls > 0.f ? 1.f : 0.f) != 0.f;
+    side = flips || !friction ? 0.f : (leaves > 0.f ? (x > 0.f ? 1.f : -1.f) : (returns > 0.f ? 0.f : side));
+    push = flips ? !push : push;
+  }
+  return 0;
+}
+
 // The env's 6 x 6 contact system gathered into EVERY lane of the env from its one-column-per-lane form (rows 0-2: the
 // left tire's normal / rolling / lateral row, 3-5: the right tire's): A packed lower by rows, right-hand sides.
 // Dg[a]: entry (a, own row) of the own tire's block, X[a]: entry (other tire's row a, own row) of the coupling block.
@@ -1277,16 +1359,22 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
           if (rhs_n <= 0.f && rhs_n_other <= 0.f) {
             lam = 0.f;
           } else {
+          // Warm start: the projected direct solution, or -- when the previous substep came through here too, with the
+          // same tires on the floor -- the impulses it ended on: a robot that skids or tumbles does so for many substeps
+          // in a row and its contact state changes little from one millisecond to the next
+          const bool from_previous = s.swept_prev == (both ? 2 : 1);
+          const float start = from_previous ? s.lam_prev : lam;
+          // round 5: an active-set solve first, one row per lane as the direct solve (oct_active_set); the gathered
+          // system and the sweeps only when none of its three sets is accepted
+          const int accepted = oct_active_set(L, Dg, X, rhs, start, OCT_HOT(friction_mu), M.pgs_tolerance, lam);
+          if (accepted) {
+            if (census) census->sweeps = -accepted;
+            swept_now = both ? 2 : 1;
+          } else {
           const bool left = L.leg == 0;
           float A6[21], rhs6[6], lam6[6];
           oct_gather_system(L, Dg, X, rhs, A6, rhs6);
           {
-            // Warm start: the projected direct solution, or -- when the previous substep swept too, with the same tires
-            // on the floor -- the impulses it converged to: a robot that skids or tumbles does so for many substeps in
-            // a row and its contact state changes little from one millisecond to the next (same fixed point, fewer
-            // sweeps: the sweeps stop on their own convergence test either way)
-            const bool from_previous = s.swept_prev == (both ? 2 : 1);
-            const float start = from_previous ? s.lam_prev : lam;
             const float l1 = oct_qb<1>(start), l2 = oct_qb<2>(start), l3 = oct_qb<3>(start);
             const float q1 = oct_swp(l1), q2 = oct_swp(l2), q3 = oct_swp(l3);
             lam6[0] = left ? l1 : q1; lam6[1] = left ? l2 : q2; lam6[2] = left ? l3 : q3;
@@ -1301,14 +1389,13 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
             const float lim = OCT_HOT(friction_mu) * lam6[3 * (r / 3)];
             lam6[r] = fminf(fmaxf(lam6[r], -lim), lim);
           }
-          // (round 5: the active-set solve first -- contact_active_set6 --, the sweeps when neither of its two sets is
-          // accepted; negative: the set that was)
-          const int sweeps = contact_solve6(M, A6, rhs6, lam6);
+          const int sweeps = contact_pgs6(M, A6, rhs6, lam6);
           if (census) census->sweeps = sweeps;
           const float mine_l = L.l == 1 ? lam6[0] : (L.l == 2 ? lam6[1] : lam6[2]);
           const float mine_r = L.l == 1 ? lam6[3] : (L.l == 2 ? lam6[4] : lam6[5]);
           lam = left ? mine_l : mine_r;
           swept_now = both ? 2 : 1;
+          }
           }
         }
       }
