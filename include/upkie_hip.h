@@ -261,8 +261,10 @@ double upkie_sim_pgs_tolerance(const UpkieSim* sim);
  * chosen from the batch size at creation (small batches spread every env over
  * several lanes so that the chip's SIMDs all hold a wave; large ones keep one
  * env per lane), or forced by the environment variable UPKIE_LANES_PER_ENV
- * (tests, sweeps). Results agree across mappings to fp32 rounding and bit for
- * bit within one. */
+ * (tests, sweeps). Results agree across mappings to fp32 rounding -- where a
+ * contact solution leaves its friction box, to the solver's tolerance: the
+ * eight-lane kernel answers such substeps by an active-set solve, the others
+ * by sweeps -- and bit for bit within one. */
 int upkie_sim_lanes_per_env(const UpkieSim* sim);
 /* ... of the step kernel a given entry point launches, named by the layout of
  * its observation output (UpkieObservationLayout): the Servos kernels, which
@@ -287,9 +289,9 @@ int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout);
 int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
 
 /* Contact model. Default (`manifold` NULL): the product's specification -- one
- * contact point per tire, exact solve with Gauss-Seidel sweeps to convergence
- * when the solution leaves the friction box, friction CFM 0.01 (DESIGN.md
- * section 3). With `manifold` set -- the caller's device buffer
+ * contact point per tire, exact solve; when the solution leaves the friction
+ * box, an active-set solve (eight-lane kernel) and Gauss-Seidel sweeps to
+ * convergence, friction CFM 0.01. With `manifold` set -- the caller's device buffer
  * [UPKIE_CONTACT_MANIFOLD_WORDS][B] fp32, zeroed by the caller, kept between
  * steps -- every step of this handle solves contacts and joint limits the way
  * Bullet's multibody solver is published to inside pybullet.stepSimulation()
