@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ENVS_PER_GPU = 4096
+C4_ENVS_PER_GPU = 8192  # BASELINE configs[3]: 65536 envs over 8 GPUs
 STEPS_PER_LAUNCH = 32  # the state stays in registers between the steps of a launch; 1 = one launch per env.step()
 GATHER_CHUNK = 64  # steps per collective: a gather costs ~27 us of queue time whatever its size (profiles/r01_gather_chunk_sweep.txt); two per 128-step rollout
 # 29 fp32 state words read + written (232 B), action 4,
@@ -258,7 +259,7 @@ def vec_env_api(envs: int = ENVS_PER_GPU, steps: int = STEADY_STEPS, warmup: int
 
 
 def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, warmup: int = STEADY_WARMUP, seed: int = 0, census_steps: int = 400,
-                       contact_model: str = "default") -> dict:
+                       contact_model: str = "default", lanes: int = 0) -> dict:
     """One GPU's share of BASELINE.json configs[4] as SURVEY.md section 8d
     writes it (C5: 32768 envs over 8 GPUs): UpkieServos, inertia_variation 0.2
     per env and link (pybullet_backend.py:571-601), wheel friction 0.1
@@ -271,8 +272,11 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
     `law`: "torque" = examples/pybullet/torque_balancing.py:15-37 (8d's law:
     wheel torques +-10 x pitch, kd_scale 0), "velocity" = the README balancer
     through the wheels' velocity loop. `contact_model`: "default" or
-    "bullet_like" (persistent manifolds, 50 fixed sweeps, cone friction: on
-    eight lanes per env for Servos steps too since round 5)."""
+    "bullet_like" (persistent manifolds, 50 fixed sweeps, cone friction; Servos
+    steps run it one env per lane by default since round 6 -- the mapping that
+    keeps joint stops inside the sweeps --, `lanes` = 8 asks for the eight-lane
+    kernel, which the C5 agents, whose servos hold the legs, never drive into
+    its joint-stop fallback: the census word says so)."""
     import numpy as np
     import torch
 
@@ -287,6 +291,8 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
                         contact_model=contact_model, joint_properties={n: JointProperties(friction=0.1) for n in ("left_wheel", "right_wheel")})
     env.reset(seed=seed)
     sim = env.sim
+    if lanes:
+        sim.set_lanes_per_env(lanes)
     push = torch.zeros((3, envs), dtype=torch.float32, device=env.device)
     sim.set_external_force(push)  # the kernels read this buffer at every substep from now on
     m = env.model.struct
@@ -314,7 +320,7 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
         "algorithmic_bytes_per_env_step": C5_BYTES_PER_ENV_STEP,
         "hbm_frac": C5_BYTES_PER_ENV_STEP * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
     }
-    if census_steps and contact_model == "default" and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8:  # (the census is counted by the eight-lane kernels)
+    if census_steps and sim.lanes_per_env_of(abi.OBSERVATION_SERVOS) == 8:  # (the census is counted by the eight-lane kernels)
         # rare-path census on its own steps afterwards (its atomics are not free), continuing the same schedule
         sim.enable_census()
         for k in range(warmup + steps, warmup + steps + census_steps):
@@ -454,7 +460,7 @@ def valu_roofline(pmc, launch_us: float):
     return out
 
 
-def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
+def main_c5(args, sim_factory=None, backend=None, keep_group: bool = False):
     """`python bench.py --config c5 --gpus N`: BASELINE.json configs[4] (SURVEY
     8d "C5"): UpkieServos, 4096 envs per GPU (32768 on 8), per-link inertia
     randomisation 0.2, wheel friction 0.1, the device-drawn push schedule,
@@ -536,7 +542,7 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
     advance(args.warmup)
     elapsed, device_ms, resets = timed(args.steps)
     if rank != 0:
-        env.shutdown()
+        env.shutdown(destroy_group=not keep_group)
         base.close()  # (the handle is `base`'s: ShardedVecEnv leaves a caller's handle open)
         return
     step_us = device_ms * 1e3 / args.steps
@@ -571,9 +577,9 @@ def main_c5(args, sim_factory=None, backend=None, json_out=None) -> None:
         s_elapsed, s_ms, s_resets = steady
         line["steady_state"] = {"value": counted_envs * STEADY_STEPS / s_elapsed, "unit": "env-steps/s", "steps": STEADY_STEPS, "warmup": STEADY_WARMUP,
                                 "ms_per_step": s_elapsed / STEADY_STEPS * 1e3, "avg_launch_us": s_ms * 1e3 / STEADY_STEPS, "autoresets_in_timed_region": s_resets}
-    env.shutdown()
+    env.shutdown(destroy_group=not keep_group)
     base.close()
-    print(json.dumps(line), file=json_out or sys.stdout, flush=True)
+    return line
 
 
 def c4_rollout_consumer(env, consumed: dict, on_gpu: bool = True):
@@ -632,11 +638,51 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
                              "32768 at --gpus 8), every env kind's sharded runner")
     parser.add_argument("--law", choices=("torque", "velocity"), default="torque", help="--config c5: the servo-level law evaluated inside the launch")
     args = parser.parse_args(argv)
+    explicit_envs = args.envs_per_gpu is not None
     if args.envs_per_gpu is None:
-        args.envs_per_gpu = 8192 if args.config == "c4" else ENVS_PER_GPU
+        args.envs_per_gpu = C4_ENVS_PER_GPU if args.config == "c4" else ENVS_PER_GPU
+    # The driver's multi-GPU runs use the default flags. Beside the weak-scaling line of configs[1]'s per-GPU workload such a
+    # run (N > 1, no --config, default sizes) ALSO measures BASELINE's own multi-GPU configs in the same launch, each with its
+    # own steady_state: configs[3] (`--config c4`: 8192 Pendulum envs per GPU = 65536 at 8 GPUs, chunked RCCL gather, rollout
+    # consumer on rank 0) and configs[4] (`--config c5`: 4096 UpkieServos envs per GPU = 32768 at 8) -> "secondary": {"c4", "c5"}.
+    both_multi_gpu_configs = args.gpus > 1 and args.config == "c2" and not explicit_envs and args.total_envs == 0 and not args.no_secondary
     if args.config == "c5":
-        return main_c5(args, sim_factory=sim_factory, backend=backend, json_out=json_out)
+        line = main_c5(args, sim_factory=sim_factory, backend=backend)
+    else:
+        line = run_pendulum(args, sim_factory=sim_factory, backend=backend, keep_group=both_multi_gpu_configs)
+    if both_multi_gpu_configs:
+        import copy
 
+        def block(config, envs_per_gpu, keep_group):
+            a = copy.copy(args)
+            a.config, a.envs_per_gpu, a.no_fused, a.no_cpu_baseline = config, envs_per_gpu, True, True
+            try:
+                if config == "c5":
+                    out = main_c5(a, sim_factory=sim_factory, backend=backend, keep_group=keep_group)
+                else:
+                    out = run_pendulum(a, sim_factory=sim_factory, backend=backend, keep_group=keep_group)
+            except Exception as exc:  # noqa: BLE001 (a block beside the contract figure never costs the line itself)
+                import traceback
+
+                return {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
+            if out is None:
+                return None
+            keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "steady_state")
+            return {k: out[k] for k in keep if k in out}
+
+        c4 = block("c4", C4_ENVS_PER_GPU, True)
+        c5 = block("c5", ENVS_PER_GPU, False)
+        if line is not None:
+            line["secondary"] = {"c4": c4, "c5": c5,
+                                 "note": "BASELINE configs[3] and configs[4] at this run's N, measured in the same launch behind the weak-scaling line above "
+                                         "(same W / K, each with SURVEY 8d's steady_state window of its own); `--config c4|c5` prints either as a line of its own"}
+    if line is not None:
+        print(json.dumps(line), file=json_out or sys.stdout, flush=True)
+
+
+def run_pendulum(args, sim_factory=None, backend=None, keep_group: bool = False):
+    """The Upkie-Pendulum lines (`--config c2`: the headline; `--config c4`:
+    BASELINE configs[3]); returns the line on rank 0, None on the others."""
     import torch
 
     from upkie_amd.distributed import ShardedPendulum, init_distributed
@@ -721,8 +767,8 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
         fused = timed(args.steps, STEPS_PER_LAUNCH)
 
     if rank != 0:
-        env.shutdown()
-        return
+        env.shutdown(destroy_group=not keep_group)
+        return None
 
     total_envs = counted_envs
     value = total_envs * args.steps / elapsed
@@ -825,7 +871,7 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
         line["cpu_baseline"] = cpu_baseline(B, float(os.environ.get("UPKIE_CPU_BASELINE_BUDGET_S", "15")))
     else:
         line["cpu_baseline"] = None
-    env.shutdown()
+    env.shutdown(destroy_group=not keep_group)
     if world == 1 and on_gpu and not args.no_secondary:
         del env
         torch.cuda.synchronize()
@@ -847,9 +893,10 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
             "c5_share_torque_law": guarded(secondary_c5_share, "torque"),
             "c5_share_velocity_law": guarded(secondary_c5_share, "velocity"),
             "c5_share_bullet_like": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 0, "bullet_like") for law in ("torque", "velocity")},
+            "c5_share_bullet_like_eight_lanes": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 200, "bullet_like", 8) for law in ("torque", "velocity")},
             "c2_bullet_like_contact_model": guarded(secondary_bullet_like, B),
         }
-    print(json.dumps(line), file=json_out or sys.stdout, flush=True)
+    return line
 
 
 if __name__ == "__main__":

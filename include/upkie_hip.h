@@ -273,6 +273,42 @@ int upkie_sim_lanes_per_env(const UpkieSim* sim);
  * counted by the eight-lane kernels only; the SAME_STEP autoreset runs inside
  * the launch there) asks for the entry point it uses. */
 int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout);
+/* Force the mapping of this handle's later launches: 1, 2 or 8 lanes per env,
+ * 0 = back to the choice by batch size (what UPKIE_LANES_PER_ENV sets at
+ * creation). A forced mapping still yields where it does not exist (the
+ * eight-lane kernels beyond 2^32 bytes of state or with forces on leg links,
+ * the two-lane kernels under the Bullet-like contact model). */
+int upkie_sim_set_lanes_per_env(UpkieSim* sim, int lanes);
+
+/* Non-finite commands and states. The reference has one robot and asserts
+ * (`assert not np.isnan(target_velocity)`, pybullet_backend.py:519); a batch of
+ * thousands must not stop -- nor keep a poisoned env for ever -- because one
+ * policy output diverged. Every step entry point therefore
+ *  1. replaces what is still NOT FINITE behind the reference's clamp
+ *     (upkie_servos.py:331-342; only NaN survives a clamp, and an infinite
+ *     position target of a joint without position limits) by the NEUTRAL
+ *     action's value (upkie_servos.py:255-262): velocity 0, feedforward torque
+ *     0, kp_scale 1, kd_scale 1, maximum_torque = the joint's effort limit; an
+ *     infinite position becomes NaN, which is the neutral position ("no
+ *     position term"). A NaN ground / yaw velocity action of the Pendulum /
+ *     Gyropod / BaseVelocity steps is 0, an infinite yaw velocity -- the yaw
+ *     word integrates the unclamped action, upkie_gyropod.py:383-385 -- is
+ *     max_yaw_velocity with its sign; a non-finite target velocity of the MPC
+ *     balancer is 0;
+ *  2. looks at the env's state behind the substeps: if a word of it is not
+ *     finite (a force, an inertial record or an uploaded state word was not),
+ *     the env is put into UpkieSimConfig's initial state WITHOUT randomisation,
+ *     at rest, its contact cache dropped; the step reports `terminated = 1`
+ *     for it -- every env kind, UpkieServos included -- and flags it done, so
+ *     the autoreset treats it like a fall (NEXT_STEP: re-initialised by its
+ *     next step; SAME_STEP: inside this call; disabled: until the caller
+ *     resets it). No NaN leaves a step in an observation.
+ * Finite values, however large, go through the reference's arithmetic
+ * untouched (its clamps bound them). Both events are counted per handle:
+ * counts[0] = command words replaced, counts[1] = env states replaced since
+ * creation (or the last call with reset != 0); the call waits for `stream`.
+ * The sound envs pay about twenty compares per step for this. */
+int upkie_sim_guard_counts(UpkieSim* sim, uint32_t counts[2], int reset, void* stream);
 
 /* gymnasium's SAME_STEP autoreset completed by the step calls themselves: with
  * `final_obs` set (a device buffer shaped like the step's observation output:
@@ -307,15 +343,18 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * normal impulse, live flag. A reset clears an env's manifold. Two kernels run
  * this model: the one-env-per-lane step kernels cover every case (several
  * points on a tire, joints at their stops in the same solve, any batch size,
- * every entry point); up to 16384 envs (upkie_sim_step_servos: 8192) the step
- * entry points run it on eight lanes per env, in the case a rolling wheel
+ * every entry point); up to 16384 envs the Pendulum / Gyropod / BaseVelocity
+ * step entry points (upkie_sim_step_servos: only when asked to,
+ * upkie_sim_set_lanes_per_env(sim, 8), and up to 8192 envs; round 6) run it on
+ * eight lanes per env, in the case a rolling wheel
  * produces (one cached point per tire, which the tire's deepest point replaces
  * every substep: the default model's contact point with the friction rows
  * rotated into the sliding direction; a robot lying flat on its side, whose
  * tires may cache several points under Bullet's rule, keeps the deepest one
  * on this variant; a joint at its stop -- which the Pendulum / Gyropod /
  * BaseVelocity envs, whose legs the servos hold, do not reach, and a Servos
- * agent may -- takes the default model's joint-stop solve for that substep and
+ * agent may, which is why Servos steps default to the one-lane kernels --
+ * takes the default model's joint-stop solve for that substep and
  * is counted by the census, word [0]; UPKIE_LANES_PER_ENV=1 selects the
  * one-lane kernels, which keep limit rows inside the same sweeps).
  * Both keep complete manifold records, so either continues from a manifold the

@@ -165,6 +165,10 @@ def set_threads(threads: int = 0) -> int:
 def lib():
     global _lib
     if _lib is None:
+        override = os.environ.get("UPKIE_ORACLE_LIBRARY")  # (tests/test_sanitizers.py: the same sources built with -fsanitize)
+        if override:
+            _load(override)
+            return _lib
         if not os.path.exists(_LIB_PATH):
             build()
         _load(_LIB_PATH)

@@ -18,7 +18,7 @@
 #define NJ UPKIE_NJ
 #define NV 12
 #define NW UPKIE_STATE_WORDS
-#define MAXROWS 10
+#define MAXROWS (6 + NJ) /* two tires x three rows + a limit row per joint (a model may bound its wheel joints too) */
 
 long oracle_debug_sweeps = 0, oracle_debug_fallbacks = 0, oracle_debug_substeps = 0;
 long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they needed */
@@ -26,6 +26,9 @@ long oracle_debug_sweep_hist[64] = {0}; /* fallbacks by number of sweeps they ne
  * per case nrows, then W + CFM row-major [6][6], rhs [6], the warm start [6], the result [6] */
 #define ORACLE_CAPTURE_CASES 4096
 double oracle_debug_capture[ORACLE_CAPTURE_CASES][1 + 36 + 18] = {{0}};
+/* Non-finite guard: [0] command words replaced by the neutral action's, [1] env states replaced by the initial state
+ * (the twin of upkie_sim_guard_counts) */
+int64_t oracle_guard_counts[2] = {0, 0};
 long oracle_debug_captured = 0;
 long oracle_debug_capture_threshold = 0; /* capture systems that needed at least this many sweeps (0: the iteration cap) */
 long oracle_debug_capture_rows = 0; /* capture systems of this many rows only (0: any) */
@@ -525,10 +528,36 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
  * speed clamp, base damping) is shared with the product's specification.
  * Enabled per call through OracleRandomization.bullet_manifold; used by
  * tools/bullet_like_deviation.py and tests/test_oracle_bullet_like.py only. */
+/* Joint position limits (URDF revolute limits; Bullet: btMultiBodyJointLimitConstraint, SURVEY App. B.1 [third party,
+ * restated]): one unilateral row per bound on the joint's velocity towards the free side. A joint still `gap` short of
+ * its stop may close that gap within the substep (sign v >= -gap / h), a joint `pen` beyond it is pushed back with
+ * Bullet's default ERP (sign v >= 0.2 pen / h); the row is listed while the joint could reach the stop within the
+ * substep (gap <= max_joint_velocity h). Until round 6 the row existed only at or beyond the stop, with the ERP bias
+ * alone: for a joint RESTING on its stop -- within rounding of gap = 0 -- its existence in a substep hung on the last
+ * bit of q (in fp64: alternately a substep with the row and one of free acceleration into the stop; the fp32 kernels,
+ * whose rounding put the joint back ON the stop, kept the row: the one-step parity test of round 6 found the two 1e-3
+ * rad apart on 1 % of such steps). Twin: joint_limit_row, upkie_amd/csrc/dynamics.hpp. */
+static int joint_limit_row(const UpkieModel* model, int j, double qj, double h, double* sign, double* bias) {
+  if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30)) return 0;
+  const double zone = model->max_joint_velocity * h;
+  double pen;
+  if (qj - model->joint_lower[j] <= zone) {
+    *sign = 1.0;
+    pen = model->joint_lower[j] - qj;
+  } else if (model->joint_upper[j] - qj <= zone) {
+    *sign = -1.0;
+    pen = qj - model->joint_upper[j];
+  } else {
+    return 0;
+  }
+  *bias = (pen > 0.0 ? 0.2 : 1.0) * pen / h;
+  return 1;
+}
+
 static _Thread_local double* g_contact_sink; /* (defined below: where a contact-point query wants the points of the substep) */
 #define BL_POINTS 4
 #define BL_POINT_WORDS 8 /* point in the wheel frame (3), on the plane (3), applied normal impulse, live */
-#define BL_ROWS (2 * BL_POINTS * 3 + 4)
+#define BL_ROWS (2 * BL_POINTS * 3 + NJ) /* every tire point's three rows + a limit row per joint (a model may bound its wheels too) */
 static _Thread_local double g_bullet_manifold[2 * BL_POINTS * BL_POINT_WORDS];
 static _Thread_local int g_bullet_active = 0;
 
@@ -545,16 +574,13 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
   /* joint limits (btMultiBodyJointLimitConstraint, ERP 0.2): solved first in every sweep */
   if (model->enforce_joint_limits) {
     for (int j = 0; j < NJ; ++j) {
-      if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30)) continue;
-      double sign = 0.0, err = 0.0;
-      if (q[j] <= model->joint_lower[j]) { sign = 1.0; err = model->joint_lower[j] - q[j]; }
-      else if (q[j] >= model->joint_upper[j]) { sign = -1.0; err = q[j] - model->joint_upper[j]; }
-      else continue;
+      double sign, bias;
+      if (!joint_limit_row(model, j, q[j], h, &sign, &bias)) continue;
       memset(J[nrows], 0, sizeof(double) * NV);
       J[nrows][6 + j] = sign;
       kind[nrows] = 2; normal_row[nrows] = nrows; cfm[nrows] = 0.0; lam[nrows] = 0.0; applied_slot[nrows] = NULL;
       row_wheel[nrows] = -1;
-      rhs[nrows] = -sign * nu[6 + j] + 0.2 * err / h;
+      rhs[nrows] = -sign * nu[6 + j] + bias;
       ++nrows;
     }
   }
@@ -886,24 +912,14 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   if (bullet_contact >= 0) any_contact = bullet_contact; /* (contacts AND joint limits were solved there) */
   if (model->enforce_joint_limits && bullet_contact < 0) {
     for (int j = 0; j < NJ; ++j) {
-      if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30))
-        continue;
-      double sign = 0.0, err = 0.0;
-      if (q[j] <= model->joint_lower[j]) {
-        sign = 1.0;
-        err = model->joint_lower[j] - q[j];
-      } else if (q[j] >= model->joint_upper[j]) {
-        sign = -1.0;
-        err = q[j] - model->joint_upper[j];
-      } else {
-        continue;
-      }
+      double sign, bias;
+      if (!joint_limit_row(model, j, q[j], h, &sign, &bias)) continue;
       memset(J[nrows], 0, sizeof(double) * NV);
       J[nrows][6 + j] = sign;
       kind[nrows] = 2;
       normal_row[nrows] = nrows;
       cfm[nrows] = 0.0;
-      rhs_c[nrows] = -sign * nu[6 + j] + 0.2 * err / h;
+      rhs_c[nrows] = -sign * nu[6 + j] + bias;
       ++nrows;
     }
   }
@@ -1366,7 +1382,51 @@ static void clamp_servo_commands(const UpkieModel* model,
     cmd[j].kp_scale = clamp_like_reference(cmd[j].kp_scale, 0.0, cfg->max_gain_scale);
     cmd[j].kd_scale = clamp_like_reference(cmd[j].kd_scale, 0.0, cfg->max_gain_scale);
     cmd[j].maximum_torque = clamp_like_reference(cmd[j].maximum_torque, 0.0, eff);
+    /* Non-finite guard (include/upkie_hip.h, "Non-finite commands and states"; the reference asserts instead,
+     * pybullet_backend.py:519): what is still not finite behind the clamp becomes the neutral action's value
+     * (upkie_servos.py:255-262) and is counted. NaN IS the neutral position; an infinite one (a wheel has no
+     * position limits to clamp it) would make 0 x inf under kp_scale = 0. */
+    int replaced = 0;
+    if (isinf(cmd[j].position)) { cmd[j].position = NAN; ++replaced; }
+    if (!isfinite(cmd[j].velocity)) { cmd[j].velocity = 0.0; ++replaced; }
+    if (!isfinite(cmd[j].feedforward_torque)) { cmd[j].feedforward_torque = 0.0; ++replaced; }
+    if (!isfinite(cmd[j].kp_scale)) { cmd[j].kp_scale = 1.0; ++replaced; }
+    if (!isfinite(cmd[j].kd_scale)) { cmd[j].kd_scale = 1.0; ++replaced; }
+    if (!isfinite(cmd[j].maximum_torque)) { cmd[j].maximum_torque = eff; ++replaced; }
+    if (replaced) {
+#pragma omp atomic
+      oracle_guard_counts[0] += replaced;
+    }
   }
+}
+
+/* Non-finite guard, second half: a state that is not finite behind the substeps (a force, an inertial record or an
+ * uploaded state word that was not) is replaced by the configuration's initial state without randomisation, at rest;
+ * returns 1 when it did (the step then reports `terminated` and flags the env done, like a fall). */
+static int guard_state(const UpkieSimConfig* cfg, double s[NW]) {
+  double mag = 0.0;
+  for (int w = UPKIE_S_POS; w < UPKIE_S_QD + NJ; ++w) mag += fabs(s[w]);
+  if (mag < 3.0e38) return 0; /* (the device's test, on fp32 words: neither NaN nor Inf, nor about to be one) */
+  for (int d = 0; d < 3; ++d) {
+    s[UPKIE_S_POS + d] = cfg->init_pos[d];
+    s[UPKIE_S_LINVEL + d] = cfg->init_linvel[d];
+    s[UPKIE_S_ANGVEL + d] = cfg->init_angvel[d];
+  }
+  for (int d = 0; d < 4; ++d) s[UPKIE_S_QUAT + d] = cfg->init_quat[d];
+  for (int j = 0; j < NJ; ++j) {
+    s[UPKIE_S_Q + j] = cfg->init_joint[j];
+    s[UPKIE_S_QD + j] = 0.0;
+    s[UPKIE_S_TORQUE + j] = 0.0;
+  }
+  s[UPKIE_S_LEGREF + 0] = s[UPKIE_S_Q + 0];
+  s[UPKIE_S_LEGREF + 1] = s[UPKIE_S_Q + 1];
+  s[UPKIE_S_LEGREF + 2] = s[UPKIE_S_Q + 3];
+  s[UPKIE_S_LEGREF + 3] = s[UPKIE_S_Q + 4];
+  s[UPKIE_S_CONTACT] = 0.0;
+  if (g_bullet_active) memset(g_bullet_manifold, 0, sizeof(g_bullet_manifold)); /* a contact cache of that state means nothing */
+#pragma omp atomic
+  oracle_guard_counts[1] += 1;
+  return 1;
 }
 
 /* PyBulletBackend.step, pybullet_backend.py:269-311 */
@@ -1477,20 +1537,31 @@ static void step_gyropod_env(const UpkieModel* model, const UpkieSimConfig* cfg,
   int did_reset;
   autoreset_or_null(model, cfg, s, env_global, sp, fp, pp, &did_reset);
   if (did_reset) {
+    guard_state(cfg, s);
     gyropod_observation(model, s, obs6);
     *terminated = 0;
     *truncated = 0;
     return;
   }
   OracleServoCommand cmd[NJ];
+  /* non-finite guard: a NaN action is the neutral one (zero velocities); an infinite one is clamped below */
+  int replaced = 0;
+  if (isnan(a0)) { a0 = 0.0; ++replaced; }
+  if (isnan(a1)) { a1 = 0.0; ++replaced; }
+  if (isinf(a1)) { a1 = a1 > 0 ? cfg->max_yaw_velocity : -cfg->max_yaw_velocity; ++replaced; } /* (the yaw integrates the unclamped action) */
+  if (replaced) {
+#pragma omp atomic
+    oracle_guard_counts[0] += replaced;
+  }
   gyropod_commands(model, cfg, s, a0, a1, cmd);
   clamp_servo_commands(model, cfg, cmd);
   backend_step(model, cfg, s, env_global, cmd, sp, fp, pp);
   s[UPKIE_S_YAW] += a1 * cfg->dt; /* upkie_gyropod.py:383-385, unclamped */
   s[UPKIE_S_YAWVEL] = a1;
+  const int unsound = guard_state(cfg, s);
   gyropod_observation(model, s, obs6);
   /* __detect_fall, upkie_gyropod.py:344-345 */
-  *terminated = fabs(obs6[1]) > cfg->fall_pitch ? 1 : 0;
+  *terminated = (fabs(obs6[1]) > cfg->fall_pitch || unsound) ? 1 : 0;
   if (*terminated) s[UPKIE_S_DONE] = 1.0;
   *truncated = time_limit(cfg, s, 0, *terminated);
 }
@@ -1657,10 +1728,12 @@ void oracle_step_servos(const UpkieModel* model, const UpkieSimConfig* cfg,
       clamp_servo_commands(model, cfg, cmd);
       backend_step(model, cfg, s, cfg->env_id_offset + e, cmd, sp, fp, pp);
     }
+    const int unsound = guard_state(cfg, s);
+    if (unsound && !did_reset) s[UPKIE_S_DONE] = 1.0;
     servo_observation(cfg, cfg->env_id_offset + e, s, obs + 30 * (int64_t)e);
     reward[e] = 0.0;
-    terminated[e] = 0; /* upkie_env.py:231-238: only the joystick ends it */
-    truncated[e] = time_limit(cfg, s, did_reset, 0);
+    terminated[e] = unsound && !did_reset ? 1 : 0; /* upkie_env.py:231-238: only the joystick ends it -- or the non-finite guard */
+    truncated[e] = time_limit(cfg, s, did_reset, terminated[e]);
     spine_end(rnd, B, e);
     store_env(state, B, e, s);
   }

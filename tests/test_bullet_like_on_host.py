@@ -82,7 +82,11 @@ def test_standing_robot_keeps_one_point_per_tire_and_matches_the_oracle(harness)
             worst_impulse = max(worst_impulse, float(np.abs(mo.reshape(2, 4, 8)[:, :, 6] - mh.reshape(2, 4, 8)[:, :, 6]).max()))
     assert worst[0:3].max() < 2e-6 and worst[3:7].max() < 2e-6, worst
     assert worst[7:10].max() < 5e-4 and worst[10:13].max() < 2e-3, worst
-    assert worst[13:19].max() < 5e-6 and worst[19:25].max() < 5e-2, worst
+    # (round 6: the robots land with free legs, which fold onto their stops; a joint within reach of its stop now lists its limit
+    # row -- joint_limit_row, dynamics.hpp -- so these substeps go through the general row list, whose running velocity change
+    # carries more fp32 rounding than the six-row fast path they used to take: wheel rates within 5e-2 rad/s as before, which
+    # over 40 substeps is up to 1e-4 rad of wheel angle; hips and knees as before)
+    assert worst[[13, 14, 16, 17]].max() < 5e-6 and worst[[15, 18]].max() < 1e-4 and worst[19:25].max() < 5e-2, worst
     assert worst_impulse < 2e-4, worst_impulse  # normal impulses ~ 0.026 N.s per tire and substep
 
 
@@ -286,7 +290,7 @@ def bullet_like_sweep_statistics(harness, trials=10, substeps=240, seed=33):  # 
     the eight-lane Bullet-like substep of the HOST build, every solve probed: per solve the first sweep that (a) changed
     no bit of any impulse, (b) reproduced the impulses of 1-8 sweeps earlier (a limit cycle: the result of all 50 sweeps
     follows from the phase), (c) moved no impulse by more than 2.4e-7 / 1e-5 of the largest one (fp32 resolution / the
-    default model's sweep tolerance); 51 = never within the 50. Also used by tools/bullet_like_sweeps.py."""
+    default model's sweep tolerance); 51 = never within the 50. Also used by tools/archive/bullet_like_sweeps.py."""
     assert harness.harness_bullet_like_probe_bytes() == C.sizeof(BulletLikeProbe)
     harness.harness_substep_octet_bullet_like.restype = C.c_int
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731

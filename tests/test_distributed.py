@@ -459,6 +459,39 @@ def test_step_blob_layout_is_aligned_and_decodes():
         assert a[0] == buf[1].data_ptr() and a[3] - a[0] == blob.truncated_offset
 
 
+def test_bench_default_multi_gpu_line_also_measures_configs_3_and_4():
+    """The driver's multi-GPU runs use the default flags:
+    `bench.py --gpus N --steps K --warmup W` with N > 1 prints the weak-scaling
+    line of configs[1]'s per-GPU workload AND, under `secondary`, BASELINE
+    configs[3] (`c4`: the Pendulum env at its own batch size, gather + rollout
+    consumer) and configs[4] (`c5`: UpkieServos with pushes and randomised
+    inertias), each with its own steady_state, all three on one process group."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "tests", "bench_double.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--gather-chunk", "4"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", UPKIE_BENCH_DOUBLE_ENVS="6,10")
+    result = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["total_envs"] == 12 and out["config"]["baseline_config"].startswith("weak-scaling line of configs[1]")
+    sec = out["secondary"]
+    c4, c5 = sec["c4"], sec["c5"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    assert c4["config"]["baseline_config"].startswith("configs[3]") and c4["config"]["total_envs"] == 20 and c4["n_gpus"] == 2
+    assert c4["config"]["rollout_consumer"]["chunks_consumed"] > 0 and c4["steady_state"]["steps"] == 6
+    assert c4["value"] == pytest.approx(20 * 12 / (c4["ms_per_step"] * 1e-3 * 12), rel=1e-6)
+    assert "C5" in c5["config"]["workload"] and c5["config"]["total_envs"] == 12 and c5["steady_state"]["steps"] == 6
+    assert c5["value"] == pytest.approx(12 * 12 / (c5["ms_per_step"] * 1e-3 * 12), rel=1e-6)
+    assert c5["config"]["gather"].startswith("RCCL gather") and c4["config"]["gather"].startswith("RCCL gather")
+
+
 def test_bench_c5_launch_line_on_cpu_doubles():
     """`bench.py --config c5 --gpus 2` under the driver's launch line (gloo,
     oracle doubles): BASELINE configs[4]'s workload on the sharded runner of

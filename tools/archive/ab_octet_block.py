@@ -7,7 +7,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 VARIANTS = {64: None, 128: "libupkie_hip_block128.so", 256: "libupkie_hip_block256.so"}
 CHILD = r'''

@@ -2,7 +2,7 @@
 through the wheel velocity loop as a separate policy launch) with the rare-path census: time per step and the histogram
 of the sweeps a wavefront waits for. Usage: [UPKIE_HIP_LIBRARY=...] python tools/c5_const_push_hist.py"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import upkie_amd.envs as envs
 from upkie_amd import abi

@@ -5,7 +5,7 @@ Usage: python tools/c5_sweep_cost.py [--law torque|velocity] [--caps 1,2,4,8,50]
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 

@@ -1,7 +1,7 @@
 """Step time of the Pendulum agent per lane mapping with one feature switched on at a time
 (noise, friction, inertia randomisation, pushes, wide initial states): where a mapping pays."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from upkie_amd import abi
 from upkie_amd.model.model import Model

@@ -5,7 +5,7 @@ Usage (GPU box): python tools/reset_cost.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch  # noqa: E402
 
 import bench  # noqa: E402

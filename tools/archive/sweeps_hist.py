@@ -2,7 +2,7 @@
 GPU's share of BASELINE's C5 under both servo laws: the rare-path census of the eight-lane kernel
 (upkie_sim_set_census, words 8..71). Usage: python tools/sweeps_hist.py [census steps]"""
 import json, os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from upkie_amd.sim import BatchedSim
 

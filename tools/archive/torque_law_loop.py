@@ -1,6 +1,6 @@
 """The C5 share with torque_balancing.py's law on the device (70 % of the substeps sweep), for profiling."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import upkie_amd.envs as envs
 from upkie_amd import abi

@@ -16,7 +16,6 @@ cfg.rand_pitch = 0.1
 cfg.autoreset_mode = abi.AUTORESET_NEXT_STEP
 sim = BatchedSim(cfg)
 sim.reset()
-act = sim.get_neutral_servo_action() if hasattr(sim, "get_neutral_servo_action") else None
 r = float(sim.model.wheel_radius)
 servo = torch.zeros((B, 6, 6), device=sim.device)
 servo[:, :, 0] = float("nan")

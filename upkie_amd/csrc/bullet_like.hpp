@@ -217,11 +217,9 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
   // ---- joint limits (btMultiBodyJointLimitConstraint, ERP 0.2): first in every sweep
   if (Lm.enforce) {
     for (int j = 0; j < UPKIE_NJ; ++j) {
-      if (!Lm.bounded[j]) continue;
-      float sign = 0.f, err = 0.f;
-      if (s.q[j] <= Lm.lower[j]) { sign = 1.f; err = Lm.lower[j] - s.q[j]; }
-      else if (s.q[j] >= Lm.upper[j]) { sign = -1.f; err = s.q[j] - Lm.upper[j]; }
-      else continue;
+      float bias;  // (the gap-aware row of joint_limit_row, dynamics.hpp: the same rule under both contact models)
+      const float sign = joint_limit_row(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], M.max_joint_velocity * h, ih, bias);
+      if (sign == 0.f) continue;
       BlRow& R = rows[nrows];
 #pragma unroll
       for (int c = 0; c < 6; ++c) R.Jb[c] = 0.f;
@@ -229,7 +227,7 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
 #pragma unroll
       for (int k = 0; k < 3; ++k) R.Jl[k] = (j % 3) == k ? sign : 0.f;
       R.kind = 2; R.normal_row = nrows; R.cfm = 0.f; R.lam = 0.f; R.slot = -1;
-      R.rhs = -sign * qdF[j] + 0.2f * err * ih;
+      R.rhs = -sign * qdF[j] + bias;
       finish_row(R);
       ++nrows;
     }

@@ -775,7 +775,7 @@ UPKIE_HD int contact_pgs6_sweeps(const ModelT& M, const float (&A)[21], const fl
 // lateral row is swept like any friction row) holds unchanged. Until then envs with one tire on the floor ran a loop of
 // their own that swept rows 2 and 5 one by one, and a wavefront that held both kinds of env -- most of them, when robots
 // tumble -- ran the two loops one after the other, each to the largest count among its envs: a sweep level cost a
-// launch of the C5 share 2.8 us where one loop's 151 instructions account for 1.4 (tools/c5_sweep_cost.py).
+// launch of the C5 share 2.8 us where one loop's 151 instructions account for 1.4 (tools/archive/c5_sweep_cost.py).
 template <class ModelT>
 UPKIE_HD int contact_pgs6(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6]) {
   // both tires leaving the floor (neither normal row asks for an impulse): lam = 0 is the solution, what the sweeps
@@ -1013,6 +1013,34 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
 // reduced onto the base: Jt (6) and the leg part (3). On return
 // (tb, tl, tr) += J' lam.
 constexpr int kRows = 10;
+// Joint position limits (URDF revolute limits; Bullet: btMultiBodyJointLimitConstraint, SURVEY App. B.1 [third party, restated]):
+// one unilateral row per bound, on the joint's velocity towards the free side. A joint still `gap` short of its stop may
+// close that gap within the substep (sign v >= -gap / h, what Bullet's row allows a separated pair), a joint `pen` beyond it
+// is pushed back with ERP 0.2 (sign v >= 0.2 pen / h); the two meet continuously at the stop. The row is LISTED while the
+// joint could reach the stop within the substep: gap <= zone = max_joint_velocity h (rows that cannot bind are left out).
+// Until round 6 a row existed only at or beyond the stop (gap <= 0), with the ERP bias alone. A joint RESTING on its stop
+// sits within rounding of gap = 0, so whether its row existed in a substep was decided by the last bit of q -- in fp32 the
+// joint stayed put, in the fp64 checker it alternated between a substep with the row and a substep of free acceleration
+// into the stop (one-step parity test of round 6, joints held at their stops: 1 % of the env-steps off by 1e-3 rad under
+// that rule; gpurun_out/parity_windows/one_step_joint_stops.json). With the gap-aware row the answer no longer depends on
+// which side of its stop a resting joint is rounded to.
+// Returns the row's sign (+1: lower bound, -1: upper bound, 0: no row) and its bias.
+UPKIE_HD float joint_limit_row(bool bounded, float q, float lower, float upper, float zone, float ih, float& bias) {
+  float sign = 0.f, pen = 0.f;
+  if (bounded && q - lower <= zone) {
+    sign = 1.f;
+    pen = lower - q;
+  } else if (bounded && upper - q <= zone) {
+    sign = -1.f;
+    pen = q - upper;
+  }
+  bias = (pen > 0.f ? 0.2f : 1.f) * pen * ih;  // Bullet's default ERP beyond the stop; the gap may close within the substep before it
+  return sign;
+}
+UPKIE_HD bool joint_limit_near(bool bounded, float q, float lower, float upper, float zone) {
+  return bounded && (q - lower <= zone || upper - q <= zone);
+}
+
 UPKIE_HD constexpr int row_leg(int r) { return r < 3 ? 0 : (r < 6 ? 1 : (r < 8 ? 0 : 1)); }
 UPKIE_HD constexpr int row_kind(int r) { return r >= 6 ? 2 : (r % 3 == 0 ? 0 : 1); }  // 0 normal, 1 friction, 2 limit
 UPKIE_HD constexpr int sym(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -1021,7 +1049,7 @@ template <class ModelT>
 UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt6)[6][6], const float (&Jb)[6][6], const float (&Jl6)[6][3], const float (&vnow)[6],
-                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float zone, const float (&rt)[6],
                          float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   float J[kRows][6], Ll[kRows][3], vn[kRows], bias[kRows], cf[kRows];
   bool on[kRows];
@@ -1041,14 +1069,8 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
   for (int i = 0; i < 4; ++i) {
     const int j = i < 2 ? i : i + 1;  // joints 0, 1, 3, 4
     const int w = j / 3, kk = j % 3, r = 6 + i;
-    float sign = 0.f, err = 0.f;
-    if (bounded[j] && q[j] <= lower[j]) {
-      sign = 1.f;
-      err = lower[j] - q[j];
-    } else if (bounded[j] && q[j] >= upper[j]) {
-      sign = -1.f;
-      err = q[j] - upper[j];
-    }
+    float row_bias;
+    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], zone, ih, row_bias);
     const Leg& G = S.leg[w];
     // J = sign * e_j: no base part, reduced row = -D_w J_leg
 #pragma unroll
@@ -1058,7 +1080,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
     on[r] = sign != 0.f;
     vn[r] = sign * qd[j];
     cf[r] = 0.f;
-    bias[r] = 0.2f * err * ih;  // Bullet's default ERP
+    bias[r] = row_bias;
   }
 
   // A = J M^-1 J' + CFM column by column (packed lower), rhs = -(v + J M^-1 t) + bias
@@ -1382,7 +1404,7 @@ template <class ModelT>
 UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt)[6][6], const float (&Jb)[6][6], const float (&Jl)[6][3], const float (&vnow)[6],
-                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, const float (&rt)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float zone, const float (&rt)[6],
                          float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   GeneralRows R;
   R.n = 0;
@@ -1410,14 +1432,8 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
   }
 #pragma unroll
   for (int j = 0; j < UPKIE_NJ; ++j) {
-    float sign = 0.f, err = 0.f;
-    if (bounded[j] && q[j] <= lower[j]) {
-      sign = 1.f;
-      err = lower[j] - q[j];
-    } else if (bounded[j] && q[j] >= upper[j]) {
-      sign = -1.f;
-      err = q[j] - upper[j];
-    }
+    float row_bias;
+    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], zone, ih, row_bias);
     if (sign != 0.f) {
       const int i = R.n, w = j / 3, kk = j % 3;
       const Leg& G = S.leg[w];
@@ -1434,7 +1450,7 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
       R.kind[i] = 2;
       R.normal_row[i] = i;
       R.cfm[i] = 0.f;
-      R.bias[i] = 0.2f * err * ih;  // Bullet's default ERP
+      R.bias[i] = row_bias;
       R.n = i + 1;
     }
   }
@@ -1522,7 +1538,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   if (Lm.enforce) {
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j)
-      any_limit = any_limit || (Lm.bounded[j] && (s.q[j] <= Lm.lower[j] || s.q[j] >= Lm.upper[j]));
+      any_limit = any_limit || joint_limit_near(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], M.max_joint_velocity * h);
   }
   const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   const float r00 = bf.r00, r01 = bf.r01, r02 = bf.r02, r10 = bf.r10, r11 = bf.r11, r12 = bf.r12, r20 = bf.r20, r21 = bf.r21, r22 = bf.r22;
@@ -1705,9 +1721,9 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   if (warm && (any_limit || !(active[0] || active[1]))) warm->swept = 0;
   if (any_limit) {
     if (SCRATCH_LIMITS)
-      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr, lam);
+      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl, tr, lam);
     else
-      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, rt, tb, tl, tr, lam);
+      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl, tr, lam);
   } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors

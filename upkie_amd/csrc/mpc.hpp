@@ -84,6 +84,7 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
 
   float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
   float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
+  if (!(fabsf(vt) < 3.0e38f)) vt = 0.f;  // non-finite guard (step_kernels.hpp): a NaN target would stay in the warm start for ever
   // envs that the coming env.step() will reset: MPCBalancer.reset() instead of
   // a solve (upkie_base_velocity.py:158): zero warm start, zero velocity
   const bool resetting = live && done != nullptr && done[env] != 0.f;

@@ -557,7 +557,7 @@ UPKIE_HD float oct_from_joint(float x) { return oct_qb<K + 1>(x); }
 template <class ModelT, class LimitsT>
 UPKIE_HD void octet_limit_path_registers(const ModelT& M, const LimitsT& Lm_, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0,
                                float hv1, float hv2, V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active,
-                               bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih,
+                               bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih, float zone,
                                float (&xb)[6], float& xl) {
   const bool left = L.leg == 0;
   DevLimits Lm;  // (a register copy: the limits may sit in the constant address space, limit_path takes plain arrays)
@@ -643,7 +643,7 @@ UPKIE_HD void octet_limit_path_registers(const ModelT& M, const LimitsT& Lm_, co
     tb[c] = v;
   }
   float contact_lam[6];
-  limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl6[0], tl6[1], contact_lam);
+  limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, zone, rt, tb, tl6[0], tl6[1], contact_lam);
   system_solve<true, true>(S, tb, tl6[0], tl6[1]);
 #pragma unroll
   for (int c = 0; c < 6; ++c) xb[c] = tb[c];
@@ -685,7 +685,7 @@ UPKIE_HD int oct_env_slot() {
 template <class ModelT>
 UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
                                V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active, bool active_partner, float qd,
-                               float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_err,
+                               float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_bias,
                                float (&xb)[6], float& xl, LimitWorkspace& ws) {
   const bool left = L.leg == 0;
   LimitSystemRef S;
@@ -787,9 +787,9 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
     constexpr int k = decltype(kc)::value;
     const bool mine = (w == 0) == left;
     const float own_s = oct_from_joint<k>(lim_sign), other_s = oct_swp(own_s);
-    const float own_e = oct_from_joint<k>(lim_err), other_e = oct_swp(own_e);
+    const float own_e = oct_from_joint<k>(lim_bias), other_e = oct_swp(own_e);
     const float own_q = oct_from_joint<k>(qd), other_q = oct_swp(own_q);
-    const float sign = mine ? own_s : other_s, err = mine ? own_e : other_e, qdj = mine ? own_q : other_q;
+    const float sign = mine ? own_s : other_s, bias = mine ? own_e : other_e, qdj = mine ? own_q : other_q;
     if (sign != 0.f) {
       const int i = R.n;
 #pragma unroll
@@ -804,7 +804,7 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
       R.kind[i] = 2;
       R.normal_row[i] = i;
       R.cfm[i] = 0.f;
-      R.bias[i] = 0.2f * err * ih;  // Bullet's default ERP
+      R.bias[i] = bias;  // (joint_limit_row, dynamics.hpp)
       R.n = i + 1;
     }
   };
@@ -1092,7 +1092,7 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   // load and a wait for it in every substep, 86-160 cycles of a lone wavefront each)
   bool at_a_stop = false;
   {
-    const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
+    const bool own_limit = joint_limit_near(L.bounded, s.q, L.lower, L.upper, OCT_HOT(max_joint_velocity) * h);
     if (__builtin_expect(oct_wave_any(own_limit), 0)) at_a_stop = oct_env_any(own_limit);
   }
 
@@ -1258,11 +1258,12 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     if (census) census->path = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
-                                 erp, ih, xb, xl);
+                                 erp, ih, OCT_HOT(max_joint_velocity) * h, xb, xl);
     } else {
-      const bool low = L.bounded && s.q <= L.lower, high = L.bounded && !low && s.q >= L.upper;
+      float lim_bias;
+      const float lim_sign = joint_limit_row(L.bounded, s.q, L.lower, L.upper, OCT_HOT(max_joint_velocity) * h, ih, lim_bias);
       octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
-                               low ? 1.f : (high ? -1.f : 0.f), low ? L.lower - s.q : (high ? s.q - L.upper : 0.f), xb, xl, ws[oct_env_slot()]);
+                               lim_sign, lim_bias, xb, xl, ws[oct_env_slot()]);
     }
   } else if (__builtin_expect(active || active_partner, 1)) {
     const float sa = oct_qb<3>(L.sg);
@@ -1503,7 +1504,7 @@ constexpr bool kServosLimitsInRegisters = true;
 #define UPKIE_PROBE_OCTET_WAVES 2
 #endif
 // Lanes per workgroup of the eight-lane kernels: one wavefront. (An A/B probe may set 128 or 256 -- wavefronts of one
-// workgroup share a CU --: tools/ab_octet_block.py, profiles/r05_ab_octet_block.txt: nothing to gain. Not for
+// workgroup share a CU --: tools/archive/ab_octet_block.py, profiles/r05_ab_octet_block.txt: nothing to gain. Not for
 // MODE_BASE_VELOCITY, whose balancer tile is per workgroup.)
 #if !defined(UPKIE_OCTET_BLOCK)
 #define UPKIE_OCTET_BLOCK 64
@@ -1804,6 +1805,7 @@ next_step:
       cmd.kp_scale = clamp_ref(a[3], 0.f, max_gain_scale);
       cmd.kd_scale = clamp_ref(a[4], 0.f, max_gain_scale);
       cmd.maximum_torque = clamp_ref(a[5], 0.f, eff);
+      guard_count(C.guard, 0, guard_servo_command(cmd, eff));  // non-finite guard (step_kernels.hpp)
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -1813,6 +1815,10 @@ next_step:
     } else {
       a0 = act0;
       a1 = act1;
+    }
+    {
+      const int replaced = guard_velocity_actions(a0, a1, max_yaw_velocity);
+      if (lead) guard_count(C.guard, 0, replaced);
     }
     const float v = clamp_ref(a0, -max_ground_velocity, max_ground_velocity);
     const float yawd = clamp_ref(a1, -max_yaw_velocity, max_yaw_velocity);
@@ -1906,6 +1912,40 @@ next_step:
     contact = status == OCT_CONTACT;
   }
 
+  // ---- non-finite guard: the state behind the substeps (step_kernels.hpp) -------
+  bool unsound;
+  {
+    float mag = oct_esum(fabsf(s.q) + fabsf(s.qd));  // (the trunk lanes hold zeros)
+    mag += fabsf(s.pos.x) + fabsf(s.pos.y) + fabsf(s.pos.z) + fabsf(s.qw) + fabsf(s.qx) + fabsf(s.qy) + fabsf(s.qz);
+    mag += fabsf(s.linvel.x) + fabsf(s.linvel.y) + fabsf(s.linvel.z) + fabsf(s.angvel.x) + fabsf(s.angvel.y) + fabsf(s.angvel.z);
+    if (YAWING) mag += fabsf(yaw);
+    unsound = !(mag < 3.0e38f);
+  }
+  if (unsound) {  // the eight lanes of the env together (the sum is the same in all of them)
+    s.pos = v3(C.init_pos[0], C.init_pos[1], C.init_pos[2]);
+    s.qw = C.init_quat[0]; s.qx = C.init_quat[1]; s.qy = C.init_quat[2]; s.qz = C.init_quat[3];
+    s.linvel = v3(C.init_linvel[0], C.init_linvel[1], C.init_linvel[2]);
+    s.angvel = v3(C.init_angvel[0], C.init_angvel[1], C.init_angvel[2]);
+    float init_q[UPKIE_NJ];
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) init_q[j] = C.init_joint[j];
+    s.q = jointed ? pick6(joint, init_q) : 0.f;
+    s.qd = 0.f;
+    s.bl_applied = 0.f;
+    tau = 0.f;
+    legref = s.q;
+    yaw = 0.f;
+    a1 = 0.f;
+    contact = false;
+    if constexpr (BULLET_LIKE) {  // a contact cache of that state means nothing: the own leg's cached point is dropped
+      if (l == 1) {  // (the lane that wrote the record in the last substep)
+        manifold[(size_t)(leg * 4 * 8 + 6) * B + e] = 0.f;
+        manifold[(size_t)(leg * 4 * 8 + 7) * B + e] = 0.f;
+      }
+    }
+    if (lead) guard_count(C.guard, 1, 1);
+  }
+
   // ---- wrapper post-processing ---------------------------------------------
   bool fallen = false, timeout = false;
   float obs6[6];
@@ -1944,10 +1984,9 @@ next_step:
       }
     }
     observe6(yaw, yawvel, obs6);
-    if (MODE != MODE_SERVOS) {
-      fallen = fabsf(obs6[1]) > fall_pitch_limit;
-      if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
-    }
+    fallen = unsound;  // (every env kind: the non-finite guard ends the episode)
+    if (MODE != MODE_SERVOS) fallen = fallen || fabsf(obs6[1]) > fall_pitch_limit;
+    if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
     if (max_episode_steps > 0) {
       const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
       timeout = elapsed >= (float)max_episode_steps && !fallen;
@@ -2055,7 +2094,8 @@ next_step:
     } else if (MODE == MODE_BASE_VELOCITY) {
       float x = 0.f, y = 0.f;
       if (!do_reset) {
-        const float lin = act[2 * (size_t)e];
+        float lin = act[2 * (size_t)e];
+        if (!is_finite(lin)) lin = 0.f;  // (non-finite guard)
         float sy, cy;
         sincosf(yaw, &sy, &cy);
         x = fmaf(lin * cy, step_dt, SW(UPKIE_S_SE2_X));

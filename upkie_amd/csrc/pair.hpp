@@ -127,7 +127,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   bool own_limit = false;
   if (Lm.enforce) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) own_limit = own_limit || (PL.bounded[k] && (s.q[k] <= PL.lower[k] || s.q[k] >= PL.upper[k]));
+    for (int k = 0; k < 3; ++k) own_limit = own_limit || joint_limit_near(PL.bounded[k] != 0, s.q[k], PL.lower[k], PL.upper[k], M.max_joint_velocity * h);
   }
   const bool any_limit = Lm.enforce ? pair_any<XL>(own_limit) : false;
 
@@ -319,7 +319,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       }
     }
     float contact_lam[6];
-    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, rt, tb, tl2, tr2, contact_lam);
+    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl2, tr2, contact_lam);
 #pragma unroll
     for (int k = 0; k < 3; ++k) tl[k] = pick(leg, tl2[k], tr2[k]);
   } else if (any_contact) {
@@ -666,6 +666,7 @@ next_step:
       cmd[k].kp_scale = clamp_ref(a[6 * k + 3], 0.f, C.max_gain_scale);
       cmd[k].kd_scale = clamp_ref(a[6 * k + 4], 0.f, C.max_gain_scale);
       cmd[k].maximum_torque = clamp_ref(a[6 * k + 5], 0.f, eff);
+      guard_count(C.guard, 0, guard_servo_command(cmd[k], eff));  // non-finite guard (step_kernels.hpp)
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -675,6 +676,10 @@ next_step:
     } else {
       a0 = act0;
       a1 = act1;
+    }
+    {
+      const int replaced = guard_velocity_actions(a0, a1, C.max_yaw_velocity);
+      if (lead) guard_count(C.guard, 0, replaced);
     }
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
@@ -750,6 +755,35 @@ next_step:
     }
   }
 
+  // ---- non-finite guard: the state behind the substeps (step_kernels.hpp) -------
+  bool unsound;
+  {
+    float mag = fabsf(s.q[0]) + fabsf(s.q[1]) + fabsf(s.q[2]) + fabsf(s.qd[0]) + fabsf(s.qd[1]) + fabsf(s.qd[2]);
+    mag = pair_sum(mag);
+    mag += fabsf(s.pos.x) + fabsf(s.pos.y) + fabsf(s.pos.z) + fabsf(s.qw) + fabsf(s.qx) + fabsf(s.qy) + fabsf(s.qz);
+    mag += fabsf(s.linvel.x) + fabsf(s.linvel.y) + fabsf(s.linvel.z) + fabsf(s.angvel.x) + fabsf(s.angvel.y) + fabsf(s.angvel.z);
+    if (YAWING) mag += fabsf(yaw);
+    unsound = !(mag < 3.0e38f);
+  }
+  if (unsound) {  // both lanes of the pair agree (the sum is the same in both)
+    s.pos = v3(C.init_pos[0], C.init_pos[1], C.init_pos[2]);
+    s.qw = C.init_quat[0]; s.qx = C.init_quat[1]; s.qy = C.init_quat[2]; s.qz = C.init_quat[3];
+    s.linvel = v3(C.init_linvel[0], C.init_linvel[1], C.init_linvel[2]);
+    s.angvel = v3(C.init_angvel[0], C.init_angvel[1], C.init_angvel[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s.q[k] = pick(leg, C.init_joint[k], C.init_joint[3 + k]);
+      s.qd[k] = 0.f;
+      tau[k] = 0.f;
+    }
+    legref[0] = s.q[0];
+    legref[1] = s.q[1];
+    yaw = 0.f;
+    a1 = 0.f;
+    contact = false;
+    if (lead) guard_count(C.guard, 1, 1);
+  }
+
   // ---- wrapper post-processing ---------------------------------------------
   bool fallen = false, timeout = false;
   float obs6[6];
@@ -790,10 +824,9 @@ next_step:
       }
     }
     observe6(yaw, yawvel, obs6);
-    if (MODE != MODE_SERVOS) {
-      fallen = fabsf(obs6[1]) > C.fall_pitch;
-      if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
-    }
+    fallen = unsound;  // (every env kind: the non-finite guard ends the episode)
+    if (MODE != MODE_SERVOS) fallen = fallen || fabsf(obs6[1]) > C.fall_pitch;
+    if (fallen && lead && !ROLLOUT) SW(UPKIE_S_DONE) = 1.f;
     if (C.max_episode_steps > 0) {  // time limit, see step_kernel
       const float elapsed = (ROLLOUT ? elapsed_word : SW(UPKIE_S_ELAPSED)) + 1.f;
       timeout = elapsed >= (float)C.max_episode_steps && !fallen;
@@ -899,7 +932,8 @@ next_step:
   } else if (MODE == MODE_BASE_VELOCITY) {
     float x = 0.f, y = 0.f;
     if (!do_reset) {
-      const float lin = act[2 * (size_t)e];
+      float lin = act[2 * (size_t)e];
+      if (!is_finite(lin)) lin = 0.f;  // (non-finite guard)
       float sy, cy;
       sincosf(yaw, &sy, &cy);
       x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));

@@ -37,6 +37,7 @@ struct DevConfig {
   float agent_clip;
   ExtSlots ext;
   ObserverDev spine;  // in-step spine observers (one cycle per physics substep), used when attached
+  unsigned* guard;    // non-finite guard counters of the handle (device, [2]: command words replaced, env states replaced) or null
 };
 
 // What the eight-lane step kernels read of a handle's settings, in DEVICE memory (round 3): by value the two structures
@@ -160,6 +161,48 @@ __device__ __forceinline__ float joint_torque(float q, float qd, const Servo& c,
   torque = torque < -c.maximum_torque ? -c.maximum_torque : torque;
   torque = torque > c.maximum_torque ? c.maximum_torque : torque;
   return torque;
+}
+
+// ------------------------------------------------------------------ non-finite guard
+// (include/upkie_hip.h, "Non-finite commands and states". The reference asserts on a NaN velocity target,
+// pybullet_backend.py:519, and has one robot; a batch of thousands cannot stop for one diverged policy output -- and
+// without this a NaN velocity or feedforward torque passed both clips of joint_torque, the state went NaN, and
+// `fabsf(pitch) > fall_pitch` is false for NaN: never terminated, never reset, NaN observations from then on.)
+//  1. Commands: what is still not finite BEHIND the reference's clamp (only NaN is, and an infinite position target of a
+//     joint without position limits) becomes the neutral action's value (upkie_servos.py:255-262: velocity 0, feedforward
+//     torque 0, gain scales 1, maximum torque = the effort limit, position NaN = no position term).
+//  2. State: an env whose state is not finite behind its substeps is put into the configuration's initial state at rest,
+//     reports `terminated` and is flagged done: the autoreset treats it like a fall.
+// Both are counted (upkie_sim_guard_counts), both cost the sound envs a handful of compares.
+__device__ __forceinline__ bool is_finite(float x) { return fabsf(x) < 3.0e38f; }  // (false for NaN)
+
+__device__ __forceinline__ int guard_servo_command(Servo& c, float effort) {
+  int replaced = 0;
+  if (fabsf(c.position) > 3.0e38f) { c.position = NAN; ++replaced; }  // +-Inf (NaN compares false: it is the neutral value)
+  if (!is_finite(c.velocity)) { c.velocity = 0.f; ++replaced; }
+  if (!is_finite(c.feedforward_torque)) { c.feedforward_torque = 0.f; ++replaced; }
+  if (!is_finite(c.kp_scale)) { c.kp_scale = 1.f; ++replaced; }
+  if (!is_finite(c.kd_scale)) { c.kd_scale = 1.f; ++replaced; }
+  if (!is_finite(c.maximum_torque)) { c.maximum_torque = effort; ++replaced; }
+  return replaced;
+}
+
+// ground / yaw velocity actions of the Gyropod family: NaN is the neutral action (0); an infinite yaw velocity would
+// integrate into the yaw word unclamped (upkie_gyropod.py:383-385)
+__device__ __forceinline__ int guard_velocity_actions(float& a0, float& a1, float max_yaw_velocity) {
+  int replaced = 0;
+  if (a0 != a0) { a0 = 0.f; ++replaced; }
+  if (a1 != a1) { a1 = 0.f; ++replaced; }
+  if (fabsf(a1) > 3.0e38f) { a1 = a1 > 0.f ? max_yaw_velocity : -max_yaw_velocity; ++replaced; }
+  return replaced;
+}
+
+__device__ __forceinline__ void guard_count(unsigned* guard, int which, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (guard && n > 0) atomicAdd(&guard[which], (unsigned)n);
+#else
+  (void)guard; (void)which; (void)n;
+#endif
 }
 
 __device__ __forceinline__ void quat_mul(const float (&a)[4], const float (&b)[4], float (&c)[4]) {
@@ -358,6 +401,7 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
       cmd[j].kp_scale = clamp_ref(a[6 * j + 3], 0.f, C.max_gain_scale);
       cmd[j].kd_scale = clamp_ref(a[6 * j + 4], 0.f, C.max_gain_scale);
       cmd[j].maximum_torque = clamp_ref(a[6 * j + 5], 0.f, eff);
+      guard_count(C.guard, 0, guard_servo_command(cmd[j], eff));
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -369,6 +413,7 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
       a0 = act0;  // Pendulum: [action[0], 0.0], upkie_pendulum.py:139
       a1 = act1;
     }
+    guard_count(C.guard, 0, guard_velocity_actions(a0, a1, C.max_yaw_velocity));
     // UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
@@ -482,6 +527,37 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
     }
   }
 
+  // ---- non-finite guard: the state behind the substeps ---------------------
+  bool unsound;
+  {
+    float mag = fabsf(s.pos.x) + fabsf(s.pos.y) + fabsf(s.pos.z) + fabsf(s.qw) + fabsf(s.qx) + fabsf(s.qy) + fabsf(s.qz);
+    mag += fabsf(s.linvel.x) + fabsf(s.linvel.y) + fabsf(s.linvel.z) + fabsf(s.angvel.x) + fabsf(s.angvel.y) + fabsf(s.angvel.z);
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) mag += fabsf(s.q[j]) + fabsf(s.qd[j]);
+    if (YAWING) mag += fabsf(yaw);
+    unsound = !(mag < 3.0e38f);
+  }
+  if (unsound) {
+    s.pos = v3(C.init_pos[0], C.init_pos[1], C.init_pos[2]);
+    s.qw = C.init_quat[0]; s.qx = C.init_quat[1]; s.qy = C.init_quat[2]; s.qz = C.init_quat[3];
+    s.linvel = v3(C.init_linvel[0], C.init_linvel[1], C.init_linvel[2]);
+    s.angvel = v3(C.init_angvel[0], C.init_angvel[1], C.init_angvel[2]);
+#pragma unroll
+    for (int j = 0; j < UPKIE_NJ; ++j) {
+      s.q[j] = C.init_joint[j];
+      s.qd[j] = 0.f;
+      tau[j] = 0.f;
+    }
+    legref[0] = s.q[0]; legref[1] = s.q[1]; legref[2] = s.q[3]; legref[3] = s.q[4];
+    yaw = 0.f;
+    a1 = 0.f;
+    contact = false;
+    if constexpr (BULLET_LIKE) {
+      for (int w = 0; w < BL_MANIFOLD_WORDS; ++w) contact_manifold[w] = 0.f;
+    }
+    guard_count(C.guard, 1, 1);
+  }
+
   // ---- wrapper post-processing -----------------------------------------
   bool fallen = false, timeout = false;
   float obs6[6];
@@ -507,10 +583,9 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
       SW(UPKIE_S_YAWVEL) = yawvel;
     }
     gyropod_observation(M, s, yaw, yawvel, obs6);
-    if (MODE != MODE_SERVOS) {
-      fallen = fabsf(obs6[1]) > C.fall_pitch;  // upkie_gyropod.py:344-345
-      if (fallen) SW(UPKIE_S_DONE) = 1.f;
-    }
+    fallen = unsound;  // (every env kind: the non-finite guard ends the episode)
+    if (MODE != MODE_SERVOS) fallen = fallen || fabsf(obs6[1]) > C.fall_pitch;  // upkie_gyropod.py:344-345
+    if (fallen) SW(UPKIE_S_DONE) = 1.f;
     if (C.max_episode_steps > 0) {
       // gymnasium's TimeLimit: the step that brings the episode to the limit is truncated unless it fell
       const float elapsed = SW(UPKIE_S_ELAPSED) + 1.f;
@@ -568,7 +643,8 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
     // dead reckoning with the TARGET linear velocity and the new yaw, :197-199
     float x = 0.f, y = 0.f;
     if (!do_reset) {
-      const float lin = act[2 * (size_t)e];
+      float lin = act[2 * (size_t)e];
+      if (!is_finite(lin)) lin = 0.f;  // (non-finite guard: the target velocity the pose integrates)
       float sy, cy;
       sincosf(yaw, &sy, &cy);
       x = fmaf(lin * cy, C.dt, SW(UPKIE_S_SE2_X));

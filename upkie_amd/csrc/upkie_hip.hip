@@ -291,6 +291,7 @@ struct UpkieSim {
   unsigned* census = nullptr;    // rare-path census of the eight-lane kernel (caller's device buffer) or null
   float* final_obs = nullptr;    // upkie_sim_set_final_observation: SAME_STEP autoreset completed by the step calls themselves
   float* manifold = nullptr;     // upkie_sim_set_contact_manifold: Bullet-like contact model on this persistent manifold (one-lane kernels)
+  unsigned* d_guard = nullptr;   // non-finite guard counters [2] (command words replaced, env states replaced): the handle's, DevConfig::guard points here
   // Device copies of {limits, config} for the eight-lane kernels: two blocks, written by a store kernel on the launching
   // stream when a setting changed or the stream did (a launch still running on the other stream keeps its block:
   // up to two streams may step one handle at a time)
@@ -371,9 +372,13 @@ extern "C" int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* 
   hipError_t err = hipMalloc(&sim->d_model, sizeof(DevModel));
   if (err == hipSuccess) err = hipMemcpy(sim->d_model, &sim->model, sizeof(DevModel), hipMemcpyHostToDevice);
   for (int i = 0; i < 2 + UPKIE_MAX_GRAPH_CAPTURES && err == hipSuccess; ++i) err = hipMalloc(&sim->d_params[i], sizeof(DevParams));
+  if (err == hipSuccess) err = hipMalloc(&sim->d_guard, 2 * sizeof(unsigned));
+  if (err == hipSuccess) err = hipMemset(sim->d_guard, 0, 2 * sizeof(unsigned));
+  sim->config.guard = sim->d_guard;
   if (err != hipSuccess) {
     std::string msg = std::string("hipMalloc/hipMemcpy(model): ") + hipGetErrorString(err);
     if (sim->d_model) (void)hipFree(sim->d_model);
+    if (sim->d_guard) (void)hipFree(sim->d_guard);
     for (int i = 0; i < 2 + UPKIE_MAX_GRAPH_CAPTURES; ++i)
       if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
     delete sim;
@@ -391,6 +396,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
   if (!convert_config(config, &next, &why)) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, why);
   next.ext = sim->config.ext;
   next.spine = sim->config.spine;
+  next.guard = sim->config.guard;
   sim->config = next;
   sim->params_version += 1;
   return UPKIE_OK;
@@ -398,6 +404,7 @@ extern "C" int upkie_sim_set_config(UpkieSim* sim, const UpkieSimConfig* config)
 
 extern "C" int upkie_sim_destroy(UpkieSim* sim) {
   if (sim && sim->d_model) (void)hipFree(sim->d_model);
+  if (sim && sim->d_guard) (void)hipFree(sim->d_guard);
   for (int i = 0; sim && i < 2 + UPKIE_MAX_GRAPH_CAPTURES; ++i)
     if (sim->d_params[i]) (void)hipFree(sim->d_params[i]);
   delete sim;
@@ -525,6 +532,13 @@ static int mapped_lanes_of_mode(const UpkieSim* sim, int mode) {
   // the default model's joint-stop path for that substep there -- counted by the census, word [0] -- where the one-lane
   // kernels put the limit row into the same 50 sweeps: UPKIE_LANES_PER_ENV=1 selects those)
   if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = sim->manifold ? 1 : 2;
+  // (round 6, ADVICE r5: under the Bullet-like model a UpkieServos step runs one env per lane BY DEFAULT -- a Servos agent may
+  // rest on a joint stop for most of an episode, and only the one-lane kernel keeps the limit rows inside the 50 sweeps and
+  // several cached points per tire, i.e. is the fp64 checker's twin in every case. The eight-lane kernel, which answers a
+  // joint at its stop with the DEFAULT model's joint-stop solve for that substep, is an opt-in: UPKIE_LANES_PER_ENV=8 /
+  // upkie_sim_set_lanes_per_env. The one-step parity test measures what that costs in fidelity:
+  // tests/test_one_step_parity_gpu.py::test_joints_held_at_their_stops...)
+  if (mode == MODE_SERVOS && lanes == 8 && sim->manifold && sim->lanes_per_env != 8) lanes = 1;
   return lanes;
 }
 extern "C" int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout) {
@@ -532,10 +546,26 @@ extern "C" int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_l
   return mapped_lanes_of_mode(sim, observation_layout == UPKIE_OBSERVATION_SERVOS ? MODE_SERVOS : MODE_PENDULUM);
 }
 
+extern "C" int upkie_sim_set_lanes_per_env(UpkieSim* sim, int lanes) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 8) return fail(sim, UPKIE_ERR_INVALID_ARGUMENT, "lanes per env: 0 (automatic), 1, 2 or 8");
+  sim->lanes_per_env = lanes;
+  return UPKIE_OK;
+}
+
 extern "C" int upkie_sim_set_census(UpkieSim* sim, uint32_t* counters) {
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   sim->census = counters;
   return UPKIE_OK;
+}
+
+// Non-finite guard (include/upkie_hip.h): what the step kernels counted so far on this handle; waits for `stream`.
+extern "C" int upkie_sim_guard_counts(UpkieSim* sim, uint32_t counts[2], int reset, void* stream) {
+  if (!sim || !counts) return UPKIE_ERR_INVALID_ARGUMENT;
+  hipError_t err = hipMemcpyAsync(counts, sim->d_guard, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (err == hipSuccess && reset) err = hipMemsetAsync(sim->d_guard, 0, 2 * sizeof(unsigned), (hipStream_t)stream);
+  if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+  return check_hip(sim, err, "upkie_sim_guard_counts");
 }
 
 extern "C" int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold) {

@@ -315,10 +315,11 @@ class ShardedPendulum:
             dist.all_reduce(n, op=dist.ReduceOp.SUM)
         return int(n.item())
 
-    def shutdown(self) -> None:
+    def shutdown(self, destroy_group: bool = True) -> None:
+        """Close the handle; leave the process group (`destroy_group=False`: another sharded env of this process follows)."""
         self.gather.flush()
         self.sim.close()
-        if self._collectives and dist.is_initialized():
+        if destroy_group and self._collectives and dist.is_initialized():
             dist.destroy_process_group()
 
 
@@ -644,11 +645,11 @@ class ShardedVecEnv:
     def lanes_per_env(self) -> int:
         return int(getattr(self.sim, "lanes_per_env", 1))
 
-    def shutdown(self) -> None:
+    def shutdown(self, destroy_group: bool = True) -> None:
         self.gather.flush()
         if self.mpc is not None:
             self.mpc.close()
         if self._owns_sim:
             self.sim.close()
-        if self._collectives and dist.is_initialized():
+        if destroy_group and self._collectives and dist.is_initialized():
             dist.destroy_process_group()

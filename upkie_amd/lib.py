@@ -48,6 +48,8 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_lanes_per_env",
     "upkie_sim_lanes_per_env_of",
     "upkie_sim_set_census",
+    "upkie_sim_set_lanes_per_env",
+    "upkie_sim_guard_counts",
     "upkie_sim_set_final_observation",
     "upkie_sim_set_contact_manifold",
     "upkie_sim_set_randomization",
@@ -240,6 +242,10 @@ def load() -> C.CDLL:
     lib.upkie_sim_lanes_per_env.argtypes = [vp]
     lib.upkie_sim_set_census.restype = C.c_int
     lib.upkie_sim_set_census.argtypes = [vp, vp]
+    lib.upkie_sim_set_lanes_per_env.restype = C.c_int
+    lib.upkie_sim_set_lanes_per_env.argtypes = [vp, C.c_int]
+    lib.upkie_sim_guard_counts.restype = C.c_int
+    lib.upkie_sim_guard_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
     lib.upkie_sim_set_final_observation.restype = C.c_int
     lib.upkie_sim_set_final_observation.argtypes = [vp, vp]
     # (round-4 entry points: bound when present, so that tools/ab_step.py can still load an OLDER build of the library

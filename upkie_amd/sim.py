@@ -586,6 +586,22 @@ class BatchedSim:
         mapping at 8192 envs, the others at 16384."""
         return int(self._lib.upkie_sim_lanes_per_env_of(self._handle, int(observation_layout)))
 
+    def set_lanes_per_env(self, lanes: int) -> None:
+        """Force the lane mapping of this handle's later launches
+        (`upkie_sim_set_lanes_per_env`): 1, 2 or 8 lanes per env, 0 = by batch
+        size again."""
+        self._check(self._lib.upkie_sim_set_lanes_per_env(self._handle, int(lanes)))
+
+    def guard_counts(self, reset: bool = False) -> dict:
+        """Non-finite guard of the step kernels (`upkie_sim_guard_counts`):
+        command words replaced by the neutral action's value and env states
+        replaced by the initial state (those envs reported `terminated`), since
+        creation or the last ``reset=True``. Waits for the current stream."""
+        counts = (C.c_uint32 * 2)()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.upkie_sim_guard_counts(self._handle, counts, 1 if reset else 0, self._stream()))
+        return {"commands_replaced": int(counts[0]), "states_replaced": int(counts[1])}
+
     CENSUS_FIELDS = ("joint_limit", "sweep_cap_hits", "friction_cone", "active_set_solves", "wavefront_substeps_limit", "wavefront_substeps_sweeps", "sweeps_total", "sweeps_max")
 
     def enable_census(self, on: bool = True) -> Optional[torch.Tensor]:
