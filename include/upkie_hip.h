@@ -226,9 +226,11 @@ int64_t upkie_hip_struct_bytes(int which);
  *     settings they were recorded with. The blocks are allocated with the
  *     handle (a capture cannot allocate): at most UPKIE_MAX_GRAPH_CAPTURES
  *     captures per handle, the next one is refused with UPKIE_ERR_HIP and a
- *     message; blocks are not recycled when a graph is destroyed (the library
- *     cannot see that). A setting changed AFTER a capture does not reach that
- *     graph's replays: re-capture.
+ *     message. The library cannot see a graph being destroyed: a long-lived
+ *     env that re-captures (after a setting change, after an aborted capture)
+ *     hands the blocks back with upkie_sim_release_graph_captures() once none
+ *     of the graphs recorded so far will be replayed again. A setting changed
+ *     AFTER a capture does not reach that graph's replays: re-capture.
  * The one- and two-lane kernels take their settings by value: no limit. */
 #define UPKIE_MAX_GRAPH_CAPTURES 8
 
@@ -240,6 +242,9 @@ int upkie_sim_create(const UpkieSimConfig* config, const UpkieModel* model,
                      UpkieSim** out);
 int upkie_sim_destroy(UpkieSim* sim);
 const char* upkie_sim_last_error(const UpkieSim* sim);
+/* "Streams and hipGraphs" above: every hipGraph recorded from this handle so
+ * far is dead to the caller; its settings blocks may be handed out again. */
+int upkie_sim_release_graph_captures(UpkieSim* sim);
 
 /* Replace the configuration of an existing handle (same num_envs): lets a
  * caller change init state, randomisation magnitudes, seed, gains, fall pitch

@@ -116,7 +116,10 @@ def use_native_build() -> bool:
     stamp = _NATIVE_PATH + ".host"
     built_for = open(stamp).read() if os.path.exists(stamp) else None
     try:
-        if built_for != cpu or not os.path.exists(_NATIVE_PATH):
+        sources = [os.path.join(_HERE, n) for n in ("upkie_oracle.c", "upkie_oracle_mpc.c", "upkie_oracle_observers.c", "upkie_oracle.h")] + [
+            os.path.join(_HERE, "..", "include", "upkie_hip.h")]
+        stale = not os.path.exists(_NATIVE_PATH) or any(os.path.getmtime(src) > os.path.getmtime(_NATIVE_PATH) for src in sources if os.path.exists(src))
+        if built_for != cpu or stale:
             subprocess.run(["make", "-C", _HERE, "native", "-B"], check=True, capture_output=True)
             with open(stamp, "w") as f:
                 f.write(cpu)

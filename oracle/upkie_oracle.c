@@ -927,7 +927,10 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   double lam[MAXROWS];
   memset(lam, 0, sizeof(lam));
   if (nrows > 0) {
-    double W[MAXROWS][MAXROWS];
+    /* (aligned explicitly: with rows of 12 doubles gcc 11 -O3 -march=native reads W with ALIGNED 32-byte loads -- the row stride
+     * is a multiple of 32 bytes -- from a frame slot that is only 16-byte aligned: a general-protection fault in the sweeps of
+     * bench.py's cpu_baseline build, round 6; neither sanitizer sees it. tests/test_oracle_native_build.py runs that build.) */
+    double W[MAXROWS][MAXROWS] __attribute__((aligned(64)));
     for (int r_ = 0; r_ < nrows; ++r_) cholesky_solve(NV, L, J[r_], MinvJt[r_]);
     for (int a = 0; a < nrows; ++a)
       for (int b = 0; b < nrows; ++b) {

@@ -287,6 +287,18 @@ def test_two_graphs_of_one_handle_replay_each_with_its_own_settings():
     assert len(loops) == abi.MAX_GRAPH_CAPTURES  # two + six more were recorded, the ninth was not
     graphed.step_pendulum_agent()
     torch.cuda.synchronize()
+    # round 6: a long-lived env that re-captures hands the blocks back once its old graphs are dead
+    del loops, loop_a, loop_b
+    graphed.release_graph_captures()
+    again = [GraphedLoop(lambda: graphed.step_pendulum_agent(), unroll=1, warmup=1) for _ in range(abi.MAX_GRAPH_CAPTURES)]
+    eager.state.copy_(graphed.state)
+    eager.obs4.copy_(graphed.obs4)
+    set_clip(eager, 0.5)
+    for loop in again[:3]:
+        loop.replay()
+        eager.step_pendulum_agent()
+    torch.cuda.synchronize()
+    assert torch.equal(eager.state, graphed.state)
 
 
 @pytest.mark.parametrize("lanes", ["1", "2", "8"])

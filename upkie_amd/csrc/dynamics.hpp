@@ -914,7 +914,12 @@ UPKIE_HD int contact_active_set6(const ModelT& M, const float (&A)[21], const fl
         side_next[r] = flips ? 0.f : (leaves > 0.f ? out : (returns > 0.f ? 0.f : side[r]));
       }
     }
-    if (worst <= 0.f && xs <= 3.0e38f) {  // (NaN fails both)
+    // (fmaxf DROPS a NaN operand: `worst` and `xs` alone let a partly NaN elimination through -- a pivot 1 -+ mu A_nt / A_nn that
+    // is exactly 0, inf - inf; the sum propagates it: ADVICE r5)
+    float every = 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) every += fabsf(x[r]) + fabsf(v[r]);
+    if (worst <= 0.f && xs <= 3.0e38f && every < 3.0e38f) {
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
         const int n = 3 * w;
@@ -1175,7 +1180,8 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
 #pragma unroll
     for (int r = 0; r < kRows; ++r) idiag[r] = fast_rcp(A[sym(r, r)]);
     float tolerance = M.pgs_tolerance;  // held in a scalar register across the sweeps (see contact_pgs6_sweeps)
-      for (int it = 0; it < M.pgs_iterations; ++it) {
+    UPKIE_KEEP_IN_SGPR(tolerance);
+    for (int it = 0; it < M.pgs_iterations; ++it) {
       float change = 0.f, scale = 0.f;
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {

@@ -894,7 +894,9 @@ UPKIE_HD int oct_active_set(const OctLane& L, const float (&Dg)[3], const float 
     const float leaves = friction && push && side == 0.f ? fabsf(x) - lim - xtol : -1.f;
     const float returns = side != 0.f ? v * side - 0.1f * vtol : -1.f;
     const float worst = fmaxf(fmaxf(fmaxf(equation, enters), fmaxf(pulls, leaves)), returns);
-    const bool bad = !(worst <= 0.f) || !(xs <= 3.0e38f);
+    // (fmaxf DROPS a NaN operand: a partly NaN elimination -- a pivot 1 -+ mu A_nt / A_nn that is exactly 0, inf - inf -- would
+    // pass every test above; the own row's impulse and velocity are looked at directly: ADVICE r5)
+    const bool bad = !(worst <= 0.f) || !(xs <= 3.0e38f) || !(fabsf(x) + fabsf(v) < 3.0e38f);
     if (!oct_env_any(bad)) {
       const float ln = push ? fmaxf(x1, 0.f) : 0.f, bound = mu * ln;
       lam = normal ? ln : (side != 0.f ? side * bound : fminf(fmaxf(x, -bound), bound));
@@ -1886,10 +1888,7 @@ next_step:
         atomicAdd(&census[0], (unsigned)__builtin_popcountll(limited));
         atomicAdd(&census[4], 1u);
       }
-      if (first && swept) {
-        atomicAdd(&census[2], (unsigned)__builtin_popcountll(swept));
-        atomicAdd(&census[5], 1u);
-      }
+      if (first && swept) atomicAdd(&census[2], (unsigned)__builtin_popcountll(swept));
       if (swept) {  // the sweeps those envs ran, summed over the wavefront first (at most eight envs: a scalar loop over their lead lanes)
         unsigned total = 0, most = 0, capped = 0, direct = 0;
         for (unsigned long long left = swept; left; left &= left - 1) {
@@ -1905,7 +1904,10 @@ next_step:
           if (direct) atomicAdd(&census[3], direct);
           atomicMax(&census[7], most);
           if (capped) atomicAdd(&census[1], capped);
-          atomicAdd(&census[8 + (most < 63u ? most : 63u)], 1u);  // what the wavefront waited for in this substep
+          if (total) {  // (a wavefront whose envs were all answered by an active set ran no sweep: not in [5], not in the histogram -- ADVICE r5)
+            atomicAdd(&census[5], 1u);
+            atomicAdd(&census[8 + (most < 63u ? most : 63u)], 1u);  // what the wavefront waited for in this substep
+          }
         }
       }
     }

@@ -304,6 +304,7 @@ struct UpkieSim {
   void* params_stream = nullptr;
   unsigned long long capture_id = ~0ull;  // the hipGraph capture being recorded
   int captures = 0;                       // blocks handed to captures so far
+  bool params_refused = false;            // the last current_params() was refused for want of a capture block (not a failed launch)
   std::string error;
 };
 
@@ -575,6 +576,16 @@ extern "C" int upkie_sim_set_contact_manifold(UpkieSim* sim, float* manifold) {
   return UPKIE_OK;
 }
 
+// The caller's word that no hipGraph recorded from this handle so far will be replayed again (they were destroyed, or are
+// about to be re-captured): their settings blocks are handed out again, the next capture takes the first one.
+extern "C" int upkie_sim_release_graph_captures(UpkieSim* sim) {
+  if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
+  sim->captures = 0;
+  sim->capture_id = ~0ull;
+  sim->capture_version = 0;
+  return UPKIE_OK;
+}
+
 extern "C" int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs) {
   if (!sim) return UPKIE_ERR_INVALID_ARGUMENT;
   sim->final_obs = final_obs;
@@ -597,7 +608,11 @@ static const DevParams* current_params(UpkieSim* sim, void* stream) {
     // for eager launches or for another graph's replay): one block and one store per capture, the store again when a
     // setting changes while capturing
     const bool new_capture = sim->capture_id != capture_id;
-    if (new_capture && sim->captures >= UPKIE_MAX_GRAPH_CAPTURES) return nullptr;  // (launch_step reports it)
+    sim->params_refused = false;
+    if (new_capture && sim->captures >= UPKIE_MAX_GRAPH_CAPTURES) {  // (launch_step reports it; upkie_sim_release_graph_captures frees the blocks)
+      sim->params_refused = true;
+      return nullptr;
+    }
     if (sim->capture_version != sim->params_version || new_capture) {
       DevParams block;
       block.limits = sim->limits;
@@ -611,6 +626,7 @@ static const DevParams* current_params(UpkieSim* sim, void* stream) {
     }
     return sim->d_params[2 + sim->captures - 1];
   }
+  sim->params_refused = false;
   if (sim->eager_version != sim->params_version || stream != sim->params_stream) {
     sim->params_slot ^= 1;
     DevParams block;
@@ -716,9 +732,10 @@ static int launch_step(UpkieSim* sim, float* state, const float* act, float* obs
   // the eight-lane kernels read limits and config from this handle's device block
   const DevParams* params = lanes == 8 ? current_params(sim, stream) : nullptr;
   if (lanes == 8 && !params)
-    return fail(sim, UPKIE_ERR_HIP, sim->captures >= UPKIE_MAX_GRAPH_CAPTURES
-                                        ? "this handle's steps have been recorded into UPKIE_MAX_GRAPH_CAPTURES hipGraph captures already (include/upkie_hip.h, Streams and hipGraphs)"
-                                        : "could not refresh the device block of the handle's settings");
+    return fail(sim, UPKIE_ERR_HIP, sim->params_refused  // (the branch that actually failed: ADVICE r5)
+                                        ? "this handle's steps have been recorded into UPKIE_MAX_GRAPH_CAPTURES hipGraph captures already: destroy graphs that are no longer "
+                                          "replayed and call upkie_sim_release_graph_captures (include/upkie_hip.h, Streams and hipGraphs)"
+                                        : "could not refresh the device block of the handle's settings (the store kernel's launch failed)");
   if (lanes == 8 && sim->manifold) {
     if (rnd) UPKIE_LAUNCH_OCTET_BULLET(true); else UPKIE_LAUNCH_OCTET_BULLET(false);
   } else if (lanes == 8) {

@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = (
     "upkie_sim_set_census",
     "upkie_sim_set_lanes_per_env",
     "upkie_sim_guard_counts",
+    "upkie_sim_release_graph_captures",
     "upkie_sim_set_final_observation",
     "upkie_sim_set_contact_manifold",
     "upkie_sim_set_randomization",
@@ -244,6 +245,8 @@ def load() -> C.CDLL:
     lib.upkie_sim_set_census.argtypes = [vp, vp]
     lib.upkie_sim_set_lanes_per_env.restype = C.c_int
     lib.upkie_sim_set_lanes_per_env.argtypes = [vp, C.c_int]
+    lib.upkie_sim_release_graph_captures.restype = C.c_int
+    lib.upkie_sim_release_graph_captures.argtypes = [vp]
     lib.upkie_sim_guard_counts.restype = C.c_int
     lib.upkie_sim_guard_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
     lib.upkie_sim_set_final_observation.restype = C.c_int

@@ -586,6 +586,12 @@ class BatchedSim:
         mapping at 8192 envs, the others at 16384."""
         return int(self._lib.upkie_sim_lanes_per_env_of(self._handle, int(observation_layout)))
 
+    def release_graph_captures(self) -> None:
+        """`upkie_sim_release_graph_captures`: the hipGraphs recorded from this
+        handle so far will not be replayed again (destroyed or about to be
+        re-captured); their settings blocks (8 per handle) are free again."""
+        self._check(self._lib.upkie_sim_release_graph_captures(self._handle))
+
     def set_lanes_per_env(self, lanes: int) -> None:
         """Force the lane mapping of this handle's later launches
         (`upkie_sim_set_lanes_per_env`): 1, 2 or 8 lanes per env, 0 = by batch
