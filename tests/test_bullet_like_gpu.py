@@ -330,7 +330,9 @@ def test_default_and_bullet_like_models_agree_on_the_headline_workload_on_the_de
         sim.obs4.copy_(o6[:, [1, 0, 4, 3]])
         sims.append(sim)
     a, b = sims
-    assert torch.equal(a.obs4, b.obs4)  # the same draws; the reset substep is torque-free and both tires just touch
+    # the same draws, then one torque-free substep under either model (a tire that starts exactly on the floor is in contact or not
+    # by the model's own rule: up to g h = 1e-2 m/s in the rates of such an env)
+    assert torch.allclose(a.obs4[:, :2], b.obs4[:, :2], rtol=0, atol=1e-6) and torch.allclose(a.obs4[:, 2:], b.obs4[:, 2:], rtol=0, atol=2e-2)
     worst = torch.zeros(4, device=a.device)
     worst_at = {}
     ends = [torch.zeros((steps, B), dtype=torch.uint8, device=a.device) for _ in sims]
@@ -405,5 +407,7 @@ def test_default_and_bullet_like_models_agree_on_c3_on_the_device():
     for env in made:
         env.close()
     assert ended == [0, 0], report
-    assert report["commanded_velocity_worst_over_window"]["q0.99"] <= 2e-3 and report["commanded_velocity_worst_over_window"]["max"] <= 1e-2, report
-    assert max(report["pose_worst_over_window"]) <= 2e-3 and report["final_pitch_difference"]["max"] <= 1e-3, report
+    # measured (round 6): commanded velocity 5.5e-5 median / 1.1e-4 at 99 % / 1.5e-4 worst over the window; the dead-reckoned pose is
+    # identical (it integrates the TARGET velocity); final pitch within 2.7e-5 rad
+    assert report["commanded_velocity_worst_over_window"]["q0.99"] <= 5e-4 and report["commanded_velocity_worst_over_window"]["max"] <= 1e-3, report
+    assert max(report["pose_worst_over_window"]) <= 1e-5 and report["final_pitch_difference"]["max"] <= 2e-4, report

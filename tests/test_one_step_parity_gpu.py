@@ -104,9 +104,9 @@ class HipStep:
 #    differs by one substep of contact impulse.
 #  - reset: the state is DRAWN (Philox: same integers on both sides), then one torque-free substep; a tire that starts exactly on
 #    the floor is in contact or not by the last bit of z: g h = 9.8e-3 m/s on 1 % of the resets.
-#  - joint_at_stop (resting on a stop) / stop_impact (arriving at one, bouncing): whether the limit row is active in a substep is
-#    `q >= upper` on fp32 numbers; a joint resting on its stop sits within rounding of it, an arriving one crosses it in one
-#    substep or the next: one substep of a joint moving at v rad/s is v x 1e-3 rad.
+#  - joint_at_stop (resting on a stop) / stop_impact (arriving at one): the limit row is listed while the joint is within reach of
+#    its stop and lets it close the gap within the substep: nothing hangs on the last bit of q any more (see the table below for
+#    what the rule of rounds 1-5 measured); what is left is the rounding of a ten-row solve.
 T = lambda pos, vel, wheel, torque: {"position": pos, "velocity": vel, "wheel_rate": wheel, "torque": torque}  # noqa: E731
 TOLERANCES = {
     # regime: {metric: (median, q0.99, worst)}
@@ -116,9 +116,13 @@ TOLERANCES = {
     "sliding": T((1e-6, 5e-5, 5e-3), (5e-5, 5e-3, 2.0), (2e-5, 5e-3, 2.0), (5e-5, 5e-3, 1.0)),  # 2.3e-7/1.3e-5/9e-4, 9.6e-6/1.5e-3/0.46, 5.9e-6/1.4e-3/0.46, 1.1e-5/1.4e-3/0.2
     "airborne": T((5e-7, 5e-6, 2e-2), (2e-5, 5e-4, 5.0), (5e-6, 5e-4, 5.0), (1e-5, 2e-4, 1.0)),  # 1.3e-7/6e-7/3.5e-3, 3.3e-6/8e-5/1.0, 5e-7/7e-5/1.0, 1.4e-6/2.6e-5/0.2
     "reset": T((1e-7, 1e-5, 3e-5), (1e-6, 1.2e-2, 2e-2), (1e-6, 1.2e-2, 2e-2), (1e-6, 1e-6, 1e-6)),  # 1.7e-8/2.9e-6/9.9e-6, 1e-8/2.8e-3/9.9e-3, torque 0
-    # (first measured round 6 with the two merged: position 1.6e-7/2.4e-3/1.8e-2, velocity 1.5e-5/4.6e-2/4.0, torque 1.1e-6/3.8e-3/0.23)
-    "joint_at_stop": T((1e-6, 1e-3, 2e-2), (1e-4, 0.1, 5.0), (2e-5, 5e-2, 2.0), (1e-5, 2e-2, 1.0)),
-    "stop_impact": T((1e-6, 2e-2, 5e-2), (1e-4, 1.0, 20.0), (2e-5, 0.2, 5.0), (1e-5, 5e-2, 1.0)),
+    # Measured with the gap-aware limit rows (joint_limit_row, dynamics.hpp; every mapping, both contact models on one lane): resting
+    # 1.4e-7/1.2e-6/4.7e-5, 2.3e-6/1.4e-4/0.14, torque 8e-8/1e-5/6e-2; arriving 1.2e-7/1.6e-6/1.1e-5, 6.4e-6/1.9e-4/5e-3, 6e-7/2e-5/8e-5.
+    # Under the rule of rounds 1-5 (a row only AT or beyond the stop, ERP bias alone) the same test measured position 1.6e-7 / 2.4e-3 /
+    # 1.8e-2 and velocity 1.5e-5 / 4.6e-2 / 4.0: the fp64 checker alternated between substeps with and without the row of a joint
+    # RESTING on its stop, the fp32 kernels kept it -- which is what made the rule change.
+    "joint_at_stop": T((1e-6, 1e-5, 5e-4), (2e-5, 1e-3, 1.0), (1e-5, 1e-3, 1.0), (5e-6, 1e-4, 0.5)),
+    "stop_impact": T((1e-6, 1e-5, 1e-4), (5e-5, 1e-3, 5e-2), (2e-5, 1e-3, 5e-2), (5e-6, 2e-4, 1e-3)),
 }
 
 

@@ -604,7 +604,9 @@ def test_joint_limit_on_one_leg_only(lanes, monkeypatch):
     assert np.all(np.abs(s[abi.S_Q + 1]) < 0.2)  # the left knee stayed where it was held
     err = state_errors(oracle.state, s)
     legs = [abi.S_Q + j for j in (0, 1, 3, 4)]  # (free wheels drift apart in fp32: 2.8e-4 kg m^2 of inertia)
-    assert np.abs(oracle.state[legs] - s[legs]).max() < 2e-3 and err["pos"] < 1e-3 and err["q"] < 2e-2, err
+    # (round 6, gap-aware limit rows: the knee arrives ON its stop in both, legs within 3e-5 rad -- 2e-3 under the old rule, which
+    # let it overshoot and pushed it back --; the free right wheel takes the arrival's kick: 3e-2 rad after 120 steps)
+    assert np.abs(oracle.state[legs] - s[legs]).max() < 2e-4 and err["pos"] < 1e-3 and err["q"] < 6e-2, err
 
 
 @pytest.mark.parametrize("lanes", ["1", "2", "8"])

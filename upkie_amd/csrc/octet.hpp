@@ -1511,6 +1511,28 @@ constexpr bool kServosLimitsInRegisters = true;
 #if !defined(UPKIE_OCTET_BLOCK)
 #define UPKIE_OCTET_BLOCK 64
 #endif
+// UPKIE_STAMPS (a probe build, never the shipped one: tools/build_variant.py ab/x.so -DUPKIE_STAMPS; tools/stamps.py): the first
+// lane of every wavefront reads the shader clock (s_memtime: 2.4 GHz on gfx950, profiles/r02_kernarg_latency.txt) at the
+// marks below, keeps the readings in scalar registers and writes them behind the census words ([UPKIE_CENSUS_WORDS ..]:
+// 16 words per wavefront) when it leaves -- where the time of a launch goes that is not substeps (profiles/r06_fixed_cost.txt).
+#if defined(UPKIE_STAMPS)
+#define UPKIE_STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#define UPKIE_STAMPS_FLUSH()                                                                                                      \
+  do {                                                                                                                            \
+    UPKIE_STAMP(5); /* stores issued */                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0);                                                                                                \
+    UPKIE_STAMP(6); /* stores acknowledged (a wave does not wait for this before it ends) */                                      \
+    if (census && (threadIdx.x & 63) == 0) {                                                                                      \
+      unsigned long long* out_ = reinterpret_cast<unsigned long long*>(census + UPKIE_CENSUS_WORDS) +                             \
+                                 (size_t)8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
+      for (int i_ = 0; i_ < 7; ++i_) out_[i_] = stamp[i_];                                                                        \
+      out_[7] = __builtin_amdgcn_s_memrealtime(); /* the 100 MHz wall clock at exit: orders the wavefronts of a launch */          \
+    }                                                                                                                             \
+  } while (0)
+#else
+#define UPKIE_STAMP(i) (void)0
+#define UPKIE_STAMPS_FLUSH() (void)0
+#endif
 template <int MODE, bool RAND, bool DEFAULT_SCALARS = false, bool IN_PLACE = false, bool BULLET_LIKE = false>
 __global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLimitsInRegisters ? 1 : UPKIE_PROBE_OCTET_WAVES) void step_kernel_octet(const DevModel* __restrict__ Mp, const DevParams* __restrict__ Pp,
                                                          int done_pass, int num_envs, float* __restrict__ state, const float* __restrict__ act,
@@ -1525,6 +1547,10 @@ __global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLi
   // state row (32 envs) sit on four different XCDs and each L2 fetches -- and writes back -- the whole line for its
   // 32 bytes. Swizzled, XCD x owns one contiguous eighth of the batch: a line lives in one L2. (A speed matter only:
   // any placement gives the same results.)
+#if defined(UPKIE_STAMPS)
+  unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  UPKIE_STAMP(0);  // kernel entry
   const int B = num_envs;  // (a kernel argument of its own: the state loads below wait for nothing but the argument segment)
   unsigned block = blockIdx.x;
   if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
@@ -1844,6 +1870,10 @@ next_step:
     }
   }
 
+#if defined(UPKIE_STAMPS)
+  __builtin_amdgcn_s_waitcnt(0);  // every load of the prologue has landed: what follows is arithmetic
+#endif
+  UPKIE_STAMP(1);  // prologue done: settings, lane constants, state, action map
   // ---- substeps ------------------------------------------------------------
   float tau = 0.f;
   bool contact = false;
@@ -1912,7 +1942,11 @@ next_step:
       }
     }
     contact = status == OCT_CONTACT;
+#if defined(UPKIE_STAMPS)
+    if (sub == 0) UPKIE_STAMP(2);  // first substep done (it carries the cold instruction cache)
+#endif
   }
+  UPKIE_STAMP(3);  // substeps done
 
   // ---- non-finite guard: the state behind the substeps (step_kernels.hpp) -------
   bool unsound;
@@ -2006,6 +2040,7 @@ next_step:
     }
   }
 
+  UPKIE_STAMP(4);  // guard, observation, flags computed
   // ---- store (last step of the launch) --------------------------------------
   if (steps_left > 1) {
     const float4 o4 = make_float4(obs6[1], obs6[0], obs6[4], obs6[3]);
@@ -2089,7 +2124,11 @@ next_step:
         float4* rec = reinterpret_cast<float4*>(records_out) + 2 * (size_t)e;
         rec[0] = o4;
         if (autoreset_mode != AUTORESET_DONE_PASS) rec[1] = make_float4(0.f, fallen ? 1.f : 0.f, timeout ? 1.f : 0.f, 0.f);
+#if defined(UPKIE_STAMPS)
+        goto stamps_flush;
+#else
         return;
+#endif
       }
       reinterpret_cast<float4*>(obs)[e] = o4;
       if (keep_last) reinterpret_cast<float4*>(final_obs)[e] = o4;
@@ -2132,6 +2171,10 @@ next_step:
     second_pass = true;
     goto next_step;
   }
+#if defined(UPKIE_STAMPS)
+stamps_flush:
+#endif
+  UPKIE_STAMPS_FLUSH();
 #undef SW
 #undef SWI
 }
