@@ -371,6 +371,17 @@ def secondary_bullet_like(envs: int = ENVS_PER_GPU, steps: int = 400, warmup: in
         wall, device_ms = _timed_loop(lambda k: sim.step_pendulum_agent(), steps, warmup)
         out[name] = {"us_per_step": wall / steps * 1e6, "device_us_per_step": device_ms * 1e3 / steps, "env_steps_per_s": envs * steps / wall,
                      "lanes_per_env": sim.lanes_per_env, "episodes": int(sim.state[40].sum().item())}
+        if name == "bullet_like":
+            # the mode closest to pybullet_backend.py:306, reported like the headline: algorithmic bytes over the
+            # launch time against HBM, and the roofline that binds it -- VALU issue -- from the committed counters of THIS kernel
+            # (tools/pmc_bullet_like.sh; refused when they belong to another version of the sources: kernel_fingerprint)
+            launch_us = device_ms * 1e3 / steps
+            bytes_per_env_step = ALGORITHMIC_BYTES_PER_ENV_STEP + 2 * (16 + 11) * 4  # + the manifold: 16 words read, 11 written per tire
+            pmc = pmc_of_launch_shape(envs, 1, PMC_BULLET_LIKE_FILE)
+            out[name]["roofline"] = {"bound": "hbm", "achieved": bytes_per_env_step * envs / (launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": bytes_per_env_step * envs / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                                     "traffic": None if pmc is None else pmc.get("hbm_bytes_per_launch"), "kernel": "step_kernel_octet<MODE_PENDULUM_AGENT, false, false, false, BULLET_LIKE = true>",
+                                     "avg_launch_us": launch_us, "valu": valu_roofline(pmc, launch_us, "profiles/pmc_bullet_like_b4096.json")}
         sim.close()
     return out
 
@@ -392,7 +403,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_step_b4096.json")  # written by t
 
 
 # what the headline kernel (step_kernel_octet<MODE_PENDULUM_AGENT>) is compiled from, and with which flags
-KERNEL_SOURCES = ("octet.hpp", "dynamics.hpp", "step_kernels.hpp", "state_words.hpp")
+KERNEL_SOURCES = ("octet.hpp", "dynamics.hpp", "step_kernels.hpp", "state_words.hpp", "bullet_like.hpp")
 
 
 def kernel_fingerprint() -> str:
@@ -413,14 +424,18 @@ def kernel_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_of_launch_shape(launch_envs: int, steps_per_launch: int):
+PMC_BULLET_LIKE_FILE = os.path.join(ROOT, "profiles", "pmc_bullet_like_b4096.json")  # tools/pmc_bullet_like.sh
+
+
+def pmc_of_launch_shape(launch_envs: int, steps_per_launch: int, path: str = None):
     """Committed PMC counters (mean per launch) of the step kernel, or None when
     they were collected on another launch shape than the one just timed -- or on
     another version of the kernel (`kernel_fingerprint`, round 5: a stale file
     yields `traffic: null`, not a number that belongs to other code)."""
-    if not os.path.exists(PMC_FILE):
+    path = path or PMC_FILE
+    if not os.path.exists(path):
         return None
-    with open(PMC_FILE) as f:
+    with open(path) as f:
         pmc = json.load(f)
     if pmc.get("launch_envs") != launch_envs or pmc.get("steps_per_launch") != steps_per_launch:
         return None
@@ -432,7 +447,7 @@ def pmc_of_launch_shape(launch_envs: int, steps_per_launch: int):
 SIMDS, CLOCK_GHZ = 1024, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max
 
 
-def valu_roofline(pmc, launch_us: float):
+def valu_roofline(pmc, launch_us: float, source: str = "profiles/pmc_step_b4096.json"):
     """The roofline that binds this kernel (~480 flop/B, fp32 VALU):
     VALU issue utilisation = wave-level VALU instructions per launch / what the
     chip's 1024 SIMD-32s can issue in the measured launch time (a wave64 VALU
@@ -450,7 +465,7 @@ def valu_roofline(pmc, launch_us: float):
         "tflops_upper_bound": insts * 64 * 2 / (launch_us * 1e-6) / 1e12,
         "peak_tflops": FP32_VALU_PEAK_TFLOPS,
         "waves_per_launch": c.get("SQ_WAVES"),
-        "source": "profiles/pmc_step_b4096.json (rocprofv3 --pmc passes of this launch shape) and the live launch duration",
+        "source": source + " (rocprofv3 --pmc passes of this launch shape) and the live launch duration",
     }
     if c.get("SQ_WAVES"):
         per_wave = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS")) / c["SQ_WAVES"]

@@ -532,14 +532,15 @@ static void lateral_pair_sweep(int nrows, const int* kind, const int* normal_row
  * restated]): one unilateral row per bound on the joint's velocity towards the free side. A joint still `gap` short of
  * its stop may close that gap within the substep (sign v >= -gap / h), a joint `pen` beyond it is pushed back with
  * Bullet's default ERP (sign v >= 0.2 pen / h); the row is listed while the joint could reach the stop within the
- * substep (gap <= max_joint_velocity h). Until round 6 the row existed only at or beyond the stop, with the ERP bias
+ * substep (gap <= (|qd| + 0.2 max_joint_velocity) h). Until round 6 the row existed only at or beyond the stop, with the ERP bias
  * alone: for a joint RESTING on its stop -- within rounding of gap = 0 -- its existence in a substep hung on the last
  * bit of q (in fp64: alternately a substep with the row and one of free acceleration into the stop; the fp32 kernels,
  * whose rounding put the joint back ON the stop, kept the row: the one-step parity test of round 6 found the two 1e-3
  * rad apart on 1 % of such steps). Twin: joint_limit_row, upkie_amd/csrc/dynamics.hpp. */
-static int joint_limit_row(const UpkieModel* model, int j, double qj, double h, double* sign, double* bias) {
+static int joint_limit_row(const UpkieModel* model, int j, double qj, double qdj, double h, double* sign, double* bias) {
   if (!(model->joint_lower[j] > -1e30 && model->joint_upper[j] < 1e30)) return 0;
-  const double zone = model->max_joint_velocity * h;
+  /* within reach of the stop in this substep: the joint's own speed plus what a substep can add to it (dynamics.hpp) */
+  const double zone = (fabs(qdj) + 0.2 * model->max_joint_velocity) * h;
   double pen;
   if (qj - model->joint_lower[j] <= zone) {
     *sign = 1.0;
@@ -561,7 +562,7 @@ static _Thread_local double* g_contact_sink; /* (defined below: where a contact-
 static _Thread_local double g_bullet_manifold[2 * BL_POINTS * BL_POINT_WORDS];
 static _Thread_local int g_bullet_active = 0;
 
-static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const double* L, const double* q, double h, double* nu) {
+static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const double* L, const double* q, const double* qd, double h, double* nu) {
   const double breaking = model->contact_breaking_threshold;
   const double n[3] = {0, 0, 1};
   double J[BL_ROWS][NV], MinvJt[BL_ROWS][NV], rhs[BL_ROWS], cfm[BL_ROWS], lam[BL_ROWS];
@@ -575,7 +576,7 @@ static int bullet_like_contacts(const UpkieModel* model, const Kin* k, const dou
   if (model->enforce_joint_limits) {
     for (int j = 0; j < NJ; ++j) {
       double sign, bias;
-      if (!joint_limit_row(model, j, q[j], h, &sign, &bias)) continue;
+      if (!joint_limit_row(model, j, q[j], qd[j], h, &sign, &bias)) continue;
       memset(J[nrows], 0, sizeof(double) * NV);
       J[nrows][6 + j] = sign;
       kind[nrows] = 2; normal_row[nrows] = nrows; cfm[nrows] = 0.0; lam[nrows] = 0.0; applied_slot[nrows] = NULL;
@@ -842,7 +843,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
 
   int bullet_contact = -1;
   if (g_contact_sink) memset(g_contact_sink, 0, sizeof(double) * 16);
-  if (g_bullet_active) bullet_contact = bullet_like_contacts(model, &k, L, q, h, nu);
+  if (g_bullet_active) bullet_contact = bullet_like_contacts(model, &k, L, q, qd, h, nu);
 
   /* constraint rows: per wheel (normal, t1, t2), then joint limits */
   double J[MAXROWS][NV], MinvJt[MAXROWS][NV];
@@ -913,7 +914,7 @@ int oracle_substep_ext(const UpkieModel* model, double* s, const double tau[6],
   if (model->enforce_joint_limits && bullet_contact < 0) {
     for (int j = 0; j < NJ; ++j) {
       double sign, bias;
-      if (!joint_limit_row(model, j, q[j], h, &sign, &bias)) continue;
+      if (!joint_limit_row(model, j, q[j], qd[j], h, &sign, &bias)) continue;
       memset(J[nrows], 0, sizeof(double) * NV);
       J[nrows][6 + j] = sign;
       kind[nrows] = 2;

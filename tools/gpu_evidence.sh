@@ -19,3 +19,6 @@ timeout 600 bash tools/pmc_pass.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1; echo "
 find gpurun_out/pmc_$TAG -name "*kernel_trace.csv" -size +8M -delete
 f=$(find gpurun_out/${TAG}_kernel_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -4 "$f" | cut -c1-160
 du -sh gpurun_out | tail -1
+# the Bullet-like kernel's counters (bench's c2_bullet_like_contact_model.bullet_like.roofline reads profiles/pmc_bullet_like_b4096.json)
+timeout 900 bash tools/pmc_bullet_like.sh $TAG > gpurun_out/pmc_bullet_like_${TAG}.log 2>&1; echo "pmc bullet-like rc $?"
+

@@ -56,7 +56,7 @@ out = {
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     out["hbm_bytes_per_launch"] = round((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
     out["hbm_bytes_per_launch_fetch_doubled"] = round((2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
-if args.envs == 4096 and args.steps_per_launch == 1 and "octet" in kernel:
+if args.envs == 4096 and args.steps_per_launch == 1 and "octet" in kernel:  # (the Bullet-like kernel is built from the same sources)
     # the version of the kernel these counters belong to (bench.py refuses them for any other: tests/test_profiles_consistency.py)
     import sys
 

@@ -218,7 +218,7 @@ UPKIE_HD bool bullet_like_contacts(const ModelT& M, const DevLimits& Lm, const S
   if (Lm.enforce) {
     for (int j = 0; j < UPKIE_NJ; ++j) {
       float bias;  // (the gap-aware row of joint_limit_row, dynamics.hpp: the same rule under both contact models)
-      const float sign = joint_limit_row(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], M.max_joint_velocity * h, ih, bias);
+      const float sign = joint_limit_row(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], joint_limit_reach(s.qd[j], M.max_joint_velocity, h), ih, bias);
       if (sign == 0.f) continue;
       BlRow& R = rows[nrows];
 #pragma unroll

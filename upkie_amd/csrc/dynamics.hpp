@@ -1022,7 +1022,12 @@ constexpr int kRows = 10;
 // one unilateral row per bound, on the joint's velocity towards the free side. A joint still `gap` short of its stop may
 // close that gap within the substep (sign v >= -gap / h, what Bullet's row allows a separated pair), a joint `pen` beyond it
 // is pushed back with ERP 0.2 (sign v >= 0.2 pen / h); the two meet continuously at the stop. The row is LISTED while the
-// joint could reach the stop within the substep: gap <= zone = max_joint_velocity h (rows that cannot bind are left out).
+// joint could reach the stop within the substep: gap <= (|qd| + 0.2 max_joint_velocity) h -- its own speed plus what a substep can
+// add to it (20 rad/s with Bullet's default clamp of 100: the servos' full torque adds 0.3-1.6 rad/s per substep, a landing a
+// few); rows that cannot bind are left out, and a joint that would need more than that to cross its stop overshoots by the
+// difference and is pushed back, as every joint was until round 6. (First stated with the clamp itself, 0.1 rad: exact, but
+// tumbling robots then took the ten-row solve for rows that never bound -- 0.8 us per step of the C5 share under
+// torque_balancing.py's law, profiles/r06_ab_c5_changes.txt.)
 // Until round 6 a row existed only at or beyond the stop (gap <= 0), with the ERP bias alone. A joint RESTING on its stop
 // sits within rounding of gap = 0, so whether its row existed in a substep was decided by the last bit of q -- in fp32 the
 // joint stayed put, in the fp64 checker it alternated between a substep with the row and a substep of free acceleration
@@ -1042,6 +1047,7 @@ UPKIE_HD float joint_limit_row(bool bounded, float q, float lower, float upper, 
   bias = (pen > 0.f ? 0.2f : 1.f) * pen * ih;  // Bullet's default ERP beyond the stop; the gap may close within the substep before it
   return sign;
 }
+UPKIE_HD float joint_limit_reach(float qd, float max_joint_velocity, float h) { return (fabsf(qd) + 0.2f * max_joint_velocity) * h; }
 UPKIE_HD bool joint_limit_near(bool bounded, float q, float lower, float upper, float zone) {
   return bounded && (q - lower <= zone || upper - q <= zone);
 }
@@ -1054,7 +1060,7 @@ template <class ModelT>
 UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt6)[6][6], const float (&Jb)[6][6], const float (&Jl6)[6][3], const float (&vnow)[6],
-                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float zone, const float (&rt)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float vmax, float h, const float (&rt)[6],
                          float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   float J[kRows][6], Ll[kRows][3], vn[kRows], bias[kRows], cf[kRows];
   bool on[kRows];
@@ -1075,7 +1081,7 @@ UPKIE_HD void limit_path(const ModelT& M, const System& S, const float (&lower)[
     const int j = i < 2 ? i : i + 1;  // joints 0, 1, 3, 4
     const int w = j / 3, kk = j % 3, r = 6 + i;
     float row_bias;
-    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], zone, ih, row_bias);
+    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], joint_limit_reach(qd[j], vmax, h), ih, row_bias);
     const Leg& G = S.leg[w];
     // J = sign * e_j: no base part, reduced row = -D_w J_leg
 #pragma unroll
@@ -1410,7 +1416,7 @@ template <class ModelT>
 UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (&lower)[UPKIE_NJ], const float (&upper)[UPKIE_NJ],
                          const int (&bounded)[UPKIE_NJ], const float (&q)[UPKIE_NJ], const float (&qd)[UPKIE_NJ],
                          const float (&Jt)[6][6], const float (&Jb)[6][6], const float (&Jl)[6][3], const float (&vnow)[6],
-                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float zone, const float (&rt)[6],
+                         const float (&dists)[2], const bool (&active)[2], float cfm, float erp, float ih, float vmax, float h, const float (&rt)[6],
                          float (&tb)[6], float (&tl)[3], float (&tr)[3], float (&contact_lam)[6]) {
   GeneralRows R;
   R.n = 0;
@@ -1439,7 +1445,7 @@ UPKIE_HD void limit_path_scratch(const ModelT& M, const System& S, const float (
 #pragma unroll
   for (int j = 0; j < UPKIE_NJ; ++j) {
     float row_bias;
-    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], zone, ih, row_bias);
+    const float sign = joint_limit_row(bounded[j] != 0, q[j], lower[j], upper[j], joint_limit_reach(qd[j], vmax, h), ih, row_bias);
     if (sign != 0.f) {
       const int i = R.n, w = j / 3, kk = j % 3;
       const Leg& G = S.leg[w];
@@ -1544,7 +1550,7 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   if (Lm.enforce) {
 #pragma unroll
     for (int j = 0; j < UPKIE_NJ; ++j)
-      any_limit = any_limit || joint_limit_near(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], M.max_joint_velocity * h);
+      any_limit = any_limit || joint_limit_near(Lm.bounded[j] != 0, s.q[j], Lm.lower[j], Lm.upper[j], joint_limit_reach(s.qd[j], M.max_joint_velocity, h));
   }
   const BaseFrame bf = base_frame(s.qw, s.qx, s.qy, s.qz, s.linvel, s.angvel);
   const float r00 = bf.r00, r01 = bf.r01, r02 = bf.r02, r10 = bf.r10, r11 = bf.r11, r12 = bf.r12, r20 = bf.r20, r21 = bf.r21, r22 = bf.r22;
@@ -1727,9 +1733,9 @@ UPKIE_HD bool physics_substep(const ModelT& M, const DevLimits& Lm, Phys& s, con
   if (warm && (any_limit || !(active[0] || active[1]))) warm->swept = 0;
   if (any_limit) {
     if (SCRATCH_LIMITS)
-      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl, tr, lam);
+      limit_path_scratch(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity, h, rt, tb, tl, tr, lam);
     else
-      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl, tr, lam);
+      limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, s.q, s.qd, Jt, Jb, Jl, vnow, dists, active, cfm, erp, ih, M.max_joint_velocity, h, rt, tb, tl, tr, lam);
   } else if (active[0] || active[1]) {
     // A = J M^-1 J' + CFM (symmetric, packed lower by rows) built column by
     // column from Y_b = A^-1 Jt_b and K_b = Hinv J_leg,b; the same two vectors

@@ -557,7 +557,7 @@ UPKIE_HD float oct_from_joint(float x) { return oct_qb<K + 1>(x); }
 template <class ModelT, class LimitsT>
 UPKIE_HD void octet_limit_path_registers(const ModelT& M, const LimitsT& Lm_, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0,
                                float hv1, float hv2, V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active,
-                               bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih, float zone,
+                               bool active_partner, float q, float qd, float tl, const float (&rt)[6], float cfm, float erp, float ih, float vmax, float h,
                                float (&xb)[6], float& xl) {
   const bool left = L.leg == 0;
   DevLimits Lm;  // (a register copy: the limits may sit in the constant address space, limit_path takes plain arrays)
@@ -643,7 +643,7 @@ UPKIE_HD void octet_limit_path_registers(const ModelT& M, const LimitsT& Lm_, co
     tb[c] = v;
   }
   float contact_lam[6];
-  limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, zone, rt, tb, tl6[0], tl6[1], contact_lam);
+  limit_path(M, S, Lm.lower, Lm.upper, Lm.bounded, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, vmax, h, rt, tb, tl6[0], tl6[1], contact_lam);
   system_solve<true, true>(S, tb, tl6[0], tl6[1]);
 #pragma unroll
   for (int c = 0; c < 6; ++c) xb[c] = tb[c];
@@ -896,7 +896,11 @@ UPKIE_HD int oct_active_set(const OctLane& L, const float (&Dg)[3], const float 
     const float worst = fmaxf(fmaxf(fmaxf(equation, enters), fmaxf(pulls, leaves)), returns);
     // (fmaxf DROPS a NaN operand: a partly NaN elimination -- a pivot 1 -+ mu A_nt / A_nn that is exactly 0, inf - inf -- would
     // pass every test above; the own row's impulse and velocity are looked at directly: ADVICE r5)
+#if defined(UPKIE_AB_NO_NANCHECK)
+    const bool bad = !(worst <= 0.f) || !(xs <= 3.0e38f);
+#else
     const bool bad = !(worst <= 0.f) || !(xs <= 3.0e38f) || !(fabsf(x) + fabsf(v) < 3.0e38f);
+#endif
     if (!oct_env_any(bad)) {
       const float ln = push ? fmaxf(x1, 0.f) : 0.f, bound = mu * ln;
       lam = normal ? ln : (side != 0.f ? side * bound : fminf(fmaxf(x, -bound), bound));
@@ -1094,7 +1098,11 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   // load and a wait for it in every substep, 86-160 cycles of a lone wavefront each)
   bool at_a_stop = false;
   {
-    const bool own_limit = joint_limit_near(L.bounded, s.q, L.lower, L.upper, OCT_HOT(max_joint_velocity) * h);
+#if defined(UPKIE_AB_OLD_LIMITS)
+    const bool own_limit = L.bounded && (s.q <= L.lower || s.q >= L.upper);
+#else
+    const bool own_limit = joint_limit_near(L.bounded, s.q, L.lower, L.upper, joint_limit_reach(s.qd, OCT_HOT(max_joint_velocity), h));
+#endif
     if (__builtin_expect(oct_wave_any(own_limit), 0)) at_a_stop = oct_env_any(own_limit);
   }
 
@@ -1260,10 +1268,10 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
     if (census) census->path = OCT_NOT_MINE_LIMIT;
     if (LIMITS_IN_REGISTERS) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
-                                 erp, ih, OCT_HOT(max_joint_velocity) * h, xb, xl);
+                                 erp, ih, OCT_HOT(max_joint_velocity), h, xb, xl);
     } else {
       float lim_bias;
-      const float lim_sign = joint_limit_row(L.bounded, s.q, L.lower, L.upper, OCT_HOT(max_joint_velocity) * h, ih, lim_bias);
+      const float lim_sign = joint_limit_row(L.bounded, s.q, L.lower, L.upper, joint_limit_reach(s.qd, OCT_HOT(max_joint_velocity), h), ih, lim_bias);
       octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
                                lim_sign, lim_bias, xb, xl, ws[oct_env_slot()]);
     }
@@ -1833,7 +1841,9 @@ next_step:
       cmd.kp_scale = clamp_ref(a[3], 0.f, max_gain_scale);
       cmd.kd_scale = clamp_ref(a[4], 0.f, max_gain_scale);
       cmd.maximum_torque = clamp_ref(a[5], 0.f, eff);
-      guard_count(C.guard, 0, guard_servo_command(cmd, eff));  // non-finite guard (step_kernels.hpp)
+#if !defined(UPKIE_AB_NO_GUARD)
+      if (const int replaced = guard_servo_command(cmd, eff)) guard_count(C.guard, 0, replaced);  // non-finite guard (step_kernels.hpp)
+#endif
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -1846,7 +1856,7 @@ next_step:
     }
     {
       const int replaced = guard_velocity_actions(a0, a1, max_yaw_velocity);
-      if (lead) guard_count(C.guard, 0, replaced);
+      if (lead && replaced) guard_count(C.guard, 0, replaced);
     }
     const float v = clamp_ref(a0, -max_ground_velocity, max_ground_velocity);
     const float yawd = clamp_ref(a1, -max_yaw_velocity, max_yaw_velocity);
@@ -1950,6 +1960,10 @@ next_step:
 
   // ---- non-finite guard: the state behind the substeps (step_kernels.hpp) -------
   bool unsound;
+#if defined(UPKIE_AB_NO_GUARD)
+  unsound = false;
+  if (false)
+#endif
   {
     float mag = oct_esum(fabsf(s.q) + fabsf(s.qd));  // (the trunk lanes hold zeros)
     mag += fabsf(s.pos.x) + fabsf(s.pos.y) + fabsf(s.pos.z) + fabsf(s.qw) + fabsf(s.qx) + fabsf(s.qy) + fabsf(s.qz);

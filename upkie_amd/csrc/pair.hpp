@@ -127,7 +127,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
   bool own_limit = false;
   if (Lm.enforce) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) own_limit = own_limit || joint_limit_near(PL.bounded[k] != 0, s.q[k], PL.lower[k], PL.upper[k], M.max_joint_velocity * h);
+    for (int k = 0; k < 3; ++k) own_limit = own_limit || joint_limit_near(PL.bounded[k] != 0, s.q[k], PL.lower[k], PL.upper[k], joint_limit_reach(s.qd[k], M.max_joint_velocity, h));
   }
   const bool any_limit = Lm.enforce ? pair_any<XL>(own_limit) : false;
 
@@ -319,7 +319,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       }
     }
     float contact_lam[6];
-    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, M.max_joint_velocity * h, rt, tb, tl2, tr2, contact_lam);
+    limit_path(M, S2, lo6, up6, bd6, q6, qd6, Jt6, Jb6, Jl6, vn6, d2, act2, cfm, erp, ih, M.max_joint_velocity, h, rt, tb, tl2, tr2, contact_lam);
 #pragma unroll
     for (int k = 0; k < 3; ++k) tl[k] = pick(leg, tl2[k], tr2[k]);
   } else if (any_contact) {
@@ -666,7 +666,7 @@ next_step:
       cmd[k].kp_scale = clamp_ref(a[6 * k + 3], 0.f, C.max_gain_scale);
       cmd[k].kd_scale = clamp_ref(a[6 * k + 4], 0.f, C.max_gain_scale);
       cmd[k].maximum_torque = clamp_ref(a[6 * k + 5], 0.f, eff);
-      guard_count(C.guard, 0, guard_servo_command(cmd[k], eff));  // non-finite guard (step_kernels.hpp)
+      if (const int replaced = guard_servo_command(cmd[k], eff)) guard_count(C.guard, 0, replaced);  // non-finite guard (step_kernels.hpp)
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -679,7 +679,7 @@ next_step:
     }
     {
       const int replaced = guard_velocity_actions(a0, a1, C.max_yaw_velocity);
-      if (lead) guard_count(C.guard, 0, replaced);
+      if (lead && replaced) guard_count(C.guard, 0, replaced);
     }
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);

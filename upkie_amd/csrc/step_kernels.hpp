@@ -177,6 +177,9 @@ __device__ __forceinline__ float joint_torque(float q, float qd, const Servo& c,
 __device__ __forceinline__ bool is_finite(float x) { return fabsf(x) < 3.0e38f; }  // (false for NaN)
 
 __device__ __forceinline__ int guard_servo_command(Servo& c, float effort) {
+  // (one test for the sound command -- every env but a diverged policy's --, the word-by-word replacement behind it)
+  const float magnitude = fabsf(c.velocity) + fabsf(c.feedforward_torque) + fabsf(c.kp_scale) + fabsf(c.kd_scale) + fabsf(c.maximum_torque);
+  if (magnitude < 3.0e38f && !(fabsf(c.position) > 3.0e38f)) return 0;
   int replaced = 0;
   if (fabsf(c.position) > 3.0e38f) { c.position = NAN; ++replaced; }  // +-Inf (NaN compares false: it is the neutral value)
   if (!is_finite(c.velocity)) { c.velocity = 0.f; ++replaced; }
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
       cmd[j].kp_scale = clamp_ref(a[6 * j + 3], 0.f, C.max_gain_scale);
       cmd[j].kd_scale = clamp_ref(a[6 * j + 4], 0.f, C.max_gain_scale);
       cmd[j].maximum_torque = clamp_ref(a[6 * j + 5], 0.f, eff);
-      guard_count(C.guard, 0, guard_servo_command(cmd[j], eff));
+      if (const int replaced = guard_servo_command(cmd[j], eff)) guard_count(C.guard, 0, replaced);
     }
   } else if (MODE != MODE_RESET) {
     if (fused_agent(MODE)) {
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64, WPS == 2 ? UPKIE_DENSE_WAVES : WPS) void step_k
       a0 = act0;  // Pendulum: [action[0], 0.0], upkie_pendulum.py:139
       a1 = act1;
     }
-    guard_count(C.guard, 0, guard_velocity_actions(a0, a1, C.max_yaw_velocity));
+    if (const int replaced = guard_velocity_actions(a0, a1, C.max_yaw_velocity)) guard_count(C.guard, 0, replaced);
     // UpkieGyropod.__get_spine_action, upkie_gyropod.py:293-331
     float v = clamp_ref(a0, -C.max_ground_velocity, C.max_ground_velocity);
     float yawd = clamp_ref(a1, -C.max_yaw_velocity, C.max_yaw_velocity);
