@@ -272,11 +272,10 @@ def secondary_c5_share(law: str, envs: int = 4096, steps: int = STEADY_STEPS, wa
     `law`: "torque" = examples/pybullet/torque_balancing.py:15-37 (8d's law:
     wheel torques +-10 x pitch, kd_scale 0), "velocity" = the README balancer
     through the wheels' velocity loop. `contact_model`: "default" or
-    "bullet_like" (persistent manifolds, 50 fixed sweeps, cone friction; Servos
-    steps run it one env per lane by default since round 6 -- the mapping that
-    keeps joint stops inside the sweeps --, `lanes` = 8 asks for the eight-lane
-    kernel, which the C5 agents, whose servos hold the legs, never drive into
-    its joint-stop fallback: the census word says so)."""
+    "bullet_like" (persistent manifolds, 50 fixed sweeps, cone friction: on
+    eight lanes per env for Servos steps too, joint stops inside the same
+    sweeps since round 6; `lanes` = 1 asks for the one-lane kernels, which also
+    keep several cached points per tire)."""
     import numpy as np
     import torch
 
@@ -907,8 +906,8 @@ def run_pendulum(args, sim_factory=None, backend=None, keep_group: bool = False)
             "c3": c3,
             "c5_share_torque_law": guarded(secondary_c5_share, "torque"),
             "c5_share_velocity_law": guarded(secondary_c5_share, "velocity"),
-            "c5_share_bullet_like": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 0, "bullet_like") for law in ("torque", "velocity")},
-            "c5_share_bullet_like_eight_lanes": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 200, "bullet_like", 8) for law in ("torque", "velocity")},
+            "c5_share_bullet_like": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 200, "bullet_like") for law in ("torque", "velocity")},
+            "c5_share_bullet_like_one_lane": {law: guarded(secondary_c5_share, law, 4096, 600, 100, 0, 0, "bullet_like", 1) for law in ("torque", "velocity")},
             "c2_bullet_like_contact_model": guarded(secondary_bullet_like, B),
         }
     return line

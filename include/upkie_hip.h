@@ -348,20 +348,17 @@ int upkie_sim_set_final_observation(UpkieSim* sim, float* final_obs);
  * normal impulse, live flag. A reset clears an env's manifold. Two kernels run
  * this model: the one-env-per-lane step kernels cover every case (several
  * points on a tire, joints at their stops in the same solve, any batch size,
- * every entry point); up to 16384 envs the Pendulum / Gyropod / BaseVelocity
- * step entry points (upkie_sim_step_servos: only when asked to,
- * upkie_sim_set_lanes_per_env(sim, 8), and up to 8192 envs; round 6) run it on
- * eight lanes per env, in the case a rolling wheel
+ * every entry point); up to 16384 envs (upkie_sim_step_servos: 8192) the step
+ * entry points run it on eight lanes per env, in the case a rolling wheel
  * produces (one cached point per tire, which the tire's deepest point replaces
  * every substep: the default model's contact point with the friction rows
  * rotated into the sliding direction; a robot lying flat on its side, whose
  * tires may cache several points under Bullet's rule, keeps the deepest one
- * on this variant; a joint at its stop -- which the Pendulum / Gyropod /
- * BaseVelocity envs, whose legs the servos hold, do not reach, and a Servos
- * agent may, which is why Servos steps default to the one-lane kernels --
- * takes the default model's joint-stop solve for that substep and
- * is counted by the census, word [0]; UPKIE_LANES_PER_ENV=1 selects the
- * one-lane kernels, which keep limit rows inside the same sweeps).
+ * on this variant -- upkie_sim_set_lanes_per_env(sim, 1) selects the one-lane
+ * kernels; a joint within reach of its stop is a row of the same 50 sweeps on
+ * both, since round 6 -- until then the eight-lane variant answered such a
+ * substep with the default model's joint-stop solve --, and is counted by the
+ * census, word [0]).
  * Both keep complete manifold records, so either continues from a manifold the
  * other wrote. About 2.3 x the default model's Pendulum step (the sweeps are ~36 packed-
  * fp32 instructions each); the default stays the product's fast

@@ -279,6 +279,57 @@ def test_eight_lane_bullet_like_substep_matches_the_oracle(harness):  # noqa: F8
     assert worst_applied < 5e-4, worst_applied
 
 
+def test_eight_lane_substep_with_joints_at_their_stops_matches_the_oracle(harness):  # noqa: F811
+    """Round 6: on the eight-lane mapping a Bullet-like substep with a hip or knee within
+    reach of its stop used to take the DEFAULT model's joint-stop solve. It now gathers its rows -- the tires' and the
+    limit rows -- into the general row list and runs the specification's own 50 sweeps on them
+    (general_constraint_solve_bullet_like): landed robots whose leg joints are PUSHED into their stops by constant
+    torques, every substep taken by the eight lockstep host threads from the oracle twin's state (one substep at a time:
+    the same rows on both sides), applied normal impulses carried along."""
+    rng = np.random.default_rng(31)
+    model = default_model()
+    harness.harness_substep_octet_bullet_like.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    lower, upper = np.array(model.joint_lower[:6]), np.array(model.joint_upper[:6])
+    worst = np.zeros(25)
+    worst_applied = 0.0
+    compared = at_stop = 0
+    for trial in range(12):
+        s = random_state(rng, True)
+        s[abi.S_QUAT:abi.S_QUAT + 4] = [1, 0, 0, 0]
+        s[abi.S_Q:abi.S_Q + 6] = 0
+        s[abi.S_LINVEL:abi.S_LINVEL + 3] = rng.uniform(-0.05, 0.05, 3)
+        s[abi.S_ANGVEL:abi.S_ANGVEL + 3] = rng.uniform(-0.1, 0.1, 3)
+        push = rng.choice([-3.0, 3.0], 6)
+        push[[2, 5]] = rng.uniform(-0.3, 0.3, 2)
+        so, mo = s.copy(), np.zeros(WORDS)
+        status = np.zeros(1, dtype=np.int32)
+        for k in range(500):
+            q, qd = so[abi.S_Q:abi.S_Q + 6], so[abi.S_QD:abi.S_QD + 6]
+            tau = push - 0.2 * qd
+            near = np.any((q[[0, 1, 3, 4]] <= lower[[0, 1, 3, 4]] + 0.02) | (q[[0, 1, 3, 4]] >= upper[[0, 1, 3, 4]] - 0.02))
+            live = mo.reshape(2, 4, 8)[:, :, 7]
+            if k >= 100 and near and live.sum(axis=1).max() <= 1:
+                sh = so.astype(np.float32)
+                applied = (mo.reshape(2, 4, 8)[:, :, 6] * live).sum(axis=1).astype(np.float32)
+                t32 = np.ascontiguousarray(tau, dtype=np.float32)
+                s_ref, m_ref, c_ref = both(harness, model, so.astype(np.float32).astype(np.float64), mo.astype(np.float32).astype(np.float64), t32.astype(np.float64))
+                ok = harness.harness_substep_octet_bullet_like(C.byref(model), p(sh), p(t32), C.c_float(1e-3), 1, p(status), p(applied))
+                assert ok == 1
+                live_ref = m_ref.reshape(2, 4, 8)[:, :, 7]
+                if live_ref.sum(axis=1).max() <= 1 and (status[0] == 1) == (c_ref == 1):
+                    compared += 1
+                    at_stop += int(np.any((q[[0, 1, 3, 4]] <= lower[[0, 1, 3, 4]]) | (q[[0, 1, 3, 4]] >= upper[[0, 1, 3, 4]])))
+                    worst = np.maximum(worst, np.abs(s_ref[:25] - sh[:25].astype(np.float64)))
+                    ref_applied = (m_ref.reshape(2, 4, 8)[:, :, 6] * live_ref).sum(axis=1)
+                    worst_applied = max(worst_applied, float(np.abs(ref_applied - applied).max()))
+            so, mo, _ = both(harness, model, so, mo, tau)
+    assert compared >= 1500 and at_stop >= 300, (compared, at_stop)
+    assert worst[0:3].max() < 2e-6 and worst[3:7].max() < 2e-6 and worst[[13, 14, 16, 17]].max() < 5e-6, worst
+    assert worst[7:10].max() < 2e-3 and worst[10:13].max() < 1e-2 and worst[19:25].max() < 5e-2, worst
+    assert worst_applied < 5e-4, worst_applied
+
+
 class BulletLikeProbe(C.Structure):
     """`BulletLikeProbe` of upkie_amd/csrc/bullet_like.hpp (host build only)."""
 

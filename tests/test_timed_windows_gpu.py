@@ -436,7 +436,7 @@ def test_c5_share_window_pushes_and_falls_match_the_oracle(law, contact_model, l
     import bench
     from oracle import oracle as O
 
-    if lanes != 8 or contact_model == "bullet_like":  # (round 6: Servos steps under the Bullet-like model run one env per lane unless asked otherwise)
+    if lanes != 8:
         monkeypatch.setenv("UPKIE_LANES_PER_ENV", str(lanes))
     B, steps, seed = 4096, 1200, 0
     env = _c5_env(B, seed, contact_model)

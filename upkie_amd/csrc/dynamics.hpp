@@ -1406,6 +1406,145 @@ UPKIE_HD void general_constraint_solve(const ModelT& M, const SystemT& S, const 
   }
 }
 
+// The same row list under the BULLET-LIKE contact specification (bullet_like.hpp), for the eight-lane kernel's joint-stop path
+// (round 6: until then a Bullet-like substep with a joint at its stop took the default model's solve above on that mapping):
+// the rows arrive as the eight-lane path has them -- contact rows of the touching tires in wheel order with the friction
+// directions of the DEFAULT basis (rolling, lateral) and no friction CFM, then the limit rows (joint_limit_row) --; the dense
+// system is built as above, each tire's friction pair is rotated into the specification's directions (along / across the
+// sliding velocity of the point at the free velocity, btPlaneSpace1 when it does not slide: Q, the rotation
+// oct_bullet_like_solve applies to its six rows), and the published FIXED number of sequential-impulse sweeps runs on it:
+// limit rows, normal rows, then each point's friction pair together, projected onto the cone -- from the normals' warm
+// start 0.85 x the impulse applied in the previous step. Row for row bullet_like_contacts' general path (which iterates on
+// velocities; the same impulses after every sweep in exact arithmetic). `first_row[w]`: index of tire w's normal row or -1;
+// `plane[w]`: the fallback directions (a . t1, a . t2, b . t1, b . t2 of btPlaneSpace1's a, b against the default t1, t2);
+// `applied[w]`: the tire's applied normal impulse, in / out. On return (tb, tl, tr) += J' lam.
+template <class ModelT, class SystemT>
+UPKIE_HD void general_constraint_solve_bullet_like(const ModelT& M, const SystemT& S, const GeneralRows& R, const float (&rt)[6], float (&tb)[6],
+                                                   float (&tl)[3], float (&tr)[3], const int (&first_row)[2], const float (&plane)[2][4],
+                                                   float (&applied)[2], GeneralWork& W) {
+  const int n = R.n;
+  auto& A = W.A;
+  auto& Y = W.Y;
+  auto& K = W.K;
+  auto& rhs = W.rhs;
+  auto& lam = W.lam;
+  for (int b = 0; b < n; ++b) {
+    float y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) y[c] = R.Jt[b][c];
+    ldl6_solve(S.A, y);
+    const float* hv = R.leg[b] == 0 ? S.leg[0].Hinv : S.leg[1].Hinv;
+    const float k0 = hv[0] * R.Jl[b][0] + hv[3] * R.Jl[b][1] + hv[4] * R.Jl[b][2];
+    const float k1 = hv[3] * R.Jl[b][0] + hv[1] * R.Jl[b][1] + hv[5] * R.Jl[b][2];
+    const float k2 = hv[4] * R.Jl[b][0] + hv[5] * R.Jl[b][1] + hv[2] * R.Jl[b][2];
+    float vf = R.vnow[b];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      Y[b][c] = y[c];
+      vf = fmaf(y[c], rt[c], vf);
+    }
+    K[b][0] = k0; K[b][1] = k1; K[b][2] = k2;
+    if (R.leg[b] == 0)
+      vf += k0 * tl[0] + k1 * tl[1] + k2 * tl[2];
+    else
+      vf += k0 * tr[0] + k1 * tr[1] + k2 * tr[2];
+    rhs[b] = -vf + R.bias[b];
+    lam[b] = 0.f;
+  }
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc = fmaf(R.Jt[a][c], Y[b][c], acc);
+      if (R.leg[a] == R.leg[b]) acc += R.Jl[a][0] * K[b][0] + R.Jl[a][1] * K[b][1] + R.Jl[a][2] * K[b][2];
+      if (a == b) acc += R.cfm[a];
+      A[a][b] = acc;
+    }
+  // each tire's friction pair into the specification's directions: A <- Q A Q', rhs <- Q rhs
+  float Q[2][4];
+  for (int w = 0; w < 2; ++w) {
+    const int i = first_row[w] + 1, j = first_row[w] + 2;
+    Q[w][0] = 1.f; Q[w][1] = 0.f; Q[w][2] = 0.f; Q[w][3] = 1.f;
+    if (first_row[w] < 0) continue;
+    const float vt1 = -rhs[i], vt2 = -rhs[j];  // (friction rows carry no bias: -rhs is the point's free velocity along t1 / t2)
+    const float lat2 = vt1 * vt1 + vt2 * vt2;
+    if (lat2 > 1.1920929e-07f) {  // SIMD_EPSILON
+      const float inv = 1.f / sqrtf(lat2);
+      const float c = vt1 * inv, sn = vt2 * inv;
+      Q[w][0] = c; Q[w][1] = sn; Q[w][2] = sn; Q[w][3] = -c;
+    } else {
+      Q[w][0] = plane[w][0]; Q[w][1] = plane[w][1]; Q[w][2] = plane[w][2]; Q[w][3] = plane[w][3];
+    }
+    for (int c = 0; c < n; ++c) {
+      const float x = A[i][c], y = A[j][c];
+      A[i][c] = Q[w][0] * x + Q[w][1] * y;
+      A[j][c] = Q[w][2] * x + Q[w][3] * y;
+    }
+    for (int r = 0; r < n; ++r) {
+      const float x = A[r][i], y = A[r][j];
+      A[r][i] = Q[w][0] * x + Q[w][1] * y;
+      A[r][j] = Q[w][2] * x + Q[w][3] * y;
+    }
+    const float x = rhs[i], y = rhs[j];
+    rhs[i] = Q[w][0] * x + Q[w][1] * y;
+    rhs[j] = Q[w][2] * x + Q[w][3] * y;
+    lam[first_row[w]] = 0.85f * applied[w];  // m_warmstartingFactor
+  }
+  const float mu = M.friction_mu;
+  for (int it = 0; it < M.pgs_iterations; ++it) {
+    for (int pass = 0; pass < 2; ++pass) {  // joint limits, then normals
+      for (int r = 0; r < n; ++r) {
+        if (R.kind[r] != (pass == 0 ? 2 : 0)) continue;
+        float al = 0.f;
+        for (int b = 0; b < n; ++b) al = fmaf(A[r][b], lam[b], al);
+        const float x = lam[r] + (rhs[r] - al) * fast_rcp(A[r][r]);
+        lam[r] = x < 0.f ? 0.f : x;
+      }
+    }
+    for (int w = 0; w < 2; ++w) {  // the two friction rows of a point together, projected onto the cone
+      if (first_row[w] < 0) continue;
+      const int i = first_row[w] + 1, j = first_row[w] + 2;
+      float a1 = 0.f, a2 = 0.f;
+      for (int b = 0; b < n; ++b) {
+        a1 = fmaf(A[i][b], lam[b], a1);
+        a2 = fmaf(A[j][b], lam[b], a2);
+      }
+      float x1 = lam[i] + (rhs[i] - a1) * fast_rcp(A[i][i]), x2 = lam[j] + (rhs[j] - a2) * fast_rcp(A[j][j]);
+      const float lim = mu * lam[first_row[w]], n2 = x1 * x1 + x2 * x2;
+      if (n2 > lim * lim) {
+        const float sc = lim * fast_rsqrt(n2);
+        x1 *= sc;
+        x2 *= sc;
+      }
+      lam[i] = x1;
+      lam[j] = x2;
+    }
+  }
+  // back to the default basis (lam = Q' lam'), the applied normal impulses, and J' lam
+  for (int w = 0; w < 2; ++w) {
+    if (first_row[w] < 0) {
+      applied[w] = 0.f;
+      continue;
+    }
+    const int i = first_row[w] + 1, j = first_row[w] + 2;
+    applied[w] = lam[first_row[w]];
+    const float x = lam[i], y = lam[j];
+    lam[i] = Q[w][0] * x + Q[w][2] * y;
+    lam[j] = Q[w][1] * x + Q[w][3] * y;
+  }
+  for (int r = 0; r < n; ++r) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tb[c] = fmaf(R.Jb[r][c], lam[r], tb[c]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (R.leg[r] == 0)
+        tl[j] = fmaf(R.Jl[r][j], lam[r], tl[j]);
+      else
+        tr[j] = fmaf(R.Jl[r][j], lam[r], tr[j]);
+    }
+  }
+}
+
 // Scratch-memory variant of limit_path() (same rows, same numerics) for the
 // register-capped build that runs two waves per SIMD on very large batches:
 // there the register-resident solve above would spill into the path every env

@@ -682,11 +682,15 @@ UPKIE_HD int oct_env_slot() {
   return 0;
 #endif
 }
-template <class ModelT>
+// BULLET_LIKE (round 6): the same rows under the Bullet-like specification -- no friction CFM, and the sweeps of
+// general_constraint_solve_bullet_like (dynamics.hpp) instead of the default model's solve: a joint within reach of its stop is
+// solved INSIDE the specification's 50 sweeps on this mapping too; `bf`: the base frame (btPlaneSpace1's directions), `applied`:
+// the own tire's applied normal impulse, in / out.
+template <bool BULLET_LIKE = false, class ModelT>
 UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const Ldl6Planar& fac, const float (&Dc)[6], float hv0, float hv1, float hv2,
                                V3 o, V3 Pc, V3 nB, float iun, V3 vB, V3 wB, float dist, bool active, bool active_partner, float qd,
                                float tl, const float (&rt)[6], float cfm, float erp, float ih, float lim_sign, float lim_bias,
-                               float (&xb)[6], float& xl, LimitWorkspace& ws) {
+                               float (&xb)[6], float& xl, LimitWorkspace& ws, const BaseFrame* bf = nullptr, float* applied = nullptr) {
   const bool left = L.leg == 0;
   LimitSystemRef S;
   S.leg = ws.leg;
@@ -743,6 +747,7 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
   const float dist_other = oct_swp(dist);
   GeneralRows& R = ws.R;
   R.n = 0;
+  int first_row[2] = {-1, -1};
   // rows of the touching tires in wheel order (left, right); each tire's rows come from its own quad
   auto tire = [&](int w) {
     const bool mine = (w == 0) == left;  // the quad this lane sits in owns tire w
@@ -771,8 +776,9 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
         R.leg[i] = w;
         R.kind[i] = k == 0 ? 0 : 1;
         R.normal_row[i] = i - k;
-        R.cfm[i] = k == 0 ? cfm : M.friction_cfm;
+        R.cfm[i] = k == 0 ? cfm : (BULLET_LIKE ? 0.f : M.friction_cfm);  // (Bullet: no friction CFM)
         R.bias[i] = k == 0 ? (dw <= 0.f ? erp * (-dw) * ih : -dw * ih) : 0.f;
+        if (k == 0) first_row[w] = i;
         R.n = i + 1;
       }
     };
@@ -823,8 +829,27 @@ UPKIE_HD void octet_limit_path_scratch(const ModelT& M, const OctLane& L, const 
       for (int k = 0; k < 3; ++k) v = fmaf(S.leg[w].D[c][k], tl6[w][k], v);
     tb[c] = v;
   }
-  float lam_rows[10];
-  general_constraint_solve(M, S, R, rt, tb, tl6[0], tl6[1], lam_rows, ws.W);
+  if constexpr (BULLET_LIKE) {
+    // btPlaneSpace1(n) for n = world z -- world (0, -1, 0) and (1, 0, 0) -- against each tire's default directions, and the tires'
+    // applied normal impulses, in the (left, right) order of the shared solve
+    const V3 a = v3(-bf->r10, -bf->r11, -bf->r12), b = v3(bf->r00, bf->r01, bf->r02);
+    const float p4[4] = {dot(a, t1), dot(a, t2), dot(b, t1), dot(b, t2)};
+    float plane[2][4], applied2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float other = oct_swp(p4[i]);
+      plane[0][i] = left ? p4[i] : other;
+      plane[1][i] = left ? other : p4[i];
+    }
+    const float other_applied = oct_swp(*applied);
+    applied2[0] = left ? *applied : other_applied;
+    applied2[1] = left ? other_applied : *applied;
+    general_constraint_solve_bullet_like(M, S, R, rt, tb, tl6[0], tl6[1], first_row, plane, applied2, ws.W);
+    *applied = left ? applied2[0] : applied2[1];
+  } else {
+    float lam_rows[10];
+    general_constraint_solve(M, S, R, rt, tb, tl6[0], tl6[1], lam_rows, ws.W);
+  }
   system_solve<true, true>(S, tb, tl6[0], tl6[1]);
 #pragma unroll
   for (int c = 0; c < 6; ++c) xb[c] = tb[c];
@@ -1266,14 +1291,15 @@ UPKIE_HD int physics_substep_octet(const ModelT& M, const LimitsT& Lm, const Oct
   float lam_now = 0.f;
   if (__builtin_expect(at_a_stop, 0)) {
     if (census) census->path = OCT_NOT_MINE_LIMIT;
-    if (LIMITS_IN_REGISTERS) {
+    if (LIMITS_IN_REGISTERS && !BULLET_LIKE) {
       octet_limit_path_registers(M, Lm, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.q, s.qd, tl, rt, cfm,
                                  erp, ih, OCT_HOT(max_joint_velocity), h, xb, xl);
     } else {
       float lim_bias;
       const float lim_sign = joint_limit_row(L.bounded, s.q, L.lower, L.upper, joint_limit_reach(s.qd, OCT_HOT(max_joint_velocity), h), ih, lim_bias);
-      octet_limit_path_scratch(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
-                               lim_sign, lim_bias, xb, xl, ws[oct_env_slot()]);
+      if (BULLET_LIKE && !active) s.bl_applied = 0.f;  // (no point cached: nothing to warm-start from)
+      octet_limit_path_scratch<BULLET_LIKE>(M, L, fac, Dc, hv0, hv1, hv2, o, Pc, nB, iun, vB, wB, dist, active, active_partner, s.qd, tl, rt, cfm, erp, ih,
+                                            lim_sign, lim_bias, xb, xl, ws[oct_env_slot()], &bf, &s.bl_applied);
     }
   } else if (__builtin_expect(active || active_partner, 1)) {
     const float sa = oct_qb<3>(L.sg);
@@ -1673,7 +1699,7 @@ __global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLi
   // joint stops of the kernels that do not solve them in registers: one workspace per env of the wavefront, in LDS
   // (octet_limit_path_scratch: 17.8 KB per wavefront, eight wavefronts per CU fit the 160 KB)
   __shared__ LimitWorkspace limit_workspaces[UPKIE_OCTET_BLOCK / 8];
-  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS && kServosLimitsInRegisters ? nullptr : limit_workspaces;
+  LimitWorkspace* const limit_ws = MODE == MODE_SERVOS && kServosLimitsInRegisters && !BULLET_LIKE ? nullptr : limit_workspaces;
   const float* records = RAND && body_inertials ? body_inertials + e : nullptr;
   const OctLane L = load_oct_lane(*(ConstModelPtr)Mp, Lm, C, l, leg, records, (size_t)B, ROW_UP_FRONT ? &lane_row : nullptr);
   const auto& M = *(ConstModelPtr)Mp;
@@ -1916,7 +1942,7 @@ next_step:
     }
     OctRare rare_path{0, 0};
     // (always handed over: a pointer that is null without a census put the two words in scratch memory, stored every substep)
-    const int status = physics_substep_octet<MODE == MODE_SERVOS && kServosLimitsInRegisters, DEFAULT_SCALARS, BULLET_LIKE>(
+    const int status = physics_substep_octet<MODE == MODE_SERVOS && kServosLimitsInRegisters && !BULLET_LIKE, DEFAULT_SCALARS, BULLET_LIKE>(
         *mp, Lm, L, s, tau, substep_h, forces ? wrench : nullptr, limit_ws, &rare_path, BULLET_LIKE && sub == nsub - 1 ? manifold + e : nullptr, (size_t)B);
     const int rare = rare_path.path;
     if (census) {  // rare-path census (upkie_sim_set_census): ONE atomic per wavefront, substep and path (per-env atomics on two

@@ -529,17 +529,12 @@ extern "C" int upkie_sim_lanes_per_env(const UpkieSim* sim) { return !sim ? 0 : 
 // ... of the step kernel a given entry point launches: the Servos kernels leave the eight-lane mapping earlier
 static int mapped_lanes_of_mode(const UpkieSim* sim, int mode) {
   int lanes = mapped_lanes(sim);
-  // (round 5: the Bullet-like contact model's eight-lane variant serves UpkieServos steps too; a joint at its stop takes
-  // the default model's joint-stop path for that substep there -- counted by the census, word [0] -- where the one-lane
-  // kernels put the limit row into the same 50 sweeps: UPKIE_LANES_PER_ENV=1 selects those)
+  // (round 5: the Bullet-like contact model's eight-lane variant serves UpkieServos steps too)
   if (mode == MODE_SERVOS && lanes == 8 && sim->lanes_per_env != 8 && sim->config.num_envs > kOctetBatchServos) lanes = sim->manifold ? 1 : 2;
-  // (round 6, ADVICE r5: under the Bullet-like model a UpkieServos step runs one env per lane BY DEFAULT -- a Servos agent may
-  // rest on a joint stop for most of an episode, and only the one-lane kernel keeps the limit rows inside the 50 sweeps and
-  // several cached points per tire, i.e. is the fp64 checker's twin in every case. The eight-lane kernel, which answers a
-  // joint at its stop with the DEFAULT model's joint-stop solve for that substep, is an opt-in: UPKIE_LANES_PER_ENV=8 /
-  // upkie_sim_set_lanes_per_env. The one-step parity test measures what that costs in fidelity:
-  // tests/test_one_step_parity_gpu.py::test_joints_held_at_their_stops...)
-  if (mode == MODE_SERVOS && lanes == 8 && sim->manifold && sim->lanes_per_env != 8) lanes = 1;
+  // (round 6, ADVICE r5: on the eight-lane Bullet-like kernel a joint within reach of its stop is now a row of the specification's
+  // own 50 sweeps -- octet_limit_path_scratch<BULLET_LIKE>, general_constraint_solve_bullet_like -- as on the one-lane kernels, so
+  // Servos steps stay on eight lanes up to kOctetBatchServos envs; what the mapping still does not restate is SEVERAL cached
+  // points on one tire, a robot lying flat on its side: upkie_sim_set_lanes_per_env(sim, 1) selects the one-lane kernels)
   return lanes;
 }
 extern "C" int upkie_sim_lanes_per_env_of(const UpkieSim* sim, int observation_layout) {

@@ -504,10 +504,10 @@ class BatchedSim:
         `pybullet.stepSimulation()` is published to do, pybullet_backend.py:306)
         on a zeroed per-env manifold this handle keeps ``[64, B]``; False = the
         product's default specification. Eight lanes per env up to 16384 envs
-        (Servos steps: up to 8192; there a joint AT ITS STOP takes the default
-        model's joint-stop solve for that substep), one env per lane
-        otherwise (every case inside the same 50 sweeps; forced by
-        UPKIE_LANES_PER_ENV=1); about 2 x the default model's step: a fidelity
+        (Servos steps: up to 8192; one cached point per tire -- a robot lying
+        flat on its side keeps the deepest one --, joint stops inside the same
+        50 sweeps since round 6), one env per lane otherwise (every case;
+        `set_lanes_per_env(1)`); about 2 x the default model's step: a fidelity
         option, not the fast path."""
         self.contact_manifold = torch.zeros((abi.CONTACT_MANIFOLD_WORDS, self.num_envs), dtype=torch.float32, device=self.device) if on else None
         self._check(self._lib.upkie_sim_set_contact_manifold(self._handle, _ptr(self.contact_manifold)))
