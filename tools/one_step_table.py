@@ -11,10 +11,10 @@ D = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.a
 TITLES = {
     "one_step_c2": "C2 (BASELINE configs[1]): 4096 Upkie-Pendulum envs, README agent, 2200 steps through the falls and NEXT_STEP autoresets",
     "one_step_c5_torque_law": "C5 share (BASELINE configs[4]), examples/pybullet/torque_balancing.py's law (the chaotic window), 4096 envs x 1200 steps, pushes, randomised inertias",
-    "one_step_c5_torque_law_bullet_like": "the same under the Bullet-like contact model (eight lanes: an opt-in for Servos steps since round 6)",
+    "one_step_c5_torque_law_bullet_like": "the same under the Bullet-like contact model (eight lanes: one cached point per tire; one lane: up to four)",
     "one_step_c5_velocity_law": "C5 share, README law through the wheels' velocity loop",
     "one_step_joint_stops": "UpkieServos agents that HOLD hips and knees against their stops, 1024 envs x 300 steps, default contact model",
-    "one_step_joint_stops_bullet_like": "the same under the Bullet-like model (eight lanes: the opt-in mapping answers a joint at its stop with the DEFAULT model's solve: a difference of model, reported, not asserted)",
+    "one_step_joint_stops_bullet_like": "the same under the Bullet-like model (limit rows inside the specification's 50 sweeps on both mappings since round 6)",
 }
 for path in sorted(glob.glob(os.path.join(D, "one_step_*.json"))):
     name = os.path.basename(path)[:-5]
