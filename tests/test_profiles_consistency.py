@@ -10,7 +10,7 @@ import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-CURRENT_ROUND = "r05"  # the round whose bench line and rocprofv3 summary this tree claims (the test read round 3's files)
+CURRENT_ROUND = "r06"  # the round whose bench line and rocprofv3 summary this tree claims (the test read round 3's files)
 
 
 def test_pmc_file_describes_the_timed_launch_shape():

@@ -131,8 +131,8 @@ for lanes in ("8", "1"):
                 un = torch.hypot(2 * (q[1] * q[3] - q[2] * q[0]), 1 - 2 * (q[1] ** 2 + q[2] ** 2))  # |world z projected on the wheel plane|
                 assert lanes == "1" and float(un[several.any(dim=0)].max()) < 0.5, "several cached points on a tire of a robot that is not lying on its side"
     print(f"lanes={lanes} Bullet-like contacts, pendulum agent + inertia 0.3 + pushes + noise: {n} steps ok, {int(sim.state[abi.S_EPISODE].sum()) - B} episode resets")
-# (round 5: Servos steps run the eight-lane Bullet-like kernel too -- a joint at its stop takes the default model's joint-stop
-# solve for that substep there --; the one-lane kernels keep limit rows and tire contacts in ONE fixed-sweep solve)
+# (round 5: Servos steps run the eight-lane Bullet-like kernel too; round 6: limit rows and tire contacts in ONE fixed-sweep solve on
+# both mappings)
 for lanes in ("8", "1"):
     os.environ["UPKIE_LANES_PER_ENV"] = lanes
     cfg = config(6)
@@ -157,5 +157,42 @@ for lanes in ("8", "1"):
             check(sim, f"bullet-like servos lanes={lanes}", k)
             assert torch.isfinite(sim.contact_manifold).all()
     print(f"lanes={lanes} Bullet-like contacts, servos random commands, no resets: {n} steps ok")
+# Round 6, the non-finite guard (include/upkie_hip.h, "Non-finite commands and states"): NaN / +-Inf / 1e30 written into a random word of
+# the action of 1 % of the envs at EVERY step (every word of a Servos action: velocity, feedforward torque, gain scales, maximum torque,
+# position; the ground / yaw velocity of the Gyropod family), NaN forces on a few envs for a while: no value that is not finite may leave
+# a step, poisoned commands are replaced and counted, poisoned states end their episode and are re-initialised by the autoreset.
+POISON = torch.tensor([float("nan"), float("inf"), float("-inf"), 1e30, -1e30])
+for lanes in ("8", "2", "1"):
+    os.environ["UPKIE_LANES_PER_ENV"] = lanes
+    for kind, width in (("pendulum", 1), ("gyropod", 2), ("servos", 36)):
+        sim = BatchedSim(config(7))
+        sim.reset()
+        n = max(steps // 5, 400)
+        force = torch.zeros((3, B), device=sim.device)
+        sim.set_external_force(force)
+        poison = POISON.to(sim.device)
+        for k in range(n):
+            if kind == "servos":
+                act = torch.zeros((B, 6, 6), device=sim.device)
+                act[:, :, 0] = float("nan")
+                act[:, :, 1] = (torch.rand((B, 6), device=sim.device) * 2 - 1) * 3.0
+                act[:, :, 3:5] = 1.0
+                act[:, :, 5] = 16.0
+            else:
+                act = (torch.rand((B, width), device=sim.device) * 2 - 1) * 0.5
+            flat = act.view(B, -1)
+            hit = torch.nonzero(torch.rand(B, device=sim.device) < 0.01).flatten()
+            flat[hit, torch.randint(0, width, (len(hit),), device=sim.device)] = poison[torch.randint(0, 5, (len(hit),), device=sim.device)]
+            if k == n // 2:
+                force[1, :8] = float("nan")  # eight envs pushed by a NaN force for 50 steps: caught and re-initialised every step
+            if k == n // 2 + 50:
+                force.zero_()
+            obs, _, term, _ = {"pendulum": sim.step_pendulum, "gyropod": sim.step_gyropod, "servos": sim.step_servos}[kind](act.view(B) if width == 1 else act)
+            assert torch.isfinite(obs).all(), f"{kind} lanes={lanes}: a non-finite observation left step {k}"
+            if k % 100 == 99:
+                assert torch.isfinite(sim.state).all(), f"{kind} lanes={lanes}: non-finite state after step {k}"
+        counts = sim.guard_counts()
+        assert counts["commands_replaced"] > 0 and counts["states_replaced"] >= 8 * 20, counts  # (a guarded env spends its next step in the autoreset, which applies no force)
+        print(f"lanes={lanes} {kind}: {n} steps with 1 % of the actions poisoned and a NaN force on 8 envs for 50 steps: finite throughout, {counts}")
 os.environ.pop("UPKIE_LANES_PER_ENV", None)
 print("soak passed")
