@@ -215,6 +215,223 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
   }
 }
 
+// The same solve for horizons 49 <= N <= 50 -- the reference's default N = 50 (mpc_balancer.py:174) -- with THREE row tiles on the
+// matrix cores (rows 0 .. 47) and the last one or two rows on the vector unit (round 6). Padded to four tiles
+// the product issued 4 x 13 = 52 MFMAs an iteration of which the fourth tile's 13 compute two useful rows out of sixteen, and the
+// launch is bound by the matrix pipe at 16384 envs. Here rows 48 + g (g = 0, 1) of U = Minv R are dot products:
+// lane (g, col) holds R[n][col] for n = g (mod 4) -- its own accumulator elements --, multiplies them with Minv[48 + j][n]
+// (13 multiply-adds per row j, issued in the shadow of the MFMAs they do not depend on), and the four lanes of a column add their
+// partial sums through two rounds of ds_bpermute (lanes col + 16 g: across the 16-lane rows, where DPP does not reach); 39 MFMAs
+// an iteration. The tail's element (horizon index 48 + g) is the B operand of k-step 12, as before. Same layout of Minv in memory
+// as mpc_tile<4> (row-permuted, lane by lane): the tail rows' coefficients are what lanes (g, 0) and (g, 4) of the fourth tile hold.
+__device__ __forceinline__ float mpc_column_sum_pair(float p0, float p1, int lane) {
+  // r_j = p_j + p_j of the lane 32 away; then each lane hands the sum its neighbour 16 away needs: lanes of group 0 want row 48
+  // (j = 0), of group 1 row 49 (j = 1); groups 2 and 3 hold padding and only contribute
+  const int a32 = ((lane ^ 32) << 2), a16 = ((lane ^ 16) << 2);
+  const float r0 = p0 + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, p0)));
+  const float r1 = p1 + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, p1)));
+  const bool odd = (lane & 16) != 0;
+  const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, odd ? r0 : r1)));
+  return (odd ? r1 : r0) + got;
+}
+
+template <int COLUMNS = 16>
+__device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
+                                              const float* __restrict__ v_target, int v_target_stride,
+                                              const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
+                                              float* __restrict__ commanded, float* __restrict__ first_input, int env0) {
+  constexpr int T = 3, KS = 13, LAYOUT_T = 4;  // (Minv is laid out for four tiles: mpc_host_setup)
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, g = lane >> 4;
+  const int B = P.num_envs;
+  const int env = env0 + col;
+  const bool live = col < COLUMNS && env < B;
+  const int N = P.n;
+  float a[T][KS];
+  {
+    const float* mine = P.minv + (size_t)lane * LAYOUT_T * LAYOUT_T * 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 v = reinterpret_cast<const float4*>(mine)[t * LAYOUT_T + s4];
+        if (4 * s4 < KS) a[t][4 * s4] = v.x;
+        if (4 * s4 + 1 < KS) a[t][4 * s4 + 1] = v.y;
+        if (4 * s4 + 2 < KS) a[t][4 * s4 + 2] = v.z;
+        if (4 * s4 + 3 < KS) a[t][4 * s4 + 3] = v.w;
+      }
+  }
+  // rows 48 and 49 of Minv at the columns n = 4 s + g this lane's elements have: Minv_perm rows 48 (i = 0) and 52 (i = 4) of tile 3
+  float mt0[KS], mt1[KS];
+  {
+    const float* row48 = P.minv + ((size_t)(16 * g + 0) * LAYOUT_T + 3) * 4 * LAYOUT_T;
+    const float* row49 = P.minv + ((size_t)(16 * g + 4) * LAYOUT_T + 3) * 4 * LAYOUT_T;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      mt0[s] = row48[s];
+      mt1[s] = row49[s];
+    }
+  }
+  float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
+  if (!(fabsf(vt) < 3.0e38f)) vt = 0.f;  // non-finite guard (step_kernels.hpp)
+  const bool resetting = live && done != nullptr && done[env] != 0.f;
+  float v_before = live ? commanded[env] : 0.f;
+  unsigned touching = live ? contact[env] : 0u;
+  asm volatile("" : "+v"(v_before), "+v"(touching));
+  float q[T][4], z[T][4], y[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      const float4 k = reinterpret_cast<const float4*>(P.kx)[n];
+      q[t][r] = k.x * x.x + k.y * x.y + k.z * x.z + k.w * x.w + P.kv[n] * vt;
+      const bool in = live && !resetting;
+      z[t][r] = in ? ws[(size_t)n * B + env] : 0.f;
+      y[t][r] = in ? ws[(size_t)(N + n) * B + env] : 0.f;
+    }
+  // the tail element of the lane: horizon index 48 + g (real for g < N - 48, padding above)
+  const int nt = 48 + g;
+  const bool tail_row = nt < N;
+  float qt = 0.f, zt = 0.f, yt = 0.f;
+  if (tail_row) {
+    const float4 k = reinterpret_cast<const float4*>(P.kx)[nt];
+    qt = k.x * x.x + k.y * x.y + k.z * x.z + k.w * x.w + P.kv[nt] * vt;
+    if (live && !resetting) {
+      zt = ws[(size_t)nt * B + env];
+      yt = ws[(size_t)(N + nt) * B + env];
+    }
+  }
+  const float rho = P.rho, bound = P.bound;
+  floatx2 rbp[T][2], qp[T][2];
+  floatx4 yv[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    yv[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      qp[t][h] = floatx2{q[t][2 * h], q[t][2 * h + 1]};
+      rbp[t][h] = floatx2{fmaf(rho, z[t][2 * h] - y[t][2 * h], -q[t][2 * h]), fmaf(rho, z[t][2 * h + 1] - y[t][2 * h + 1], -q[t][2 * h + 1])};
+    }
+  }
+  floatx2 zp[T][2];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) zp[t][h] = floatx2{z[t][2 * h], z[t][2 * h + 1]};
+  const floatx2 rho2 = floatx2{rho, rho}, two = floatx2{2.f, 2.f};
+  const float alpha = P.alpha, beta = 1.f - P.alpha;
+  const floatx2 alpha2 = floatx2{alpha, alpha}, beta2 = floatx2{beta, beta};
+  floatx2 carry[T][2];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) carry[t][h] = beta2 * (zp[t][h] + floatx2{y[t][2 * h], y[t][2 * h + 1]});
+  float rbt = fmaf(rho, zt - yt, -qt), carry_t = beta * (zt + yt);
+  for (int it = 0; it < P.iterations; ++it) {
+    floatx4 acc0[T], acc1[T];
+    // the B operand of k-step s: horizon elements 4 s + g -- tile s / 4, register s % 4 -- and, for s = 12, the tail element
+    auto rb_of = [&](int s) { return s == 12 ? rbt : ((s % 4) / 2 ? ((s % 2) ? rbp[s / 4][1].y : rbp[s / 4][1].x) : ((s % 2) ? rbp[s / 4][0].y : rbp[s / 4][0].x)); };
+    // rows 48 / 49 on the vector unit WHILE the matrix pipe works: a wavefront issues in order and a dependent MFMA holds the
+    // issue until its accumulator is ready, so the tail's multiply-adds are written BETWEEN the MFMAs of the first tile (inline
+    // asm keeps them there: two per k-step, in the 32 cycles an MFMA occupies the pipe), the column sums behind that tile --
+    // their LDS-crossbar latency passes under the second and third tile's MFMAs
+    float p0 = 0.f, p1 = 0.f, ut = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(acc0[t]) : "v"(a[t][0]), "v"(rbp[0][0].x), "v"(yv[t]));
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rbp[0][0].y));
+      if (t == 0) {
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[0]), "v"(rb_of(0)));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[0]), "v"(rb_of(0)));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[1]), "v"(rb_of(1)));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[1]), "v"(rb_of(1)));
+      }
+#pragma unroll
+      for (int s = 2; s < KS; s += 2) {
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rb_of(s)));
+        if (t == 0) {
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[s]), "v"(rb_of(s)));
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[s]), "v"(rb_of(s)));
+        }
+        if (s + 1 < KS) {
+          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rb_of(s + 1)));
+          if (t == 0) {
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[s + 1]), "v"(rb_of(s + 1)));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[s + 1]), "v"(rb_of(s + 1)));
+          }
+        }
+      }
+      if (t == 0) ut = mpc_column_sum_pair(p0, p1, lane);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) asm volatile("s_nop 12" : "+v"(acc0[t]), "+v"(acc1[t]));
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      floatx2 yn[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const floatx2 plain = (h == 0 ? floatx2{acc0[t][0], acc0[t][1]} : floatx2{acc0[t][2], acc0[t][3]}) +
+                              (h == 0 ? floatx2{acc1[t][0], acc1[t][1]} : floatx2{acc1[t][2], acc1[t][3]});  // U + y
+        const floatx2 w = __builtin_elementwise_fma(alpha2, plain, carry[t][h]);
+        carry[t][h] = beta2 * w;
+        const floatx2 zi = floatx2{__builtin_amdgcn_fmed3f(w.x, -bound, bound), __builtin_amdgcn_fmed3f(w.y, -bound, bound)};
+        yn[h] = w - zi;
+        zp[t][h] = zi;
+        rbp[t][h] = __builtin_elementwise_fma(rho2, __builtin_elementwise_fma(two, zi, -w), -qp[t][h]);
+      }
+      yv[t] = floatx4{yn[0].x, yn[0].y, yn[1].x, yn[1].y};
+    }
+    {  // the tail element, the same recurrences (padding lanes: everything stays 0)
+      const float plain = tail_row ? ut + yt : 0.f;
+      const float w = fmaf(alpha, plain, carry_t);
+      carry_t = beta * w;
+      zt = __builtin_amdgcn_fmed3f(w, -bound, bound);
+      yt = w - zt;
+      rbt = fmaf(rho, fmaf(2.f, zt, -w), -qt);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      if (live) {
+        ws[(size_t)n * B + env] = resetting ? 0.f : (r < 2 ? zp[t][0][r] : zp[t][1][r - 2]);
+        ws[(size_t)(N + n) * B + env] = resetting ? 0.f : yv[t][r];
+      }
+    }
+  if (live && tail_row) {
+    ws[(size_t)nt * B + env] = resetting ? 0.f : zt;
+    ws[(size_t)(N + nt) * B + env] = resetting ? 0.f : yt;
+  }
+  if (live && g == 0) {
+    const float u0 = zp[0][0].x;  // plan.first_input, mpc_balancer.py:307
+    if (first_input) first_input[env] = u0;
+    const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
+    float v = v_before;
+    if (resetting) {
+      v = 0.f;  // mpc_balancer.py:232
+    } else if (fallen || !touching) {
+      v = v + (dt / 0.1f) * (0.f - v);  // :295-301
+    } else {
+      v = v + u0 * dt / 2.0f;  // :305-311
+      v = fminf(fmaxf(v, -P.max_ground_velocity), P.max_ground_velocity);
+    }
+    commanded[env] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void mpc_step_tail_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
+                                                            const float* __restrict__ v_target, int v_target_stride,
+                                                            const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
+                                                            float* __restrict__ commanded, float* __restrict__ first_input) {
+  unsigned block = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
+  mpc_tile_tail(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16);
+}
+
 template <int T, int KS = 4 * T>
 __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
                                                        const float* __restrict__ v_target, int v_target_stride,

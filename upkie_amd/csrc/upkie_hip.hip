@@ -1017,7 +1017,10 @@ static int mpc_launch(UpkieMpc* mpc, float* workspace, const float* x0, const fl
     case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
     case 3: hipLaunchKernelGGL(mpc_step_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
     default:
-      if (mpc->dev.n <= 52)  // (the reference's default horizon N = 50: k-steps 13-15 of every row tile only read padding, mpc.hpp)
+      static const bool four_tiles = [] { const char* v = std::getenv("UPKIE_MPC_FOUR_TILES"); return v && v[0] == '1'; }();  // (A/B: the round-5 kernel)
+      if (mpc->dev.n >= 49 && mpc->dev.n <= 50 && !four_tiles)  // (round 6: three row tiles on the matrix cores, rows 48 / 49 on the vector unit, mpc.hpp)
+        hipLaunchKernelGGL(mpc_step_tail_kernel, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input);
+      else if (mpc->dev.n <= 52)  // (k-steps 13-15 of every row tile only read padding, mpc.hpp)
         hipLaunchKernelGGL((mpc_step_kernel<4, 13>), grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input);
       else
         hipLaunchKernelGGL(mpc_step_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input);
