@@ -143,14 +143,18 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
     for (int h = 0; h < 2; ++h) carry[t][h] = beta2 * (zp[t][h] + floatx2{y[t][2 * h], y[t][2 * h + 1]});
   for (int it = 0; it < P.iterations; ++it) {
     floatx4 acc0[T], acc1[T];
+    // Two accumulator chains per tile. Accumulators in VGPRs (gfx950's register file is
+    // unified; hipcc keeps MFMA results in AGPRs and pays twelve v_accvgpr moves per iteration, and its
+    // -amdgpu-mfma-vgpr-form option allocates a destination that PARTLY overlaps the C operand, which the hardware
+    // does not allow): written as inline asm, destination either tied to C or early-clobber. The wait states the
+    // hazard recogniser would insert are written out: VALU write -> MFMA read of rb (s_nop 1), MFMA write -> VALU
+    // read (s_nop 12).
+    // (round 6: with the k-step as the OUTER loop and the row tile as the inner one -- 2 T accumulator chains in flight instead of
+    // two -- the launch takes the same time (N = 48 / 50 / 64 at 16384 envs: 27.1 / 33.1 / 43.1 against 27.2 / 33.1 / 42.8 us,
+    // tools/mpc_time.py): the product is bound by the matrix pipe's rate, 46 cycles per 16 x 16 x 4 fp32 MFMA as measured, not by
+    // the chains; the tile-by-tile order stays)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      // Two accumulator chains per tile overlap the MFMA latencies. Accumulators in VGPRs (gfx950's register file is
-      // unified; hipcc keeps MFMA results in AGPRs and pays twelve v_accvgpr moves per iteration, and its
-      // -amdgpu-mfma-vgpr-form option allocates a destination that PARTLY overlaps the C operand, which the hardware
-      // does not allow): written as inline asm, destination either tied to C or early-clobber. The wait states the
-      // hazard recogniser would insert are written out: VALU write -> MFMA read of rb (s_nop 1), MFMA write -> VALU
-      // read (s_nop 12).
       asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(acc0[t]) : "v"(a[t][0]), "v"(rbp[0][0].x), "v"(yv[t]));
       asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rbp[0][0].y));
 #pragma unroll
@@ -224,17 +228,6 @@ __device__ __forceinline__ void mpc_tile(const MpcDev& P, float* __restrict__ ws
 // partial sums through two rounds of ds_bpermute (lanes col + 16 g: across the 16-lane rows, where DPP does not reach); 39 MFMAs
 // an iteration. The tail's element (horizon index 48 + g) is the B operand of k-step 12, as before. Same layout of Minv in memory
 // as mpc_tile<4> (row-permuted, lane by lane): the tail rows' coefficients are what lanes (g, 0) and (g, 4) of the fourth tile hold.
-__device__ __forceinline__ float mpc_column_sum_pair(float p0, float p1, int lane) {
-  // r_j = p_j + p_j of the lane 32 away; then each lane hands the sum its neighbour 16 away needs: lanes of group 0 want row 48
-  // (j = 0), of group 1 row 49 (j = 1); groups 2 and 3 hold padding and only contribute
-  const int a32 = ((lane ^ 32) << 2), a16 = ((lane ^ 16) << 2);
-  const float r0 = p0 + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, p0)));
-  const float r1 = p1 + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, p1)));
-  const bool odd = (lane & 16) != 0;
-  const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, odd ? r0 : r1)));
-  return (odd ? r1 : r0) + got;
-}
-
 template <int COLUMNS = 16>
 __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
                                               const float* __restrict__ v_target, int v_target_stride,
@@ -262,15 +255,12 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
       }
   }
   // rows 48 and 49 of Minv at the columns n = 4 s + g this lane's elements have: Minv_perm rows 48 (i = 0) and 52 (i = 4) of tile 3
-  float mt0[KS], mt1[KS];
+  floatx2 mt[KS];  // {Minv[48][4 s + g], Minv[49][4 s + g]}: both tail rows advance with ONE packed multiply-add per k-step
   {
     const float* row48 = P.minv + ((size_t)(16 * g + 0) * LAYOUT_T + 3) * 4 * LAYOUT_T;
     const float* row49 = P.minv + ((size_t)(16 * g + 4) * LAYOUT_T + 3) * 4 * LAYOUT_T;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      mt0[s] = row48[s];
-      mt1[s] = row49[s];
-    }
+    for (int s = 0; s < KS; ++s) mt[s] = floatx2{row48[s], row49[s]};
   }
   float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
   float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
@@ -329,6 +319,8 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
 #pragma unroll
     for (int h = 0; h < 2; ++h) carry[t][h] = beta2 * (zp[t][h] + floatx2{y[t][2 * h], y[t][2 * h + 1]});
   float rbt = fmaf(rho, zt - yt, -qt), carry_t = beta * (zt + yt);
+  const int addr32 = (lane ^ 32) << 2, addr16 = (lane ^ 16) << 2;  // ds_bpermute byte addresses of the lanes 32 / 16 away
+  const bool odd = (lane & 16) != 0;
   for (int it = 0; it < P.iterations; ++it) {
     floatx4 acc0[T], acc1[T];
     // the B operand of k-step s: horizon elements 4 s + g -- tile s / 4, register s % 4 -- and, for s = 12, the tail element
@@ -337,34 +329,62 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
     // issue until its accumulator is ready, so the tail's multiply-adds are written BETWEEN the MFMAs of the first tile (inline
     // asm keeps them there: two per k-step, in the 32 cycles an MFMA occupies the pipe), the column sums behind that tile --
     // their LDS-crossbar latency passes under the second and third tile's MFMAs
+    floatx2 p01 = floatx2{0.f, 0.f};  // partial sums of rows 48 / 49 over this lane's horizon elements
     float p0 = 0.f, p1 = 0.f, ut = 0.f;
+    int got0 = 0, got1 = 0, got2 = 0;
+    float keep = 0.f;
+    // (a packed multiply-add p01 += mt[s] * rb broadcast to both halves: the element 4 s + g is one HALF of a register pair of
+    // rbp -- op_sel picks it for both results -- or, for s = 12, the tail element itself)
+#define UPKIE_TAIL_STEP(S)                                                                                                             \
+  do {                                                                                                                                 \
+    if ((S) == 12) {                                                                                                                   \
+      const floatx2 both = floatx2{rbt, rbt};                                                                                          \
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p01) : "v"(mt[12]), "v"(both));                                                \
+    } else if ((S) % 2 == 0) {                                                                                                         \
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p01) : "v"(mt[(S)]), "v"(rbp[(S) / 4][((S) % 4) / 2]));      \
+    } else {                                                                                                                           \
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p01) : "v"(mt[(S)]), "v"(rbp[(S) / 4][((S) % 4) / 2]));         \
+    }                                                                                                                                  \
+  } while (0)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(acc0[t]) : "v"(a[t][0]), "v"(rbp[0][0].x), "v"(yv[t]));
       asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc1[t]) : "v"(a[t][1]), "v"(rbp[0][0].y));
       if (t == 0) {
-        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[0]), "v"(rb_of(0)));
-        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[0]), "v"(rb_of(0)));
-        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[1]), "v"(rb_of(1)));
-        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[1]), "v"(rb_of(1)));
+        UPKIE_TAIL_STEP(0);
+        UPKIE_TAIL_STEP(1);
       }
 #pragma unroll
       for (int s = 2; s < KS; s += 2) {
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc0[t]) : "v"(a[t][s]), "v"(rb_of(s)));
-        if (t == 0) {
-          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[s]), "v"(rb_of(s)));
-          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[s]), "v"(rb_of(s)));
-        }
+        if (t == 0) UPKIE_TAIL_STEP(s);
         if (s + 1 < KS) {
           asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc1[t]) : "v"(a[t][s + 1]), "v"(rb_of(s + 1)));
-          if (t == 0) {
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p0) : "v"(mt0[s + 1]), "v"(rb_of(s + 1)));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p1) : "v"(mt1[s + 1]), "v"(rb_of(s + 1)));
-          }
+          if (t == 0) UPKIE_TAIL_STEP(s + 1);
         }
       }
-      if (t == 0) ut = mpc_column_sum_pair(p0, p1, lane);
+      if (t == 0) {
+        p0 = p01.x;
+        p1 = p01.y;
+      }
+      // The column sums, two rounds of exchanges, each ISSUED behind one tile's MFMAs and COLLECTED behind the next
+      // one's: written as inline asm with their own waits -- left to the compiler the wait lands right behind the exchange and
+      // the matrix pipe drains for two LDS round trips an iteration (measured: 37.1 us per launch at 16384 envs, what the
+      // thirteen MFMAs of the fourth tile had cost)
+      // (round 1: r_j = p_j + p_j of the lane 32 away; round 2: each lane hands the sum its neighbour 16 away wants -- lanes of
+      // group 0 want row 48, of group 1 row 49; groups 2 and 3 hold padding and only contribute)
+      if (t == 0) {
+        asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4" : "=&v"(got0), "=&v"(got1) : "v"(addr32), "v"(p0), "v"(p1));
+      } else if (t == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(p0), "+v"(p1) : "v"(got0), "v"(got1));
+        const float send = odd ? p0 : p1;
+        keep = odd ? p1 : p0;
+        asm volatile("ds_bpermute_b32 %0, %1, %2" : "=&v"(got2) : "v"(addr16), "v"(send));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, %1, %2" : "=v"(ut) : "v"(keep), "v"(got2));
+      }
     }
+#undef UPKIE_TAIL_STEP
 #pragma unroll
     for (int t = 0; t < T; ++t) asm volatile("s_nop 12" : "+v"(acc0[t]), "+v"(acc1[t]));
 #pragma unroll
@@ -423,6 +443,7 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
   }
 }
 
+#if !defined(UPKIE_STEP_INSTANCES_ONLY)  // (a non-template kernel: the C-ABI's translation unit alone defines it)
 __global__ __launch_bounds__(64) void mpc_step_tail_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
                                                             const float* __restrict__ v_target, int v_target_stride,
                                                             const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
@@ -431,6 +452,7 @@ __global__ __launch_bounds__(64) void mpc_step_tail_kernel(MpcDev P, float* __re
   if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
   mpc_tile_tail(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16);
 }
+#endif
 
 template <int T, int KS = 4 * T>
 __global__ __launch_bounds__(64) void mpc_step_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
