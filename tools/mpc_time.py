@@ -1,8 +1,10 @@
-"""Time of one launch of the MPC balancer's ADMM kernel by horizon and batch size (round 6): N = 48 (three MFMA row tiles),
-N = 50 (the reference's default: three tiles + rows 48 / 49 on the vector unit; `UPKIE_MPC_FOUR_TILES=1` in the environment
-selects round 5's padding to four tiles, the A/B of profiles/r06_mpc_tail.txt) and N = 64 (four tiles).
+"""Time of one launch of the MPC balancer's ADMM kernel by horizon and batch size (round 6): N = 16 (fp32 MFMA, one row tile),
+N = 48 / 50 (the reference's default) / 64 on the fp16 matrix path with two terms per operand (mpc_tile_h). `UPKIE_MPC_FP32=1`
+in the environment selects the fp32 MFMA kernels (N = 50: three row tiles + rows 48 / 49 on the vector unit; with
+`UPKIE_MPC_FOUR_TILES=1` as well, round 5's padding to four tiles): the A/Bs of profiles/r06_mpc_tail.txt and
+profiles/r06_mpc_f16_split.txt.
 
-Usage (GPU box): python tools/mpc_time.py; UPKIE_MPC_FOUR_TILES=1 python tools/mpc_time.py
+Usage (GPU box): python tools/mpc_time.py; UPKIE_MPC_FP32=1 python tools/mpc_time.py
 """
 import os
 import sys
@@ -16,7 +18,9 @@ from upkie_amd import abi  # noqa: E402
 from upkie_amd.mpc import BatchedMpc  # noqa: E402
 
 if __name__ == "__main__":
-    print("four tiles at N = 50" if os.environ.get("UPKIE_MPC_FOUR_TILES") == "1" else "three tiles + two rows on the vector unit at N = 50")
+    fp32 = os.environ.get("UPKIE_MPC_FP32") == "1"
+    four = os.environ.get("UPKIE_MPC_FOUR_TILES") == "1"
+    print("horizons > 16: " + (("fp32 MFMA, " + ("four tiles at N = 50" if four else "three tiles + two rows on the vector unit at N = 50")) if fp32 else "fp16 MFMA, two terms per operand"))
     for N in (16, 48, 50, 64):
         for B in (2048, 16384):
             cfg = abi.default_mpc_config(B, N)

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,9 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 struct MpcDev {
   const float* minv;  // [Np][Np] row-permuted
+  const float* gx;    // [Np][4]  Minv Kx  and
+  const float* gv;    // [Np]     Minv kv: the constant part of every iteration's product, u_q = Minv q (mpc_tile_h)
+  const void* minv_h;  // the same matrix as two fp16 terms (hi + lo) in the A-operand layout of v_mfma_f32_16x16x32_f16, horizons > 16 (mpc_tile_h)
   const float* kx;    // [Np][4]
   const float* kv;    // [Np]
   int num_envs;
@@ -443,6 +447,207 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
   }
 }
 
+// The same solve for horizons N > 16 with the product on the fp16 matrix path (round 6). v_mfma_f32_16x16x4_f32 runs at the
+// vector unit's own fp32 rate -- 32 cycles for 2048 multiply-adds -- and a wavefront that has its SIMD to itself issues nothing
+// else in its shadow (tools/microbench/mfma_shadow.hip: 32.4 cycles per MFMA alone, 52 with two vector instructions behind
+// each): the N = 50 iteration was 39 of them + 70 vector instructions, one after the other. v_mfma_f32_16x16x32_f16 does eight
+// times the multiply-adds in half the time, and two fp16 terms carry 22 of fp32's 24 significand bits:
+//   Minv = Ah + Al (split once on the host, from fp64),   r = rh + rl (split every iteration: rh = fp16(r),
+//   rl = fp16(r - rh), the difference is exact in fp32; round to nearest),   Minv r ~= Ah rh + Ah rl + Al rh   (fp32 accumulation; the term
+//   Al rl, 2^-22 of the product, is dropped).
+// Against the fp64 checker this is as close as the fp32 product is (N = 50, 30 iterations: first input within 3e-3 m/s2 on the
+// parity test's inputs, 9e-3 on its saturating ones, fp32: 4e-3 / 1e-2 -- the iteration's own conditioning, not the product's:
+// profiles/r06_mpc_f16_split.txt). Range: |r| < 65504 (the parity test's largest is 1e3; beyond, the conversion saturates and
+// the env -- a robot far outside anything the balancer is for -- gets a wrong but finite plan).
+// Layout: K-step j of the 32-wide product reads, from lane (g, col), the eight elements the lane itself holds in row tiles 2 j
+// and 2 j + 1 (four registers each) -- as in mpc_tile no element ever changes lanes --, so the permuted column index of element
+// (t, g, r) is 32 (t / 2) + 8 g + 4 (t % 2) + r; rows as before (mpc_host_setup).
+typedef int intx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mpc_split_pair(floatx2 r, int& hi, int& lo) {
+  // round to NEAREST, both terms (v_cvt_pk_f16_f32, new on gfx950): with v_cvt_pkrtz_f16_f32 every term errs towards zero and
+  // the errors of a row's fifty products add up instead of averaging out -- 6e-2 m/s2 on the parity test's saturating steps
+  // where this gives 9e-3, the fp32 product's figure
+  float lx, ly;  // r - float(rh), exact, one instruction each: a mixed-precision multiply-add reads the fp16 half directly
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(r.x), "v"(r.y));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lx) : "v"(hi), "v"(r.x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ly) : "v"(hi), "v"(r.y));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(lx), "v"(ly));
+}
+
+template <int T>
+__device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
+                                           const float* __restrict__ v_target, int v_target_stride,
+                                           const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
+                                           float* __restrict__ commanded, float* __restrict__ first_input, int env0) {
+  constexpr int KJ = (T + 1) / 2;  // 32-wide K-steps
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, g = lane >> 4;
+  const int B = P.num_envs;
+  const int env = env0 + col;
+  const bool live = env < B;
+  const int N = P.n;
+  intx4 ah[T][KJ], al[T][KJ];
+  {
+    const intx4* mine = reinterpret_cast<const intx4*>(P.minv_h) + (size_t)lane * T * KJ * 2;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        ah[t][j] = mine[(t * KJ + j) * 2];
+        al[t][j] = mine[(t * KJ + j) * 2 + 1];
+      }
+  }
+  float4 x = live ? reinterpret_cast<const float4*>(x0)[env] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float vt = live ? v_target[(size_t)env * v_target_stride] : 0.f;
+  if (!(fabsf(vt) < 3.0e38f)) vt = 0.f;  // non-finite guard (step_kernels.hpp)
+  const bool resetting = live && done != nullptr && done[env] != 0.f;
+  float v_before = live ? commanded[env] : 0.f;
+  unsigned touching = live ? contact[env] : 0u;
+  asm volatile("" : "+v"(v_before), "+v"(touching));
+  // u_q = Minv q = (Minv Kx) x0 + (Minv kv) v*, from the host's fp64 products: see "the iteration" below
+  float uq[T][4], z[T][4], y[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      const float4 k = reinterpret_cast<const float4*>(P.gx)[n];
+      uq[t][r] = k.x * x.x + k.y * x.y + k.z * x.z + k.w * x.w + P.gv[n] * vt;
+      const bool in = live && n < N && !resetting;
+      z[t][r] = in ? ws[(size_t)n * B + env] : 0.f;
+      y[t][r] = in ? ws[(size_t)(N + n) * B + env] : 0.f;
+    }
+  // The iteration, re-associated (round 6): U = Minv (rho (z - y) - q) is computed as Minv r - u_q with r = rho (z - y) and the
+  // constant u_q = Minv q taken out of the loop. In the first form the two parts of the right-hand side cancel to a thousandth
+  // of their size in every product (|Minv| reaches 490 at rho = 1e-3, |q| 180, U is ~10) and fp32 keeps three digits of U less
+  // than it could: against the fp64 checker the first input of the fp32 kernels above is 4e-3 .. 1e-2 m/s2 off on the parity
+  // test's inputs at N = 50 (5e-2 at N = 49). In this form the product's operand is small (|r| < 1) and u_q comes from five
+  // multiply-adds on the host's fp64 Minv Kx, Minv kv: 2e-6 with the same number of instructions (the -q of the right-hand side
+  // becomes a -alpha u_q in the relaxed update). Same recurrences otherwise (mpc_tile): w = alpha (U + y) + (1 - alpha) w_prev,
+  // z = clip(w), y' = w - z, r' = rho (2 z - w).
+  // r is carried TIMES 64 and Minv divided by 64 on the host (powers of two: nothing rounds): fp16's normal range, 6e-5 .. 65504,
+  // then holds both terms of |r| from 2e-3 to 1e3; u_q is clamped once, so that a state far outside anything the balancer is for
+  // (|w| follows |u_q|) gives a wrong but finite plan.
+  constexpr float kScale = 64.f, kLargest = 1.0e5f;
+  const float rho = P.rho * kScale, bound = P.bound;
+  floatx2 rbp[T][2], nauq[T][2], zp[T][2], carry[T][2];
+  floatx4 yv[T];
+  const floatx2 rho2 = floatx2{rho, rho}, two = floatx2{2.f, 2.f};
+  const floatx2 alpha2 = floatx2{P.alpha, P.alpha}, beta2 = floatx2{1.f - P.alpha, 1.f - P.alpha};
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    yv[t] = floatx4{y[t][0], y[t][1], y[t][2], y[t][3]};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      nauq[t][h] = floatx2{-P.alpha * __builtin_amdgcn_fmed3f(uq[t][2 * h], -kLargest, kLargest), -P.alpha * __builtin_amdgcn_fmed3f(uq[t][2 * h + 1], -kLargest, kLargest)};
+      zp[t][h] = floatx2{z[t][2 * h], z[t][2 * h + 1]};
+      const floatx2 yh = floatx2{y[t][2 * h], y[t][2 * h + 1]};
+      rbp[t][h] = rho2 * (zp[t][h] - yh);
+      carry[t][h] = __builtin_elementwise_fma(beta2, zp[t][h] + yh, nauq[t][h]);  // (1 - alpha) x the previous relaxed w, - alpha u_q
+    }
+  }
+  for (int it = 0; it < P.iterations; ++it) {
+    // the right-hand side as two fp16 terms, in B-operand order: register 2 (t % 2) + h of K-step t / 2
+    intx4 bh[KJ], bl[KJ];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) bh[j] = bl[j] = intx4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int hi, lo;
+        mpc_split_pair(rbp[t][h], hi, lo);
+        bh[t / 2][2 * (t % 2) + h] = hi;
+        bl[t / 2][2 * (t % 2) + h] = lo;
+      }
+    // six rounds (three with one K-step) over the tiles, row tile innermost: MFMAs on one accumulator are T apart. Accumulators
+    // in VGPRs, destination tied to C or early-clobber, wait states written out (see mpc_tile)
+    floatx4 acc[T];
+    // every term of the split is complete, and four wait states old, before the first MFMA: the compiler does not know that the
+    // asm statements below read their operands as MFMAs do, and sinks a conversion right in front of its consumer otherwise
+    // (tools/microbench/f16_split_check.hip: a B register written by the instruction in front of the MFMA is read stale)
+    if (KJ > 1)
+      asm volatile("s_nop 3" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[KJ - 1]), "+v"(bl[KJ - 1]));
+    else
+      asm volatile("s_nop 3" : "+v"(bh[0]), "+v"(bl[0]));
+#pragma unroll
+    for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc[t]) : "v"(ah[t][0]), "v"(bh[0]), "v"(yv[t]));
+    if (KJ > 1) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(ah[t][KJ - 1]), "v"(bh[KJ - 1]));
+    }
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(ah[t][j]), "v"(bl[j]));
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(al[t][j]), "v"(bh[j]));
+    // MFMA result -> vector unit: 11 wait states cover either pass count; tile 0's last MFMA is T - 1 MFMAs (four wait states
+    // each, at least) back, the later tiles' are read behind the updates of the tiles in front of them
+    if (T >= 4) {
+      asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[T - 1]));
+    } else if (T == 3) {
+      asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[T - 1]));
+    } else {
+      asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[T - 1]));
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t > 0) asm volatile("" : "+v"(acc[t]), "+v"(rbp[t - 1][1]));  // (tile t's accumulators are read behind tile t - 1's update)
+      floatx2 yn[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const floatx2 plain = h == 0 ? floatx2{acc[t][0], acc[t][1]} : floatx2{acc[t][2], acc[t][3]};  // Minv r + y
+        const floatx2 w = __builtin_elementwise_fma(alpha2, plain, carry[t][h]);
+        carry[t][h] = __builtin_elementwise_fma(beta2, w, nauq[t][h]);
+        const floatx2 zi = floatx2{__builtin_amdgcn_fmed3f(w.x, -bound, bound), __builtin_amdgcn_fmed3f(w.y, -bound, bound)};
+        yn[h] = w - zi;
+        zp[t][h] = zi;
+        rbp[t][h] = rho2 * __builtin_elementwise_fma(two, zi, -w);
+      }
+      yv[t] = floatx4{yn[0].x, yn[0].y, yn[1].x, yn[1].y};
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = mpc_index(t, g, r);
+      if (live && n < N) {
+        ws[(size_t)n * B + env] = resetting ? 0.f : (r < 2 ? zp[t][0][r] : zp[t][1][r - 2]);
+        ws[(size_t)(N + n) * B + env] = resetting ? 0.f : yv[t][r];
+      }
+    }
+  if (live && g == 0) {
+    const float u0 = zp[0][0].x;  // plan.first_input, mpc_balancer.py:307
+    if (first_input) first_input[env] = u0;
+    const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
+    float v = v_before;
+    if (resetting) {
+      v = 0.f;  // mpc_balancer.py:232
+    } else if (fallen || !touching) {
+      v = v + (dt / 0.1f) * (0.f - v);  // :295-301
+    } else {
+      v = v + u0 * dt / 2.0f;  // :305-311
+      v = fminf(fmaxf(v, -P.max_ground_velocity), P.max_ground_velocity);
+    }
+    commanded[env] = v;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void mpc_step_h_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
+                                                         const float* __restrict__ v_target, int v_target_stride,
+                                                         const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
+                                                         float* __restrict__ commanded, float* __restrict__ first_input) {
+  unsigned block = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) block = (block & 7u) * (gridDim.x >> 3) + (block >> 3);
+  mpc_tile_h<T>(P, ws, x0, v_target, v_target_stride, contact, done, dt, commanded, first_input, (int)block * 16);
+}
+
 #if !defined(UPKIE_STEP_INSTANCES_ONLY)  // (a non-template kernel: the C-ABI's translation unit alone defines it)
 __global__ __launch_bounds__(64) void mpc_step_tail_kernel(MpcDev P, float* __restrict__ ws, const float* __restrict__ x0,
                                                             const float* __restrict__ v_target, int v_target_stride,
@@ -484,7 +689,8 @@ __global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __re
 // condensing, as qpmpc's WheeledInvertedPendulum.build_mpc_problem + MPCQP do
 // (third-party, restated from the published algorithm).
 inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* minv_perm, std::vector<float>* kx,
-                           std::vector<float>* kv, std::string* why) {
+                           std::vector<float>* kv, std::string* why, std::vector<uint16_t>* minv_h = nullptr, std::vector<float>* gx = nullptr,
+                           std::vector<float>* gv = nullptr) {
   const int N = c.nb_timesteps;
   const double T = c.sampling_period, g = 9.81;
   const double omega = std::sqrt(g / c.leg_length);
@@ -580,6 +786,49 @@ inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* 
   for (int n = 0; n < N; ++n) {
     for (int col = 0; col < 4; ++col) (*kx)[(size_t)n * 4 + col] = (float)Kx[(size_t)n * 4 + col];
     (*kv)[n] = (float)Kv[n];
+  }
+  if (gx && gv) {  // Minv Kx, Minv kv (mpc_tile_h's u_q)
+    gx->assign((size_t)np * 4, 0.f);
+    gv->assign(np, 0.f);
+    for (int n = 0; n < N; ++n) {
+      double sv = 0.0, sx[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = 0; k < N; ++k) {
+        const double m = Minv[(size_t)n * N + k];
+        sv += m * Kv[k];
+        for (int col = 0; col < 4; ++col) sx[col] += m * Kx[(size_t)k * 4 + col];
+      }
+      (*gv)[n] = (float)sv;
+      for (int col = 0; col < 4; ++col) (*gx)[(size_t)n * 4 + col] = (float)sx[col];
+    }
+  }
+  if (minv_h) {
+    // mpc_tile_h's A operands: lane (g, i) holds, for row tile t and K-step j, the eight columns 32 j + 8 g + c of permuted row
+    // 16 t + i -- column slot c is element (row tile 2 j + c / 4, group g, register c % 4) -- as fp16 hi and lo terms:
+    // [lane][t][j][hi | lo][c], 16 bytes per term
+    const int kj = (tiles + 1) / 2;
+    minv_h->assign((size_t)64 * tiles * kj * 2 * 8, 0);
+    auto entry = [&](int row, int col) { return row < N && col < N ? Minv[(size_t)row * N + col] : (row == col ? 1.0 / (1.0 + c.admm_rho) : 0.0); };
+    auto bits = [](_Float16 h) {
+      uint16_t u;
+      std::memcpy(&u, &h, sizeof(u));
+      return u;
+    };
+    for (int lane = 0; lane < 64; ++lane) {
+      const int group = lane / 16, i = lane % 16;
+      for (int t = 0; t < tiles; ++t) {
+        const int row = 16 * t + 4 * (i % 4) + i / 4;
+        for (int j = 0; j < kj; ++j)
+          for (int slot = 0; slot < 8; ++slot) {
+            const int tk = 2 * j + slot / 4;
+            const double v = (tk < tiles ? entry(row, 16 * tk + 4 * (slot % 4) + group) : 0.0) / 64.0;  // (mpc_tile_h carries 64 r)
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (double)hi);
+            const size_t at = ((((size_t)lane * tiles + t) * kj + j) * 2) * 8 + slot;
+            (*minv_h)[at] = bits(hi);
+            (*minv_h)[at + 8] = bits(lo);
+          }
+      }
+    }
   }
   return true;
 }

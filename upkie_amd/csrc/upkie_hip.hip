@@ -924,6 +924,9 @@ struct UpkieMpc {
   MpcDev dev;
   int tiles = 0;
   float* d_minv = nullptr;
+  void* d_minv_h = nullptr;
+  float* d_gx = nullptr;
+  float* d_gv = nullptr;
   float* d_kx = nullptr;
   float* d_kv = nullptr;
   std::string error;
@@ -950,8 +953,11 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   mpc->tiles = (config->nb_timesteps + 15) / 16;
   const int np = 16 * mpc->tiles;
   std::vector<float> minv, kx, kv;
+  std::vector<uint16_t> minv_h;
+  std::vector<float> gx, gv;
   std::string why;
-  if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why)) {
+  const bool fp16_path = mpc->tiles > 1;
+  if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why, fp16_path ? &minv_h : nullptr, fp16_path ? &gx : nullptr, fp16_path ? &gv : nullptr)) {
     delete mpc;
     return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
@@ -961,12 +967,23 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   if (err == hipSuccess) err = hipMemcpy(mpc->d_minv, minv.data(), minv.size() * sizeof(float), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMemcpy(mpc->d_kx, kx.data(), kx.size() * sizeof(float), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMemcpy(mpc->d_kv, kv.data(), kv.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (err == hipSuccess && !minv_h.empty()) {
+    err = hipMalloc(&mpc->d_minv_h, minv_h.size() * sizeof(uint16_t));
+    if (err == hipSuccess) err = hipMemcpy(mpc->d_minv_h, minv_h.data(), minv_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc(&mpc->d_gx, gx.size() * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&mpc->d_gv, gv.size() * sizeof(float));
+    if (err == hipSuccess) err = hipMemcpy(mpc->d_gx, gx.data(), gx.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(mpc->d_gv, gv.data(), gv.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (err != hipSuccess) {
     std::string msg = std::string("hipMalloc/hipMemcpy: ") + hipGetErrorString(err);
     upkie_mpc_destroy(mpc);
     return mpc_fail(nullptr, UPKIE_ERR_HIP, msg);
   }
   mpc->dev.minv = mpc->d_minv;
+  mpc->dev.minv_h = mpc->d_minv_h;
+  mpc->dev.gx = mpc->d_gx;
+  mpc->dev.gv = mpc->d_gv;
   mpc->dev.kx = mpc->d_kx;
   mpc->dev.kv = mpc->d_kv;
   mpc->dev.num_envs = config->num_envs;
@@ -984,6 +1001,9 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
 extern "C" int upkie_mpc_destroy(UpkieMpc* mpc) {
   if (!mpc) return UPKIE_OK;
   if (mpc->d_minv) (void)hipFree(mpc->d_minv);
+  if (mpc->d_minv_h) (void)hipFree(mpc->d_minv_h);
+  if (mpc->d_gx) (void)hipFree(mpc->d_gx);
+  if (mpc->d_gv) (void)hipFree(mpc->d_gv);
   if (mpc->d_kx) (void)hipFree(mpc->d_kx);
   if (mpc->d_kv) (void)hipFree(mpc->d_kv);
   delete mpc;
@@ -1012,6 +1032,18 @@ static int mpc_launch(UpkieMpc* mpc, float* workspace, const float* x0, const fl
   if (!(dt / 0.1 < 0.5)) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
   dim3 grid((unsigned)((mpc->dev.num_envs + 15) / 16)), block(64);
   hipStream_t st = (hipStream_t)stream;
+  // horizons > 16: the product on the fp16 matrix path, two terms per operand (mpc_tile_h); UPKIE_MPC_FP32=1 selects the fp32
+  // MFMA kernels of rounds 2-6 (A/B, profiles/r06_mpc_f16_split.txt)
+  static const bool fp32_product = [] { const char* v = std::getenv("UPKIE_MPC_FP32"); return v && v[0] == '1'; }();
+  if (mpc->tiles > 1 && !fp32_product) {
+    switch (mpc->tiles) {
+      case 2: hipLaunchKernelGGL(mpc_step_h_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+      case 3: hipLaunchKernelGGL(mpc_step_h_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+      default: hipLaunchKernelGGL(mpc_step_h_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
+    }
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? UPKIE_OK : mpc_fail(mpc, UPKIE_ERR_HIP, hipGetErrorString(err));
+  }
   switch (mpc->tiles) {
     case 1: hipLaunchKernelGGL(mpc_step_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
     case 2: hipLaunchKernelGGL(mpc_step_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
