@@ -397,12 +397,12 @@ def test_c3_timed_window_with_resampled_targets_matches_the_oracle_doubles(B, st
         assert np.quantile(worst_v, 0.5) <= 2e-5 and np.quantile(worst_v, 0.99) <= 1e-4 and worst_v.max() <= 5e-4, report  # measured at 4096 / 16384 envs: 2.8e-6 / 2.7e-6, 1.0e-5 / 9.4e-6, 2.6e-5 / 3.3e-5
         assert np.quantile(np.abs(pitch(sg) - pitch(sc)), 0.99) <= 2e-5, report  # measured: 7e-7 / 8e-7
     else:
-        # N = 50 (30 over-relaxed iterations on four MFMA tiles): the condensed QP is stiffer and 30 fp32 iterations sit
-        # further from the fp64 twin's than 15 do at N = 16 -- commanded velocity within 3e-4 m/s for the typical env, 2e-3
-        # for every env over the whole window (measured: 9.9e-5 median, 3.2e-4 p99, 4.3e-4 max; the reference's own solver
-        # tolerance leaves 4.7e-3 m/s per step open)
-        assert np.quantile(worst_v, 0.5) <= 3e-4 and np.quantile(worst_v, 0.99) <= 1e-3 and worst_v.max() <= 2e-3, report
-        assert np.quantile(np.abs(pitch(sg) - pitch(sc)), 0.99) <= 5e-5, report  # measured: 1.6e-5
+        # N = 50 (30 over-relaxed iterations on the fp16 matrix path, the constant part of the product out of the loop:
+        # round 6): the same bounds as N = 16 (measured at 2048 / 16384 envs: 2.7e-6 / 2.5e-6 median, 1.0e-5 / 1.1e-5 p99,
+        # 2.8e-5 / 4.8e-5 max; the fp32 kernels of round 5, whose products cancelled three digits away, were 9.9e-5 /
+        # 3.2e-4 / 4.3e-4; the reference's own solver tolerance leaves 4.7e-3 m/s per step open)
+        assert np.quantile(worst_v, 0.5) <= 2e-5 and np.quantile(worst_v, 0.99) <= 1e-4 and worst_v.max() <= 5e-4, report
+        assert np.quantile(np.abs(pitch(sg) - pitch(sc)), 0.99) <= 2e-5, report  # measured: 6e-7 (round 5: 1.6e-5)
 
 
 # ------------------------------------------------------------------ C5
