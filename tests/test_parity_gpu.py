@@ -264,7 +264,7 @@ def test_randomization_buffers():
     assert err["pos"] < 2e-4, err
 
 
-@pytest.mark.parametrize("N", [16, 32, 48, 49, 50, 64])  # (one fp32 row tile; above 16: the fp16 matrix path on two, three, four row tiles)
+@pytest.mark.parametrize("N", [16, 17, 32, 33, 48, 49, 50, 64])  # (one fp32 row tile; above 16: the fp16 matrix path on two, three, four row tiles)
 def test_mpc_step_matches_oracle(N):
     """MFMA ADMM kernel vs the fp64 oracle ADMM (same recurrences) and vs the
     exact QP solution. Tolerance on plan.first_input: 2e-3 * a_max (SURVEY.md
@@ -309,6 +309,19 @@ def test_mpc_step_matches_oracle(N):
     v = mpc.commanded_velocity.cpu().numpy()
     assert np.all(v[::2] == 0.0) and np.any(v[1::2] != 0.0)
     assert float(mpc.workspace[:, ::2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("four_tiles", ["0", "1"])
+def test_mpc_fp32_kernels_of_the_long_horizons(four_tiles):
+    """`UPKIE_MPC_FP32=1` (read once per process): the fp32 MFMA kernels for horizons > 16, kept as the A/B partners of
+    the fp16 matrix path -- three row tiles + vector tail at N = 49 / 50, or round 5's four tiles."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, UPKIE_MPC_FP32="1", UPKIE_MPC_FOUR_TILES=four_tiles)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mpc_fp32_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_packed_records_match_unpacked_step():
