@@ -143,9 +143,9 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     upkie_base_velocity.py:164-202), horizon N = 16 (T = 0.02 s), leg length
     0.58 m, a_max 10, v_max 3 (mpc_balancer.py:170-178), target
     v* ~ U(-0.5, 0.5) per env RESAMPLED every 400 steps, yaw rate 0, warm
-    started over-relaxed ADMM iterations on the matrix cores (15 at N <= 16 on
-    the fp32 MFMA, 30 beyond on the fp16 one with two terms per operand:
-    csrc/mpc.hpp), NEXT_STEP autoreset. `horizon` = 50: the reference's own default
+    started over-relaxed ADMM iterations on the matrix cores (15 at N <= 16, 30
+    beyond; v_mfma_f32_16x16x32_f16 on two fp16 terms per operand with fp32
+    accumulation: csrc/mpc.hpp), NEXT_STEP autoreset. `horizon` = 50: the reference's own default
     (mpc_balancer.py:174), reported beside BASELINE's N = 16 as `n50`."""
     import numpy as np
     import torch
@@ -169,7 +169,7 @@ def secondary_c3(envs: int = 16384, steps: int = STEADY_STEPS, warmup: int = STE
     wall, device_ms = _timed_loop(step, steps, warmup)
     us = wall / steps * 1e6
     out = {
-        "config": f"C3: UpkieBaseVelocity + MPC balancer N = {horizon} ({int(env.mpc_balancer.config.admm_iterations)} over-relaxed ADMM iterations, {'v_mfma_f32_16x16x4_f32' if horizon <= 16 else 'v_mfma_f32_16x16x32_f16 on two fp16 terms per operand'}), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
+        "config": f"C3: UpkieBaseVelocity + MPC balancer N = {horizon} ({int(env.mpc_balancer.config.admm_iterations)} over-relaxed ADMM iterations, v_mfma_f32_16x16x32_f16 on two fp16 terms per operand), v* ~ U(-0.5, 0.5) resampled every 400 steps, NEXT_STEP autoreset; "
                   + ("ONE launch per env.step() (upkie_sim_step_base_velocity_mpc: the balancer's QPs solved by the step's own wavefronts)" if env.fuse_mpc and horizon <= 16
                      else "two launches per env.step() (the balancer's kernel, then the step)") + ", Python loop",
         "horizon": horizon,

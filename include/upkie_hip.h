@@ -680,12 +680,12 @@ int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded_velocity,
  * contact flags; commanded_velocity[B] in/out; first_input[B] (may be NULL)
  * receives plan.first_input.
  * Arithmetic: fixed-iteration ADMM on the condensed QP, its dense product on the
- * matrix cores -- fp32 MFMA for horizons up to 16, above (the reference's default
- * N = 50) v_mfma_f32_16x16x32_f16 on two fp16 terms per operand with fp32
+ * matrix cores: v_mfma_f32_16x16x32_f16 on two fp16 terms per operand with fp32
  * accumulation, the constant part of the product (Minv q) computed once per step
  * from fp64 host products (csrc/mpc.hpp: first input within 5e-4 m/s2 of the fp64
- * oracle's at N = 32 .. 64). The environment variable UPKIE_MPC_FP32=1, read at the
- * first step of the process, keeps the fp32 MFMA kernels for horizons > 16 (A/B). */
+ * oracle's at N = 16 .. 64). The environment variable UPKIE_MPC_FP32=1, read at the
+ * first step of the process, selects the fp32 MFMA kernels of earlier rounds for this
+ * entry point (A/B). */
 int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0,
                    const float* target_velocity, const uint8_t* contact,
                    double dt, float* commanded_velocity, float* first_input,

@@ -264,14 +264,13 @@ def test_randomization_buffers():
     assert err["pos"] < 2e-4, err
 
 
-@pytest.mark.parametrize("N", [16, 17, 32, 33, 48, 49, 50, 64])  # (one fp32 row tile; above 16: the fp16 matrix path on two, three, four row tiles)
+@pytest.mark.parametrize("N", [16, 17, 32, 33, 48, 49, 50, 64])  # (one .. four row tiles; 17 / 33 / 49: a tile that is mostly padding)
 def test_mpc_step_matches_oracle(N):
     """MFMA ADMM kernel vs the fp64 oracle ADMM (same recurrences) and vs the
-    exact QP solution. Tolerance on plan.first_input: 2e-3 * a_max (SURVEY.md
-    A.9; ProxQP itself only guarantees eps_abs = 1e-3) for the fp32 kernel of N = 16; 1e-4 * a_max for the horizons
-    above, whose kernel takes the constant part of the product out of the loop (measured, round 6: 2e-6 m/s2 on the
-    first two steps, 3e-4 .. 5e-4 on the saturating ones at N = 49 / 50; the fp32 kernels of rounds 2-6 were
-    5e-3 .. 1e-2 there, 5e-2 at N = 49)."""
+    exact QP solution. Tolerance on plan.first_input: 1e-4 * a_max = 1e-3 m/s2 (SURVEY.md A.9 asks 2e-3 * a_max;
+    ProxQP itself only guarantees eps_abs = 1e-3). Measured, round 6 (fp16 matrix path, the constant part of the product
+    out of the loop): 2e-6 m/s2 on the first two steps at every horizon, 3e-4 .. 5e-4 on the saturating ones at
+    N = 49 / 50; the fp32 kernels of rounds 2-6 were 2e-5 at N = 16, 5e-3 .. 1e-2 at N = 50, 5e-2 at N = 49."""
     import ctypes as C
 
     from oracle import oracle as O
@@ -292,17 +291,12 @@ def test_mpc_step_matches_oracle(N):
         contact = (rng.uniform(size=B) > 0.1).astype(np.uint8)
         O.lib().oracle_mpc_step(C.byref(cfg), p(ws), p(np.ascontiguousarray(x0)), p(vt), p(contact), C.c_double(0.005), p(v_o), p(first_o))
         v_h, first_h = mpc.step(torch.from_numpy(x0).float(), torch.from_numpy(vt).float(), torch.from_numpy(contact), dt=0.005)
-        assert np.max(np.abs(first_h.cpu().numpy() - first_o)) <= (2e-3 if N == 16 else 1e-4) * cfg.max_ground_accel
-        assert np.max(np.abs(v_h.cpu().numpy() - v_o)) <= (1e-4 if N == 16 else 5e-6)
-    # the tail of the horizon is a nearly flat direction of the cost (P's small
-    # eigenvalues are 1e-3): warm starts agree loosely there, tightly up front
+        assert np.max(np.abs(first_h.cpu().numpy() - first_o)) <= 1e-4 * cfg.max_ground_accel
+        assert np.max(np.abs(v_h.cpu().numpy() - v_o)) <= 5e-6
+    # the whole plan and its duals, not only the first input
     ws_h = mpc.workspace.cpu().numpy()
-    np.testing.assert_allclose(ws_h[0], ws[0], atol=(2e-3 if N == 16 else 1e-4) * cfg.max_ground_accel)
-    if N == 16:
-        assert_mostly_close(ws_h[:N].T, ws[:N].T, atol=0.1, fraction=0.99, hard_atol=0.5)
-    else:  # (the whole plan and its duals, not only the first input)
-        np.testing.assert_allclose(ws_h[:N], ws[:N], atol=2e-3)
-        np.testing.assert_allclose(ws_h[N:], ws[N:], atol=2e-3)
+    np.testing.assert_allclose(ws_h[:N], ws[:N], atol=2e-3)
+    np.testing.assert_allclose(ws_h[N:], ws[N:], atol=2e-3)
     mask = torch.zeros(B, dtype=torch.uint8)
     mask[::2] = 1
     mpc.reset(mask)

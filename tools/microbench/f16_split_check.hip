@@ -128,6 +128,40 @@ __global__ __launch_bounds__(64) void k_valu_to_mfma(const float* A, const float
   for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + i] = acc[r];
 }
 
+// (4c) the MFMA's result read by a vector instruction NOPS wait states behind it (fixed registers as above)
+template <int NOPS>
+__global__ __launch_bounds__(64) void k_mfma_to_valu(const float* A, const float* B, float* D) {
+  const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+  i4 ah, bh;
+  for (int p = 0; p < 4; ++p) {
+    ah[p] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(A[i * 32 + 8 * g + 2 * p], A[i * 32 + 8 * g + 2 * p + 1]));
+    bh[p] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(B[(8 * g + 2 * p) * 16 + i], B[(8 * g + 2 * p + 1) * 16 + i]));
+  }
+  f4 acc;
+#define M2V_HEAD                                                                                                               \
+  "v_mov_b32 v32, %1\n\tv_mov_b32 v33, %2\n\tv_mov_b32 v34, %3\n\tv_mov_b32 v35, %4\n\t"                                       \
+  "v_mov_b32 v36, %5\n\tv_mov_b32 v37, %6\n\tv_mov_b32 v38, %7\n\tv_mov_b32 v39, %8\n\t"                                       \
+  "v_mov_b32 v40, 0\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, 0\n\tv_mov_b32 v43, 0\n\ts_nop 7\n\t"                                \
+  "v_mfma_f32_16x16x32_f16 v[40:43], v[32:35], v[36:39], v[40:43]\n\t"
+#define M2V_TAIL "v_mov_b32 %0, v40\n\tv_mov_b32 %9, v41\n\tv_mov_b32 %10, v42\n\tv_mov_b32 %11, v43\n\ts_nop 15"
+#define M2V_OPS                                                                                                                \
+  : "=&v"(acc[0]), "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]),     \
+    "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])                                                                                \
+  :                                                                                                                            \
+  : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43"
+  if (NOPS == 0) asm volatile(M2V_HEAD M2V_TAIL M2V_OPS);
+  if (NOPS == 1) asm volatile(M2V_HEAD "s_nop 0\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 2) asm volatile(M2V_HEAD "s_nop 1\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 3) asm volatile(M2V_HEAD "s_nop 2\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 4) asm volatile(M2V_HEAD "s_nop 3\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 5) asm volatile(M2V_HEAD "s_nop 4\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 6) asm volatile(M2V_HEAD "s_nop 5\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 7) asm volatile(M2V_HEAD "s_nop 6\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 8) asm volatile(M2V_HEAD "s_nop 7\n\t" M2V_TAIL M2V_OPS);
+  if (NOPS == 12) asm volatile(M2V_HEAD "s_nop 11\n\t" M2V_TAIL M2V_OPS);
+  for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + i] = acc[r];
+}
+
 static float half_bits(unsigned short u) {
   _Float16 h;
   __builtin_memcpy(&h, &u, 2);
@@ -201,5 +235,8 @@ int main() {
   printf("(4b) v_cvt_pkrtz_f16_f32 writes a B register, wait states, MFMA reads it -> worst |D - fp64| (1-term product: 1 when right)\n");
 #define V2M(N) hipLaunchKernelGGL(k_valu_to_mfma<N>, dim3(1), dim3(64), 0, 0, dA, dB, dD); printf("   wait states %d: %.3g\n", N, worst_of(1));
   V2M(0) V2M(1) V2M(2) V2M(3) V2M(4) V2M(6)
+  printf("(4c) MFMA, wait states, vector instruction reads the result -> worst |D - fp64| (1-term product: 1 when right)\n");
+#define M2V(N) hipLaunchKernelGGL(k_mfma_to_valu<N>, dim3(1), dim3(64), 0, 0, dA, dB, dD); printf("   wait states %d: %.3g\n", N, worst_of(1));
+  M2V(0) M2V(1) M2V(2) M2V(3) M2V(4) M2V(5) M2V(6) M2V(7) M2V(8) M2V(12)
   return 0;
 }

@@ -1,5 +1,5 @@
-"""Time of one launch of the MPC balancer's ADMM kernel by horizon and batch size (round 6): N = 16 (fp32 MFMA, one row tile),
-N = 48 / 50 (the reference's default) / 64 on the fp16 matrix path with two terms per operand (mpc_tile_h). `UPKIE_MPC_FP32=1`
+"""Time of one launch of the MPC balancer's ADMM kernel by horizon and batch size (round 6): N = 16 / 48 / 50 (the reference's
+default) / 64 on the fp16 matrix path with two terms per operand (mpc_tile_h). `UPKIE_MPC_FP32=1`
 in the environment selects the fp32 MFMA kernels (N = 50: three row tiles + rows 48 / 49 on the vector unit; with
 `UPKIE_MPC_FOUR_TILES=1` as well, round 5's padding to four tiles): the A/Bs of profiles/r06_mpc_tail.txt and
 profiles/r06_mpc_f16_split.txt.
@@ -20,7 +20,7 @@ from upkie_amd.mpc import BatchedMpc  # noqa: E402
 if __name__ == "__main__":
     fp32 = os.environ.get("UPKIE_MPC_FP32") == "1"
     four = os.environ.get("UPKIE_MPC_FOUR_TILES") == "1"
-    print("horizons > 16: " + (("fp32 MFMA, " + ("four tiles at N = 50" if four else "three tiles + two rows on the vector unit at N = 50")) if fp32 else "fp16 MFMA, two terms per operand"))
+    print("product: " + (("fp32 MFMA, " + ("four tiles at N = 50" if four else "three tiles + two rows on the vector unit at N = 50")) if fp32 else "fp16 MFMA, two terms per operand"))
     for N in (16, 48, 50, 64):
         for B in (2048, 16384):
             cfg = abi.default_mpc_config(B, N)

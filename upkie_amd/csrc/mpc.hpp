@@ -13,6 +13,9 @@
 //   16-row tile (i -> 4 (i % 4) + i / 4) so that the accumulator a lane ends up
 //   holding is exactly the B-operand element it must feed to the next
 //   iteration: no cross-lane movement at all in the loop.
+// Round 6: the kernels that run are mpc_tile_h's below -- the same iteration with the product on the fp16 matrix path
+// (v_mfma_f32_16x16x32_f16, two fp16 terms per operand, fp32 accumulation) and the constant part Minv q of the product taken
+// out of the loop; mpc_tile / mpc_tile_tail (fp32 MFMA) stay as their A/B partners (UPKIE_MPC_FP32=1, -DUPKIE_FUSED_MPC_FP32).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,7 +36,7 @@ struct MpcDev {
   const float* minv;  // [Np][Np] row-permuted
   const float* gx;    // [Np][4]  Minv Kx  and
   const float* gv;    // [Np]     Minv kv: the constant part of every iteration's product, u_q = Minv q (mpc_tile_h)
-  const void* minv_h;  // the same matrix as two fp16 terms (hi + lo) in the A-operand layout of v_mfma_f32_16x16x32_f16, horizons > 16 (mpc_tile_h)
+  const void* minv_h;  // the same matrix as two fp16 terms (hi + lo) in the A-operand layout of v_mfma_f32_16x16x32_f16 (mpc_tile_h)
   const float* kx;    // [Np][4]
   const float* kv;    // [Np]
   int num_envs;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
   }
 }
 
-// The same solve for horizons N > 16 with the product on the fp16 matrix path (round 6). v_mfma_f32_16x16x4_f32 runs at the
+// The same solve with the product on the fp16 matrix path (round 6; every horizon, worked out on N = 50). v_mfma_f32_16x16x4_f32 runs at the
 // vector unit's own fp32 rate -- 32 cycles for 2048 multiply-adds -- and a wavefront that has its SIMD to itself issues nothing
 // else in its shadow (tools/microbench/mfma_shadow.hip: 32.4 cycles per MFMA alone, 52 with two vector instructions behind
 // each): the N = 50 iteration was 39 of them + 70 vector instructions, one after the other. v_mfma_f32_16x16x32_f16 does eight
@@ -475,17 +478,19 @@ __device__ __forceinline__ void mpc_split_pair(floatx2 r, int& hi, int& lo) {
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(lx), "v"(ly));
 }
 
-template <int T>
+// COLUMNS, handover: as mpc_tile's (a step kernel solves its own wavefront's QPs in front of their step).
+template <int T, int COLUMNS = 16>
 __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ ws, const float* __restrict__ x0,
                                            const float* __restrict__ v_target, int v_target_stride,
                                            const uint8_t* __restrict__ contact, const float* __restrict__ done, float dt,
-                                           float* __restrict__ commanded, float* __restrict__ first_input, int env0) {
+                                           float* __restrict__ commanded, float* __restrict__ first_input, int env0,
+                                           float* handover = nullptr) {
   constexpr int KJ = (T + 1) / 2;  // 32-wide K-steps
   const int lane = threadIdx.x & 63;
   const int col = lane & 15, g = lane >> 4;
   const int B = P.num_envs;
   const int env = env0 + col;
-  const bool live = env < B;
+  const bool live = col < COLUMNS && env < B;
   const int N = P.n;
   intx4 ah[T][KJ], al[T][KJ];
   {
@@ -564,13 +569,13 @@ __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ 
     // six rounds (three with one K-step) over the tiles, row tile innermost: MFMAs on one accumulator are T apart. Accumulators
     // in VGPRs, destination tied to C or early-clobber, wait states written out (see mpc_tile)
     floatx4 acc[T];
-    // every term of the split is complete, and four wait states old, before the first MFMA: the compiler does not know that the
+    // every term of the split is complete, and two to four wait states old (one is required), before the first MFMA: the compiler does not know that the
     // asm statements below read their operands as MFMAs do, and sinks a conversion right in front of its consumer otherwise
     // (tools/microbench/f16_split_check.hip: a B register written by the instruction in front of the MFMA is read stale)
     if (KJ > 1)
       asm volatile("s_nop 3" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[KJ - 1]), "+v"(bl[KJ - 1]));
     else
-      asm volatile("s_nop 3" : "+v"(bh[0]), "+v"(bl[0]));
+      asm volatile("s_nop 1" : "+v"(bh[0]), "+v"(bl[0]));
 #pragma unroll
     for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc[t]) : "v"(ah[t][0]), "v"(bh[0]), "v"(yv[t]));
     if (KJ > 1) {
@@ -585,14 +590,17 @@ __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ 
     for (int j = 0; j < KJ; ++j)
 #pragma unroll
       for (int t = 0; t < T; ++t) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(al[t][j]), "v"(bh[j]));
-    // MFMA result -> vector unit: 11 wait states cover either pass count; tile 0's last MFMA is T - 1 MFMAs (four wait states
-    // each, at least) back, the later tiles' are read behind the updates of the tiles in front of them
+    // MFMA result -> vector unit: 7 wait states (measured, f16_split_check.hip (4c): 6 read a partly written result); tile 0's
+    // last MFMA is T - 1 MFMAs (four wait states each, at least) back, the later tiles' are read behind the updates of the tiles
+    // in front of them
     if (T >= 4) {
       asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[T - 1]));
     } else if (T == 3) {
       asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[T - 1]));
-    } else {
+    } else if (T == 2) {
       asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[T - 1]));
+    } else {
+      asm volatile("s_nop 7" : "+v"(acc[0]));
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -635,6 +643,7 @@ __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ 
       v = fminf(fmaxf(v, -P.max_ground_velocity), P.max_ground_velocity);
     }
     commanded[env] = v;
+    if (handover) handover[col] = v;
   }
 }
 

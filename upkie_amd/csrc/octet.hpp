@@ -1692,7 +1692,11 @@ __global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLi
   __shared__ float mpc_velocity[MODE == MODE_BASE_VELOCITY ? 16 : 1];
   if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
     const float* done_row = autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
+#if defined(UPKIE_FUSED_MPC_FP32)  // (A/B build: the fp32 MFMA tile of rounds 4-5)
     mpc_tile<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)block, mpc_velocity);
+#else  // round 6: the fp16 matrix path, whose MFMAs leave the vector unit to the wavefront this one shares its SIMD with
+    mpc_tile_h<1, 8>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, 8 * (int)block, mpc_velocity);
+#endif
     __syncthreads();
   }
   if (!in_batch) return;

@@ -488,8 +488,13 @@ __global__ __launch_bounds__(64) void step_kernel_pair(const DevModel* __restric
   if (MODE == MODE_BASE_VELOCITY && bv.mpc_fused) {
     const int env0 = 32 * blockIdx.x;
     const float* done_row = C.autoreset_mode != 0 ? state + (size_t)UPKIE_S_DONE * B : nullptr;
+#if defined(UPKIE_FUSED_MPC_FP32)
     mpc_tile<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0, mpc_velocity);
     mpc_tile<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0 + 16, mpc_velocity + 16);
+#else
+    mpc_tile_h<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0, mpc_velocity);
+    mpc_tile_h<1>(bv.mpc, bv.mpc_ws, bv.x0, act, 2, bv.contact, done_row, C.dt, bv.mpc_commanded, nullptr, env0 + 16, mpc_velocity + 16);
+#endif
     __syncthreads();
   }
   if (e >= B) return;  // both lanes of a pair leave together

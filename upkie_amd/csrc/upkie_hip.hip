@@ -956,7 +956,7 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   std::vector<uint16_t> minv_h;
   std::vector<float> gx, gv;
   std::string why;
-  const bool fp16_path = mpc->tiles > 1;
+  const bool fp16_path = true;  // (every horizon since round 6; the fp32 operands stay for UPKIE_MPC_FP32=1)
   if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why, fp16_path ? &minv_h : nullptr, fp16_path ? &gx : nullptr, fp16_path ? &gv : nullptr)) {
     delete mpc;
     return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
@@ -1032,11 +1032,12 @@ static int mpc_launch(UpkieMpc* mpc, float* workspace, const float* x0, const fl
   if (!(dt / 0.1 < 0.5)) return mpc_fail(mpc, UPKIE_ERR_INVALID_ARGUMENT, "dt too large for the 0.1 s low-pass (filters.py:78-79)");
   dim3 grid((unsigned)((mpc->dev.num_envs + 15) / 16)), block(64);
   hipStream_t st = (hipStream_t)stream;
-  // horizons > 16: the product on the fp16 matrix path, two terms per operand (mpc_tile_h); UPKIE_MPC_FP32=1 selects the fp32
-  // MFMA kernels of rounds 2-6 (A/B, profiles/r06_mpc_f16_split.txt)
+  // the product on the fp16 matrix path, two terms per operand (mpc_tile_h); UPKIE_MPC_FP32=1 selects the fp32
+  // MFMA kernels of rounds 2-6 for this entry point (the balancer inside a step's launch: a build flag, UPKIE_FUSED_MPC_FP32) (A/B, profiles/r06_mpc_f16_split.txt)
   static const bool fp32_product = [] { const char* v = std::getenv("UPKIE_MPC_FP32"); return v && v[0] == '1'; }();
-  if (mpc->tiles > 1 && !fp32_product) {
+  if (!fp32_product) {
     switch (mpc->tiles) {
+      case 1: hipLaunchKernelGGL(mpc_step_h_kernel<1>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
       case 2: hipLaunchKernelGGL(mpc_step_h_kernel<2>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
       case 3: hipLaunchKernelGGL(mpc_step_h_kernel<3>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
       default: hipLaunchKernelGGL(mpc_step_h_kernel<4>, grid, block, 0, st, mpc->dev, workspace, x0, target_velocity, target_stride, contact, done, (float)dt, commanded_velocity, first_input); break;
