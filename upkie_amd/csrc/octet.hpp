@@ -1636,7 +1636,11 @@ __global__ __launch_bounds__(UPKIE_OCTET_BLOCK, MODE == MODE_SERVOS && kServosLi
   }
   // (and the lane's row of constants: eight more loads that wait for nothing but the model pointer)
   // (not in front of the balancer's tile, which wants the registers and has its own loads to wait for: measured, C3)
+#if defined(UPKIE_AB_ROW_UP_FRONT)  // (A/B, round 6, with the balancer's tile on the fp16 path: C3 27.1 -> 27.7 us, still not)
+  constexpr bool ROW_UP_FRONT = true;
+#else
   constexpr bool ROW_UP_FRONT = MODE != MODE_BASE_VELOCITY;
+#endif
   float lane_row[OT_WORDS];
   if (ROW_UP_FRONT) load_oct_table_row(*(const __attribute__((address_space(4))) DevModel*)Mp, l, leg, lane_row);
   // (they stay in front of the settings block: its touch sequence is a memory barrier to the compiler -- and nothing
