@@ -683,7 +683,12 @@ int upkie_mpc_reset(UpkieMpc* mpc, float* workspace, float* commanded_velocity,
  * matrix cores: v_mfma_f32_16x16x32_f16 on two fp16 terms per operand with fp32
  * accumulation, the constant part of the product (Minv q) computed once per step
  * from fp64 host products (csrc/mpc.hpp: first input within 5e-4 m/s2 of the fp64
- * oracle's at N = 16 .. 64). The environment variable UPKIE_MPC_FP32=1, read at the
+ * oracle's at N = 16 .. 64). A solve whose iterates leave fp16's range (a finite but
+ * absurd target or state, e.g. a target velocity of 1e30: |64 rho (2 z - w)| > 65504)
+ * is discarded as a whole: zero warm start, first_input 0, the commanded velocity
+ * decays as for a fallen robot; nothing non-finite is ever stored (non-finite TARGETS
+ * are replaced by 0 up front, see "Non-finite commands and states").
+ * The environment variable UPKIE_MPC_FP32=1, read at the
  * first step of the process, selects the fp32 MFMA kernels of earlier rounds for this
  * entry point (A/B). */
 int upkie_mpc_step(UpkieMpc* mpc, float* workspace, const float* x0,

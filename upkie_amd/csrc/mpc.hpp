@@ -460,8 +460,8 @@ __device__ __forceinline__ void mpc_tile_tail(const MpcDev& P, float* __restrict
 //   Al rl, 2^-22 of the product, is dropped).
 // Against the fp64 checker this is as close as the fp32 product is (N = 50, 30 iterations: first input within 3e-3 m/s2 on the
 // parity test's inputs, 9e-3 on its saturating ones, fp32: 4e-3 / 1e-2 -- the iteration's own conditioning, not the product's:
-// profiles/r06_mpc_f16_split.txt). Range: |r| < 65504 (the parity test's largest is 1e3; beyond, the conversion saturates and
-// the env -- a robot far outside anything the balancer is for -- gets a wrong but finite plan).
+// profiles/r06_mpc_f16_split.txt; with the re-association below: 2e-6). Range: see kScale below; a solve that leaves it is
+// discarded as a whole at the end (tests/test_nonfinite_guard_gpu.py poisons targets with 1e30).
 // Layout: K-step j of the 32-wide product reads, from lane (g, col), the eight elements the lane itself holds in row tiles 2 j
 // and 2 j + 1 (four registers each) -- as in mpc_tile no element ever changes lanes --, so the permuted column index of element
 // (t, g, r) is 32 (t / 2) + 8 g + 4 (t % 2) + r; rows as before (mpc_host_setup).
@@ -619,20 +619,29 @@ __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ 
       yv[t] = floatx4{yn[0].x, yn[0].y, yn[1].x, yn[1].y};
     }
   }
+  // A solve that left fp16's range (a finite but absurd target or state: |64 r| > 65504 turns into an infinity in the split and
+  // into NaNs in every row of the next product) is discarded as a whole: zero warm start, the commanded velocity decays as for
+  // a fallen robot. Every lane of the column sees it in its own elements (the matrix is dense), so each decides alone.
+  bool sound = true;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sound = sound && fabsf(r < 2 ? zp[t][0][r] : zp[t][1][r - 2]) < 3.0e38f && fabsf(yv[t][r]) < 3.0e38f;
+  const bool discard = resetting || !sound;
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = mpc_index(t, g, r);
       if (live && n < N) {
-        ws[(size_t)n * B + env] = resetting ? 0.f : (r < 2 ? zp[t][0][r] : zp[t][1][r - 2]);
-        ws[(size_t)(N + n) * B + env] = resetting ? 0.f : yv[t][r];
+        ws[(size_t)n * B + env] = discard ? 0.f : (r < 2 ? zp[t][0][r] : zp[t][1][r - 2]);
+        ws[(size_t)(N + n) * B + env] = discard ? 0.f : yv[t][r];
       }
     }
   if (live && g == 0) {
-    const float u0 = zp[0][0].x;  // plan.first_input, mpc_balancer.py:307
+    const float u0 = sound ? zp[0][0].x : 0.f;  // plan.first_input, mpc_balancer.py:307
     if (first_input) first_input[env] = u0;
-    const bool fallen = fabsf(x.y) > P.fall_pitch;  // :260
+    const bool fallen = fabsf(x.y) > P.fall_pitch || !sound;  // :260
     float v = v_before;
     if (resetting) {
       v = 0.f;  // mpc_balancer.py:232
