@@ -239,3 +239,21 @@ extern "C" int harness_substep_octet_bullet_like(const UpkieModel* model, float*
 extern "C" void harness_bullet_like_probe(void* probe) { g_bullet_like_probe = static_cast<BulletLikeProbe*>(probe); }
 extern "C" int harness_bullet_like_probe_bytes(void) { return (int)sizeof(BulletLikeProbe); }
 #endif  // host pass only
+
+// The balancer's host setup (csrc/mpc.hpp: condensing, Minv, its fp32 layout, the fp16 two-term layout of round 6, Minv Kx and
+// Minv kv), for tests/test_mpc_host_setup.py. `np` = 16 x tiles; buffers sized by the caller: minv_perm [np * np], kx [np * 4],
+// kv [np], minv_h [64 * tiles * ceil(tiles / 2) * 16] (uint16), gx [np * 4], gv [np].
+extern "C" int harness_mpc_host_setup(const UpkieMpcConfig* config, int np, float* minv_perm, float* kx, float* kv, uint16_t* minv_h,
+                                      float* gx, float* gv) {
+  std::vector<float> m, x, v, g4, g1;
+  std::vector<uint16_t> h;
+  std::string why;
+  if (!upkie::mpc_host_setup(*config, np, &m, &x, &v, &why, &h, &g4, &g1)) return -1;
+  std::copy(m.begin(), m.end(), minv_perm);
+  std::copy(x.begin(), x.end(), kx);
+  std::copy(v.begin(), v.end(), kv);
+  std::copy(h.begin(), h.end(), minv_h);
+  std::copy(g4.begin(), g4.end(), gx);
+  std::copy(g1.begin(), g1.end(), gv);
+  return (int)h.size();
+}
