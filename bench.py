@@ -685,14 +685,40 @@ def main(argv=None, sim_factory=None, backend=None, json_out=None) -> None:
             keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "steady_state")
             return {k: out[k] for k in keep if k in out}
 
+        # The blocks below run collectives of their own: a rank that fails inside one leaves the others waiting for it. The
+        # contract figure is measured by now -- a watchdog prints it if the blocks do not come back (never seen; no multi-GPU
+        # box to try it on: the 2 / 4 / 8-GPU runs are the driver's).
+        watchdog = _arm_line_watchdog(line, SECONDARY_BLOCKS_TIMEOUT_S, json_out)
         c4 = block("c4", C4_ENVS_PER_GPU, True)
         c5 = block("c5", ENVS_PER_GPU, False)
+        watchdog.cancel()
         if line is not None:
             line["secondary"] = {"c4": c4, "c5": c5,
                                  "note": "BASELINE configs[3] and configs[4] at this run's N, measured in the same launch behind the weak-scaling line above "
                                          "(same W / K, each with SURVEY 8d's steady_state window of its own); `--config c4|c5` prints either as a line of its own"}
     if line is not None:
         print(json.dumps(line), file=json_out or sys.stdout, flush=True)
+
+
+SECONDARY_BLOCKS_TIMEOUT_S = float(os.environ.get("UPKIE_BENCH_SECONDARY_TIMEOUT_S", "300"))
+
+
+def _arm_line_watchdog(line, seconds: float, json_out=None):
+    """A timer that ends the process if the multi-GPU secondary blocks hang: rank 0 (the one that holds `line`) prints
+    the contract line first, with the reason in place of the blocks; the other ranks leave a little later."""
+    import threading
+
+    def fire():
+        if line is not None:
+            out = dict(line)
+            out["secondary"] = {"error": f"the c4 / c5 blocks behind the contract figure did not finish within {seconds:g} s (a rank stuck in a collective?); the line above them is complete"}
+            print(json.dumps(out), file=json_out or sys.stdout, flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(seconds if line is not None else seconds + 5.0, fire)
+    timer.daemon = True
+    timer.start()
+    return timer
 
 
 def run_pendulum(args, sim_factory=None, backend=None, keep_group: bool = False):

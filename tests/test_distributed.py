@@ -513,3 +513,28 @@ def test_bench_c5_launch_line_on_cpu_doubles():
     assert "UpkieServos" in out["metric"] and "C5" in out["config"]["workload"] and out["config"]["gather"].startswith("RCCL gather")
     assert out["value"] == pytest.approx(10 * 9 / (out["ms_per_step"] * 1e-3 * 9), rel=1e-6)
     assert out["roofline"]["algorithmic_bytes_per_env_step"] == 630 and out["steady_state"]["steps"] == 6
+
+
+def test_the_contract_line_survives_hanging_secondary_blocks():
+    """`bench.py --gpus N` (N > 1, default flags) measures BASELINE's configs[3] / configs[4] behind the contract figure; those
+    blocks run collectives of their own, and a rank stuck in one must not cost the line: the watchdog prints it and ends the
+    process (rank 0), or just ends it (the others)."""
+    import json
+    import subprocess
+    import sys
+
+    script = (
+        "import sys, time; sys.path.insert(0, %r); import bench\n"
+        "line = {'metric': 'm', 'value': 1.0} if sys.argv[1] == '0' else None\n"
+        "bench._arm_line_watchdog(line, 0.5)\n"
+        "time.sleep(30)\n"
+        "print('never')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    )
+    for rank, want_line in (("0", True), ("1", False)):
+        out = subprocess.run([sys.executable, "-c", script, rank], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and "never" not in out.stdout
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == (1 if want_line else 0)
+        if want_line:
+            parsed = json.loads(lines[0])
+            assert parsed["value"] == 1.0 and "did not finish" in parsed["secondary"]["error"]
