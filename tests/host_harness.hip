@@ -244,11 +244,11 @@ extern "C" int harness_bullet_like_probe_bytes(void) { return (int)sizeof(Bullet
 // Minv kv), for tests/test_mpc_host_setup.py. `np` = 16 x tiles; buffers sized by the caller: minv_perm [np * np], kx [np * 4],
 // kv [np], minv_h [64 * tiles * ceil(tiles / 2) * 16] (uint16), gx [np * 4], gv [np].
 extern "C" int harness_mpc_host_setup(const UpkieMpcConfig* config, int np, float* minv_perm, float* kx, float* kv, uint16_t* minv_h,
-                                      float* gx, float* gv) {
+                                      float* gx, float* gv, float* scale) {
   std::vector<float> m, x, v, g4, g1;
   std::vector<uint16_t> h;
   std::string why;
-  if (!upkie::mpc_host_setup(*config, np, &m, &x, &v, &why, &h, &g4, &g1)) return -1;
+  if (!upkie::mpc_host_setup(*config, np, &m, &x, &v, &why, &h, &g4, &g1, scale)) return -1;
   std::copy(m.begin(), m.end(), minv_perm);
   std::copy(x.begin(), x.end(), kx);
   std::copy(v.begin(), v.end(), kv);

@@ -315,6 +315,36 @@ def test_mpc_step_matches_oracle(N):
     assert float(mpc.workspace[:, ::2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N, rho, relaxation, leg_length", [(50, 1e-4, 1.5, 0.58), (50, 1e-2, 1.0, 0.58), (16, 1e-5, 1.6, 0.4), (32, 1e-1, 1.2, 0.7)])
+def test_mpc_other_solver_settings_and_models(N, rho, relaxation, leg_length):
+    """The fp16 operands are scaled by a power of two chosen from the matrix itself (csrc/mpc.hpp: the largest entry of
+    Minv / scale lies in [8, 16)): other ADMM penalties, relaxations and pendulum lengths -- Minv's entries range over
+    six decades here -- stay as close to the fp64 ADMM of the same settings as the defaults do."""
+    import ctypes as C
+
+    from oracle import oracle as O
+    from upkie_amd.mpc import BatchedMpc
+
+    B = 256
+    cfg = abi.default_mpc_config(B, N)
+    cfg.admm_rho, cfg.admm_relaxation, cfg.leg_length = rho, relaxation, leg_length
+    mpc = BatchedMpc(cfg)
+    rng = np.random.default_rng(1)
+    ws, v_o, first_o = np.zeros((2 * N, B)), np.zeros(B), np.zeros(B)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for step in range(3):
+        scale = 1.0 if step < 2 else 5.0
+        x0 = np.stack([rng.uniform(-0.5, 0.5, B), rng.uniform(-0.15, 0.15, B) * scale, rng.uniform(-0.5, 0.5, B) * scale, rng.uniform(-0.5, 0.5, B) * scale], axis=1)
+        vt = rng.uniform(-0.5, 0.5, B)
+        contact = np.ones(B, dtype=np.uint8)
+        O.lib().oracle_mpc_step(C.byref(cfg), p(ws), p(np.ascontiguousarray(x0)), p(vt), p(contact), C.c_double(0.005), p(v_o), p(first_o))
+        v_h, first_h = mpc.step(torch.from_numpy(x0).float(), torch.from_numpy(vt).float(), torch.from_numpy(contact), dt=0.005)
+        err = float(np.max(np.abs(first_h.cpu().numpy() - first_o)))
+        print(f"N={N} rho={rho} alpha={relaxation} l={leg_length} step {step}: |first input - checker| {err:.2e}")
+        assert err <= 2e-4 * cfg.max_ground_accel, (step, err)
+    assert torch.isfinite(mpc.workspace).all()
+
+
 @pytest.mark.parametrize("four_tiles", ["0", "1"])
 def test_mpc_fp32_kernels_of_the_long_horizons(four_tiles):
     """`UPKIE_MPC_FP32=1` (read once per process): the fp32 MFMA kernels for horizons > 16, kept as the A/B partners of

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -44,6 +45,7 @@ struct MpcDev {
   int iterations;
   float rho;
   float alpha;  // over-relaxation (1: the plain iteration)
+  float scale;  // mpc_tile_h carries scale x r and reads Minv / scale: a power of two that brings max |Minv| / scale into [8, 16)
   float bound;  // max_ground_accel
   float max_ground_velocity;
   float fall_pitch;
@@ -531,11 +533,12 @@ __device__ __forceinline__ void mpc_tile_h(const MpcDev& P, float* __restrict__ 
   // multiply-adds on the host's fp64 Minv Kx, Minv kv: 2e-6 with the same number of instructions (the -q of the right-hand side
   // becomes a -alpha u_q in the relaxed update). Same recurrences otherwise (mpc_tile): w = alpha (U + y) + (1 - alpha) w_prev,
   // z = clip(w), y' = w - z, r' = rho (2 z - w).
-  // r is carried TIMES 64 and Minv divided by 64 on the host (powers of two: nothing rounds): fp16's normal range, 6e-5 .. 65504,
-  // then holds both terms of |r| from 2e-3 to 1e3; u_q is clamped once, so that a state far outside anything the balancer is for
+  // r is carried TIMES P.scale and Minv divided by it on the host (a power of two: nothing rounds; 32 with the default weights,
+  // chosen so that the largest entry of Minv / scale lies in [8, 16) whatever rho and the cost weights are): fp16's normal
+  // range, 6e-5 .. 65504, then holds both terms of |r| from 4e-3 to 2e3; u_q is clamped once, so that a state far outside anything the balancer is for
   // (|w| follows |u_q|) gives a wrong but finite plan.
-  constexpr float kScale = 64.f, kLargest = 1.0e5f;
-  const float rho = P.rho * kScale, bound = P.bound;
+  constexpr float kLargest = 1.0e5f;
+  const float rho = P.rho * P.scale, bound = P.bound;
   floatx2 rbp[T][2], nauq[T][2], zp[T][2], carry[T][2];
   floatx4 yv[T];
   const floatx2 rho2 = floatx2{rho, rho}, two = floatx2{2.f, 2.f};
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(64) void mpc_reset_kernel(int B, int N, float* __re
 // (third-party, restated from the published algorithm).
 inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* minv_perm, std::vector<float>* kx,
                            std::vector<float>* kv, std::string* why, std::vector<uint16_t>* minv_h = nullptr, std::vector<float>* gx = nullptr,
-                           std::vector<float>* gv = nullptr) {
+                           std::vector<float>* gv = nullptr, float* scale_out = nullptr) {
   const int N = c.nb_timesteps;
   const double T = c.sampling_period, g = 9.81;
   const double omega = std::sqrt(g / c.leg_length);
@@ -825,6 +828,11 @@ inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* 
     // [lane][t][j][hi | lo][c], 16 bytes per term
     const int kj = (tiles + 1) / 2;
     minv_h->assign((size_t)64 * tiles * kj * 2 * 8, 0);
+    // the power of two that brings the largest entry into [8, 16): fp16 then holds both terms of every entry down to 1e-3 of it
+    double largest = 1.0 / (1.0 + c.admm_rho);
+    for (double v : Minv) largest = std::max(largest, std::fabs(v));
+    const double scale = std::exp2(std::ceil(std::log2(largest / 16.0)));
+    if (scale_out) *scale_out = (float)scale;
     auto entry = [&](int row, int col) { return row < N && col < N ? Minv[(size_t)row * N + col] : (row == col ? 1.0 / (1.0 + c.admm_rho) : 0.0); };
     auto bits = [](_Float16 h) {
       uint16_t u;
@@ -838,7 +846,7 @@ inline bool mpc_host_setup(const UpkieMpcConfig& c, int np, std::vector<float>* 
         for (int j = 0; j < kj; ++j)
           for (int slot = 0; slot < 8; ++slot) {
             const int tk = 2 * j + slot / 4;
-            const double v = (tk < tiles ? entry(row, 16 * tk + 4 * (slot % 4) + group) : 0.0) / 64.0;  // (mpc_tile_h carries 64 r)
+            const double v = (tk < tiles ? entry(row, 16 * tk + 4 * (slot % 4) + group) : 0.0) / scale;  // (mpc_tile_h carries scale x r)
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (double)hi);
             const size_t at = ((((size_t)lane * tiles + t) * kj + j) * 2) * 8 + slot;

@@ -957,7 +957,7 @@ extern "C" int upkie_mpc_create(const UpkieMpcConfig* config, UpkieMpc** out) {
   std::vector<float> gx, gv;
   std::string why;
   const bool fp16_path = true;  // (every horizon since round 6; the fp32 operands stay for UPKIE_MPC_FP32=1)
-  if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why, fp16_path ? &minv_h : nullptr, fp16_path ? &gx : nullptr, fp16_path ? &gv : nullptr)) {
+  if (!mpc_host_setup(*config, np, &minv, &kx, &kv, &why, fp16_path ? &minv_h : nullptr, fp16_path ? &gx : nullptr, fp16_path ? &gv : nullptr, &mpc->dev.scale)) {
     delete mpc;
     return mpc_fail(nullptr, UPKIE_ERR_INVALID_ARGUMENT, why);
   }
