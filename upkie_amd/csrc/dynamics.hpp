@@ -968,7 +968,10 @@ struct SweepWarmStart {
 // The contact impulses of a substep whose direct solution `lam` left the friction box / pulls: projected Gauss-Seidel
 // sweeps (contact_pgs6) from the projected direct solution, or from the previous substep's impulses (`warm`); both tires
 // leaving the floor (neither normal row asks for an impulse) is lam = 0 without a sweep. Returns the sweeps run.
-template <class ModelT>
+// ACTIVE_SET (round 6): the active-set solve in front of the sweeps, from the same warm start -- what the eight-lane kernel does
+// (oct_active_set) -- for the instantiations whose envs skid and tumble as a matter of course: the two-lane UpkieServos kernels
+// (batches of 8192 .. 32768 Servos envs). Returns minus the accepted attempt then, as contact_solve6.
+template <bool ACTIVE_SET = false, class ModelT>
 UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const float (&rhs)[6], float (&lam)[6], bool both, SweepWarmStart* warm) {
   if (rhs[0] <= 0.f && rhs[3] <= 0.f) {
 #pragma unroll
@@ -990,10 +993,22 @@ UPKIE_HD int contact_sweeps_warm(const ModelT& M, const float (&A)[21], const fl
     const float lim = mu * lam[3 * (r / 3)];
     lam[r] = fminf(fmaxf(lam[r], -lim), lim);
   }
-  // (the sweeps alone: the one- and two-lane kernels that come through here serve batches of 20 000 envs and more, and the
-  // active-set solve inlined into them -- 800 instructions of a path one substep in five hundred takes -- cost their COMMON
-  // path 3-6 %: register allocation of a body that much larger, 25.9 -> 27.4 us at 32768 envs, 494 -> 523 us at a
-  // million; as a call it cost the dense kernels 40 %. The eight-lane kernel, whose common path it leaves alone, has it.)
+  // (the sweeps alone, except where ACTIVE_SET says otherwise: the one- and two-lane kernels that come through here serve batches
+  // of 20 000 envs and more, and the active-set solve inlined into them -- 800 instructions of a path one substep in five hundred
+  // takes -- cost their COMMON path 3-6 %: register allocation of a body that much larger, 25.9 -> 27.4 us at 32768 envs,
+  // 494 -> 523 us at a million; as a call it cost the dense kernels 40 %. The eight-lane kernel, whose common path it leaves
+  // alone, has it.)
+  if (ACTIVE_SET) {
+    const int accepted = contact_active_set6(M, A, rhs, lam);  // (lam: the projected warm start; unchanged when no set is accepted)
+    if (accepted) {
+      if (warm) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) warm->lam[r] = lam[r];
+        warm->swept = state;
+      }
+      return -accepted;
+    }
+  }
   const int sweeps = contact_pgs6(M, A, rhs, lam);
   if (warm) {
 #pragma unroll

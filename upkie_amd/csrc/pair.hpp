@@ -120,7 +120,7 @@ struct PhysPair {
 // One physics substep, two lanes per env. Mirrors physics_substep() step by
 // step; comments there apply. `leg` = 0 (left) / 1 (right) is the leg this lane
 // owns. Returns the floor-contact flag (identical in both lanes).
-template <class XL = AdjacentLanes, class ModelT>
+template <bool ACTIVE_SET = false, class XL = AdjacentLanes, class ModelT>
 __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevLimits& Lm, const PairLeg& PL, int leg, PhysPair& s,
                                                      const float (&tau)[3], float h, const TrunkInertial* trunk, const ExtForces& ext,
                                                      SweepWarmStart* warm = nullptr) {
@@ -416,7 +416,7 @@ __device__ __forceinline__ bool physics_substep_pair(const ModelT& M, const DevL
       }
     }
     if (need_pgs) {
-      contact_sweeps_warm(M, A, rhs, lam, active_l && active_r, warm);  // identical data in both lanes: they iterate in lockstep
+      contact_sweeps_warm<ACTIVE_SET>(M, A, rhs, lam, active_l && active_r, warm);  // identical data in both lanes: they iterate in lockstep
     } else if (warm) {
       warm->swept = 0;
     }
@@ -728,7 +728,11 @@ next_step:
       ConstModelPtr mp = (ConstModelPtr)Mp;
       asm volatile("" : "+s"(mp));
       const ExtForces ext_now{do_reset ? nullptr : ext.force, ext.stride, ext.slots};  // reset steps once without external forces
+#if defined(UPKIE_AB_PAIR_SWEEPS_ONLY)  // (A/B build: the two-lane Servos kernels without the active-set solve, as until round 6)
       contact = physics_substep_pair(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext_now, &sweep_warm_start);
+#else  // UpkieServos envs skid and tumble as a matter of course: their instantiations carry the active-set solve (contact_sweeps_warm)
+      contact = physics_substep_pair<MODE == MODE_SERVOS>(*mp, Lm, PL, leg, s, tau, C.h, RAND ? &trunk : nullptr, ext_now, &sweep_warm_start);
+#endif
     }
     if (SPINE) {
       // one cycle of the spine's observer pipeline: each lane runs the WheelContact estimator of its
